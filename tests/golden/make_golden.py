@@ -1,0 +1,150 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures under tests/golden/.
+
+Run in the build container (needs /root/reference for `make -C oracle ref`):
+
+    python tests/golden/make_golden.py
+
+solve_golden.npz  -- outputs of the COMPILED REFERENCE Matrix class
+                     (oracle/_ref, built from the reference's matrix.cpp):
+                     H -> V*U^T, full fitStep solve halves, 3x3 solves,
+                     U*V^T re-orthonormalisation.  These pin the oracle.
+icp_chain_golden.npz -- BASELINE config 1 (scan 0 vs the 10k map, 20 iters):
+                     per iteration, correspondences from the oracle's kd-tree
+                     restatement fed through the compiled reference solve
+                     (ref_fitstep_solve), so R,t,delta per step carry the
+                     reference's own arithmetic for everything after the NN.
+grid_golden.npz   -- small endpoint / Bresenham cases from the oracle
+                     (regression vectors; the reference has none).
+The fixtures hold data only: inputs and expected outputs.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+
+import oracle_lib as O  # noqa: E402
+from slam_amd import synth  # noqa: E402
+
+
+def icp_like_H(rs):
+    n = rs.randint(3, 60)  # n = 2 gives a rank-1 H: V*U^T is then not unique
+    q = rs.randn(n, 2) * [rs.uniform(0.01, 20), rs.uniform(0.01, 20)]
+    th = rs.randn() * 10 ** rs.uniform(-9, 0)
+    c, s = np.cos(th), np.sin(th)
+    qm = q @ np.array([[c, s], [-s, c]]) + rs.randn(n, 2) * 10 ** rs.uniform(-6, -1)
+    q = q - q.mean(0)
+    qm = qm - qm.mean(0)
+    if rs.rand() < 0.25:  # reflections: the reference applies no det fix
+        qm = qm * [1.0, -1.0]
+    return (q.T @ qm).reshape(4)
+
+
+def main():
+    assert O.ref_available(), "build oracle/_ref first: make -C oracle ref"
+    rs = np.random.RandomState(20261003)
+
+    # ---- H -> R_ = V U^T
+    Hs = [icp_like_H(rs) for _ in range(400)] + \
+         [rs.randn(4) * 10 ** rs.uniform(-3, 5) for _ in range(200)]
+    # rank-deficient H (collinear correspondences) has no unique V*U^T and the
+    # reference returns a rotation or a reflection depending on rounding: keep
+    # well-conditioned inputs only.
+    Hs = np.array([H for H in Hs if np.linalg.cond(H.reshape(2, 2)) < 1e10])
+    Rs = np.array([O.ref_p2p_rotation(H).reshape(4) for H in Hs])
+
+    # ---- whole solve half of fitStep
+    fs_pm, fs_pt, fs_R, fs_t, fs_Ro, fs_to, fs_d, fs_n = [], [], [], [], [], [], [], []
+    for _ in range(60):
+        n = rs.randint(3, 200)
+        pm = rs.uniform(-20, 20, size=(n, 2))
+        th = rs.randn() * 0.05
+        c, s = np.cos(th), np.sin(th)
+        pt = (pm - rs.uniform(-0.3, 0.3, 2)) @ np.array([[c, -s], [s, c]]) + rs.randn(n, 2) * 0.01
+        pm = pm.astype(np.float32).astype(np.float64)  # as the reference stores them
+        pt = pt.astype(np.float32).astype(np.float64)
+        R0, t0 = synth.pose_to_Rt(rs.uniform(-1, 1), rs.uniform(-1, 1), rs.uniform(-3, 3))
+        d, R1, t1 = O.ref_fitstep_solve(pm, pt, R0, t0)
+        buf_m = np.zeros((200, 2)); buf_m[:n] = pm
+        buf_t = np.zeros((200, 2)); buf_t[:n] = pt
+        fs_pm.append(buf_m); fs_pt.append(buf_t); fs_n.append(n)
+        fs_R.append(R0.reshape(4)); fs_t.append(t0)
+        fs_Ro.append(R1.reshape(4)); fs_to.append(t1); fs_d.append(d)
+
+    # ---- 3x3 solves (A^T A of point-to-line rows)
+    s3_A, s3_b, s3_x, s3_ok = [], [], [], []
+    for _ in range(200):
+        rows = rs.randn(rs.randint(3, 40), 3) * [5.0, 1.0, 1.0]
+        A = rows.T @ rows
+        if rs.rand() < 0.1:
+            A[2] = A[1]  # singular
+        b = rs.randn(3)
+        ok, x = O.ref_solve3(A, b)
+        s3_A.append(A.reshape(9)); s3_b.append(b); s3_x.append(x); s3_ok.append(ok)
+
+    # ---- U V^T of [[1,-w],[w,1]]; keep only inputs on which the reference's
+    # svd converged (positive singular values) -- it does not always.
+    om_w, om_R = [], []
+    for w in rs.randn(300) * 0.5:
+        _, W, _ = O.ref_svd2([1, -w, w, 1])
+        if W.min() > 0:
+            om_w.append(w)
+            om_R.append(O.ref_orthonormal_from_omega(w).reshape(4))
+
+    np.savez_compressed(os.path.join(HERE, "solve_golden.npz"),
+                        H=Hs, R_=Rs,
+                        fs_pm=np.array(fs_pm), fs_pt=np.array(fs_pt), fs_n=np.array(fs_n),
+                        fs_R=np.array(fs_R), fs_t=np.array(fs_t), fs_Ro=np.array(fs_Ro),
+                        fs_to=np.array(fs_to), fs_d=np.array(fs_d),
+                        s3_A=np.array(s3_A), s3_b=np.array(s3_b), s3_x=np.array(s3_x),
+                        s3_ok=np.array(s3_ok), om_w=np.array(om_w), om_R=np.array(om_R))
+
+    # ---- BASELINE config 1 chain: oracle NN + compiled reference solve
+    m_ga, m_nga = synth.make_map()
+    batch = synth.make_batch(1, n_loop=256)
+    t_ga, t_nga = batch.scan(0)
+    model = O.IcpModel(m_ga, m_nga)
+    p = O.icp_params(max_iter=20, min_delta=1e-6, indist=5.0, nn_method=O.NN_KDTREE)
+    R, t = batch.R[0].reshape(2, 2).copy(), batch.t[0].copy()
+    mga32 = m_ga.astype(np.float32).astype(np.float64)
+    mnga32 = m_nga.astype(np.float32).astype(np.float64)
+    chain = []
+    for it in range(20):
+        _, _, _, nc, corr = model.fit_step(t_ga, t_nga, R, t, p)
+        q = np.concatenate([O.transform_points(t_ga, R, t), O.transform_points(t_nga, R, t)])
+        cls_ga = np.arange(len(corr)) < len(t_ga)
+        sel = corr >= 0
+        pm = np.where(cls_ga[sel, None], mga32[np.clip(corr[sel], 0, len(mga32) - 1)],
+                      mnga32[np.clip(corr[sel], 0, len(mnga32) - 1)])
+        pt = q[sel].astype(np.float64)
+        d, R, t = O.ref_fitstep_solve(pm, pt, R, t)
+        chain.append(np.concatenate([R.reshape(4), t, [d, nc]]))
+        if d < 1e-6:
+            break
+    np.savez_compressed(os.path.join(HERE, "icp_chain_golden.npz"), chain=np.array(chain),
+                        R0=batch.R[0], t0=batch.t[0], n_ga=len(t_ga), n_nga=len(t_nga),
+                        map_seed=12345, scan_k=0, n_loop=256)
+
+    # ---- grid regression vectors (oracle-made)
+    g = O.grid_params(500, 500, 0.1, min_cluster_points=20)
+    Rt = synth.pose_to_Rt(*batch.true_poses[0])
+    end = O.transform_points(batch.pts, Rt[0], Rt[1])
+    origin = np.tile(np.array(Rt[1], dtype=np.float32), (len(end), 1))
+    hits, misses, n_upd = O.grid_raycast(g, origin, end)
+    nzh = np.flatnonzero(hits)
+    nzm = np.flatnonzero(misses)
+    eh, em, cells, n_end = O.grid_add_endpoints(g, end[:600], end[600:])
+    np.savez_compressed(os.path.join(HERE, "grid_golden.npz"), ray_n_upd=n_upd,
+                        ray_hit_cells=nzh, ray_hit_counts=hits[nzh],
+                        ray_miss_cells=nzm, ray_miss_counts=misses[nzm],
+                        end_cells=cells, end_n=n_end, true_pose=batch.true_poses[0])
+    print("golden fixtures written:", sorted(f for f in os.listdir(HERE) if f.endswith(".npz")))
+
+
+if __name__ == "__main__":
+    main()
