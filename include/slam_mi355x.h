@@ -1,0 +1,223 @@
+/*
+ * slam_mi355x.h -- C-ABI of the MI355X (gfx950) implementation of the
+ * servos/SLAM per-scan hot path: the ccicp2d class-constrained 2-D ICP scan
+ * matcher and the mls/local_mapper occupancy-grid update.
+ *
+ * This is the drop-in boundary.  The reference has no
+ * FFI layer: its hot path sits behind two C++ classes, so each entry point
+ * below names the reference member it stands for (file:line under the
+ * reference checkout).  INTEGRATION.md shows the adapter a maintainer adds to
+ * ccicp2d/mls to call it; the headers in include/slam_amd/ are those adapters.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ or framework types cross the ABI;
+ *   - every function returns SLAM_OK (0) or a negative SLAM_E_* code and never
+ *     throws; slam_last_error() gives the text of the calling thread's last
+ *     failure;
+ *   - "host" entry points take host memory and return when the result is in
+ *     the caller's buffers (reference semantics: fit() is synchronous);
+ *   - "_dev" entry points take DEVICE pointers, enqueue on `stream` and return
+ *     without synchronising; inputs are borrowed until the stream reaches
+ *     that point;
+ *   - handles are opaque and not thread-safe (the reference is single-threaded:
+ *     matrix.cpp:26-31 statics, node globals); use one handle per host thread.
+ *   - there is no CPU fallback: without a usable HIP device every compute
+ *     entry point fails with SLAM_E_NO_DEVICE.
+ */
+#ifndef SLAM_MI355X_H
+#define SLAM_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAM_OK                       0
+#define SLAM_E_INVALID               -1 /* bad argument */
+#define SLAM_E_NO_DEVICE             -2 /* no HIP device / runtime not usable */
+#define SLAM_E_HIP                   -3 /* a HIP call failed, see slam_last_error() */
+#define SLAM_E_TOO_FEW_MODEL_POINTS  -4 /* icp.cpp:38-43: fewer than 5 model points */
+#define SLAM_E_TOO_FEW_SCENE_POINTS  -5 /* icp.cpp:100-103, icpTools.cpp:179-184 */
+#define SLAM_E_NOMEM                 -6
+#define SLAM_E_UNSUPPORTED           -7
+
+typedef void *slam_stream_t; /* a hipStream_t; NULL = the default stream */
+typedef void *slam_event_t;  /* a hipEvent_t */
+
+const char *slam_last_error(void);
+const char *slam_version(void);
+
+/* ------------------------------------------------------------ device plumbing */
+int slam_device_count(int *n);
+int slam_set_device(int ordinal);
+int slam_device_info(char *name, int name_len, int *compute_units, size_t *hbm_bytes);
+int slam_malloc(void **dptr, size_t bytes);
+int slam_free(void *dptr);
+int slam_memset(void *dptr, int value, size_t bytes, slam_stream_t stream);
+int slam_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, slam_stream_t stream);
+int slam_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, slam_stream_t stream);
+int slam_stream_create(slam_stream_t *stream);
+int slam_stream_destroy(slam_stream_t stream);
+int slam_stream_synchronize(slam_stream_t stream);
+int slam_device_synchronize(void);
+int slam_event_create(slam_event_t *ev);
+int slam_event_destroy(slam_event_t ev);
+int slam_event_record(slam_event_t ev, slam_stream_t stream);
+int slam_event_synchronize(slam_event_t ev);
+int slam_event_elapsed_ms(slam_event_t start, slam_event_t stop, float *ms);
+
+/* ------------------------------------------------------------------- ICP
+ * Stands for class IcpPointToPoint : Icp (icpPointToPoint.h:26-40, icp.h:33-102). */
+typedef struct slam_icp slam_icp_t;
+
+#define SLAM_ICP_P2P 0 /* IcpPointToPoint::fitStep, icpPointToPoint.cpp:33-172 (what the reference runs) */
+#define SLAM_ICP_P2L 1 /* point-to-line 3x3 normal equations, icpPointToPlane.cpp:37-107 (not compiled upstream) */
+
+typedef struct {
+    int    max_iter;        /* icp.cpp:27 max_iter(20); icp.h:51 setMaxIterations */
+    double min_delta;       /* icp.cpp:27 min_delta(1e-6); icp.h:54 setMinDeltaParam */
+    int    mode;            /* SLAM_ICP_P2P | SLAM_ICP_P2L */
+    int    normals_k;       /* P2L: neighbours per normal (icpPointToPlane.h: 10) */
+    int    lanes_per_point; /* lanes of a wavefront that share one scene point's
+                               search: 1,2,4,8,16,32,64; 0 = library default */
+    double cell_size;       /* model lattice pitch in metres; 0 = sized to fit LDS */
+    int    force_global;    /* 1 = keep the model index in HBM/L2 even if it fits LDS */
+} slam_icp_params;
+
+typedef struct {
+    int    iters;  /* fitStep calls executed (icp.cpp:116-122) */
+    int    n_corr; /* Icp::getNumberCorrespondences of the last step */
+    double delta;  /* last fitStep return value; -1 = no correspondences */
+} slam_icp_result;
+
+void slam_icp_default_params(slam_icp_params *p);
+
+/* Icp::Icp(M_GA, M_NGA, M_GA_num, M_NGA_num, dim=2), icp.cpp:26-70.  The host
+ * arrays (xy, f64) are copied (stored as f32, icp.cpp:51-60) and a uniform-cell
+ * index replaces the two kd-trees; the exact-1-NN-in-float contract is kept. */
+int  slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga,
+                     const slam_icp_params *params, slam_icp_t **out);
+void slam_icp_destroy(slam_icp_t *icp);
+int  slam_icp_set_max_iterations(slam_icp_t *icp, int val);  /* icp.h:51 */
+int  slam_icp_set_min_delta(slam_icp_t *icp, double val);    /* icp.h:54 */
+int  slam_icp_set_subsampling_step(slam_icp_t *icp, int val);/* icp.h:48 (stored, unused there too) */
+
+/* Icp::fit(T_GA, T_NGA, T_GA_num, T_NGA_num, R, t, indist, h_dist), icp.cpp:80-114.
+ * R (2x2 row-major) and t are in/out; host pointers; synchronous.  Returns
+ * SLAM_E_TOO_FEW_SCENE_POINTS (R,t untouched) where the reference logs and
+ * returns early. */
+int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t_nga,
+                 int n_tnga, double R[4], double t[2], double indist,
+                 slam_icp_result *result);
+
+/* The same over a batch of independent scans, all operands resident in HBM.
+ *   d_pts      xy f64 of all scans, scan s = points [d_scan_off[s], d_scan_off[s+1])
+ *   d_scan_nga number of class-GA points at the front of scan s (the rest is NGA)
+ *   d_R, d_t   n_scans x 4 / x 2 doubles, in/out (initial -> registered pose)
+ *   d_result   n_scans slam_icp_result (nullable)
+ *   d_trace    nullable; n_scans x max_iter x 8 doubles: R00 R01 R10 R11 t0 t1
+ *              delta n_corr after each executed step
+ * Scans with fewer than 5 points are left untouched (iters = 0). */
+int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *d_scan_off,
+                           const int32_t *d_scan_nga, int n_scans, double *d_R, double *d_t,
+                           double indist, slam_icp_result *d_result, double *d_trace,
+                           slam_stream_t stream);
+
+/* KDTree::n_nearest(qv, 1, result), kdtree.cpp:378-391, for n float queries
+ * against one class (0 = GA, 1 = NGA): squared float distance and ORIGINAL
+ * model index (kdtree.h:31-35).  Device pointers. */
+int slam_icp_nearest_dev(slam_icp_t *icp, int cls, const float *d_query_xy, int n,
+                         float *d_dis, int32_t *d_idx, slam_stream_t stream);
+
+/* IcpPointToPoint::getEdgeWeight(eW), icpPointToPoint.cpp:233-316, for the
+ * correspondences of the last slam_icp_fit() call. */
+int slam_icp_get_edge_weight(slam_icp_t *icp, double eW[9]);
+
+/* what the index looks like (for DESIGN.md / bench reporting) */
+int slam_icp_index_info(slam_icp_t *icp, int *nx, int *ny, double *cell, int *in_lds,
+                        size_t *lds_bytes, int *lanes_per_point);
+
+/* ------------------------------------------------------------------ grid
+ * Stands for class MLS in rolling/occupancy mode (mls.h:104-242) as
+ * local_mapper uses it (local_mapper.cpp:29,86,107). */
+typedef struct slam_grid slam_grid_t;
+
+#define SLAM_RAYCAST_TILED  0 /* LDS-binned tiles, coalesced write-back */
+#define SLAM_RAYCAST_GLOBAL 1 /* one global atomic per traversed cell */
+
+typedef struct {
+    double max_range;           /* mls.h:161 (75) */
+    double occupancy_increment; /* mls.h:188 (1.0) */
+    double occupancy_decrement; /* mls.h:189 (0.3) */
+    int    min_cluster_points;  /* mls.h:165 (10); local_mapper.cpp:86 sets 20 */
+    int    rolling;             /* MLS(..., bool roll) mls.h:154 */
+    int    raycast_impl;        /* SLAM_RAYCAST_* */
+} slam_grid_params;
+
+void slam_grid_default_params(slam_grid_params *p);
+
+/* MLS::MLS(size_x, size_y, res, roll), mls.h:154-207 */
+int  slam_grid_create(int size_x, int size_y, double resolution,
+                      const slam_grid_params *params, slam_grid_t **out);
+void slam_grid_destroy(slam_grid_t *g);
+int  slam_grid_clear(slam_grid_t *g, slam_stream_t stream);            /* MLS::clearMap, mls.cpp:18-31 */
+int  slam_grid_set_min_cluster_points(slam_grid_t *g, int v);          /* mls.h:235 */
+int  slam_grid_set_max_range(slam_grid_t *g, double v);                /* mls.h:237 */
+/* MLS::setPose, mls.cpp:408-479.  Non-rolling: records curPose for the range
+ * gate (mls.cpp:84-86).  Rolling: shifts the toroidal origin by
+ * round(delta/res) cells and clears the cells that rolled in. */
+int  slam_grid_set_pose(slam_grid_t *g, double x, double y, slam_stream_t stream);
+int  slam_grid_get_pose(slam_grid_t *g, double *x, double *y);
+
+/* MLS::addToOccupancy point loops, mls.cpp:73-142, on already segmented
+ * clouds: obstacle points raise hits, ground points raise misses.  Points are
+ * `stride` floats apart (x,y first; PCL PointXYZGD has stride 4). */
+int slam_grid_add_endpoints(slam_grid_t *g, const float *obs, int n_obs, const float *gnd,
+                            int n_gnd, int stride);
+int slam_grid_add_endpoints_dev(slam_grid_t *g, const float *d_obs, int n_obs,
+                                const float *d_gnd, int n_gnd, int stride,
+                                slam_stream_t stream);
+
+/* Bresenham free-space update (north-star extension; not in the reference):
+ * for every beam the cells from the sensor cell up to (excluding) the end cell
+ * get misses += 1, the end cell hits += 1.  origin/end are map-frame xy f32. */
+int slam_grid_raycast(slam_grid_t *g, const float *origin_xy, const float *end_xy, int n);
+int slam_grid_raycast_dev(slam_grid_t *g, const float *d_origin_xy, const float *d_end_xy,
+                          int n, slam_stream_t stream);
+/* The same straight from registered scans: end = (float)(R_s * p + t_s) formed
+ * as icpPointToPoint.cpp:69-70 forms its query, origin = (float)t_s.
+ * n_points = d_scan_off[n_scans] (the host built that array and knows it). */
+int slam_grid_raycast_scans_dev(slam_grid_t *g, const double *d_pts, const int32_t *d_scan_off,
+                                int n_scans, int n_points, const double *d_R, const double *d_t,
+                                slam_stream_t stream);
+
+/* Folds the counts gathered since the last finalize into the per-cell evidence
+ * value (Cluster::num_pts) and the occupancy byte by SURVEY 8(a) G3:
+ *   c += inc*h; if (h>0 && c>min) occ=100;  c -= dec*m; if (m>0 && c<min) occ=0.
+ * The count planes keep accumulating (they are the bit-exact contract). */
+int slam_grid_finalize(slam_grid_t *g, slam_stream_t stream);
+
+/* One scan with the reference's own ordering and rounding (mls.cpp:73-142):
+ * sequential += / -= on the per-cell double, thresholds after every point. */
+int slam_grid_add_scan_inorder(slam_grid_t *g, const float *obs, int n_obs, const float *gnd,
+                               int n_gnd, int stride);
+
+/* read-back in WINDOW coordinates, row-major data[x + size_x*y] as
+ * nav_msgs/OccupancyGrid (mls.h:167-175). Host pointers; synchronous. */
+int slam_grid_read_counts(slam_grid_t *g, int32_t *hits, int32_t *misses);
+int slam_grid_read_occupancy(slam_grid_t *g, int8_t *occ);      /* MLS::getDrivability()->data */
+int slam_grid_read_num_pts(slam_grid_t *g, double *num_pts);
+int slam_grid_total_updates(slam_grid_t *g, uint64_t *n);       /* counter increments so far */
+int slam_grid_info(slam_grid_t *g, int *size_x, int *size_y, double *resolution,
+                   int *origin_x, int *origin_y);
+
+/* the two int32 planes ([hits | misses], 2*size_x*size_y ints, toroidal
+ * storage order) for a collective merge; see slam_mi355x_rccl.h */
+int slam_grid_counts_dev(slam_grid_t *g, int32_t **d_planes, size_t *n_ints);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAM_MI355X_H */

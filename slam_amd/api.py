@@ -1,0 +1,460 @@
+"""ctypes binding of the C-ABI in include/slam_mi355x.h -- plumbing for tests,
+bench.py and __graft_entry__.py.  The product is the shared library (HIP
+kernels + C++ host code); this file only marshals numpy arrays and device
+pointers across that ABI.  There is no CPU path: if the library is missing or
+no HIP device is usable, calls raise SlamError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libslam_mi355x.so")
+RCCL_LIB_PATH = os.path.join(HERE, "lib", "libslam_mi355x_rccl.so")
+
+SLAM_OK = 0
+E_INVALID, E_NO_DEVICE, E_HIP, E_TOO_FEW_MODEL, E_TOO_FEW_SCENE, E_NOMEM, E_UNSUPPORTED = \
+    -1, -2, -3, -4, -5, -6, -7
+ICP_P2P, ICP_P2L = 0, 1
+RAYCAST_TILED, RAYCAST_GLOBAL = 0, 1
+
+
+class SlamError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("slam_mi355x error %d: %s" % (code, msg))
+        self.code = code
+
+
+class IcpParams(C.Structure):
+    _fields_ = [("max_iter", C.c_int), ("min_delta", C.c_double), ("mode", C.c_int),
+                ("normals_k", C.c_int), ("lanes_per_point", C.c_int), ("cell_size", C.c_double),
+                ("force_global", C.c_int)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("iters", C.c_int), ("n_corr", C.c_int), ("delta", C.c_double)]
+
+
+class GridParams(C.Structure):
+    _fields_ = [("max_range", C.c_double), ("occupancy_increment", C.c_double),
+                ("occupancy_decrement", C.c_double), ("min_cluster_points", C.c_int),
+                ("rolling", C.c_int), ("raycast_impl", C.c_int)]
+
+
+RESULT_DTYPE = np.dtype([("iters", np.int32), ("n_corr", np.int32), ("delta", np.float64)])
+
+_vp = C.c_void_p
+_lib = None
+
+# every symbol include/slam_mi355x.h declares (tests check the .so exports them all)
+EXPORTS = [
+    "slam_last_error", "slam_version", "slam_device_count", "slam_set_device", "slam_device_info",
+    "slam_malloc", "slam_free", "slam_memset", "slam_memcpy_h2d", "slam_memcpy_d2h",
+    "slam_stream_create", "slam_stream_destroy", "slam_stream_synchronize",
+    "slam_device_synchronize", "slam_event_create", "slam_event_destroy", "slam_event_record",
+    "slam_event_synchronize", "slam_event_elapsed_ms",
+    "slam_icp_default_params", "slam_icp_create", "slam_icp_destroy",
+    "slam_icp_set_max_iterations", "slam_icp_set_min_delta", "slam_icp_set_subsampling_step",
+    "slam_icp_fit", "slam_icp_fit_batch_dev", "slam_icp_nearest_dev", "slam_icp_get_edge_weight",
+    "slam_icp_index_info",
+    "slam_grid_default_params", "slam_grid_create", "slam_grid_destroy", "slam_grid_clear",
+    "slam_grid_set_min_cluster_points", "slam_grid_set_max_range", "slam_grid_set_pose",
+    "slam_grid_get_pose", "slam_grid_add_endpoints", "slam_grid_add_endpoints_dev",
+    "slam_grid_raycast", "slam_grid_raycast_dev", "slam_grid_raycast_scans_dev",
+    "slam_grid_finalize", "slam_grid_add_scan_inorder", "slam_grid_read_counts",
+    "slam_grid_read_occupancy", "slam_grid_read_num_pts", "slam_grid_total_updates",
+    "slam_grid_info", "slam_grid_counts_dev",
+]
+
+
+def lib():
+    """Loads slam_amd/lib/libslam_mi355x.so (built by slam_amd.build).  Loud if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlamError(E_NO_DEVICE, "HIP library not built: %s is missing "
+                        "(run `python -m slam_amd.build`); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.slam_last_error.restype = C.c_char_p
+    L.slam_version.restype = C.c_char_p
+    L.slam_icp_destroy.restype = None
+    L.slam_grid_destroy.restype = None
+    L.slam_icp_default_params.restype = None
+    L.slam_grid_default_params.restype = None
+    L.slam_malloc.argtypes = [C.POINTER(_vp), C.c_size_t]
+    L.slam_free.argtypes = [_vp]
+    L.slam_memset.argtypes = [_vp, C.c_int, C.c_size_t, _vp]
+    L.slam_memcpy_h2d.argtypes = [_vp, _vp, C.c_size_t, _vp]
+    L.slam_memcpy_d2h.argtypes = [_vp, _vp, C.c_size_t, _vp]
+    L.slam_stream_create.argtypes = [C.POINTER(_vp)]
+    L.slam_stream_destroy.argtypes = [_vp]
+    L.slam_stream_synchronize.argtypes = [_vp]
+    L.slam_event_create.argtypes = [C.POINTER(_vp)]
+    L.slam_event_destroy.argtypes = [_vp]
+    L.slam_event_record.argtypes = [_vp, _vp]
+    L.slam_event_synchronize.argtypes = [_vp]
+    L.slam_event_elapsed_ms.argtypes = [_vp, _vp, C.POINTER(C.c_float)]
+    L.slam_device_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
+    L.slam_icp_create.argtypes = [_vp, C.c_int, _vp, C.c_int, C.POINTER(IcpParams), C.POINTER(_vp)]
+    L.slam_icp_destroy.argtypes = [_vp]
+    L.slam_icp_set_max_iterations.argtypes = [_vp, C.c_int]
+    L.slam_icp_set_min_delta.argtypes = [_vp, C.c_double]
+    L.slam_icp_set_subsampling_step.argtypes = [_vp, C.c_int]
+    L.slam_icp_fit.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, _vp, _vp, C.c_double,
+                               C.POINTER(IcpResult)]
+    L.slam_icp_fit_batch_dev.argtypes = [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_double, _vp,
+                                         _vp, _vp]
+    L.slam_icp_nearest_dev.argtypes = [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp]
+    L.slam_icp_get_edge_weight.argtypes = [_vp, _vp]
+    L.slam_icp_index_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_int),
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+    L.slam_grid_create.argtypes = [C.c_int, C.c_int, C.c_double, C.POINTER(GridParams),
+                                   C.POINTER(_vp)]
+    L.slam_grid_destroy.argtypes = [_vp]
+    L.slam_grid_clear.argtypes = [_vp, _vp]
+    L.slam_grid_set_min_cluster_points.argtypes = [_vp, C.c_int]
+    L.slam_grid_set_max_range.argtypes = [_vp, C.c_double]
+    L.slam_grid_set_pose.argtypes = [_vp, C.c_double, C.c_double, _vp]
+    L.slam_grid_get_pose.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.slam_grid_add_endpoints.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int]
+    L.slam_grid_add_endpoints_dev.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp]
+    L.slam_grid_raycast.argtypes = [_vp, _vp, _vp, C.c_int]
+    L.slam_grid_raycast_dev.argtypes = [_vp, _vp, _vp, C.c_int, _vp]
+    L.slam_grid_raycast_scans_dev.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]
+    L.slam_grid_finalize.argtypes = [_vp, _vp]
+    L.slam_grid_add_scan_inorder.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int]
+    L.slam_grid_read_counts.argtypes = [_vp, _vp, _vp]
+    L.slam_grid_read_occupancy.argtypes = [_vp, _vp]
+    L.slam_grid_read_num_pts.argtypes = [_vp, _vp]
+    L.slam_grid_total_updates.argtypes = [_vp, C.POINTER(C.c_uint64)]
+    L.slam_grid_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                 C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.slam_grid_counts_dev.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != SLAM_OK:
+        raise SlamError(rc, lib().slam_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().slam_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(i):
+    check(lib().slam_set_device(int(i)))
+
+
+def device_info():
+    name = C.create_string_buffer(256)
+    cu, mem = C.c_int(), C.c_size_t()
+    check(lib().slam_device_info(name, 256, C.byref(cu), C.byref(mem)))
+    return name.value.decode(), cu.value, mem.value
+
+
+def synchronize():
+    check(lib().slam_device_synchronize())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp) if a is not None and a.size else None
+
+
+class DeviceArray:
+    """A typed block of HBM owned through slam_malloc / slam_free."""
+
+    def __init__(self, shape, dtype):
+        self.shape = tuple(np.atleast_1d(shape).tolist()) if not isinstance(shape, tuple) else shape
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = _vp()
+        check(lib().slam_malloc(C.byref(p), max(self.nbytes, 1)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_host(cls, a, dtype=None):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        d = cls(a.shape, a.dtype)
+        d.upload(a)
+        return d
+
+    def upload(self, a, stream=None):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.nbytes == self.nbytes
+        check(lib().slam_memcpy_h2d(self.ptr, _ptr(a), self.nbytes, stream))
+
+    def download(self, stream=None):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(lib().slam_memcpy_d2h(_ptr(out), self.ptr, self.nbytes, stream))
+        return out
+
+    def zero(self, stream=None):
+        check(lib().slam_memset(self.ptr, 0, self.nbytes, stream))
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib().slam_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Stream:
+    def __init__(self):
+        p = _vp()
+        check(lib().slam_stream_create(C.byref(p)))
+        self.ptr = p.value
+
+    def synchronize(self):
+        check(lib().slam_stream_synchronize(self.ptr))
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().slam_stream_destroy(self.ptr)
+            self.ptr = None
+
+
+class Event:
+    def __init__(self):
+        p = _vp()
+        check(lib().slam_event_create(C.byref(p)))
+        self.ptr = p.value
+
+    def record(self, stream=None):
+        check(lib().slam_event_record(self.ptr, stream.ptr if isinstance(stream, Stream) else stream))
+
+    def synchronize(self):
+        check(lib().slam_event_synchronize(self.ptr))
+
+    def elapsed_ms(self, later):
+        ms = C.c_float()
+        check(lib().slam_event_elapsed_ms(self.ptr, later.ptr, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().slam_event_destroy(self.ptr)
+            self.ptr = None
+
+
+def _sp(stream):
+    return stream.ptr if isinstance(stream, Stream) else stream
+
+
+def icp_default_params(**kw):
+    p = IcpParams()
+    lib().slam_icp_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class Icp:
+    """IcpPointToPoint-shaped handle (icpPointToPoint.h:26-40) over the C-ABI."""
+
+    def __init__(self, m_ga, m_nga, params=None, **kw):
+        self.m_ga = np.ascontiguousarray(m_ga, dtype=np.float64).reshape(-1, 2)
+        self.m_nga = np.ascontiguousarray(m_nga, dtype=np.float64).reshape(-1, 2)
+        self.params = params or icp_default_params(**kw)
+        h = _vp()
+        check(lib().slam_icp_create(_ptr(self.m_ga), len(self.m_ga), _ptr(self.m_nga),
+                                    len(self.m_nga), C.byref(self.params), C.byref(h)))
+        self.h = h.value
+
+    def set_max_iterations(self, v):
+        check(lib().slam_icp_set_max_iterations(self.h, int(v)))
+
+    def set_min_delta(self, v):
+        check(lib().slam_icp_set_min_delta(self.h, float(v)))
+
+    def index_info(self):
+        nx, ny, lanes, in_lds = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        cell, lds = C.c_double(), C.c_size_t()
+        check(lib().slam_icp_index_info(self.h, C.byref(nx), C.byref(ny), C.byref(cell),
+                                        C.byref(in_lds), C.byref(lds), C.byref(lanes)))
+        return dict(nx=nx.value, ny=ny.value, cell=cell.value, in_lds=bool(in_lds.value),
+                    lds_bytes=lds.value, lanes_per_point=lanes.value)
+
+    def fit(self, t_ga, t_nga, R, t, indist=5.0):
+        """Icp::fit (icp.cpp:80-114), host arrays; returns (R, t, IcpResult)."""
+        t_ga = np.ascontiguousarray(t_ga, dtype=np.float64).reshape(-1, 2)
+        t_nga = np.ascontiguousarray(t_nga, dtype=np.float64).reshape(-1, 2)
+        R = np.ascontiguousarray(R, dtype=np.float64).reshape(4).copy()
+        t = np.ascontiguousarray(t, dtype=np.float64).reshape(2).copy()
+        res = IcpResult()
+        check(lib().slam_icp_fit(self.h, _ptr(t_ga), len(t_ga), _ptr(t_nga), len(t_nga),
+                                 _ptr(R), _ptr(t), float(indist), C.byref(res)))
+        return R.reshape(2, 2), t, res
+
+    def fit_batch_dev(self, d_pts, d_off, d_nga, n_scans, d_R, d_t, indist=5.0, d_result=None,
+                      d_trace=None, stream=None):
+        check(lib().slam_icp_fit_batch_dev(
+            self.h, d_pts.ptr, d_off.ptr, d_nga.ptr, int(n_scans), d_R.ptr, d_t.ptr, float(indist),
+            d_result.ptr if d_result is not None else None,
+            d_trace.ptr if d_trace is not None else None, _sp(stream)))
+
+    def fit_batch(self, batch, indist=5.0, trace=False):
+        """Host convenience: uploads a synth.ScanBatch, runs, downloads.
+        Returns (R[S,4], t[S,2], result[S], trace[S,max_iter,8] or None)."""
+        S = batch.n_scans
+        d_pts = DeviceArray.from_host(batch.pts, np.float64)
+        d_off = DeviceArray.from_host(batch.scan_off, np.int32)
+        d_nga = DeviceArray.from_host(batch.scan_nga, np.int32)
+        d_R = DeviceArray.from_host(batch.R, np.float64)
+        d_t = DeviceArray.from_host(batch.t, np.float64)
+        d_res = DeviceArray((S,), RESULT_DTYPE)
+        d_res.zero()
+        d_tr = None
+        if trace:
+            d_tr = DeviceArray((S, max(self.params.max_iter, 1), 8), np.float64)
+            d_tr.zero()
+        self.fit_batch_dev(d_pts, d_off, d_nga, S, d_R, d_t, indist, d_res, d_tr)
+        synchronize()
+        return d_R.download(), d_t.download(), d_res.download(), (d_tr.download() if trace else None)
+
+    def nearest(self, cls, q_xy):
+        """KDTree::n_nearest(q, 1) for every row of q_xy (f32): (dis[n], idx[n])."""
+        q = np.ascontiguousarray(q_xy, dtype=np.float32).reshape(-1, 2)
+        d_q = DeviceArray.from_host(q)
+        d_d = DeviceArray((len(q),), np.float32)
+        d_i = DeviceArray((len(q),), np.int32)
+        check(lib().slam_icp_nearest_dev(self.h, int(cls), d_q.ptr, len(q), d_d.ptr, d_i.ptr, None))
+        synchronize()
+        return d_d.download(), d_i.download()
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().slam_icp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def grid_default_params(**kw):
+    p = GridParams()
+    lib().slam_grid_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class Grid:
+    """MLS-in-occupancy-mode-shaped handle (mls.h:104-242) over the C-ABI."""
+
+    def __init__(self, size_x, size_y, resolution, params=None, **kw):
+        self.size_x, self.size_y, self.resolution = int(size_x), int(size_y), float(resolution)
+        self.params = params or grid_default_params(**kw)
+        h = _vp()
+        check(lib().slam_grid_create(self.size_x, self.size_y, self.resolution,
+                                     C.byref(self.params), C.byref(h)))
+        self.h = h.value
+        self.cells = self.size_x * self.size_y
+
+    def clear(self, stream=None):
+        check(lib().slam_grid_clear(self.h, _sp(stream)))
+
+    def set_pose(self, x, y, stream=None):
+        check(lib().slam_grid_set_pose(self.h, float(x), float(y), _sp(stream)))
+
+    def get_pose(self):
+        x, y = C.c_double(), C.c_double()
+        check(lib().slam_grid_get_pose(self.h, C.byref(x), C.byref(y)))
+        return x.value, y.value
+
+    def set_min_cluster_points(self, v):
+        check(lib().slam_grid_set_min_cluster_points(self.h, int(v)))
+
+    def set_max_range(self, v):
+        check(lib().slam_grid_set_max_range(self.h, float(v)))
+
+    @staticmethod
+    def _pts(a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        if a.ndim == 1:
+            a = a.reshape(-1, 2)
+        return a
+
+    def add_endpoints(self, obs, gnd):
+        obs, gnd = self._pts(obs), self._pts(gnd)
+        stride = obs.shape[1] if obs.size else (gnd.shape[1] if gnd.size else 2)
+        check(lib().slam_grid_add_endpoints(self.h, _ptr(obs), len(obs), _ptr(gnd), len(gnd), stride))
+
+    def add_scan_inorder(self, obs, gnd):
+        obs, gnd = self._pts(obs), self._pts(gnd)
+        stride = obs.shape[1] if obs.size else (gnd.shape[1] if gnd.size else 2)
+        check(lib().slam_grid_add_scan_inorder(self.h, _ptr(obs), len(obs), _ptr(gnd), len(gnd),
+                                               stride))
+
+    def raycast(self, origin_xy, end_xy):
+        o, e = self._pts(origin_xy), self._pts(end_xy)
+        assert o.shape == e.shape and o.shape[1] == 2
+        check(lib().slam_grid_raycast(self.h, _ptr(o), _ptr(e), len(e)))
+
+    def raycast_dev(self, d_origin, d_end, n, stream=None):
+        check(lib().slam_grid_raycast_dev(self.h, d_origin.ptr, d_end.ptr, int(n), _sp(stream)))
+
+    def raycast_scans_dev(self, d_pts, d_off, n_scans, n_points, d_R, d_t, stream=None):
+        check(lib().slam_grid_raycast_scans_dev(self.h, d_pts.ptr, d_off.ptr, int(n_scans),
+                                                int(n_points), d_R.ptr, d_t.ptr, _sp(stream)))
+
+    def finalize(self, stream=None):
+        check(lib().slam_grid_finalize(self.h, _sp(stream)))
+
+    def read_counts(self):
+        hits = np.empty(self.cells, dtype=np.int32)
+        misses = np.empty(self.cells, dtype=np.int32)
+        check(lib().slam_grid_read_counts(self.h, _ptr(hits), _ptr(misses)))
+        return hits, misses
+
+    def read_occupancy(self):
+        occ = np.empty(self.cells, dtype=np.int8)
+        check(lib().slam_grid_read_occupancy(self.h, _ptr(occ)))
+        return occ
+
+    def read_num_pts(self):
+        v = np.empty(self.cells, dtype=np.float64)
+        check(lib().slam_grid_read_num_pts(self.h, _ptr(v)))
+        return v
+
+    def total_updates(self):
+        n = C.c_uint64()
+        check(lib().slam_grid_total_updates(self.h, C.byref(n)))
+        return n.value
+
+    def info(self):
+        sx, sy, ox, oy, res = C.c_int(), C.c_int(), C.c_int(), C.c_int(), C.c_double()
+        check(lib().slam_grid_info(self.h, C.byref(sx), C.byref(sy), C.byref(res), C.byref(ox),
+                                   C.byref(oy)))
+        return dict(size_x=sx.value, size_y=sy.value, resolution=res.value, origin_x=ox.value,
+                    origin_y=oy.value)
+
+    def counts_dev(self):
+        p, n = _vp(), C.c_size_t()
+        check(lib().slam_grid_counts_dev(self.h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().slam_grid_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

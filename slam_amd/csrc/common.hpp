@@ -1,0 +1,40 @@
+// common.hpp -- error plumbing shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+
+#include "slam_mi355x.h"
+
+namespace slam {
+
+void set_error(const char *fmt, ...);
+int  hip_fail(hipError_t e, const char *what, const char *file, int line);
+// SLAM_OK once a HIP device is usable, SLAM_E_NO_DEVICE otherwise (and every
+// compute entry point returns that: there is no CPU path in this library).
+int  require_device();
+
+inline hipStream_t as_stream(slam_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+} // namespace slam
+
+#define SLAM_HIP(expr)                                                          \
+    do {                                                                        \
+        hipError_t e__ = (expr);                                                \
+        if (e__ != hipSuccess) return slam::hip_fail(e__, #expr, __FILE__, __LINE__); \
+    } while (0)
+
+#define SLAM_REQUIRE(cond, code, ...)  \
+    do {                               \
+        if (!(cond)) {                 \
+            slam::set_error(__VA_ARGS__); \
+            return (code);             \
+        }                              \
+    } while (0)
+
+#define SLAM_TRY(expr)              \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__ != SLAM_OK) return rc__; \
+    } while (0)

@@ -1,0 +1,882 @@
+// grid.hip -- occupancy-grid update on gfx950 behind the C-ABI.
+//
+// Reference path (under /root/reference/mls):
+//   MLS::addToOccupancy  src/mls.cpp:59-150   endpoint binning: obstacle +1.0, ground -0.3
+//   Grid::operator()     include/mls/mls.h:76-85   toroidal wrap
+//   MLS::setPose         src/mls.cpp:408-479  rolling window
+// plus the north-star Bresenham free-space traversal, which the reference does
+// not have; its definition is oracle/slam_oracle.c
+// ogrid_raycast and the closed form in bres_y() below.
+//
+// Data layout in HBM (DESIGN.md "Grid"): two int32 planes [hits | misses] of
+// size_x*size_y cells each, contiguous (one RCCL all-reduce merges both), in
+// toroidal STORAGE order; a f64 evidence plane (Cluster::num_pts) and an int8
+// occupancy plane derived from the counts by finalize.  The reference's
+// per-cell `Cell` object (vector<Cluster> + deque, mls.h:37-51) is not
+// reproduced: in occupancy mode only clusters[0].num_pts and `drivable` are
+// ever touched.
+//
+// Raycast, tiled implementation: a pre-pass turns every beam into integer
+// (x0,y0,x1,y1) cells once; each workgroup owns one 128x128-cell tile for a
+// slice of the beams, accumulates hit/miss counts for that tile in LDS (ds_add,
+// 16+16 bit packed per cell), and writes the tile back with coalesced global
+// atomics -- one per touched cell per workgroup instead of one per traversed
+// cell per beam.  Each beam's cells inside a tile come from the closed form of
+// the integer Bresenham line, so clipping to the tile cannot change them.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace slam;
+
+namespace {
+
+struct GridView {
+    int      sx, sy;       // window size in cells
+    int      ox, oy;       // toroidal origin (Grid::origin_x/y, mls.h:69-70)
+    double   res;
+    double   max_range;
+    double   pose_x, pose_y;
+    int      rolling;
+    int32_t *hits;         // [sx*sy] storage order
+    int32_t *misses;       // [sx*sy] storage order
+    unsigned long long *updates;
+};
+
+__device__ inline int storage_index(const GridView &g, int x, int y)
+{
+    int ix = x + g.ox, iy = y + g.oy; // mls.h:76-85
+    if (ix >= g.sx) ix -= g.sx;
+    if (iy >= g.sy) iy -= g.sy;
+    return ix + g.sx * iy;
+}
+
+// (int)(v/res + size/2) of mls.cpp:77-78; false when an int cannot hold it
+// (undefined in the reference; x86 gives INT_MIN there, i.e. "skip").
+__device__ inline bool cell_coord(float v, double res, int half, int *out)
+{
+    const double f = __dadd_rn(__ddiv_rn((double)v, res), (double)half);
+    if (!(f > -2147483648.0 && f < 2147483648.0)) return false;
+    *out = (int)f; // truncation toward zero
+    return true;
+}
+
+// mls.cpp:77-90: window cell of a point, or false when the range gate or the
+// bounds test (with its `y >= size_x` quirk) drops it.
+__device__ inline bool point_cell(const GridView &g, float px, float py, int *cx, int *cy)
+{
+    int x, y;
+    if (!cell_coord(px, g.res, g.sx / 2, &x)) return false;
+    if (!cell_coord(py, g.res, g.sy / 2, &y)) return false;
+    double rng;
+    if (g.rolling) {
+        // mls.cpp:82: float expression, float sqrt, widened for the compare
+        rng = (double)__fsqrt_rn(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)));
+    } else {
+        const double rx = g.pose_x - (double)px, ry = g.pose_y - (double)py; // :84-86
+        rng = __dsqrt_rn(__dadd_rn(__dmul_rn(rx, rx), __dmul_rn(ry, ry)));
+    }
+    if (x < 0 || y < 0 || x >= g.sx || y >= g.sx || rng > g.max_range) return false; // :90
+    if (y >= g.sy) return false;
+    *cx = x;
+    *cy = y;
+    return true;
+}
+
+__device__ inline void block_add_updates(unsigned long long *counter, unsigned n)
+{
+    // wave reduction, then one atomic per wavefront
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor((int)n, off);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(counter, (unsigned long long)n);
+}
+
+// ------------------------------------------------------------- endpoints
+__global__ __launch_bounds__(256) void endpoints_kernel(GridView g, const float *obs, int n_obs,
+                                                        const float *gnd, int n_gnd, int stride)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned  did = 0;
+    if (i < n_obs + n_gnd) {
+        const bool   is_obs = i < n_obs;
+        const float *p = is_obs ? obs + (size_t)i * stride : gnd + (size_t)(i - n_obs) * stride;
+        int cx, cy;
+        if (point_cell(g, p[0], p[1], &cx, &cy)) {
+            const int s = storage_index(g, cx, cy);
+            atomicAdd(is_obs ? &g.hits[s] : &g.misses[s], 1); // mls.cpp:99 / :135 as counts
+            did = 1;
+        }
+    }
+    block_add_updates(g.updates, did);
+}
+
+// --------------------------------------------------------------- raycast
+struct Beam { // integer Bresenham endpoints in window cells; x0 < 0 marks a dropped beam
+    short x0, y0, x1, y1;
+};
+
+__device__ inline Beam make_beam(const GridView &g, float ox, float oy, float ex, float ey)
+{
+    Beam b;
+    b.x0 = -1;
+    b.y0 = b.x1 = b.y1 = 0;
+    int x1, y1, x0, y0;
+    if (!point_cell(g, ex, ey, &x1, &y1)) return b;
+    if (!cell_coord(ox, g.res, g.sx / 2, &x0)) return b;
+    if (!cell_coord(oy, g.res, g.sy / 2, &y0)) return b;
+    if (x0 < 0 || y0 < 0 || x0 >= g.sx || y0 >= g.sy) return b;
+    b.x0 = (short)x0;
+    b.y0 = (short)y0;
+    b.x1 = (short)x1;
+    b.y1 = (short)y1;
+    return b;
+}
+
+__global__ __launch_bounds__(256) void beams_from_rays_kernel(GridView g, const float2 *origin,
+                                                              const float2 *end, int n, Beam *beams,
+                                                              int4 *chunk_box, int chunk)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float2 o = origin[i], e = end[i];
+    const Beam   b = make_beam(g, o.x, o.y, e.x, e.y);
+    beams[i] = b;
+    if (b.x0 >= 0 && chunk_box) {
+        int4 *cb = &chunk_box[i / chunk];
+        atomicMin(&cb->x, min((int)b.x0, (int)b.x1));
+        atomicMin(&cb->y, min((int)b.y0, (int)b.y1));
+        atomicMax(&cb->z, max((int)b.x0, (int)b.x1));
+        atomicMax(&cb->w, max((int)b.y0, (int)b.y1));
+    }
+}
+
+__global__ __launch_bounds__(256) void beams_from_scans_kernel(GridView g, const double2 *pts,
+                                                               const int *scan_off, int n_scans,
+                                                               const double *R, const double *t, int n,
+                                                               Beam *beams, int4 *chunk_box, int chunk)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int lo = 0, hi = n_scans - 1; // scan of point i: last s with scan_off[s] <= i
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (scan_off[mid] <= i)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const double *Rs = R + 4 * (size_t)lo, *ts = t + 2 * (size_t)lo;
+    const double2 P = pts[i];
+    // end point formed as icpPointToPoint.cpp:69-70 forms its query
+    const float ex = (float)__dadd_rn(__dadd_rn(__dmul_rn(Rs[0], P.x), __dmul_rn(Rs[1], P.y)), ts[0]);
+    const float ey = (float)__dadd_rn(__dadd_rn(__dmul_rn(Rs[2], P.x), __dmul_rn(Rs[3], P.y)), ts[1]);
+    const Beam  b = make_beam(g, (float)ts[0], (float)ts[1], ex, ey);
+    beams[i] = b;
+    if (b.x0 >= 0 && chunk_box) {
+        int4 *cb = &chunk_box[i / chunk];
+        atomicMin(&cb->x, min((int)b.x0, (int)b.x1));
+        atomicMin(&cb->y, min((int)b.y0, (int)b.y1));
+        atomicMax(&cb->z, max((int)b.x0, (int)b.x1));
+        atomicMax(&cb->w, max((int)b.y0, (int)b.y1));
+    }
+}
+
+__global__ void init_chunk_box_kernel(int4 *cb, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cb[i] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);
+}
+
+// one global atomic per traversed cell (baseline implementation)
+__global__ __launch_bounds__(256) void raycast_global_kernel(GridView g, const Beam *beams, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned  did = 0;
+    if (i < n) {
+        const Beam b = beams[i];
+        if (b.x0 >= 0) {
+            const int dx = abs(b.x1 - b.x0), dy = abs(b.y1 - b.y0);
+            const int sx = b.x1 > b.x0 ? 1 : -1, sy = b.y1 > b.y0 ? 1 : -1;
+            int x = b.x0, y = b.y0;
+            if (dx >= dy) {
+                int e = dx;
+                for (int k = 0; k < dx; ++k) {
+                    atomicAdd(&g.misses[storage_index(g, x, y)], 1);
+                    x += sx;
+                    e += 2 * dy;
+                    if (e >= 2 * dx) {
+                        y += sy;
+                        e -= 2 * dx;
+                    }
+                }
+                did = dx + 1;
+            } else {
+                int e = dy;
+                for (int k = 0; k < dy; ++k) {
+                    atomicAdd(&g.misses[storage_index(g, x, y)], 1);
+                    y += sy;
+                    e += 2 * dx;
+                    if (e >= 2 * dy) {
+                        x += sx;
+                        e -= 2 * dy;
+                    }
+                }
+                did = dy + 1;
+            }
+            atomicAdd(&g.hits[storage_index(g, b.x1, b.y1)], 1);
+        }
+    }
+    block_add_updates(g.updates, did);
+}
+
+constexpr int kTile = 128;          // cells per tile side
+constexpr int kTileThreads = 1024;
+constexpr int kChunk = 1024;        // beams per culling chunk
+constexpr int kChunksPerGroup = 8;
+
+__device__ inline int floordiv(int a, int b) // b > 0
+{
+    int q = a / b;
+    if ((a % b) != 0 && (a < 0)) --q;
+    return q;
+}
+__device__ inline int ceildiv(int a, int b) { return -floordiv(-a, b); } // b > 0
+
+// Tiled raycast: blockIdx.x = tile, blockIdx.y = group of beam chunks.
+__global__ __launch_bounds__(kTileThreads) void raycast_tiled_kernel(GridView g, const Beam *beams, int n,
+                                                                     const int4 *chunk_box, int n_chunks,
+                                                                     int tiles_x)
+{
+    __shared__ unsigned tile[kTile * kTile]; // hits << 16 | misses
+    __shared__ int      any_overlap;
+
+    const int tx0 = (blockIdx.x % tiles_x) * kTile, ty0 = (blockIdx.x / tiles_x) * kTile;
+    const int tx1 = min(tx0 + kTile, g.sx) - 1, ty1 = min(ty0 + kTile, g.sy) - 1;
+    const int c_first = blockIdx.y * kChunksPerGroup;
+    const int c_last = min(c_first + kChunksPerGroup, n_chunks);
+    const int tid = threadIdx.x;
+
+    if (tid == 0) any_overlap = 0;
+    __syncthreads();
+    if (tid < c_last - c_first) {
+        const int4 cb = chunk_box[c_first + tid];
+        if (cb.z >= tx0 && cb.x <= tx1 && cb.w >= ty0 && cb.y <= ty1) any_overlap = 1;
+    }
+    __syncthreads();
+    if (!any_overlap) return; // uniform
+
+    for (int i = tid; i < kTile * kTile; i += kTileThreads) tile[i] = 0u;
+    __syncthreads();
+
+    unsigned did = 0;
+    for (int c = c_first; c < c_last; ++c) {
+        const int4 cb = chunk_box[c];
+        if (!(cb.z >= tx0 && cb.x <= tx1 && cb.w >= ty0 && cb.y <= ty1)) continue; // uniform
+        const int b_end = min((c + 1) * kChunk, n);
+        for (int bi = c * kChunk + tid; bi < b_end; bi += kTileThreads) {
+            const Beam b = beams[bi];
+            if (b.x0 < 0) continue;
+            const int x0 = b.x0, y0 = b.y0, x1 = b.x1, y1 = b.y1;
+            if (max(x0, x1) < tx0 || min(x0, x1) > tx1 || max(y0, y1) < ty0 || min(y0, y1) > ty1) continue;
+            const int dx = abs(x1 - x0), dy = abs(y1 - y0);
+            // u = major axis, v = minor axis; step i in [0, L], cell i = (u0 + su*i, v0 + sv*k_i),
+            // k_i = floor((2*i*dv + du) / (2*du)); i == L is the end cell (hit)
+            const bool xm = dx >= dy;
+            const int  u0 = xm ? x0 : y0, v0 = xm ? y0 : x0;
+            const int  su = xm ? (x1 > x0 ? 1 : -1) : (y1 > y0 ? 1 : -1);
+            const int  sv = xm ? (y1 > y0 ? 1 : -1) : (x1 > x0 ? 1 : -1);
+            const int  du = xm ? dx : dy, dv = xm ? dy : dx;
+            const int  tu0 = xm ? tx0 : ty0, tu1 = xm ? tx1 : ty1;
+            const int  tv0 = xm ? ty0 : tx0, tv1 = xm ? ty1 : tx1;
+            int i_lo = 0, i_hi = du;
+            // u0 + su*i in [tu0, tu1]
+            if (su > 0) {
+                i_lo = max(i_lo, tu0 - u0);
+                i_hi = min(i_hi, tu1 - u0);
+            } else {
+                i_lo = max(i_lo, u0 - tu1);
+                i_hi = min(i_hi, u0 - tu0);
+            }
+            // v0 + sv*k in [tv0, tv1]  ->  k in [k_lo, k_hi]
+            int k_lo, k_hi;
+            if (sv > 0) {
+                k_lo = tv0 - v0;
+                k_hi = tv1 - v0;
+            } else {
+                k_lo = v0 - tv1;
+                k_hi = v0 - tv0;
+            }
+            k_hi = min(k_hi, dv); // k never exceeds dv; keeps the products below inside int32
+            if (dv == 0) {
+                if (k_lo > 0 || k_hi < 0) continue;
+            } else {
+                // k_i >= k_lo  <=>  i >= ceil((2*du*k_lo - du) / (2*dv))
+                // k_i <= k_hi  <=>  i <= floor((2*du*(k_hi+1) - du - 1) / (2*dv))
+                if (k_lo > 0) i_lo = max(i_lo, ceildiv(2 * du * k_lo - du, 2 * dv));
+                i_hi = min(i_hi, floordiv(2 * du * (k_hi + 1) - du - 1, 2 * dv));
+            }
+            if (i_lo > i_hi) continue;
+            const int num = 2 * i_lo * dv + du;
+            int       k = du ? num / (2 * du) : 0;
+            int       e = du ? num - k * 2 * du : 0; // running remainder, < 2*du
+            int       u = u0 + su * i_lo, v = v0 + sv * k;
+            for (int i = i_lo; i <= i_hi; ++i) {
+                const int lx = (xm ? u : v) - tx0, ly = (xm ? v : u) - ty0;
+                atomicAdd(&tile[ly * kTile + lx], i == du ? 0x10000u : 1u);
+                u += su;
+                e += 2 * dv;
+                if (e >= 2 * du) {
+                    v += sv;
+                    e -= 2 * du;
+                }
+            }
+            did += (unsigned)(i_hi - i_lo + 1);
+        }
+    }
+    __syncthreads();
+
+    // coalesced write-back: consecutive lanes -> consecutive x of one row
+    for (int i = tid; i < kTile * kTile; i += kTileThreads) {
+        const unsigned v = tile[i];
+        if (!v) continue;
+        const int x = tx0 + (i % kTile), y = ty0 + (i / kTile);
+        const int s = storage_index(g, x, y);
+        if (v & 0xffffu) atomicAdd(&g.misses[s], (int)(v & 0xffffu));
+        if (v >> 16) atomicAdd(&g.hits[s], (int)(v >> 16));
+    }
+    block_add_updates(g.updates, did);
+}
+
+// --------------------------------------------------------------- finalize
+// SURVEY 8(a) G3 on the summed counts, window order out (mls.h:167-175 data[x + size_x*y]).
+__global__ __launch_bounds__(256) void finalize_kernel(GridView g, double inc, double dec, double minp,
+                                                       double *num_pts, int8_t *occ)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= g.sx) return;
+    const int s = storage_index(g, x, y);
+    const int h = g.hits[s], m = g.misses[s];
+    double    v = inc * (double)h;
+    int8_t    o = -1;
+    if (h > 0 && v > minp) o = 100; // mls.cpp:101-105
+    v = v - dec * (double)m;
+    if (m > 0 && v < minp) o = 0; // mls.cpp:137-141
+    num_pts[x + (size_t)g.sx * y] = v;
+    occ[x + (size_t)g.sx * y] = o;
+}
+
+__global__ __launch_bounds__(256) void gather_counts_kernel(GridView g, int32_t *hits_w, int32_t *misses_w)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= g.sx) return;
+    const int s = storage_index(g, x, y);
+    hits_w[x + (size_t)g.sx * y] = g.hits[s];
+    misses_w[x + (size_t)g.sx * y] = g.misses[s];
+}
+
+// MLS::setPose roll, mls.cpp:461-468: cells that rolled into the window are cleared
+__global__ __launch_bounds__(256) void roll_clear_kernel(GridView g, int dx, int dy, double *num_pts,
+                                                         int8_t *occ_state)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= g.sx) return;
+    if (x < -dx || x >= g.sx - dx || y < -dy || y >= g.sy - dy) {
+        const int s = storage_index(g, x, y);
+        g.hits[s] = 0;
+        g.misses[s] = 0;
+        num_pts[s] = 0.0;
+        occ_state[s] = -1;
+    }
+}
+
+// in-order single scan: per touched cell replay the reference's += / -= sequence
+// per-scan delta of a cell: hits in the high, misses in the low 32 bits of one 64-bit word,
+// so exactly one point sees the cell untouched and lists it
+__global__ __launch_bounds__(256) void inorder_count_kernel(GridView g, const float *obs, int n_obs,
+                                                            const float *gnd, int n_gnd, int stride,
+                                                            unsigned long long *delta, int *touched,
+                                                            int *n_touched)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_obs + n_gnd) return;
+    const bool   is_obs = i < n_obs;
+    const float *p = is_obs ? obs + (size_t)i * stride : gnd + (size_t)(i - n_obs) * stride;
+    int cx, cy;
+    if (!point_cell(g, p[0], p[1], &cx, &cy)) return;
+    const int s = storage_index(g, cx, cy);
+    const unsigned long long old = atomicAdd(&delta[s], is_obs ? (1ull << 32) : 1ull);
+    atomicAdd(is_obs ? &g.hits[s] : &g.misses[s], 1);
+    if (old == 0ull) {
+        const int k = atomicAdd(n_touched, 1);
+        touched[k] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void inorder_apply_kernel(GridView g, double inc, double dec, double minp,
+                                                            unsigned long long *delta, const int *touched,
+                                                            const int *n_touched, double *num_pts,
+                                                            int8_t *occ_state, unsigned long long *updates)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned  did = 0;
+    if (i < *n_touched) {
+        const int s = touched[i];
+        const unsigned long long d = delta[s];
+        delta[s] = 0ull; // each touched cell is listed once: no other thread reads it
+        const int h = (int)(d >> 32), m = (int)(d & 0xffffffffull);
+        {
+            double v = num_pts[s];
+            int8_t o = occ_state[s];
+            for (int k = 0; k < h; ++k) v = __dadd_rn(v, inc); // mls.cpp:99, one += per point
+            if (h > 0 && v > minp) o = 100;                    // monotone: last test decides
+            for (int k = 0; k < m; ++k) v = __dsub_rn(v, dec); // mls.cpp:135
+            if (m > 0 && v < minp) o = 0;
+            num_pts[s] = v;
+            occ_state[s] = o;
+            did = (unsigned)(h + m);
+        }
+    }
+    block_add_updates(updates, did);
+}
+
+__global__ __launch_bounds__(256) void window_from_storage_kernel(GridView g, const double *num_s,
+                                                                  const int8_t *occ_s, double *num_w,
+                                                                  int8_t *occ_w)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= g.sx) return;
+    const int s = storage_index(g, x, y);
+    num_w[x + (size_t)g.sx * y] = num_s[s];
+    occ_w[x + (size_t)g.sx * y] = occ_s[s];
+}
+
+__global__ void fill_i8_kernel(int8_t *p, size_t n, int8_t v)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+} // namespace
+
+struct slam_grid {
+    slam_grid_params prm;
+    GridView         gv;
+    size_t           cells = 0;
+    int32_t         *d_planes = nullptr;  // [hits | misses]
+    double          *d_num_w = nullptr;   // window order, written by finalize
+    int8_t          *d_occ_w = nullptr;   // window order, written by finalize
+    double          *d_num_s = nullptr;   // storage order, in-order mode state
+    int8_t          *d_occ_s = nullptr;   // storage order, in-order mode state
+    unsigned long long *d_delta = nullptr; // [cells] per-scan deltas of the in-order mode
+    int             *d_touched = nullptr; // [2*cap_points] + counter
+    size_t           cap_touched = 0;
+    unsigned long long *d_updates = nullptr;
+    Beam            *d_beams = nullptr;
+    size_t           cap_beams = 0;
+    int4            *d_chunk_box = nullptr;
+    size_t           cap_chunks = 0;
+    void            *d_stage = nullptr;   // host-API staging
+    size_t           cap_stage = 0;
+    bool             state_from_inorder = false;
+};
+
+namespace {
+
+int reserve(void **p, size_t *cap, size_t bytes)
+{
+    if (bytes <= *cap) return SLAM_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *cap = 0;
+    size_t want = std::max(bytes, (size_t)4096);
+    SLAM_HIP(hipMalloc(p, want));
+    *cap = want;
+    return SLAM_OK;
+}
+
+int reserve_beams(slam_grid *g, size_t n)
+{
+    size_t cb = g->cap_beams * sizeof(Beam);
+    void  *p = g->d_beams;
+    SLAM_TRY(reserve(&p, &cb, n * sizeof(Beam)));
+    g->d_beams = static_cast<Beam *>(p);
+    g->cap_beams = cb / sizeof(Beam);
+    const size_t chunks = (n + kChunk - 1) / kChunk + 1;
+    size_t       cc = g->cap_chunks * sizeof(int4);
+    p = g->d_chunk_box;
+    SLAM_TRY(reserve(&p, &cc, chunks * sizeof(int4)));
+    g->d_chunk_box = static_cast<int4 *>(p);
+    g->cap_chunks = cc / sizeof(int4);
+    return SLAM_OK;
+}
+
+int walk_beams(slam_grid *g, int n, hipStream_t st)
+{
+    const int  n_chunks = (n + kChunk - 1) / kChunk;
+    const bool tiled = g->prm.raycast_impl == SLAM_RAYCAST_TILED;
+    if (tiled) {
+        const int tiles_x = (g->gv.sx + kTile - 1) / kTile, tiles_y = (g->gv.sy + kTile - 1) / kTile;
+        const int groups = (n_chunks + kChunksPerGroup - 1) / kChunksPerGroup;
+        hipLaunchKernelGGL(raycast_tiled_kernel, dim3(tiles_x * tiles_y, groups), dim3(kTileThreads), 0, st,
+                           g->gv, g->d_beams, n, g->d_chunk_box, n_chunks, tiles_x);
+    } else {
+        hipLaunchKernelGGL(raycast_global_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g->gv, g->d_beams, n);
+    }
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+dim3 grid2d(const slam_grid *g) { return dim3((g->gv.sx + 255) / 256, g->gv.sy); }
+
+} // namespace
+
+extern "C" {
+
+void slam_grid_default_params(slam_grid_params *p)
+{
+    if (!p) return;
+    p->max_range = 75.0;          // mls.h:161
+    p->occupancy_increment = 1.0; // mls.h:188
+    p->occupancy_decrement = 0.3; // mls.h:189
+    p->min_cluster_points = 10;   // mls.h:165
+    p->rolling = 1;               // local_mapper.cpp:29 MLS(200,200,0.2,true)
+    p->raycast_impl = SLAM_RAYCAST_TILED;
+}
+
+int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_params *params,
+                     slam_grid_t **out)
+{
+    SLAM_REQUIRE(out, SLAM_E_INVALID, "slam_grid_create: null out pointer");
+    *out = nullptr;
+    SLAM_REQUIRE(size_x > 0 && size_y > 0 && size_x <= 32767 && size_y <= 32767 && resolution > 0,
+                 SLAM_E_INVALID, "slam_grid_create: size must be 1..32767 cells and resolution > 0");
+    SLAM_TRY(require_device());
+    slam_grid *g = new (std::nothrow) slam_grid();
+    SLAM_REQUIRE(g, SLAM_E_NOMEM, "slam_grid_create: out of host memory");
+    if (params)
+        g->prm = *params;
+    else
+        slam_grid_default_params(&g->prm);
+    g->cells = (size_t)size_x * size_y;
+    int rc = SLAM_OK;
+    auto alloc = [&](void **p, size_t bytes) {
+        if (rc == SLAM_OK && hipMalloc(p, bytes) != hipSuccess) {
+            set_error("slam_grid_create: hipMalloc of %zu bytes failed", bytes);
+            (void)hipGetLastError();
+            rc = SLAM_E_NOMEM;
+        }
+    };
+    alloc((void **)&g->d_planes, 2 * g->cells * sizeof(int32_t));
+    alloc((void **)&g->d_num_w, g->cells * sizeof(double));
+    alloc((void **)&g->d_occ_w, g->cells);
+    alloc((void **)&g->d_num_s, g->cells * sizeof(double));
+    alloc((void **)&g->d_occ_s, g->cells);
+    alloc((void **)&g->d_updates, sizeof(unsigned long long));
+    if (rc != SLAM_OK) {
+        slam_grid_destroy(g);
+        return rc;
+    }
+    GridView &v = g->gv;
+    v.sx = size_x;
+    v.sy = size_y;
+    v.ox = v.oy = 0;
+    v.res = resolution;
+    v.max_range = g->prm.max_range;
+    v.pose_x = v.pose_y = 0.0;
+    v.rolling = g->prm.rolling ? 1 : 0;
+    v.hits = g->d_planes;
+    v.misses = g->d_planes + g->cells;
+    v.updates = g->d_updates;
+    rc = slam_grid_clear(g, nullptr);
+    if (rc == SLAM_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = SLAM_E_HIP;
+    if (rc != SLAM_OK) {
+        slam_grid_destroy(g);
+        return rc;
+    }
+    *out = g;
+    return SLAM_OK;
+}
+
+void slam_grid_destroy(slam_grid_t *g)
+{
+    if (!g) return;
+    void *ptrs[] = {g->d_planes, g->d_num_w, g->d_occ_w, g->d_num_s,     g->d_occ_s, g->d_delta,
+                    g->d_touched, g->d_updates, g->d_beams, g->d_chunk_box, g->d_stage};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete g;
+}
+
+int slam_grid_clear(slam_grid_t *g, slam_stream_t stream)
+{
+    SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
+    hipStream_t st = as_stream(stream);
+    SLAM_HIP(hipMemsetAsync(g->d_planes, 0, 2 * g->cells * sizeof(int32_t), st));
+    SLAM_HIP(hipMemsetAsync(g->d_num_w, 0, g->cells * sizeof(double), st));
+    SLAM_HIP(hipMemsetAsync(g->d_num_s, 0, g->cells * sizeof(double), st));
+    SLAM_HIP(hipMemsetAsync(g->d_occ_w, 0xff, g->cells, st)); // -1 = unknown (mls.cpp:26)
+    SLAM_HIP(hipMemsetAsync(g->d_occ_s, 0xff, g->cells, st));
+    SLAM_HIP(hipMemsetAsync(g->d_updates, 0, sizeof(unsigned long long), st));
+    g->state_from_inorder = false;
+    return SLAM_OK;
+}
+
+int slam_grid_set_min_cluster_points(slam_grid_t *g, int v)
+{
+    SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
+    g->prm.min_cluster_points = v;
+    return SLAM_OK;
+}
+
+int slam_grid_set_max_range(slam_grid_t *g, double v)
+{
+    SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
+    g->prm.max_range = v;
+    g->gv.max_range = v;
+    return SLAM_OK;
+}
+
+int slam_grid_get_pose(slam_grid_t *g, double *x, double *y)
+{
+    SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
+    if (x) *x = g->gv.pose_x;
+    if (y) *y = g->gv.pose_y;
+    return SLAM_OK;
+}
+
+int slam_grid_set_pose(slam_grid_t *g, double x, double y, slam_stream_t stream)
+{
+    SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
+    GridView &v = g->gv;
+    if (!v.rolling) { // mls.cpp:411-415
+        v.pose_x = x;
+        v.pose_y = y;
+        return SLAM_OK;
+    }
+    const double xdiff = x - v.pose_x, ydiff = y - v.pose_y; // mls.cpp:419-424
+    const int    dx = (int)std::round(xdiff / v.res), dy = (int)std::round(ydiff / v.res);
+    if (dx == 0 && dy == 0) return SLAM_OK;
+    // Grid::shiftOrigin, mls.h:87-97 (one wrap, as there; larger jumps clear everything anyway)
+    auto wrap = [](int o, int d, int n) {
+        long v2 = ((long)o + d) % n;
+        if (v2 < 0) v2 += n;
+        return (int)v2;
+    };
+    v.ox = wrap(v.ox, dx, v.sx);
+    v.oy = wrap(v.oy, dy, v.sy);
+    v.pose_x += dx * v.res; // mls.cpp:430-431
+    v.pose_y += dy * v.res;
+    hipLaunchKernelGGL(roll_clear_kernel, grid2d(g), dim3(256), 0, as_stream(stream), v, dx, dy, g->d_num_s,
+                       g->d_occ_s);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+int slam_grid_add_endpoints_dev(slam_grid_t *g, const float *d_obs, int n_obs, const float *d_gnd, int n_gnd,
+                                int stride, slam_stream_t stream)
+{
+    SLAM_REQUIRE(g && n_obs >= 0 && n_gnd >= 0 && stride >= 2, SLAM_E_INVALID,
+                 "slam_grid_add_endpoints_dev: bad arguments");
+    const int n = n_obs + n_gnd;
+    if (n == 0) return SLAM_OK;
+    hipLaunchKernelGGL(endpoints_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), g->gv, d_obs,
+                       n_obs, d_gnd, n_gnd, stride);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+static int stage_points(slam_grid *g, const float *obs, int n_obs, const float *gnd, int n_gnd, int stride,
+                        float **d_obs, float **d_gnd)
+{
+    const size_t bo = (size_t)n_obs * stride * sizeof(float), bg = (size_t)n_gnd * stride * sizeof(float);
+    SLAM_TRY(reserve(&g->d_stage, &g->cap_stage, bo + bg + 16));
+    *d_obs = static_cast<float *>(g->d_stage);
+    *d_gnd = *d_obs + (size_t)n_obs * stride;
+    if (bo) SLAM_HIP(hipMemcpyAsync(*d_obs, obs, bo, hipMemcpyHostToDevice, nullptr));
+    if (bg) SLAM_HIP(hipMemcpyAsync(*d_gnd, gnd, bg, hipMemcpyHostToDevice, nullptr));
+    return SLAM_OK;
+}
+
+int slam_grid_add_endpoints(slam_grid_t *g, const float *obs, int n_obs, const float *gnd, int n_gnd,
+                            int stride)
+{
+    SLAM_REQUIRE(g && n_obs >= 0 && n_gnd >= 0 && stride >= 2 && (obs || !n_obs) && (gnd || !n_gnd),
+                 SLAM_E_INVALID, "slam_grid_add_endpoints: bad arguments");
+    SLAM_TRY(require_device());
+    float *d_obs, *d_gnd;
+    SLAM_TRY(stage_points(g, obs, n_obs, gnd, n_gnd, stride, &d_obs, &d_gnd));
+    SLAM_TRY(slam_grid_add_endpoints_dev(g, d_obs, n_obs, d_gnd, n_gnd, stride, nullptr));
+    SLAM_HIP(hipStreamSynchronize(nullptr));
+    return SLAM_OK;
+}
+
+int slam_grid_raycast_dev(slam_grid_t *g, const float *d_origin_xy, const float *d_end_xy, int n,
+                          slam_stream_t stream)
+{
+    SLAM_REQUIRE(g && n >= 0 && (n == 0 || (d_origin_xy && d_end_xy)), SLAM_E_INVALID,
+                 "slam_grid_raycast_dev: bad arguments");
+    if (n == 0) return SLAM_OK;
+    hipStream_t st = as_stream(stream);
+    SLAM_TRY(reserve_beams(g, (size_t)n));
+    const int n_chunks = (n + kChunk - 1) / kChunk;
+    hipLaunchKernelGGL(init_chunk_box_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, st, g->d_chunk_box,
+                       n_chunks);
+    hipLaunchKernelGGL(beams_from_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g->gv,
+                       reinterpret_cast<const float2 *>(d_origin_xy), reinterpret_cast<const float2 *>(d_end_xy),
+                       n, g->d_beams, g->d_chunk_box, kChunk);
+    SLAM_HIP(hipGetLastError());
+    return walk_beams(g, n, st);
+}
+
+int slam_grid_raycast(slam_grid_t *g, const float *origin_xy, const float *end_xy, int n)
+{
+    SLAM_REQUIRE(g && n >= 0 && (n == 0 || (origin_xy && end_xy)), SLAM_E_INVALID,
+                 "slam_grid_raycast: bad arguments");
+    SLAM_TRY(require_device());
+    if (n == 0) return SLAM_OK;
+    float *d_o, *d_e;
+    SLAM_TRY(stage_points(g, origin_xy, n, end_xy, n, 2, &d_o, &d_e));
+    SLAM_TRY(slam_grid_raycast_dev(g, d_o, d_e, n, nullptr));
+    SLAM_HIP(hipStreamSynchronize(nullptr));
+    return SLAM_OK;
+}
+
+int slam_grid_raycast_scans_dev(slam_grid_t *g, const double *d_pts, const int32_t *d_scan_off, int n_scans,
+                                int n_points, const double *d_R, const double *d_t, slam_stream_t stream)
+{
+    SLAM_REQUIRE(g && n_scans >= 0 && n_points >= 0 && d_scan_off && d_R && d_t, SLAM_E_INVALID,
+                 "slam_grid_raycast_scans_dev: bad arguments");
+    if (n_scans == 0 || n_points == 0) return SLAM_OK;
+    hipStream_t st = as_stream(stream);
+    const int   n = n_points;
+    SLAM_TRY(reserve_beams(g, (size_t)n));
+    const int n_chunks = (n + kChunk - 1) / kChunk;
+    hipLaunchKernelGGL(init_chunk_box_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, st, g->d_chunk_box,
+                       n_chunks);
+    hipLaunchKernelGGL(beams_from_scans_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g->gv,
+                       reinterpret_cast<const double2 *>(d_pts), d_scan_off, n_scans, d_R, d_t, n, g->d_beams,
+                       g->d_chunk_box, kChunk);
+    SLAM_HIP(hipGetLastError());
+    return walk_beams(g, n, st);
+}
+
+int slam_grid_finalize(slam_grid_t *g, slam_stream_t stream)
+{
+    SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
+    hipLaunchKernelGGL(finalize_kernel, grid2d(g), dim3(256), 0, as_stream(stream), g->gv,
+                       g->prm.occupancy_increment, g->prm.occupancy_decrement,
+                       (double)g->prm.min_cluster_points, g->d_num_w, g->d_occ_w);
+    SLAM_HIP(hipGetLastError());
+    g->state_from_inorder = false;
+    return SLAM_OK;
+}
+
+int slam_grid_add_scan_inorder(slam_grid_t *g, const float *obs, int n_obs, const float *gnd, int n_gnd,
+                               int stride)
+{
+    SLAM_REQUIRE(g && n_obs >= 0 && n_gnd >= 0 && stride >= 2 && (obs || !n_obs) && (gnd || !n_gnd),
+                 SLAM_E_INVALID, "slam_grid_add_scan_inorder: bad arguments");
+    SLAM_TRY(require_device());
+    const int n = n_obs + n_gnd;
+    if (n == 0) return SLAM_OK;
+    if (!g->d_delta) {
+        SLAM_HIP(hipMalloc((void **)&g->d_delta, g->cells * sizeof(unsigned long long)));
+        SLAM_HIP(hipMemset(g->d_delta, 0, g->cells * sizeof(unsigned long long)));
+    }
+    {
+        void  *p = g->d_touched;
+        size_t cap = g->cap_touched;
+        SLAM_TRY(reserve(&p, &cap, ((size_t)n + 1) * sizeof(int)));
+        g->d_touched = static_cast<int *>(p);
+        g->cap_touched = cap;
+    }
+    float *d_obs, *d_gnd;
+    SLAM_TRY(stage_points(g, obs, n_obs, gnd, n_gnd, stride, &d_obs, &d_gnd));
+    int *counter = g->d_touched + n;
+    SLAM_HIP(hipMemsetAsync(counter, 0, sizeof(int), nullptr));
+    hipLaunchKernelGGL(inorder_count_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, g->gv, d_obs, n_obs,
+                       d_gnd, n_gnd, stride, g->d_delta, g->d_touched, counter);
+    hipLaunchKernelGGL(inorder_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, g->gv,
+                       g->prm.occupancy_increment, g->prm.occupancy_decrement,
+                       (double)g->prm.min_cluster_points, g->d_delta, g->d_touched, counter, g->d_num_s,
+                       g->d_occ_s, g->d_updates);
+    SLAM_HIP(hipGetLastError());
+    SLAM_HIP(hipStreamSynchronize(nullptr));
+    g->state_from_inorder = true;
+    return SLAM_OK;
+}
+
+int slam_grid_read_counts(slam_grid_t *g, int32_t *hits, int32_t *misses)
+{
+    SLAM_REQUIRE(g && hits && misses, SLAM_E_INVALID, "slam_grid_read_counts: bad arguments");
+    SLAM_TRY(require_device());
+    int32_t *tmp = nullptr;
+    SLAM_HIP(hipMalloc((void **)&tmp, 2 * g->cells * sizeof(int32_t)));
+    hipLaunchKernelGGL(gather_counts_kernel, grid2d(g), dim3(256), 0, nullptr, g->gv, tmp, tmp + g->cells);
+    hipError_t e = hipMemcpy(hits, tmp, g->cells * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(misses, tmp + g->cells, g->cells * sizeof(int32_t), hipMemcpyDeviceToHost);
+    (void)hipFree(tmp);
+    SLAM_HIP(e);
+    return SLAM_OK;
+}
+
+static int sync_window_state(slam_grid *g)
+{
+    if (g->state_from_inorder) {
+        hipLaunchKernelGGL(window_from_storage_kernel, grid2d(g), dim3(256), 0, nullptr, g->gv, g->d_num_s,
+                           g->d_occ_s, g->d_num_w, g->d_occ_w);
+        SLAM_HIP(hipGetLastError());
+    }
+    return SLAM_OK;
+}
+
+int slam_grid_read_occupancy(slam_grid_t *g, int8_t *occ)
+{
+    SLAM_REQUIRE(g && occ, SLAM_E_INVALID, "slam_grid_read_occupancy: bad arguments");
+    SLAM_TRY(require_device());
+    SLAM_TRY(sync_window_state(g));
+    SLAM_HIP(hipMemcpy(occ, g->d_occ_w, g->cells, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+int slam_grid_read_num_pts(slam_grid_t *g, double *num_pts)
+{
+    SLAM_REQUIRE(g && num_pts, SLAM_E_INVALID, "slam_grid_read_num_pts: bad arguments");
+    SLAM_TRY(require_device());
+    SLAM_TRY(sync_window_state(g));
+    SLAM_HIP(hipMemcpy(num_pts, g->d_num_w, g->cells * sizeof(double), hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+int slam_grid_total_updates(slam_grid_t *g, uint64_t *n)
+{
+    SLAM_REQUIRE(g && n, SLAM_E_INVALID, "slam_grid_total_updates: bad arguments");
+    SLAM_TRY(require_device());
+    unsigned long long v = 0;
+    SLAM_HIP(hipMemcpy(&v, g->d_updates, sizeof v, hipMemcpyDeviceToHost));
+    *n = (uint64_t)v;
+    return SLAM_OK;
+}
+
+int slam_grid_info(slam_grid_t *g, int *size_x, int *size_y, double *resolution, int *origin_x, int *origin_y)
+{
+    SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
+    if (size_x) *size_x = g->gv.sx;
+    if (size_y) *size_y = g->gv.sy;
+    if (resolution) *resolution = g->gv.res;
+    if (origin_x) *origin_x = g->gv.ox;
+    if (origin_y) *origin_y = g->gv.oy;
+    return SLAM_OK;
+}
+
+int slam_grid_counts_dev(slam_grid_t *g, int32_t **d_planes, size_t *n_ints)
+{
+    SLAM_REQUIRE(g && d_planes, SLAM_E_INVALID, "slam_grid_counts_dev: bad arguments");
+    *d_planes = g->d_planes;
+    if (n_ints) *n_ints = 2 * g->cells;
+    return SLAM_OK;
+}
+
+} // extern "C"

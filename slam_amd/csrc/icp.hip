@@ -1,0 +1,889 @@
+// icp.hip -- class-constrained 2-D ICP on gfx950 behind the C-ABI.
+//
+// Reference path (all under /root/reference/ccicp2d):
+//   Icp::Icp            src/icp.cpp:26-70        model f64 -> f32, two kd-trees
+//   Icp::fit/fitIterate src/icp.cpp:80-122       <= max_iter x fitStep, stop on delta < min_delta
+//   IcpPointToPoint::fitStep src/icpPointToPoint.cpp:33-172
+//   KDTree::n_nearest   src/kdtree.cpp:378-391   exact 1-NN in float
+//
+// MI355X design (DESIGN.md "ICP kernel"):
+//   * one workgroup (16 wavefronts) per scan, resident for ALL iterations: the
+//     pose never leaves registers, one s_barrier per iteration, no host round
+//     trip (the reference's loop-carried dependency is per scan, scans are
+//     independent: SURVEY 8(a) I6);
+//   * the model is held in LDS as a uniform-cell index (points sorted by cell,
+//     row-major, per class) instead of two kd-trees: a (2r+1)^2 neighbourhood is
+//     (2r+1) CONTIGUOUS spans, so the lanes that share a scene point read
+//     consecutive float2 (conflict-free ds_read_b64) with no pointer chasing;
+//   * G lanes of a wavefront cooperate on one scene point (G = 64 is the
+//     north-star "one wavefront per scan point"; the default is measured);
+//   * the per-iteration normal-equation sums (9 doubles) are reduced with
+//     cross-lane shuffles inside the wavefront and once through LDS across the
+//     16 wavefronts; every thread then solves the 2x2 (or 3x3) system
+//     redundantly, so no broadcast and no second barrier is needed;
+//   * the float distance is fl(fl(dx*dx)+fl(dy*dy)) with contraction off and
+//     the query is (float)(double transform), as icpPointToPoint.cpp:69-70 and
+//     kdtree.cpp:610-612 compute them, so the correspondence set is the
+//     reference's (ties: lowest original index).
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace slam;
+
+namespace {
+
+constexpr int kBlock = 1024;          // threads per scan workgroup
+constexpr int kWaves = kBlock / 64;
+constexpr int kNumAcc = 9;            // doubles reduced per iteration
+constexpr unsigned kLdsTotal = 160u * 1024u;
+
+struct Lattice {
+    int   nx, ny;
+    float x0, y0, h, inv_h;
+    float margin; // subtracted from r*h before squaring: absorbs f32 rounding of the cell assignment
+};
+
+// Device view of the model index.  All offsets are bytes into `blob`.
+struct ModelView {
+    const unsigned char *blob;
+    unsigned blob_bytes;
+    unsigned off_pts;       // float2[n_all]: class 0 (GA) sorted by cell, then class 1 (NGA)
+    unsigned off_start[2];  // StartT[ncells+1] per class, positions relative to the class base
+    unsigned off_oidx;      // StartT[n_all]: original index within the class
+    int      n_cls[2];
+    int      base[2];       // first point of each class in pts
+    Lattice  lat;
+    double   cx, cy;        // shift origin for the running sums (model centroid)
+    const double *normals;  // P2L: double2 per ORIGINAL all-index (GA then NGA), or null
+};
+
+template <typename StartT>
+struct IndexPtrs {
+    const float2 *pts;
+    const StartT *start[2];
+    const StartT *oidx;
+};
+
+template <typename StartT>
+__device__ inline IndexPtrs<StartT> make_ptrs(const unsigned char *base, const ModelView &mv)
+{
+    IndexPtrs<StartT> ix;
+    ix.pts = reinterpret_cast<const float2 *>(base + mv.off_pts);
+    ix.start[0] = reinterpret_cast<const StartT *>(base + mv.off_start[0]);
+    ix.start[1] = reinterpret_cast<const StartT *>(base + mv.off_start[1]);
+    ix.oidx = reinterpret_cast<const StartT *>(base + mv.off_oidx);
+    return ix;
+}
+
+__device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct Best {
+    float    d;    // squared float distance (kdtree.h:33)
+    unsigned oidx; // original index within the class (kdtree.h:34)
+    int      pos;  // position in the sorted pts array
+};
+
+// Exact 1-NN of (qx,qy) among the points of class `cls`, searched by the G
+// lanes of a group (`sub` = lane within the group).  `gate` (double, squared
+// metres) lets the search stop once no unseen point can pass the inlier test
+// of icpPointToPoint.cpp:76; pass +inf for an ungated search.  On return all
+// G lanes hold the same result; pos < 0 when the class is empty.
+template <int G, typename StartT>
+__device__ inline Best nn_search(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls,
+                                 float qx, float qy, int sub, double gate)
+{
+    const Lattice &L = mv.lat;
+    const StartT *start = ix.start[cls];
+    const float2 *pts = ix.pts + mv.base[cls];
+    const StartT *oidx = ix.oidx + mv.base[cls];
+
+    Best b;
+    b.d = FLT_MAX;
+    b.oidx = 0xffffffffu;
+    b.pos = -1;
+    if (mv.n_cls[cls] <= 0) return b;
+
+    const int cx = clampi((int)floorf((qx - L.x0) * L.inv_h), 0, L.nx - 1);
+    const int cy = clampi((int)floorf((qy - L.y0) * L.inv_h), 0, L.ny - 1);
+
+    for (int r = 1;; r *= 2) {
+        const int y_lo = max(cy - r, 0), y_hi = min(cy + r, L.ny - 1);
+        const int x_lo = max(cx - r, 0), x_hi = min(cx + r, L.nx - 1);
+        for (int y = y_lo; y <= y_hi; ++y) {
+            const int row = y * L.nx;
+            const int a = (int)start[row + x_lo];
+            const int e = (int)start[row + x_hi + 1];
+            for (int i = a + sub; i < e; i += G) {
+                const float2 m = pts[i];
+                const float dx = m.x - qx;
+                const float dy = m.y - qy;
+                // kdtree.cpp:610-612: dis += squared(data[i][k]-qv[k]), k = 0 then 1, no FMA
+                const float d = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+                if (d <= b.d) {
+                    const unsigned oi = (unsigned)oidx[i];
+                    if (d < b.d || oi < b.oidx) {
+                        b.d = d;
+                        b.oidx = oi;
+                        b.pos = i;
+                    }
+                }
+            }
+        }
+        if (G > 1) {
+#pragma unroll
+            for (int off = 1; off < G; off <<= 1) {
+                const float    od = __shfl_xor(b.d, off);
+                const unsigned oo = (unsigned)__shfl_xor((int)b.oidx, off);
+                const int      op = __shfl_xor(b.pos, off);
+                if (od < b.d || (od == b.d && oo < b.oidx)) {
+                    b.d = od;
+                    b.oidx = oo;
+                    b.pos = op;
+                }
+            }
+        }
+        const bool  covers = (x_lo == 0) & (y_lo == 0) & (x_hi == L.nx - 1) & (y_hi == L.ny - 1);
+        const float bound = (float)r * L.h - L.margin;
+        const float b2 = bound * bound;
+        // every unseen point is farther than `bound` in x or in y
+        if (covers || b.d < b2 || (double)b2 >= gate) break;
+    }
+    return b;
+}
+
+__device__ inline double wave_sum(double v, int first_off)
+{
+    for (int off = first_off; off < 64; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// icpPointToPoint.cpp:159-162, closed form of svd -> V*U^T (oracle: o_p2p_rotation)
+__device__ inline void p2p_rotation(const double H[4], double R_[4])
+{
+    const double det = H[0] * H[3] - H[1] * H[2];
+    double a, b;
+    if (det >= 0.0) {
+        a = H[0] + H[3];
+        b = H[1] - H[2];
+    } else {
+        a = H[0] - H[3];
+        b = H[1] + H[2];
+    }
+    const double n = sqrt(a * a + b * b);
+    double c = 1.0, s = 0.0;
+    if (n > 0.0) {
+        c = a / n;
+        s = b / n;
+    }
+    if (det >= 0.0) {
+        R_[0] = c;
+        R_[1] = -s;
+        R_[2] = s;
+        R_[3] = c;
+    } else {
+        R_[0] = c;
+        R_[1] = s;
+        R_[2] = s;
+        R_[3] = -c;
+    }
+}
+
+// matrix.cpp:420-508 Gauss-Jordan with full pivoting, 3x3, one rhs (oracle: o_solve3)
+__device__ inline bool solve3(double A[9], double b[3])
+{
+    int indxc[3], indxr[3], ipiv[3] = {0, 0, 0};
+    int irow = 0, icol = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double big = 0.0;
+        for (int j = 0; j < 3; j++)
+            if (ipiv[j] != 1)
+                for (int k = 0; k < 3; k++)
+                    if (ipiv[k] == 0 && fabs(A[3 * j + k]) >= big) {
+                        big = fabs(A[3 * j + k]);
+                        irow = j;
+                        icol = k;
+                    }
+        ++ipiv[icol];
+        if (irow != icol) {
+            for (int l = 0; l < 3; l++) {
+                const double tmp = A[3 * irow + l];
+                A[3 * irow + l] = A[3 * icol + l];
+                A[3 * icol + l] = tmp;
+            }
+            const double tmp = b[irow];
+            b[irow] = b[icol];
+            b[icol] = tmp;
+        }
+        indxr[i] = irow;
+        indxc[i] = icol;
+        if (fabs(A[3 * icol + icol]) < 1e-20) return false;
+        const double pivinv = 1.0 / A[3 * icol + icol];
+        A[3 * icol + icol] = 1.0;
+        for (int l = 0; l < 3; l++) A[3 * icol + l] *= pivinv;
+        b[icol] *= pivinv;
+        for (int ll = 0; ll < 3; ll++)
+            if (ll != icol) {
+                const double dum = A[3 * ll + icol];
+                A[3 * ll + icol] = 0.0;
+                for (int l = 0; l < 3; l++) A[3 * ll + l] -= A[3 * icol + l] * dum;
+                b[ll] -= b[icol] * dum;
+            }
+    }
+    (void)indxr;
+    (void)indxc; // column unscrambling only affects the inverse, not the solution vector
+    return true;
+}
+
+struct FitArgs {
+    const double2 *pts;
+    const int     *scan_off;
+    const int     *scan_nga;
+    double        *R;
+    double        *t;
+    slam_icp_result *result;
+    double        *trace;
+    int            max_iter;
+    double         min_delta;
+    double         indist;
+};
+
+// One workgroup = one scan, all iterations.  MODE: SLAM_ICP_P2P / SLAM_ICP_P2L.
+template <int G, bool LDS, typename StartT, int MODE>
+__global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs fa)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *partial = reinterpret_cast<double *>(smem); // [2][kWaves][kNumAcc]
+    constexpr unsigned kScratch = 2u * kWaves * kNumAcc * sizeof(double);
+    static_assert(kScratch % 16 == 0, "scratch keeps the blob 16-B aligned");
+
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int sub = tid % G, group = tid / G;
+    constexpr int kGroups = kBlock / G;
+
+    const int off = fa.scan_off[s];
+    const int n = fa.scan_off[s + 1] - off;
+    const int nga = fa.scan_nga[s];
+
+    const unsigned char *base = mv.blob;
+    if (LDS) {
+        unsigned char *dst = smem + kScratch;
+        const uint4 *src = reinterpret_cast<const uint4 *>(mv.blob);
+        uint4       *d4 = reinterpret_cast<uint4 *>(dst);
+        for (unsigned i = tid; i < mv.blob_bytes / 16u; i += kBlock) d4[i] = src[i];
+        base = dst;
+        __syncthreads();
+    }
+    const IndexPtrs<StartT> ix = make_ptrs<StartT>(base, mv);
+
+    double r00 = fa.R[4 * s + 0], r01 = fa.R[4 * s + 1], r10 = fa.R[4 * s + 2], r11 = fa.R[4 * s + 3];
+    double t0 = fa.t[2 * s + 0], t1 = fa.t[2 * s + 1];
+
+    int    iters = 0, n_corr = 0;
+    double delta = 0.0;
+
+    if (n >= 5) { // icp.cpp:100-103
+        for (int iter = 0; iter < fa.max_iter; ++iter) {
+            double acc[kNumAcc];
+#pragma unroll
+            for (int k = 0; k < kNumAcc; ++k) acc[k] = 0.0;
+
+            for (int p = group; p < n; p += kGroups) {
+                const double2 P = fa.pts[off + p];
+                // icpPointToPoint.cpp:69-70: (r00*x + r01*y) + t0 in double, stored to float
+                const float qx = (float)__dadd_rn(__dadd_rn(__dmul_rn(r00, P.x), __dmul_rn(r01, P.y)), t0);
+                const float qy = (float)__dadd_rn(__dadd_rn(__dmul_rn(r10, P.x), __dmul_rn(r11, P.y)), t1);
+                if (MODE == SLAM_ICP_P2P) {
+                    const int cls = p < nga ? 0 : 1;
+                    if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
+                        const Best b = nn_search<G, StartT>(ix, mv, cls, qx, qy, sub, fa.indist);
+                        if (sub == 0 && b.pos >= 0 && (double)b.d < fa.indist) { // :76
+                            const float2 m = ix.pts[mv.base[cls] + b.pos];
+                            const double ax = (double)m.x - mv.cx, ay = (double)m.y - mv.cy;
+                            const double bx = (double)qx - mv.cx, by = (double)qy - mv.cy;
+                            acc[0] += 1.0;
+                            acc[1] += ax;
+                            acc[2] += ay;
+                            acc[3] += bx;
+                            acc[4] += by;
+                            acc[5] += bx * ax; // H[a][b] = sum q_t[a]*q_m[b]  (:159)
+                            acc[6] += bx * ay;
+                            acc[7] += by * ax;
+                            acc[8] += by * ay;
+                        }
+                    }
+                } else {
+                    // icpPointToPlane.cpp:55-77: single class, no inlier gate
+                    const Best b0 = nn_search<G, StartT>(ix, mv, 0, qx, qy, sub, INFINITY);
+                    const Best b1 = nn_search<G, StartT>(ix, mv, 1, qx, qy, sub, INFINITY);
+                    const bool use1 = b0.pos < 0 || (b1.pos >= 0 && b1.d < b0.d);
+                    const Best b = use1 ? b1 : b0;
+                    if (sub == 0 && b.pos >= 0) {
+                        const int    cls = use1 ? 1 : 0;
+                        const float2 m = ix.pts[mv.base[cls] + b.pos];
+                        const int    all = (cls ? mv.n_cls[0] : 0) + (int)b.oidx;
+                        const double nx = mv.normals[2 * all], ny = mv.normals[2 * all + 1];
+                        const double dx = (double)m.x, dy = (double)m.y;
+                        const double sx = (double)qx, sy = (double)qy;
+                        const double a0 = ny * sx - nx * sy, a1 = nx, a2 = ny;
+                        const double bb = nx * dx + ny * dy - nx * sx - ny * sy;
+                        acc[0] += a0 * a0;
+                        acc[1] += a0 * a1;
+                        acc[2] += a0 * a2;
+                        acc[3] += a1 * a1;
+                        acc[4] += a1 * a2;
+                        acc[5] += a2 * a2;
+                        acc[6] += a0 * bb;
+                        acc[7] += a1 * bb;
+                        acc[8] += a2 * bb;
+                    }
+                }
+            }
+
+            // wavefront reduction (lanes with sub != 0 hold zeros), then LDS across wavefronts
+            double *my = partial + ((iter & 1) * kWaves + wave) * kNumAcc;
+#pragma unroll
+            for (int k = 0; k < kNumAcc; ++k) {
+                const double v = wave_sum(acc[k], G >= 64 ? 64 : G);
+                if (lane == 0) my[k] = v;
+            }
+            __syncthreads();
+            double S[kNumAcc];
+#pragma unroll
+            for (int k = 0; k < kNumAcc; ++k) S[k] = 0.0;
+            const double *all = partial + (iter & 1) * kWaves * kNumAcc;
+            for (int w = 0; w < kWaves; ++w)
+#pragma unroll
+                for (int k = 0; k < kNumAcc; ++k) S[k] += all[w * kNumAcc + k];
+
+            double R_[4], t_[2];
+            bool   have = true;
+            if (MODE == SLAM_ICP_P2P) {
+                n_corr = (int)S[0];
+                if (n_corr == 0) { // icpPointToPoint.cpp:128-131
+                    delta = -1.0;
+                    have = false;
+                } else {
+                    const double inv = 1.0 / S[0];
+                    const double ma0 = S[1] * inv, ma1 = S[2] * inv; // mean of (p_m - c)
+                    const double mb0 = S[3] * inv, mb1 = S[4] * inv; // mean of (p_t - c)
+                    double H[4];
+                    H[0] = S[5] - S[3] * ma0;
+                    H[1] = S[6] - S[3] * ma1;
+                    H[2] = S[7] - S[4] * ma0;
+                    H[3] = S[8] - S[4] * ma1;
+                    p2p_rotation(H, R_);
+                    const double mm0 = mv.cx + ma0, mm1 = mv.cy + ma1;
+                    const double mt0 = mv.cx + mb0, mt1 = mv.cy + mb1;
+                    t_[0] = mm0 - (R_[0] * mt0 + R_[1] * mt1); // :163
+                    t_[1] = mm1 - (R_[2] * mt0 + R_[3] * mt1);
+                }
+            } else {
+                n_corr = n;
+                double A[9] = {S[0], S[1], S[2], S[1], S[3], S[4], S[2], S[4], S[5]};
+                double b[3] = {S[6], S[7], S[8]};
+                if (solve3(A, b)) { // icpPointToPlane.cpp:85
+                    const double w = b[0], nn = sqrt(1.0 + w * w); // :88-95 U*V^T
+                    R_[0] = 1.0 / nn;
+                    R_[1] = -w / nn;
+                    R_[2] = w / nn;
+                    R_[3] = 1.0 / nn;
+                    t_[0] = b[1];
+                    t_[1] = b[2];
+                } else {
+                    delta = 0.0; // falls out of the if at :85 and returns 0
+                    have = false;
+                }
+            }
+            if (have) {
+                // :166-167 R = R_*R ; t = R_*t + t_
+                const double n00 = R_[0] * r00 + R_[1] * r10, n01 = R_[0] * r01 + R_[1] * r11;
+                const double n10 = R_[2] * r00 + R_[3] * r10, n11 = R_[2] * r01 + R_[3] * r11;
+                const double nt0 = (R_[0] * t0 + R_[1] * t1) + t_[0];
+                const double nt1 = (R_[2] * t0 + R_[3] * t1) + t_[1];
+                r00 = n00;
+                r01 = n01;
+                r10 = n10;
+                r11 = n11;
+                t0 = nt0;
+                t1 = nt1;
+                const double a0 = R_[0] - 1.0, a3 = R_[3] - 1.0;
+                const double nr = sqrt(a0 * a0 + R_[1] * R_[1] + R_[2] * R_[2] + a3 * a3);
+                const double nt = sqrt(t_[0] * t_[0] + t_[1] * t_[1]);
+                delta = nr > nt ? nr : nt; // :170
+            }
+            ++iters;
+            if (fa.trace && tid == 0) {
+                double *tr = fa.trace + ((size_t)s * fa.max_iter + iter) * 8;
+                tr[0] = r00;
+                tr[1] = r01;
+                tr[2] = r10;
+                tr[3] = r11;
+                tr[4] = t0;
+                tr[5] = t1;
+                tr[6] = delta;
+                tr[7] = (double)n_corr;
+            }
+            if (delta < fa.min_delta) break; // icp.cpp:119-121
+        }
+    }
+
+    if (tid == 0) {
+        fa.R[4 * s + 0] = r00;
+        fa.R[4 * s + 1] = r01;
+        fa.R[4 * s + 2] = r10;
+        fa.R[4 * s + 3] = r11;
+        fa.t[2 * s + 0] = t0;
+        fa.t[2 * s + 1] = t1;
+        if (fa.result) {
+            fa.result[s].iters = iters;
+            fa.result[s].n_corr = n_corr;
+            fa.result[s].delta = delta;
+        }
+    }
+}
+
+// KDTree::n_nearest(q, 1): G lanes per query, index read from HBM/L2.
+template <int G, typename StartT>
+__global__ __launch_bounds__(256) void icp_nearest_kernel(ModelView mv, int cls, const float2 *q, int n,
+                                                          float *dis, int *idx)
+{
+    const IndexPtrs<StartT> ix = make_ptrs<StartT>(mv.blob, mv);
+    const int gid = (blockIdx.x * 256 + threadIdx.x) / G;
+    const int sub = threadIdx.x % G;
+    if (gid >= n) return;
+    const float2 qq = q[gid];
+    const Best   b = nn_search<G, StartT>(ix, mv, cls, qq.x, qq.y, sub, INFINITY);
+    if (sub == 0) {
+        dis[gid] = b.pos >= 0 ? b.d : 1.0e38f; // kdtree.cpp:325 "infinity"
+        idx[gid] = b.pos >= 0 ? (int)b.oidx : -1;
+    }
+}
+
+// ---------------------------------------------------------------- host side
+
+struct DevBuf {
+    void  *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return SLAM_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        SLAM_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+        return SLAM_OK;
+    }
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+};
+
+} // namespace
+
+struct slam_icp {
+    slam_icp_params prm;
+    int             sub_step = 10; // icp.cpp:27
+    ModelView       mv;
+    bool            in_lds = false;
+    bool            start32 = false;
+    int             G = 8;
+    size_t          lds_bytes = 0;
+    void           *d_blob = nullptr;
+    double         *d_normals = nullptr;
+    DevBuf          w_pts, w_off, w_nga, w_R, w_t, w_res;
+};
+
+namespace {
+
+template <typename StartT>
+void fill_index(std::vector<unsigned char> &blob, const ModelView &mv, const std::vector<float> cls_xy[2],
+                const std::vector<int> cell_of[2])
+{
+    const int ncells = mv.lat.nx * mv.lat.ny;
+    float2   *pts = reinterpret_cast<float2 *>(blob.data() + mv.off_pts);
+    StartT   *oidx = reinterpret_cast<StartT *>(blob.data() + mv.off_oidx);
+    for (int c = 0; c < 2; ++c) {
+        StartT *start = reinterpret_cast<StartT *>(blob.data() + mv.off_start[c]);
+        const int n = mv.n_cls[c];
+        std::vector<int> count(ncells + 1, 0);
+        for (int i = 0; i < n; ++i) count[cell_of[c][i] + 1]++;
+        for (int k = 0; k < ncells; ++k) count[k + 1] += count[k];
+        for (int k = 0; k <= ncells; ++k) start[k] = (StartT)count[k];
+        std::vector<int> fill(count.begin(), count.end() - 1);
+        for (int i = 0; i < n; ++i) { // stable: equal cells keep original order
+            const int pos = fill[cell_of[c][i]]++;
+            pts[mv.base[c] + pos] = make_float2(cls_xy[c][2 * i], cls_xy[c][2 * i + 1]);
+            oidx[mv.base[c] + pos] = (StartT)i;
+        }
+    }
+}
+
+inline unsigned align16(unsigned v) { return (v + 15u) & ~15u; }
+
+int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, int n_nga)
+{
+    std::vector<float> xy[2];
+    const double *src[2] = {m_ga, m_nga};
+    const int     cnt[2] = {n_ga, n_nga};
+    float  lo[2] = {FLT_MAX, FLT_MAX}, hi[2] = {-FLT_MAX, -FLT_MAX};
+    double sum[2] = {0, 0};
+    size_t nfin = 0;
+    for (int c = 0; c < 2; ++c) {
+        xy[c].resize(2 * (size_t)cnt[c]);
+        for (int i = 0; i < 2 * cnt[c]; ++i) xy[c][i] = (float)src[c][i]; // icp.cpp:54,60
+        for (int i = 0; i < cnt[c]; ++i) {
+            const float x = xy[c][2 * i], y = xy[c][2 * i + 1];
+            if (!std::isfinite(x) || !std::isfinite(y)) continue;
+            lo[0] = std::min(lo[0], x);
+            hi[0] = std::max(hi[0], x);
+            lo[1] = std::min(lo[1], y);
+            hi[1] = std::max(hi[1], y);
+            sum[0] += x;
+            sum[1] += y;
+            ++nfin;
+        }
+    }
+    if (nfin == 0) {
+        lo[0] = lo[1] = 0.f;
+        hi[0] = hi[1] = 1.f;
+        nfin = 1;
+    }
+    const int n_all = n_ga + n_nga;
+    const int max_cls = std::max(n_ga, n_nga);
+
+    int lds_cap = 0;
+    int dev = 0;
+    SLAM_HIP(hipGetDevice(&dev));
+    SLAM_HIP(hipDeviceGetAttribute(&lds_cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+    const unsigned lds_total = std::min<unsigned>((unsigned)lds_cap, kLdsTotal);
+    const unsigned scratch = 2u * kWaves * kNumAcc * sizeof(double);
+
+    // LDS budget for the two start arrays (u16 entries) after points + original indices
+    const long fixed16 = (long)scratch + align16(8u * n_all) + align16(2u * n_all) + 64;
+    long       cells_lds = ((long)lds_total - fixed16) / (2 * 2) - 1;
+    bool       lds = !h->prm.force_global && max_cls <= 65535 && cells_lds >= 256;
+
+    const float w = std::max(hi[0] - lo[0], 1e-3f), ht = std::max(hi[1] - lo[1], 1e-3f);
+    const float maxabs = std::max(std::max(std::fabs(lo[0]), std::fabs(hi[0])),
+                                  std::max(std::fabs(lo[1]), std::fabs(hi[1])));
+    long budget = lds ? cells_lds : std::min<long>(std::max<long>(4L * n_all, 1024), 1L << 22);
+    // target about two cells per point on wall-like maps; never more than the budget
+    long want = std::min<long>(budget, std::max<long>(64, 2L * n_all));
+    double hcell = h->prm.cell_size > 0 ? h->prm.cell_size : std::sqrt((double)w * ht / (double)want);
+    hcell = std::max(hcell, (double)maxabs * 1.52587890625e-05 /* 2^-16 */);
+    hcell = std::max(hcell, 1e-4);
+    int nx, ny;
+    for (;;) {
+        nx = (int)std::floor(w / hcell) + 1;
+        ny = (int)std::floor(ht / hcell) + 1;
+        if ((long)nx * ny <= budget) break;
+        hcell *= 1.05;
+    }
+
+    ModelView &mv = h->mv;
+    memset(&mv, 0, sizeof mv);
+    mv.lat.nx = nx;
+    mv.lat.ny = ny;
+    mv.lat.x0 = lo[0];
+    mv.lat.y0 = lo[1];
+    mv.lat.h = (float)hcell;
+    mv.lat.inv_h = 1.0f / mv.lat.h;
+    mv.lat.margin = mv.lat.h * 0.0625f;
+    mv.n_cls[0] = n_ga;
+    mv.n_cls[1] = n_nga;
+    mv.base[0] = 0;
+    mv.base[1] = n_ga;
+    mv.cx = sum[0] / (double)nfin;
+    mv.cy = sum[1] / (double)nfin;
+
+    h->start32 = !lds; // the HBM-resident index always uses 32-bit positions
+    const unsigned esz = h->start32 ? 4u : 2u;
+    const int      ncells = nx * ny;
+    unsigned       o = 0;
+    mv.off_pts = o;
+    o = align16(o + 8u * (unsigned)n_all);
+    mv.off_start[0] = o;
+    o = align16(o + esz * (unsigned)(ncells + 1));
+    mv.off_start[1] = o;
+    o = align16(o + esz * (unsigned)(ncells + 1));
+    mv.off_oidx = o;
+    o = align16(o + esz * (unsigned)n_all);
+    mv.blob_bytes = o;
+    if (lds && scratch + o > lds_total) lds = false, h->start32 = false; // keeps u16 entries, read from HBM
+    h->in_lds = lds;
+    h->lds_bytes = lds ? scratch + o : scratch;
+
+    // cell of every model point, with the SAME float expression the kernels use
+    std::vector<int> cell_of[2];
+    for (int c = 0; c < 2; ++c) {
+        cell_of[c].resize(cnt[c]);
+        for (int i = 0; i < cnt[c]; ++i) {
+            const float x = xy[c][2 * i], y = xy[c][2 * i + 1];
+            int cxi = (int)std::floor((x - mv.lat.x0) * mv.lat.inv_h);
+            int cyi = (int)std::floor((y - mv.lat.y0) * mv.lat.inv_h);
+            if (!std::isfinite(x)) cxi = 0;
+            if (!std::isfinite(y)) cyi = 0;
+            cxi = std::min(std::max(cxi, 0), nx - 1);
+            cyi = std::min(std::max(cyi, 0), ny - 1);
+            cell_of[c][i] = cyi * nx + cxi;
+        }
+    }
+    std::vector<unsigned char> blob(mv.blob_bytes, 0);
+    if (h->start32)
+        fill_index<uint32_t>(blob, mv, xy, cell_of);
+    else
+        fill_index<uint16_t>(blob, mv, xy, cell_of);
+
+    SLAM_HIP(hipMalloc(&h->d_blob, mv.blob_bytes));
+    SLAM_HIP(hipMemcpy(h->d_blob, blob.data(), mv.blob_bytes, hipMemcpyHostToDevice));
+    mv.blob = static_cast<const unsigned char *>(h->d_blob);
+    return SLAM_OK;
+}
+
+template <int G, bool LDS, typename StartT, int MODE>
+int launch_fit_t(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
+{
+    auto kern = icp_fit_kernel<G, LDS, StartT, MODE>;
+    const size_t lds = h->lds_bytes;
+    if (lds > 48 * 1024)
+        SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(n_scans), dim3(kBlock), lds, st, h->mv, fa);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+template <int G, int MODE>
+int launch_fit_g(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
+{
+    if (h->in_lds) return launch_fit_t<G, true, uint16_t, MODE>(h, fa, n_scans, st);
+    if (h->start32) return launch_fit_t<G, false, uint32_t, MODE>(h, fa, n_scans, st);
+    return launch_fit_t<G, false, uint16_t, MODE>(h, fa, n_scans, st);
+}
+
+template <int MODE>
+int launch_fit_m(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
+{
+    switch (h->G) {
+    case 1: return launch_fit_g<1, MODE>(h, fa, n_scans, st);
+    case 2: return launch_fit_g<2, MODE>(h, fa, n_scans, st);
+    case 4: return launch_fit_g<4, MODE>(h, fa, n_scans, st);
+    case 8: return launch_fit_g<8, MODE>(h, fa, n_scans, st);
+    case 16: return launch_fit_g<16, MODE>(h, fa, n_scans, st);
+    case 32: return launch_fit_g<32, MODE>(h, fa, n_scans, st);
+    case 64: return launch_fit_g<64, MODE>(h, fa, n_scans, st);
+    }
+    set_error("lanes_per_point must be one of 1,2,4,8,16,32,64 (got %d)", h->G);
+    return SLAM_E_INVALID;
+}
+
+int launch_fit(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
+{
+    if (n_scans <= 0) return SLAM_OK;
+    if (h->prm.mode == SLAM_ICP_P2L) {
+        SLAM_REQUIRE(h->d_normals, SLAM_E_INVALID, "point-to-line mode needs model normals");
+        return launch_fit_m<SLAM_ICP_P2L>(h, fa, n_scans, st);
+    }
+    return launch_fit_m<SLAM_ICP_P2P>(h, fa, n_scans, st);
+}
+
+} // namespace
+
+extern "C" {
+
+void slam_icp_default_params(slam_icp_params *p)
+{
+    if (!p) return;
+    p->max_iter = 20;      // icp.cpp:27
+    p->min_delta = 1e-6;   // icp.cpp:27
+    p->mode = SLAM_ICP_P2P;
+    p->normals_k = 10;
+    p->lanes_per_point = 0;
+    p->cell_size = 0.0;
+    p->force_global = 0;
+}
+
+int slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga,
+                    const slam_icp_params *params, slam_icp_t **out)
+{
+    SLAM_REQUIRE(out, SLAM_E_INVALID, "slam_icp_create: null out pointer");
+    *out = nullptr;
+    SLAM_REQUIRE(n_ga >= 0 && n_nga >= 0 && (m_ga || n_ga == 0) && (m_nga || n_nga == 0),
+                 SLAM_E_INVALID, "slam_icp_create: bad model arrays");
+    // icp.cpp:38-43 "LIBICP works only with at least 5 model points"
+    SLAM_REQUIRE(n_ga + n_nga >= 5, SLAM_E_TOO_FEW_MODEL_POINTS,
+                 "LIBICP works only with at least 5 model points (got %d)", n_ga + n_nga);
+    SLAM_TRY(require_device());
+    slam_icp *h = new (std::nothrow) slam_icp();
+    SLAM_REQUIRE(h, SLAM_E_NOMEM, "slam_icp_create: out of host memory");
+    if (params)
+        h->prm = *params;
+    else
+        slam_icp_default_params(&h->prm);
+    h->G = h->prm.lanes_per_point > 0 ? h->prm.lanes_per_point : 8;
+    int rc = build_index(h, m_ga, n_ga, m_nga, n_nga);
+    if (rc == SLAM_OK && (h->G & (h->G - 1) || h->G > 64)) {
+        set_error("lanes_per_point must be one of 1,2,4,8,16,32,64 (got %d)", h->G);
+        rc = SLAM_E_INVALID;
+    }
+    if (rc == SLAM_OK && h->prm.mode == SLAM_ICP_P2L) {
+        set_error("point-to-line mode: normals kernel not built yet");
+        rc = SLAM_E_UNSUPPORTED;
+    }
+    if (rc != SLAM_OK) {
+        slam_icp_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return SLAM_OK;
+}
+
+void slam_icp_destroy(slam_icp_t *icp)
+{
+    if (!icp) return;
+    if (icp->d_blob) (void)hipFree(icp->d_blob);
+    if (icp->d_normals) (void)hipFree(icp->d_normals);
+    delete icp;
+}
+
+int slam_icp_set_max_iterations(slam_icp_t *icp, int val)
+{
+    SLAM_REQUIRE(icp, SLAM_E_INVALID, "null handle");
+    icp->prm.max_iter = val;
+    return SLAM_OK;
+}
+
+int slam_icp_set_min_delta(slam_icp_t *icp, double val)
+{
+    SLAM_REQUIRE(icp, SLAM_E_INVALID, "null handle");
+    icp->prm.min_delta = val;
+    return SLAM_OK;
+}
+
+int slam_icp_set_subsampling_step(slam_icp_t *icp, int val)
+{
+    SLAM_REQUIRE(icp, SLAM_E_INVALID, "null handle");
+    icp->sub_step = val;
+    return SLAM_OK;
+}
+
+int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *d_scan_off,
+                           const int32_t *d_scan_nga, int n_scans, double *d_R, double *d_t,
+                           double indist, slam_icp_result *d_result, double *d_trace,
+                           slam_stream_t stream)
+{
+    SLAM_REQUIRE(icp && d_scan_off && d_scan_nga && d_R && d_t && n_scans >= 0, SLAM_E_INVALID,
+                 "slam_icp_fit_batch_dev: bad arguments");
+    SLAM_TRY(require_device());
+    FitArgs fa;
+    fa.pts = reinterpret_cast<const double2 *>(d_pts);
+    fa.scan_off = d_scan_off;
+    fa.scan_nga = d_scan_nga;
+    fa.R = d_R;
+    fa.t = d_t;
+    fa.result = d_result;
+    fa.trace = d_trace;
+    fa.max_iter = icp->prm.max_iter;
+    fa.min_delta = icp->prm.min_delta;
+    fa.indist = indist;
+    return launch_fit(icp, fa, n_scans, as_stream(stream));
+}
+
+int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t_nga, int n_tnga,
+                 double R[4], double t[2], double indist, slam_icp_result *result)
+{
+    SLAM_REQUIRE(icp && R && t && n_tga >= 0 && n_tnga >= 0, SLAM_E_INVALID,
+                 "slam_icp_fit: bad arguments");
+    SLAM_REQUIRE((t_ga || n_tga == 0) && (t_nga || n_tnga == 0), SLAM_E_INVALID,
+                 "slam_icp_fit: null template array");
+    if (result) {
+        result->iters = 0;
+        result->n_corr = 0;
+        result->delta = 0.0;
+    }
+    // icp.cpp:100-103 "ERROR: Total template has N points" -> return, R,t untouched
+    SLAM_REQUIRE(n_tga + n_tnga >= 5, SLAM_E_TOO_FEW_SCENE_POINTS, "Total template has %d points",
+                 n_tga + n_tnga);
+    SLAM_TRY(require_device());
+    const int n = n_tga + n_tnga;
+    SLAM_TRY(icp->w_pts.reserve(16 * (size_t)n));
+    SLAM_TRY(icp->w_off.reserve(8));
+    SLAM_TRY(icp->w_nga.reserve(4));
+    SLAM_TRY(icp->w_R.reserve(32));
+    SLAM_TRY(icp->w_t.reserve(16));
+    SLAM_TRY(icp->w_res.reserve(sizeof(slam_icp_result)));
+    hipStream_t st = nullptr;
+    double *dp = static_cast<double *>(icp->w_pts.p);
+    if (n_tga) SLAM_HIP(hipMemcpyAsync(dp, t_ga, 16 * (size_t)n_tga, hipMemcpyHostToDevice, st));
+    if (n_tnga)
+        SLAM_HIP(hipMemcpyAsync(dp + 2 * (size_t)n_tga, t_nga, 16 * (size_t)n_tnga, hipMemcpyHostToDevice, st));
+    const int32_t off[2] = {0, n};
+    const int32_t nga = n_tga;
+    SLAM_HIP(hipMemcpyAsync(icp->w_off.p, off, 8, hipMemcpyHostToDevice, st));
+    SLAM_HIP(hipMemcpyAsync(icp->w_nga.p, &nga, 4, hipMemcpyHostToDevice, st));
+    SLAM_HIP(hipMemcpyAsync(icp->w_R.p, R, 32, hipMemcpyHostToDevice, st));
+    SLAM_HIP(hipMemcpyAsync(icp->w_t.p, t, 16, hipMemcpyHostToDevice, st));
+    SLAM_TRY(slam_icp_fit_batch_dev(icp, dp, static_cast<int32_t *>(icp->w_off.p),
+                                    static_cast<int32_t *>(icp->w_nga.p), 1,
+                                    static_cast<double *>(icp->w_R.p), static_cast<double *>(icp->w_t.p),
+                                    indist, static_cast<slam_icp_result *>(icp->w_res.p), nullptr, st));
+    slam_icp_result res;
+    SLAM_HIP(hipMemcpyAsync(R, icp->w_R.p, 32, hipMemcpyDeviceToHost, st));
+    SLAM_HIP(hipMemcpyAsync(t, icp->w_t.p, 16, hipMemcpyDeviceToHost, st));
+    SLAM_HIP(hipMemcpyAsync(&res, icp->w_res.p, sizeof res, hipMemcpyDeviceToHost, st));
+    SLAM_HIP(hipStreamSynchronize(st));
+    if (result) *result = res;
+    return SLAM_OK;
+}
+
+int slam_icp_nearest_dev(slam_icp_t *icp, int cls, const float *d_query_xy, int n, float *d_dis,
+                         int32_t *d_idx, slam_stream_t stream)
+{
+    SLAM_REQUIRE(icp && (cls == 0 || cls == 1) && n >= 0 && d_dis && d_idx, SLAM_E_INVALID,
+                 "slam_icp_nearest_dev: bad arguments");
+    SLAM_TRY(require_device());
+    if (n == 0) return SLAM_OK;
+    constexpr int G = 8;
+    const int     blocks = (int)(((size_t)n * G + 255) / 256);
+    const float2 *q = reinterpret_cast<const float2 *>(d_query_xy);
+    if (icp->start32)
+        hipLaunchKernelGGL((icp_nearest_kernel<G, uint32_t>), dim3(blocks), dim3(256), 0, as_stream(stream),
+                           icp->mv, cls, q, n, d_dis, d_idx);
+    else
+        hipLaunchKernelGGL((icp_nearest_kernel<G, uint16_t>), dim3(blocks), dim3(256), 0, as_stream(stream),
+                           icp->mv, cls, q, n, d_dis, d_idx);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+int slam_icp_get_edge_weight(slam_icp_t *icp, double eW[9])
+{
+    SLAM_REQUIRE(icp && eW, SLAM_E_INVALID, "slam_icp_get_edge_weight: bad arguments");
+    set_error("getEdgeWeight: not built yet (its only call site is commented out upstream, icpTools.cpp:191-192)");
+    return SLAM_E_UNSUPPORTED;
+}
+
+int slam_icp_index_info(slam_icp_t *icp, int *nx, int *ny, double *cell, int *in_lds, size_t *lds_bytes,
+                        int *lanes_per_point)
+{
+    SLAM_REQUIRE(icp, SLAM_E_INVALID, "null handle");
+    if (nx) *nx = icp->mv.lat.nx;
+    if (ny) *ny = icp->mv.lat.ny;
+    if (cell) *cell = icp->mv.lat.h;
+    if (in_lds) *in_lds = icp->in_lds ? 1 : 0;
+    if (lds_bytes) *lds_bytes = icp->lds_bytes;
+    if (lanes_per_point) *lanes_per_point = icp->G;
+    return SLAM_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,189 @@
+// runtime.hip -- device plumbing behind the C-ABI (memory, streams, events).
+#include <cstring>
+
+#include "common.hpp"
+
+namespace slam {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    (void)hipGetLastError();
+    return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? SLAM_E_NO_DEVICE : SLAM_E_HIP;
+}
+
+int require_device()
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        set_error("no usable HIP device (hipGetDeviceCount: %s, count %d): this library has no CPU path",
+                  hipGetErrorString(e), n);
+        return SLAM_E_NO_DEVICE;
+    }
+    return SLAM_OK;
+}
+
+} // namespace slam
+
+using namespace slam;
+
+extern "C" {
+
+const char *slam_last_error(void) { return g_err; }
+const char *slam_version(void) { return "slam_mi355x 0.1 (gfx950)"; }
+
+int slam_device_count(int *n)
+{
+    SLAM_REQUIRE(n, SLAM_E_INVALID, "slam_device_count: null out pointer");
+    *n = 0;
+    hipError_t e = hipGetDeviceCount(n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *n = 0;
+    }
+    return SLAM_OK;
+}
+
+int slam_set_device(int ordinal)
+{
+    SLAM_TRY(require_device());
+    SLAM_HIP(hipSetDevice(ordinal));
+    return SLAM_OK;
+}
+
+int slam_device_info(char *name, int name_len, int *compute_units, size_t *hbm_bytes)
+{
+    SLAM_TRY(require_device());
+    int dev = 0;
+    SLAM_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    SLAM_HIP(hipGetDeviceProperties(&p, dev));
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s (%s)", p.name, p.gcnArchName);
+    }
+    if (compute_units) *compute_units = p.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = p.totalGlobalMem;
+    return SLAM_OK;
+}
+
+int slam_malloc(void **dptr, size_t bytes)
+{
+    SLAM_REQUIRE(dptr, SLAM_E_INVALID, "slam_malloc: null out pointer");
+    SLAM_TRY(require_device());
+    *dptr = nullptr;
+    SLAM_HIP(hipMalloc(dptr, bytes ? bytes : 1));
+    return SLAM_OK;
+}
+
+int slam_free(void *dptr)
+{
+    if (!dptr) return SLAM_OK;
+    SLAM_HIP(hipFree(dptr));
+    return SLAM_OK;
+}
+
+int slam_memset(void *dptr, int value, size_t bytes, slam_stream_t stream)
+{
+    SLAM_TRY(require_device());
+    SLAM_HIP(hipMemsetAsync(dptr, value, bytes, as_stream(stream)));
+    return SLAM_OK;
+}
+
+int slam_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, slam_stream_t stream)
+{
+    SLAM_TRY(require_device());
+    if (!bytes) return SLAM_OK;
+    SLAM_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    SLAM_HIP(hipStreamSynchronize(as_stream(stream)));
+    return SLAM_OK;
+}
+
+int slam_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, slam_stream_t stream)
+{
+    SLAM_TRY(require_device());
+    if (!bytes) return SLAM_OK;
+    SLAM_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    SLAM_HIP(hipStreamSynchronize(as_stream(stream)));
+    return SLAM_OK;
+}
+
+int slam_stream_create(slam_stream_t *stream)
+{
+    SLAM_REQUIRE(stream, SLAM_E_INVALID, "slam_stream_create: null out pointer");
+    SLAM_TRY(require_device());
+    hipStream_t s;
+    SLAM_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (slam_stream_t)s;
+    return SLAM_OK;
+}
+
+int slam_stream_destroy(slam_stream_t stream)
+{
+    if (!stream) return SLAM_OK;
+    SLAM_HIP(hipStreamDestroy(as_stream(stream)));
+    return SLAM_OK;
+}
+
+int slam_stream_synchronize(slam_stream_t stream)
+{
+    SLAM_TRY(require_device());
+    SLAM_HIP(hipStreamSynchronize(as_stream(stream)));
+    return SLAM_OK;
+}
+
+int slam_device_synchronize(void)
+{
+    SLAM_TRY(require_device());
+    SLAM_HIP(hipDeviceSynchronize());
+    return SLAM_OK;
+}
+
+int slam_event_create(slam_event_t *ev)
+{
+    SLAM_REQUIRE(ev, SLAM_E_INVALID, "slam_event_create: null out pointer");
+    SLAM_TRY(require_device());
+    hipEvent_t e;
+    SLAM_HIP(hipEventCreate(&e));
+    *ev = (slam_event_t)e;
+    return SLAM_OK;
+}
+
+int slam_event_destroy(slam_event_t ev)
+{
+    if (!ev) return SLAM_OK;
+    SLAM_HIP(hipEventDestroy((hipEvent_t)ev));
+    return SLAM_OK;
+}
+
+int slam_event_record(slam_event_t ev, slam_stream_t stream)
+{
+    SLAM_HIP(hipEventRecord((hipEvent_t)ev, as_stream(stream)));
+    return SLAM_OK;
+}
+
+int slam_event_synchronize(slam_event_t ev)
+{
+    SLAM_HIP(hipEventSynchronize((hipEvent_t)ev));
+    return SLAM_OK;
+}
+
+int slam_event_elapsed_ms(slam_event_t start, slam_event_t stop, float *ms)
+{
+    SLAM_REQUIRE(ms, SLAM_E_INVALID, "slam_event_elapsed_ms: null out pointer");
+    SLAM_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return SLAM_OK;
+}
+
+} // extern "C"

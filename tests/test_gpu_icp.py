@@ -1,0 +1,241 @@
+"""GPU parity of the ICP path through the C-ABI against the CPU oracle
+(icp.cpp / icpPointToPoint.cpp / kdtree.cpp restated) and the golden chain.
+
+Tolerances (BASELINE.json north_star): pose within 1e-4 m / 1e-5 rad of the
+reference arithmetic; correspondences (float NN distance and index) bit-exact.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from slam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL, ANG_TOL = 1e-4, 1e-5
+
+
+def yaw(R):
+    R = np.asarray(R).reshape(-1, 4)
+    return np.arctan2(R[:, 2], R[:, 0])  # icpTools.cpp:197 atan2(R10, R00)
+
+
+def ang_diff(a, b):
+    d = a - b
+    return np.abs((d + np.pi) % (2 * np.pi) - np.pi)
+
+
+@pytest.fixture(scope="module")
+def world():
+    m_ga, m_nga = synth.make_map()
+    return m_ga, m_nga, O.IcpModel(m_ga, m_nga)
+
+
+@pytest.mark.parametrize("lanes", [1, 4, 8, 16, 64])
+@pytest.mark.parametrize("force_global", [0, 1])
+def test_nearest_is_bit_exact(world, lanes, force_global):
+    """KDTree::n_nearest(q,1) contract: same float distance, same index
+    (kdtree.cpp:378-391; brute force of :360-375 as the tie-free arbiter)."""
+    m_ga, m_nga, _ = world
+    icp = api.Icp(m_ga, m_nga, lanes_per_point=lanes, force_global=force_global)
+    info = icp.index_info()
+    assert info["in_lds"] == (not force_global)
+    rs = np.random.RandomState(lanes)
+    for cls, model in ((0, m_ga), (1, m_nga)):
+        xy = model.astype(np.float32)
+        q = xy[rs.randint(0, len(xy), 300)] + rs.randn(300, 2).astype(np.float32) * \
+            rs.choice([0.01, 0.3, 3.0, 30.0], size=(300, 1)).astype(np.float32)
+        dis, idx = icp.nearest(cls, q)
+        for k in range(len(q)):
+            d, i = O.brute_nn1(xy, q[k, 0], q[k, 1])
+            assert dis[k] == np.float32(d) and idx[k] == i, (cls, k, q[k])
+    icp.close()
+
+
+def test_nearest_ties_pick_lowest_index_and_empty_class():
+    gx, gy = np.meshgrid(np.arange(12), np.arange(12))
+    xy = np.stack([gx.ravel(), gy.ravel()], 1).astype(np.float64)
+    xy = np.concatenate([xy, xy[:30]])              # duplicates
+    icp = api.Icp(np.zeros((0, 2)), xy)
+    q = np.array([[0.5, 0.5], [3.5, 7.0], [5.0, 5.0], [-4, 3.5], [11.5, 11.5]], np.float32)
+    dis, idx = icp.nearest(1, q)
+    for k in range(len(q)):
+        d, i = O.brute_nn1(xy.astype(np.float32), q[k, 0], q[k, 1])
+        assert dis[k] == np.float32(d) and idx[k] == i
+    dis, idx = icp.nearest(0, q)                     # empty class
+    assert (idx == -1).all() and (dis == np.float32(1e38)).all()
+    icp.close()
+
+
+def test_config1_matches_golden_chain_and_oracle(world, golden_dir):
+    """BASELINE config 1: one 1081-beam scan, 10k-point map, 20 iterations."""
+    m_ga, m_nga, model = world
+    G = np.load(os.path.join(golden_dir, "icp_chain_golden.npz"))
+    batch = synth.make_batch(1, n_loop=256)
+    icp = api.Icp(m_ga, m_nga)  # defaults: 20 iterations, 1e-6 (icp.cpp:27)
+    R, t, res, trace = icp.fit_batch(batch, indist=5.0, trace=True)
+    chain = G["chain"]
+    steps = int(res["iters"][0])
+    assert steps == len(chain)
+    tr = trace[0, :steps]
+    assert np.array_equal(tr[:, 7], chain[:, 7])                 # correspondences per step
+    assert np.abs(tr[:, 4:6] - chain[:, 4:6]).max() < POS_TOL
+    assert ang_diff(yaw(tr[:, :4]), yaw(chain[:, :4])).max() < ANG_TOL
+    assert np.abs(tr[:, :6] - chain[:, :6]).max() < 1e-9        # in fact far tighter
+    # host entry point, same answer
+    t_ga, t_nga = batch.scan(0)
+    R2, t2, r2 = icp.fit(t_ga, t_nga, batch.R[0], batch.t[0], 5.0)
+    assert np.array_equal(R2.reshape(4), R[0]) and np.array_equal(t2, t[0])
+    assert (r2.iters, r2.n_corr) == (steps, int(res["n_corr"][0]))
+    icp.close()
+
+
+@pytest.mark.parametrize("lanes", [1, 8, 64])
+def test_batch_matches_oracle(world, lanes):
+    """32 scans of the config-2 loop, 30 iterations, fixed count (min_delta -1)."""
+    m_ga, m_nga, model = world
+    batch = synth.make_batch(32, n_loop=256)
+    icp = api.Icp(m_ga, m_nga, max_iter=30, min_delta=-1.0, lanes_per_point=lanes)
+    R, t, res, _ = icp.fit_batch(batch, indist=5.0)
+    Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R,
+                                                  batch.t, O.icp_params(30, -1.0, 5.0))
+    assert np.array_equal(res["iters"], iters) and (iters == 30).all()
+    assert np.array_equal(res["n_corr"], ncorr)
+    assert np.abs(t - to).max() < POS_TOL
+    assert ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL
+    assert np.abs(res["delta"] - delta).max() < 1e-9
+    icp.close()
+
+
+def test_early_exit_and_iteration_counts(world):
+    m_ga, m_nga, model = world
+    batch = synth.make_batch(8, n_loop=256)
+    icp = api.Icp(m_ga, m_nga, max_iter=200, min_delta=1e-6)
+    R, t, res, _ = icp.fit_batch(batch)
+    Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R,
+                                                  batch.t, O.icp_params(200, 1e-6, 5.0))
+    assert np.array_equal(res["iters"], iters) and (iters < 200).all()
+    assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL
+    # converged pose is the true pose to within the noise
+    assert np.abs(t - batch.true_poses[:, :2]).max() < 0.03
+    icp.close()
+
+
+def test_setters_mirror_reference(world):
+    m_ga, m_nga, model = world
+    batch = synth.make_batch(1, n_loop=256)
+    icp = api.Icp(m_ga, m_nga)
+    icp.set_max_iterations(3)       # icp.h:51
+    icp.set_min_delta(-1.0)         # icp.h:54
+    t_ga, t_nga = batch.scan(0)
+    R, t, res = icp.fit(t_ga, t_nga, batch.R[0], batch.t[0], 5.0)
+    assert res.iters == 3
+    Ro, to, tr, steps = model.fit(t_ga, t_nga, batch.R[0], batch.t[0], O.icp_params(3, -1.0, 5.0))
+    assert np.abs(t - to).max() < 1e-9
+    icp.close()
+
+
+def test_edge_cases_follow_reference(world):
+    m_ga, m_nga, model = world
+    icp = api.Icp(m_ga, m_nga)
+    R0, t0 = synth.pose_to_Rt(0.1, 0.2, 0.3)
+    # icp.cpp:100-103: fewer than 5 template points -> error, R,t untouched
+    with pytest.raises(api.SlamError) as e:
+        icp.fit(np.zeros((2, 2)), np.zeros((2, 2)), R0, t0)
+    assert e.value.code == api.E_TOO_FEW_SCENE
+    # icpPointToPoint.cpp:128-131: no correspondence -> -1, loop stops, R,t unchanged
+    far = np.full((10, 2), 500.0)
+    R, t, res = icp.fit(far, np.zeros((0, 2)), R0, t0)
+    assert (res.iters, res.n_corr, res.delta) == (1, 0, -1.0)
+    assert np.array_equal(R, R0) and np.array_equal(t, t0)
+    # batch: a short scan between two good ones is left untouched (ragged input)
+    good = synth.make_batch(2, n_loop=256)
+    pts = np.concatenate([good.scan(0)[0], good.scan(0)[1], np.zeros((3, 2)), good.scan(1)[0], good.scan(1)[1]])
+    n0 = good.scan_off[1]
+    off = np.array([0, n0, n0 + 3, n0 + 3 + (good.scan_off[2] - good.scan_off[1])], np.int32)
+    nga = np.array([good.scan_nga[0], 1, good.scan_nga[1]], np.int32)
+    Rb = np.stack([good.R[0], R0.reshape(4), good.R[1]])
+    tb = np.stack([good.t[0], t0, good.t[1]])
+    b3 = synth.ScanBatch(pts, off, nga, Rb, tb, np.zeros((3, 3)))
+    R3, t3, res3, _ = icp.fit_batch(b3)
+    assert res3["iters"][1] == 0 and np.array_equal(R3[1], R0.reshape(4)) and np.array_equal(t3[1], t0)
+    Rg, tg, resg, _ = icp.fit_batch(good)
+    assert np.array_equal(R3[[0, 2]], Rg) and np.array_equal(t3[[0, 2]], tg)
+    icp.close()
+
+
+def test_class_constraint_and_small_class_skip():
+    # icpPointToPoint.cpp:59,93: a class with <= 3 MODEL points is skipped entirely
+    rs = np.random.RandomState(9)
+    m_nga = rs.uniform(-5, 5, (200, 2))
+    m_ga = rs.uniform(-5, 5, (3, 2))
+    icp = api.Icp(m_ga, m_nga, max_iter=1, min_delta=-1)
+    model = O.IcpModel(m_ga, m_nga)
+    R0, t0 = synth.pose_to_Rt(0.01, 0.0, 0.0)
+    t_ga, t_nga = m_ga + 0.01, m_nga[:50] + 0.01
+    R, t, res = icp.fit(t_ga, t_nga, R0, t0)
+    d, Ro, to, nc, corr = model.fit_step(t_ga, t_nga, R0, t0, O.icp_params())
+    assert res.n_corr == nc == 50
+    assert np.abs(t - to).max() < 1e-12 and np.abs(R - Ro).max() < 1e-12
+    # scene GA points only ever match model GA points
+    m_ga2 = rs.uniform(-5, 5, (50, 2))
+    icp2 = api.Icp(m_ga2, m_nga + 100.0, max_iter=1, min_delta=-1)   # NGA model far away
+    R, t, res = icp2.fit(np.zeros((0, 2)), m_ga2[:20] + 0.01, R0, t0)  # scene is all NGA
+    assert res.n_corr == 0 and res.delta == -1.0
+    icp.close(); icp2.close()
+
+
+def test_all_nga_variant_and_global_memory_index(world):
+    """nGA = 0 is legal (guarded at icpPointToPoint.cpp:59); and the HBM-resident
+    index gives the same poses as the LDS-resident one."""
+    m_ga, m_nga = synth.make_map(all_nga=True)
+    assert len(m_ga) == 0
+    batch = synth.make_batch(4, n_loop=256, all_nga=True)
+    model = O.IcpModel(m_ga, m_nga)
+    Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R,
+                                                  batch.t, O.icp_params(20, 1e-6, 5.0))
+    outs = []
+    for fg in (0, 1):
+        icp = api.Icp(m_ga, m_nga, force_global=fg)
+        R, t, res, _ = icp.fit_batch(batch)
+        assert np.array_equal(res["n_corr"], ncorr) and np.array_equal(res["iters"], iters)
+        assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL
+        outs.append((R, t))
+        icp.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_large_model_falls_back_to_hbm_index():
+    """A model too large for 160 KB of LDS (2 x 19 999 points, the CCICP cap,
+    icpTools.h:21) is served from HBM/L2 with identical results."""
+    m_ga, m_nga = synth.make_map(39998)
+    icp = api.Icp(m_ga, m_nga, max_iter=10, min_delta=-1)
+    assert not icp.index_info()["in_lds"]
+    batch = synth.make_batch(4, n_loop=256)
+    R, t, res, _ = icp.fit_batch(batch)
+    model = O.IcpModel(m_ga, m_nga)
+    Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R,
+                                                  batch.t, O.icp_params(10, -1, 5.0))
+    assert np.array_equal(res["n_corr"], ncorr)
+    assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL
+    icp.close()
+
+
+def test_config2_full_size_properties(world):
+    """256 scans x 30 iterations (BASELINE config 2) -- size-independent checks:
+    determinism, per-scan independence of the batch, convergence to the truth."""
+    m_ga, m_nga, _ = world
+    batch = synth.make_batch(256)
+    icp = api.Icp(m_ga, m_nga, max_iter=30, min_delta=-1.0)
+    R, t, res, _ = icp.fit_batch(batch)
+    R2, t2, res2, _ = icp.fit_batch(batch)
+    assert np.array_equal(R, R2) and np.array_equal(t, t2)            # bitwise reproducible
+    sub = batch.shard(3, 8)                                           # scans 96..127 alone
+    Rs, ts, _, _ = icp.fit_batch(sub)
+    assert np.array_equal(Rs, R[96:128]) and np.array_equal(ts, t[96:128])
+    assert (res["iters"] == 30).all() and (res["n_corr"] > 900).all()
+    assert np.abs(t - batch.true_poses[:, :2]).max() < 0.03
+    assert ang_diff(yaw(R), batch.true_poses[:, 2]).max() < 3e-3
+    icp.close()
