@@ -58,6 +58,7 @@ int slam_free(void *dptr);
 int slam_memset(void *dptr, int value, size_t bytes, slam_stream_t stream);
 int slam_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, slam_stream_t stream);
 int slam_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, slam_stream_t stream);
+int slam_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, slam_stream_t stream); /* asynchronous */
 int slam_stream_create(slam_stream_t *stream);
 int slam_stream_destroy(slam_stream_t stream);
 int slam_stream_synchronize(slam_stream_t stream);

@@ -51,6 +51,7 @@ _lib = None
 EXPORTS = [
     "slam_last_error", "slam_version", "slam_device_count", "slam_set_device", "slam_device_info",
     "slam_malloc", "slam_free", "slam_memset", "slam_memcpy_h2d", "slam_memcpy_d2h",
+    "slam_memcpy_d2d",
     "slam_stream_create", "slam_stream_destroy", "slam_stream_synchronize",
     "slam_device_synchronize", "slam_event_create", "slam_event_destroy", "slam_event_record",
     "slam_event_synchronize", "slam_event_elapsed_ms",
@@ -88,6 +89,7 @@ def lib():
     L.slam_memset.argtypes = [_vp, C.c_int, C.c_size_t, _vp]
     L.slam_memcpy_h2d.argtypes = [_vp, _vp, C.c_size_t, _vp]
     L.slam_memcpy_d2h.argtypes = [_vp, _vp, C.c_size_t, _vp]
+    L.slam_memcpy_d2d.argtypes = [_vp, _vp, C.c_size_t, _vp]
     L.slam_stream_create.argtypes = [C.POINTER(_vp)]
     L.slam_stream_destroy.argtypes = [_vp]
     L.slam_stream_synchronize.argtypes = [_vp]
@@ -194,6 +196,10 @@ class DeviceArray:
         out = np.empty(self.shape, dtype=self.dtype)
         check(lib().slam_memcpy_d2h(_ptr(out), self.ptr, self.nbytes, stream))
         return out
+
+    def copy_from(self, other, stream=None):
+        assert other.nbytes == self.nbytes
+        check(lib().slam_memcpy_d2d(self.ptr, other.ptr, self.nbytes, _sp(stream)))
 
     def zero(self, stream=None):
         check(lib().slam_memset(self.ptr, 0, self.nbytes, stream))

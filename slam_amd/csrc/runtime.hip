@@ -119,6 +119,14 @@ int slam_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, slam_stre
     return SLAM_OK;
 }
 
+int slam_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, slam_stream_t stream)
+{
+    SLAM_TRY(require_device());
+    if (!bytes) return SLAM_OK;
+    SLAM_HIP(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return SLAM_OK;
+}
+
 int slam_stream_create(slam_stream_t *stream)
 {
     SLAM_REQUIRE(stream, SLAM_E_INVALID, "slam_stream_create: null out pointer");

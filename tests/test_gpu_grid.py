@@ -172,7 +172,7 @@ def test_inorder_mode_is_reference_order_exact():
     drv = np.full(g.cells, -1, np.int8)
     occ = np.full(g.cells, -1, np.int8)
     for scan in range(12):
-        c = rs.randn(2) * 3
+        c = np.concatenate([rs.randn(2) * 3, [0, 0]])
         obs = (c + rs.randn(4000, 4) * [1.5, 1.5, 1, 1]).astype(np.float32)
         gnd = (rs.randn(6000, 4) * 6).astype(np.float32)
         g.add_scan_inorder(obs, gnd)
