@@ -117,6 +117,12 @@ struct Beam { // integer Bresenham endpoints in window cells; x0 < 0 marks a dro
     short x0, y0, x1, y1;
 };
 
+constexpr int kTile = 128;             // cells per tile side
+constexpr int kTileStride = kTile + 1; // LDS row pitch in words: vertical neighbours fall on adjacent banks
+constexpr int kTileThreads = 1024;
+constexpr int kTileWaves = kTileThreads / 64;
+constexpr int kChunk = 1024;           // beams per chunk = 64 per wavefront of a tile workgroup
+
 __device__ inline Beam make_beam(const GridView &g, float ox, float oy, float ex, float ey)
 {
     Beam b;
@@ -134,59 +140,83 @@ __device__ inline Beam make_beam(const GridView &g, float ox, float oy, float ex
     return b;
 }
 
-__global__ __launch_bounds__(256) void beams_from_rays_kernel(GridView g, const float2 *origin,
-                                                              const float2 *end, int n, Beam *beams,
-                                                              int4 *chunk_box, int chunk)
+// One workgroup = one chunk of kChunk beams: stores the integer beams and the
+// chunk's bounding box (block reduction, no atomics).
+__device__ inline void store_beam_and_box(const Beam &b, bool in_range, int i, Beam *beams, int4 *chunk_box)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float2 o = origin[i], e = end[i];
-    const Beam   b = make_beam(g, o.x, o.y, e.x, e.y);
-    beams[i] = b;
-    if (b.x0 >= 0 && chunk_box) {
-        int4 *cb = &chunk_box[i / chunk];
-        atomicMin(&cb->x, min((int)b.x0, (int)b.x1));
-        atomicMin(&cb->y, min((int)b.y0, (int)b.y1));
-        atomicMax(&cb->z, max((int)b.x0, (int)b.x1));
-        atomicMax(&cb->w, max((int)b.y0, (int)b.y1));
+    __shared__ int red[4][kTileWaves];
+    if (in_range) beams[i] = b;
+    const bool ok = in_range && b.x0 >= 0;
+    int lo_x = ok ? min((int)b.x0, (int)b.x1) : 0x7fffffff, lo_y = ok ? min((int)b.y0, (int)b.y1) : 0x7fffffff;
+    int hi_x = ok ? max((int)b.x0, (int)b.x1) : -1, hi_y = ok ? max((int)b.y0, (int)b.y1) : -1;
+    for (int off = 32; off > 0; off >>= 1) {
+        lo_x = min(lo_x, __shfl_xor(lo_x, off));
+        lo_y = min(lo_y, __shfl_xor(lo_y, off));
+        hi_x = max(hi_x, __shfl_xor(hi_x, off));
+        hi_y = max(hi_y, __shfl_xor(hi_y, off));
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[0][wave] = lo_x;
+        red[1][wave] = lo_y;
+        red[2][wave] = hi_x;
+        red[3][wave] = hi_y;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kTileWaves; ++w) {
+            lo_x = min(lo_x, red[0][w]);
+            lo_y = min(lo_y, red[1][w]);
+            hi_x = max(hi_x, red[2][w]);
+            hi_y = max(hi_y, red[3][w]);
+        }
+        chunk_box[blockIdx.x] = make_int4(lo_x, lo_y, hi_x, hi_y);
     }
 }
 
-__global__ __launch_bounds__(256) void beams_from_scans_kernel(GridView g, const double2 *pts,
-                                                               const int *scan_off, int n_scans,
-                                                               const double *R, const double *t, int n,
-                                                               Beam *beams, int4 *chunk_box, int chunk)
+__global__ __launch_bounds__(kChunk) void beams_from_rays_kernel(GridView g, const float2 *origin,
+                                                                 const float2 *end, int n, Beam *beams,
+                                                                 int4 *chunk_box)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    int lo = 0, hi = n_scans - 1; // scan of point i: last s with scan_off[s] <= i
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (scan_off[mid] <= i)
-            lo = mid;
-        else
-            hi = mid - 1;
+    const int  i = blockIdx.x * kChunk + threadIdx.x;
+    const bool in = i < n;
+    Beam       b;
+    b.x0 = -1;
+    b.y0 = b.x1 = b.y1 = 0;
+    if (in) {
+        const float2 o = origin[i], e = end[i];
+        b = make_beam(g, o.x, o.y, e.x, e.y);
     }
-    const double *Rs = R + 4 * (size_t)lo, *ts = t + 2 * (size_t)lo;
-    const double2 P = pts[i];
-    // end point formed as icpPointToPoint.cpp:69-70 forms its query
-    const float ex = (float)__dadd_rn(__dadd_rn(__dmul_rn(Rs[0], P.x), __dmul_rn(Rs[1], P.y)), ts[0]);
-    const float ey = (float)__dadd_rn(__dadd_rn(__dmul_rn(Rs[2], P.x), __dmul_rn(Rs[3], P.y)), ts[1]);
-    const Beam  b = make_beam(g, (float)ts[0], (float)ts[1], ex, ey);
-    beams[i] = b;
-    if (b.x0 >= 0 && chunk_box) {
-        int4 *cb = &chunk_box[i / chunk];
-        atomicMin(&cb->x, min((int)b.x0, (int)b.x1));
-        atomicMin(&cb->y, min((int)b.y0, (int)b.y1));
-        atomicMax(&cb->z, max((int)b.x0, (int)b.x1));
-        atomicMax(&cb->w, max((int)b.y0, (int)b.y1));
-    }
+    store_beam_and_box(b, in, i, beams, chunk_box);
 }
 
-__global__ void init_chunk_box_kernel(int4 *cb, int n)
+__global__ __launch_bounds__(kChunk) void beams_from_scans_kernel(GridView g, const double2 *pts,
+                                                                  const int *scan_off, int n_scans,
+                                                                  const double *R, const double *t, int n,
+                                                                  Beam *beams, int4 *chunk_box)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) cb[i] = make_int4(0x7fffffff, 0x7fffffff, -1, -1);
+    const int  i = blockIdx.x * kChunk + threadIdx.x;
+    const bool in = i < n;
+    Beam       b;
+    b.x0 = -1;
+    b.y0 = b.x1 = b.y1 = 0;
+    if (in) {
+        int lo = 0, hi = n_scans - 1; // scan of point i: last s with scan_off[s] <= i
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (scan_off[mid] <= i)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        const double *Rs = R + 4 * (size_t)lo, *ts = t + 2 * (size_t)lo;
+        const double2 P = pts[i];
+        // end point formed as icpPointToPoint.cpp:69-70 forms its query
+        const float ex = (float)__dadd_rn(__dadd_rn(__dmul_rn(Rs[0], P.x), __dmul_rn(Rs[1], P.y)), ts[0]);
+        const float ey = (float)__dadd_rn(__dadd_rn(__dmul_rn(Rs[2], P.x), __dmul_rn(Rs[3], P.y)), ts[1]);
+        b = make_beam(g, (float)ts[0], (float)ts[1], ex, ey);
+    }
+    store_beam_and_box(b, in, i, beams, chunk_box);
 }
 
 // one global atomic per traversed cell (baseline implementation)
@@ -231,122 +261,214 @@ __global__ __launch_bounds__(256) void raycast_global_kernel(GridView g, const B
     block_add_updates(g.updates, did);
 }
 
-constexpr int kTile = 128;          // cells per tile side
-constexpr int kTileThreads = 1024;
-constexpr int kChunk = 1024;        // beams per culling chunk
-constexpr int kChunksPerGroup = 8;
+// Work list for the tiled raycast, built without atomics (so its order is
+// deterministic): for every tile the chunks whose bounding box overlaps it.
+//   tile_count : one wavefront per tile, ballot + popcount over the chunk boxes
+//   tile_scan  : exclusive prefix sums -> item_off[] (items) and seg_off[]
+//                (segments of <= kSeg items of ONE tile: the unit a workgroup takes)
+//   tile_fill  : same loop as tile_count, writes the chunk ids in chunk order
+constexpr int kSeg = 8;
 
-__device__ inline int floordiv(int a, int b) // b > 0
+__device__ inline bool box_overlaps_tile(const int4 cb, int tx0, int ty0, int tx1, int ty1)
 {
-    int q = a / b;
-    if ((a % b) != 0 && (a < 0)) --q;
-    return q;
+    return cb.z >= tx0 && cb.x <= tx1 && cb.w >= ty0 && cb.y <= ty1; // empty boxes have z = w = -1
 }
-__device__ inline int ceildiv(int a, int b) { return -floordiv(-a, b); } // b > 0
 
-// Tiled raycast: blockIdx.x = tile, blockIdx.y = group of beam chunks.
-__global__ __launch_bounds__(kTileThreads) void raycast_tiled_kernel(GridView g, const Beam *beams, int n,
-                                                                     const int4 *chunk_box, int n_chunks,
-                                                                     int tiles_x)
+template <bool FILL>
+__global__ __launch_bounds__(256) void tile_items_kernel(const int4 *chunk_box, int n_chunks, int tiles_x,
+                                                         int n_tiles, int sx, int sy, int *cnt,
+                                                         const int *item_off, int *items)
 {
-    __shared__ unsigned tile[kTile * kTile]; // hits << 16 | misses
-    __shared__ int      any_overlap;
-
-    const int tx0 = (blockIdx.x % tiles_x) * kTile, ty0 = (blockIdx.x / tiles_x) * kTile;
-    const int tx1 = min(tx0 + kTile, g.sx) - 1, ty1 = min(ty0 + kTile, g.sy) - 1;
-    const int c_first = blockIdx.y * kChunksPerGroup;
-    const int c_last = min(c_first + kChunksPerGroup, n_chunks);
-    const int tid = threadIdx.x;
-
-    if (tid == 0) any_overlap = 0;
-    __syncthreads();
-    if (tid < c_last - c_first) {
-        const int4 cb = chunk_box[c_first + tid];
-        if (cb.z >= tx0 && cb.x <= tx1 && cb.w >= ty0 && cb.y <= ty1) any_overlap = 1;
+    const int t = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (t >= n_tiles) return;
+    const int tx0 = (t % tiles_x) * kTile, ty0 = (t / tiles_x) * kTile;
+    const int tx1 = min(tx0 + kTile, sx) - 1, ty1 = min(ty0 + kTile, sy) - 1;
+    int       c = 0;
+    const int base_out = FILL ? item_off[t] : 0;
+    for (int base = 0; base < n_chunks; base += 64) {
+        const int  ch = base + lane;
+        const bool ov = ch < n_chunks && box_overlaps_tile(chunk_box[ch], tx0, ty0, tx1, ty1);
+        const unsigned long long m = __ballot(ov);
+        if (FILL && ov) items[base_out + c + __popcll(m & ((1ull << lane) - 1ull))] = ch;
+        c += __popcll(m);
     }
-    __syncthreads();
-    if (!any_overlap) return; // uniform
+    if (!FILL && lane == 0) cnt[t] = c;
+}
 
-    for (int i = tid; i < kTile * kTile; i += kTileThreads) tile[i] = 0u;
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const int *cnt, int n_tiles, int *item_off, int *seg_off,
+                                                         int *queue)
+{
+    __shared__ int carry[2];
+    __shared__ int wsum[2][16];
+    const int tid = threadIdx.x;
+    if (tid == 0) carry[0] = carry[1] = 0;
     __syncthreads();
+    for (int base = 0; base < n_tiles; base += 1024) {
+        const int i = base + tid;
+        const int v0 = i < n_tiles ? cnt[i] : 0;
+        const int v1 = (v0 + kSeg - 1) / kSeg;
+        int       x0 = v0, x1 = v1;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y0 = __shfl_up(x0, off), y1 = __shfl_up(x1, off);
+            if ((tid & 63) >= off) {
+                x0 += y0;
+                x1 += y1;
+            }
+        }
+        if ((tid & 63) == 63) {
+            wsum[0][tid >> 6] = x0;
+            wsum[1][tid >> 6] = x1;
+        }
+        __syncthreads();
+        int w0 = 0, w1 = 0;
+        for (int w = 0; w < (tid >> 6); ++w) {
+            w0 += wsum[0][w];
+            w1 += wsum[1][w];
+        }
+        const int in0 = carry[0] + w0 + x0, in1 = carry[1] + w1 + x1;
+        if (i < n_tiles) {
+            item_off[i] = in0 - v0;
+            seg_off[i] = in1 - v1;
+        }
+        __syncthreads();
+        if (tid == 1023) {
+            carry[0] = in0;
+            carry[1] = in1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        item_off[n_tiles] = carry[0];
+        seg_off[n_tiles] = carry[1];
+        queue[0] = 0;        // next segment to take
+        queue[1] = carry[1]; // number of segments
+    }
+}
 
-    unsigned did = 0;
-    for (int c = c_first; c < c_last; ++c) {
-        const int4 cb = chunk_box[c];
-        if (!(cb.z >= tx0 && cb.x <= tx1 && cb.w >= ty0 && cb.y <= ty1)) continue; // uniform
-        const int b_end = min((c + 1) * kChunk, n);
-        for (int bi = c * kChunk + tid; bi < b_end; bi += kTileThreads) {
-            const Beam b = beams[bi];
-            if (b.x0 < 0) continue;
-            const int x0 = b.x0, y0 = b.y0, x1 = b.x1, y1 = b.y1;
-            if (max(x0, x1) < tx0 || min(x0, x1) > tx1 || max(y0, y1) < ty0 || min(y0, y1) > ty1) continue;
-            const int dx = abs(x1 - x0), dy = abs(y1 - y0);
-            // u = major axis, v = minor axis; step i in [0, L], cell i = (u0 + su*i, v0 + sv*k_i),
-            // k_i = floor((2*i*dv + du) / (2*du)); i == L is the end cell (hit)
-            const bool xm = dx >= dy;
-            const int  u0 = xm ? x0 : y0, v0 = xm ? y0 : x0;
-            const int  su = xm ? (x1 > x0 ? 1 : -1) : (y1 > y0 ? 1 : -1);
-            const int  sv = xm ? (y1 > y0 ? 1 : -1) : (x1 > x0 ? 1 : -1);
-            const int  du = xm ? dx : dy, dv = xm ? dy : dx;
-            const int  tu0 = xm ? tx0 : ty0, tu1 = xm ? tx1 : ty1;
-            const int  tv0 = xm ? ty0 : tx0, tv1 = xm ? ty1 : tx1;
-            int i_lo = 0, i_hi = du;
-            // u0 + su*i in [tu0, tu1]
-            if (su > 0) {
-                i_lo = max(i_lo, tu0 - u0);
-                i_hi = min(i_hi, tu1 - u0);
-            } else {
-                i_lo = max(i_lo, u0 - tu1);
-                i_hi = min(i_hi, u0 - tu0);
+// Tiled raycast.  Persistent workgroups take SEGMENTS (<= kSeg chunks of one
+// tile) from a global queue.  For a segment the workgroup zeroes a 128x128
+// tile of packed (hits<<16 | misses) counters in LDS, its 16 wavefronts pull
+// (chunk, 64-beam block) pairs from an LDS counter, and the tile is written
+// back once with coalesced global atomics.  Within a block the lanes first
+// prepare "their" beam against the tile (clip along the major axis, pack the
+// line parameters), one ballot finds the beams that enter the tile, and the
+// wavefront then walks those beams one at a time with the 64 lanes on 64
+// CONSECUTIVE Bresenham steps, each from the closed form
+//   v_i = v0 + sv*floor((2*i*dv + du) / (2*du)),
+// so there is no per-lane walk and no divergence, and with the 129-word row
+// pitch x-major and y-major beams both spread over distinct LDS banks.
+__global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView g, const Beam *beams, int n,
+                                                                        const int *items, const int *item_off,
+                                                                        const int *seg_off, int n_tiles,
+                                                                        int *queue, int tiles_x)
+{
+    __shared__ __attribute__((aligned(16))) unsigned tile[kTile * kTileStride];
+    __shared__ int s_seg, s_pair;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n_segs = queue[1];
+    unsigned  did = 0; // wave-uniform count, added once by lane 0
+
+    for (;;) {
+        __syncthreads(); // the previous segment's write-back has read the tile
+        if (tid == 0) {
+            s_seg = atomicAdd(&queue[0], 1);
+            s_pair = 0;
+        }
+        for (int i = tid * 4; i < kTile * kTileStride; i += kTileThreads * 4)
+            *reinterpret_cast<uint4 *>(&tile[i]) = make_uint4(0u, 0u, 0u, 0u);
+        __syncthreads();
+        const int seg = s_seg;
+        if (seg >= n_segs) break;
+
+        int lo = 0, hi = n_tiles - 1; // tile of the segment: last t with seg_off[t] <= seg
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (seg_off[mid] <= seg)
+                lo = mid;
+            else
+                hi = mid - 1;
+        }
+        const int t = lo;
+        const int it0 = item_off[t] + (seg - seg_off[t]) * kSeg;
+        const int n_pairs = (min(it0 + kSeg, item_off[t + 1]) - it0) * kTileWaves;
+        const int tx0 = (t % tiles_x) * kTile, ty0 = (t / tiles_x) * kTile;
+        const int tx1 = min(tx0 + kTile, g.sx) - 1, ty1 = min(ty0 + kTile, g.sy) - 1;
+
+        for (;;) {
+            int p = 0;
+            if (lane == 0) p = atomicAdd(&s_pair, 1);
+            p = __builtin_amdgcn_readfirstlane(p);
+            if (p >= n_pairs) break;
+            const int bi = items[it0 + p / kTileWaves] * kChunk + (p % kTileWaves) * 64 + lane;
+
+            // ---- per lane: prepare this lane's beam against the tile
+            int  W0 = 0, W1 = 0, W2 = 0, W3 = 0;
+            bool enters = false;
+            if (bi < n) {
+                const int2 raw = *reinterpret_cast<const int2 *>(&beams[bi]);
+                const int  x0 = (short)(raw.x & 0xffff), y0 = raw.x >> 16;
+                const int  x1 = (short)(raw.y & 0xffff), y1 = raw.y >> 16;
+                const int  dx = abs(x1 - x0), dy = abs(y1 - y0);
+                // u = major axis, v = minor axis; step i in [0, du]; i == du is the end cell (hit)
+                const bool xm = dx >= dy;
+                const int  u0 = xm ? x0 : y0, v0 = xm ? y0 : x0, u1 = xm ? x1 : y1, v1 = xm ? y1 : x1;
+                const int  du = xm ? dx : dy, dv = xm ? dy : dx;
+                const int  tu0 = xm ? tx0 : ty0, tu1 = xm ? tx1 : ty1;
+                const int  tv0 = xm ? ty0 : tx0, tv1 = xm ? ty1 : tx1;
+                const bool up = u1 > u0, vp = v1 > v0;
+                const int  i_lo = max(0, up ? tu0 - u0 : u0 - tu1);
+                const int  i_hi = min(du, up ? tu1 - u0 : u0 - tu0);
+                enters = x0 >= 0 && i_lo <= i_hi && max(v0, v1) >= tv0 && min(v0, v1) <= tv1;
+                W0 = du | (dv << 15) | ((int)xm << 30);
+                W1 = ((u0 - tu0) & 0xffff) | ((v0 - tv0) << 16);
+                W2 = i_lo | (i_hi << 15) | ((int)up << 30) | ((int)vp << 31);
+                W3 = __float_as_int(1.0f / (float)max(2 * du, 1));
             }
-            // v0 + sv*k in [tv0, tv1]  ->  k in [k_lo, k_hi]
-            int k_lo, k_hi;
-            if (sv > 0) {
-                k_lo = tv0 - v0;
-                k_hi = tv1 - v0;
-            } else {
-                k_lo = v0 - tv1;
-                k_hi = v0 - tv0;
-            }
-            k_hi = min(k_hi, dv); // k never exceeds dv; keeps the products below inside int32
-            if (dv == 0) {
-                if (k_lo > 0 || k_hi < 0) continue;
-            } else {
-                // k_i >= k_lo  <=>  i >= ceil((2*du*k_lo - du) / (2*dv))
-                // k_i <= k_hi  <=>  i <= floor((2*du*(k_hi+1) - du - 1) / (2*dv))
-                if (k_lo > 0) i_lo = max(i_lo, ceildiv(2 * du * k_lo - du, 2 * dv));
-                i_hi = min(i_hi, floordiv(2 * du * (k_hi + 1) - du - 1, 2 * dv));
-            }
-            if (i_lo > i_hi) continue;
-            const int num = 2 * i_lo * dv + du;
-            int       k = du ? num / (2 * du) : 0;
-            int       e = du ? num - k * 2 * du : 0; // running remainder, < 2*du
-            int       u = u0 + su * i_lo, v = v0 + sv * k;
-            for (int i = i_lo; i <= i_hi; ++i) {
-                const int lx = (xm ? u : v) - tx0, ly = (xm ? v : u) - ty0;
-                atomicAdd(&tile[ly * kTile + lx], i == du ? 0x10000u : 1u);
-                u += su;
-                e += 2 * dv;
-                if (e >= 2 * du) {
-                    v += sv;
-                    e -= 2 * du;
+            unsigned long long mask = __ballot(enters);
+
+            // ---- per entering beam: 64 lanes on 64 consecutive steps
+            while (mask) {
+                const int src = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                const int   w0 = __builtin_amdgcn_readlane(W0, src), w1 = __builtin_amdgcn_readlane(W1, src);
+                const int   w2 = __builtin_amdgcn_readlane(W2, src);
+                const float rden = __int_as_float(__builtin_amdgcn_readlane(W3, src));
+                const int   du = w0 & 0x7fff, dv = (w0 >> 15) & 0x7fff;
+                const bool  xm = (w0 >> 30) & 1;
+                const int   ub = (short)(w1 & 0xffff), vb = w1 >> 16;
+                const int   i_lo = w2 & 0x7fff, i_hi = (w2 >> 15) & 0x7fff;
+                const int   su = ((w2 >> 30) & 1) ? 1 : -1, sv = (w2 < 0) ? 1 : -1;
+                const int   den = max(2 * du, 1), dv2 = 2 * dv;
+                const int   tvn = xm ? ty1 - ty0 : tx1 - tx0;
+                const int   rs = xm ? kTileStride : 1, cs = xm ? 1 : kTileStride; // LDS pitch along v / along u
+                for (int i = i_lo + lane; i <= i_hi; i += 64) {
+                    const int num = __mul24(i, dv2) + du;   // < 2^31: i, dv < 2^15
+                    int       k = (int)((float)num * rden); // floor(num/den) up to +-1 ...
+                    const int r = num - __mul24(k, den);
+                    k += (r >= den) - (r < 0);              // ... fixed by the exact remainder
+                    const int  v = vb + __mul24(k, sv);
+                    const bool in = (unsigned)v <= (unsigned)tvn;
+                    if (in) {
+                        const int u = ub + __mul24(i, su);
+                        atomicAdd(&tile[__mul24(v, rs) + __mul24(u, cs)], i == du ? 0x10000u : 1u);
+                    }
+                    did += (unsigned)__popcll(__ballot(in));
                 }
             }
-            did += (unsigned)(i_hi - i_lo + 1);
+        }
+        __syncthreads();
+        // coalesced write-back: consecutive lanes -> consecutive x of one row
+        for (int i = tid; i < kTile * kTile; i += kTileThreads) {
+            const int      lx = i & (kTile - 1), ly = i / kTile;
+            const unsigned v = tile[ly * kTileStride + lx];
+            if (!v) continue;
+            const int s = storage_index(g, tx0 + lx, ty0 + ly);
+            if (v & 0xffffu) atomicAdd(&g.misses[s], (int)(v & 0xffffu));
+            if (v >> 16) atomicAdd(&g.hits[s], (int)(v >> 16));
         }
     }
-    __syncthreads();
-
-    // coalesced write-back: consecutive lanes -> consecutive x of one row
-    for (int i = tid; i < kTile * kTile; i += kTileThreads) {
-        const unsigned v = tile[i];
-        if (!v) continue;
-        const int x = tx0 + (i % kTile), y = ty0 + (i / kTile);
-        const int s = storage_index(g, x, y);
-        if (v & 0xffffu) atomicAdd(&g.misses[s], (int)(v & 0xffffu));
-        if (v >> 16) atomicAdd(&g.hits[s], (int)(v >> 16));
-    }
-    block_add_updates(g.updates, did);
+    if (lane == 0 && did) atomicAdd(g.updates, (unsigned long long)did);
 }
 
 // --------------------------------------------------------------- finalize
@@ -477,6 +599,12 @@ struct slam_grid {
     size_t           cap_beams = 0;
     int4            *d_chunk_box = nullptr;
     size_t           cap_chunks = 0;
+    int             *d_tile_cnt = nullptr; // [n_tiles] overlapping chunks per tile
+    int             *d_tile_fill = nullptr; // [2][n_tiles+1] item_off | seg_off
+    int             *d_queue = nullptr;    // [2] next segment, number of segments
+    int             *d_items = nullptr;    // chunk ids bucketed by tile
+    size_t           cap_items = 0;
+    int              n_cu = 256;
     void            *d_stage = nullptr;   // host-API staging
     size_t           cap_stage = 0;
     bool             state_from_inorder = false;
@@ -509,18 +637,39 @@ int reserve_beams(slam_grid *g, size_t n)
     SLAM_TRY(reserve(&p, &cc, chunks * sizeof(int4)));
     g->d_chunk_box = static_cast<int4 *>(p);
     g->cap_chunks = cc / sizeof(int4);
+    if (g->prm.raycast_impl == SLAM_RAYCAST_TILED) {
+        const size_t n_tiles = (size_t)((g->gv.sx + kTile - 1) / kTile) * ((g->gv.sy + kTile - 1) / kTile);
+        if (!g->d_tile_cnt) {
+            SLAM_HIP(hipMalloc((void **)&g->d_tile_cnt, n_tiles * sizeof(int)));
+            SLAM_HIP(hipMalloc((void **)&g->d_tile_fill, 2 * (n_tiles + 1) * sizeof(int)));
+            SLAM_HIP(hipMalloc((void **)&g->d_queue, 2 * sizeof(int)));
+        }
+        size_t ci = g->cap_items * sizeof(int);
+        p = g->d_items;
+        SLAM_TRY(reserve(&p, &ci, (chunks * n_tiles) * sizeof(int)));
+        g->d_items = static_cast<int *>(p);
+        g->cap_items = ci / sizeof(int);
+    }
     return SLAM_OK;
 }
 
 int walk_beams(slam_grid *g, int n, hipStream_t st)
 {
-    const int  n_chunks = (n + kChunk - 1) / kChunk;
-    const bool tiled = g->prm.raycast_impl == SLAM_RAYCAST_TILED;
-    if (tiled) {
+    const int n_chunks = (n + kChunk - 1) / kChunk;
+    if (g->prm.raycast_impl == SLAM_RAYCAST_TILED) {
         const int tiles_x = (g->gv.sx + kTile - 1) / kTile, tiles_y = (g->gv.sy + kTile - 1) / kTile;
-        const int groups = (n_chunks + kChunksPerGroup - 1) / kChunksPerGroup;
-        hipLaunchKernelGGL(raycast_tiled_kernel, dim3(tiles_x * tiles_y, groups), dim3(kTileThreads), 0, st,
-                           g->gv, g->d_beams, n, g->d_chunk_box, n_chunks, tiles_x);
+        const int n_tiles = tiles_x * tiles_y;
+        int      *item_off = g->d_tile_fill, *seg_off = g->d_tile_fill + (n_tiles + 1);
+        const dim3 tgrid((n_tiles * 64 + 255) / 256);
+        hipLaunchKernelGGL((tile_items_kernel<false>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
+                           n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, g->d_tile_cnt, n_tiles, item_off, seg_off,
+                           g->d_queue);
+        hipLaunchKernelGGL((tile_items_kernel<true>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
+                           n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items);
+        // persistent workgroups, two per CU (66 KB of LDS each); each drains the queue and exits
+        hipLaunchKernelGGL(raycast_tiled_kernel, dim3(2 * g->n_cu), dim3(kTileThreads), 0, st, g->gv, g->d_beams, n,
+                           g->d_items, item_off, seg_off, n_tiles, g->d_queue, tiles_x);
     } else {
         hipLaunchKernelGGL(raycast_global_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g->gv, g->d_beams, n);
     }
@@ -560,6 +709,12 @@ int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_
     else
         slam_grid_default_params(&g->prm);
     g->cells = (size_t)size_x * size_y;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            g->n_cu = std::max(1, prop.multiProcessorCount);
+    }
     int rc = SLAM_OK;
     auto alloc = [&](void **p, size_t bytes) {
         if (rc == SLAM_OK && hipMalloc(p, bytes) != hipSuccess) {
@@ -603,7 +758,8 @@ void slam_grid_destroy(slam_grid_t *g)
 {
     if (!g) return;
     void *ptrs[] = {g->d_planes, g->d_num_w, g->d_occ_w, g->d_num_s,     g->d_occ_s, g->d_delta,
-                    g->d_touched, g->d_updates, g->d_beams, g->d_chunk_box, g->d_stage};
+                    g->d_touched, g->d_updates, g->d_beams, g->d_chunk_box, g->d_stage,
+                    g->d_tile_cnt, g->d_tile_fill, g->d_queue, g->d_items};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -721,11 +877,9 @@ int slam_grid_raycast_dev(slam_grid_t *g, const float *d_origin_xy, const float 
     hipStream_t st = as_stream(stream);
     SLAM_TRY(reserve_beams(g, (size_t)n));
     const int n_chunks = (n + kChunk - 1) / kChunk;
-    hipLaunchKernelGGL(init_chunk_box_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, st, g->d_chunk_box,
-                       n_chunks);
-    hipLaunchKernelGGL(beams_from_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g->gv,
+    hipLaunchKernelGGL(beams_from_rays_kernel, dim3(n_chunks), dim3(kChunk), 0, st, g->gv,
                        reinterpret_cast<const float2 *>(d_origin_xy), reinterpret_cast<const float2 *>(d_end_xy),
-                       n, g->d_beams, g->d_chunk_box, kChunk);
+                       n, g->d_beams, g->d_chunk_box);
     SLAM_HIP(hipGetLastError());
     return walk_beams(g, n, st);
 }
@@ -753,11 +907,9 @@ int slam_grid_raycast_scans_dev(slam_grid_t *g, const double *d_pts, const int32
     const int   n = n_points;
     SLAM_TRY(reserve_beams(g, (size_t)n));
     const int n_chunks = (n + kChunk - 1) / kChunk;
-    hipLaunchKernelGGL(init_chunk_box_kernel, dim3((n_chunks + 255) / 256), dim3(256), 0, st, g->d_chunk_box,
-                       n_chunks);
-    hipLaunchKernelGGL(beams_from_scans_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g->gv,
+    hipLaunchKernelGGL(beams_from_scans_kernel, dim3(n_chunks), dim3(kChunk), 0, st, g->gv,
                        reinterpret_cast<const double2 *>(d_pts), d_scan_off, n_scans, d_R, d_t, n, g->d_beams,
-                       g->d_chunk_box, kChunk);
+                       g->d_chunk_box);
     SLAM_HIP(hipGetLastError());
     return walk_beams(g, n, st);
 }
