@@ -246,7 +246,8 @@ def main():
                                    "finalize%s" % (S, P, N_ITERS, M, GRID, GRID, RES,
                                                    ", RCCL all-reduce of int32 planes" if multi else ""),
                        "scans_per_gpu": S, "icp_iters": N_ITERS, "grid": [GRID, GRID], "resolution": RES,
-                       "map_points": M, "icp_index": info, "raycast": args.raycast},
+                       "map_points": M, "icp_index": info, "raycast": args.raycast,
+                       "raycast_worklist": grid.raycast_stats()},
             "grid_cell_updates_per_s": total_upd * args.steps / elapsed,
             "cell_updates_per_step": total_upd,
             "point_iterations_per_s": total_pts * N_ITERS * args.steps / elapsed,

@@ -214,6 +214,10 @@ int slam_grid_total_updates(slam_grid_t *g, uint64_t *n);       /* counter incre
 int slam_grid_info(slam_grid_t *g, int *size_x, int *size_y, double *resolution,
                    int *origin_x, int *origin_y);
 
+/* work-list size of the last tiled raycast: tiles of the window, (tile, 64-beam block)
+ * items and workgroup segments (for reporting) */
+int slam_grid_raycast_stats(slam_grid_t *g, int *n_tiles, int *n_items, int *n_segments);
+
 /* the two int32 planes ([hits | misses], 2*size_x*size_y ints, toroidal
  * storage order) for a collective merge; see slam_mi355x_rccl.h */
 int slam_grid_counts_dev(slam_grid_t *g, int32_t **d_planes, size_t *n_ints);

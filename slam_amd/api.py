@@ -65,7 +65,7 @@ EXPORTS = [
     "slam_grid_raycast", "slam_grid_raycast_dev", "slam_grid_raycast_scans_dev",
     "slam_grid_finalize", "slam_grid_add_scan_inorder", "slam_grid_read_counts",
     "slam_grid_read_occupancy", "slam_grid_read_num_pts", "slam_grid_total_updates",
-    "slam_grid_info", "slam_grid_counts_dev",
+    "slam_grid_info", "slam_grid_counts_dev", "slam_grid_raycast_stats",
 ]
 
 
@@ -135,6 +135,7 @@ def lib():
     L.slam_grid_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.slam_grid_counts_dev.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]
+    L.slam_grid_raycast_stats.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -448,6 +449,11 @@ class Grid:
                                    C.byref(oy)))
         return dict(size_x=sx.value, size_y=sy.value, resolution=res.value, origin_x=ox.value,
                     origin_y=oy.value)
+
+    def raycast_stats(self):
+        t, i, s = C.c_int(), C.c_int(), C.c_int()
+        check(lib().slam_grid_raycast_stats(self.h, C.byref(t), C.byref(i), C.byref(s)))
+        return dict(tiles=t.value, items=i.value, segments=s.value)
 
     def counts_dev(self):
         p, n = _vp(), C.c_size_t()

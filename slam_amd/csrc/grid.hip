@@ -25,6 +25,7 @@
 // the integer Bresenham line, so clipping to the tile cannot change them.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -86,11 +87,18 @@ __device__ inline bool point_cell(const GridView &g, float px, float py, int *cx
     return true;
 }
 
-__device__ inline void block_add_updates(unsigned long long *counter, unsigned n)
+constexpr int kUpdateSlots = 1024;
+
+// Counter of cell updates: wave reduction, then one atomic per wavefront into
+// one of kUpdateSlots slots (same-address device atomics retire at ~11 ns each,
+// so thousands of wavefronts must not share one word); the reader sums the slots.
+__device__ inline void block_add_updates(unsigned long long *slots, unsigned n)
 {
-    // wave reduction, then one atomic per wavefront
     for (int off = 32; off > 0; off >>= 1) n += __shfl_xor((int)n, off);
-    if ((threadIdx.x & 63) == 0 && n) atomicAdd(counter, (unsigned long long)n);
+    if ((threadIdx.x & 63) == 0 && n) {
+        const unsigned wave = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) + blockIdx.y * 7919u;
+        atomicAdd(&slots[wave & (kUpdateSlots - 1)], (unsigned long long)n);
+    }
 }
 
 // ------------------------------------------------------------- endpoints
@@ -121,7 +129,8 @@ constexpr int kTile = 128;             // cells per tile side
 constexpr int kTileStride = kTile + 1; // LDS row pitch in words: vertical neighbours fall on adjacent banks
 constexpr int kTileThreads = 1024;
 constexpr int kTileWaves = kTileThreads / 64;
-constexpr int kChunk = 1024;           // beams per chunk = 64 per wavefront of a tile workgroup
+constexpr int kChunk = 1024;           // beams per pre-pass workgroup
+constexpr int kBlock = 64;             // beams per culling block = one wavefront
 
 __device__ inline Beam make_beam(const GridView &g, float ox, float oy, float ex, float ey)
 {
@@ -140,11 +149,11 @@ __device__ inline Beam make_beam(const GridView &g, float ox, float oy, float ex
     return b;
 }
 
-// One workgroup = one chunk of kChunk beams: stores the integer beams and the
-// chunk's bounding box (block reduction, no atomics).
-__device__ inline void store_beam_and_box(const Beam &b, bool in_range, int i, Beam *beams, int4 *chunk_box)
+// Stores the lane's integer beam and, per wavefront, the bounding box of its
+// 64 beams (the culling unit of the tiled raycast: 64 consecutive beams of a
+// scan are a narrow wedge).  Wave reduction only: no LDS, no atomics.
+__device__ inline void store_beam_and_box(const Beam &b, bool in_range, int i, Beam *beams, int4 *block_box)
 {
-    __shared__ int red[4][kTileWaves];
     if (in_range) beams[i] = b;
     const bool ok = in_range && b.x0 >= 0;
     int lo_x = ok ? min((int)b.x0, (int)b.x1) : 0x7fffffff, lo_y = ok ? min((int)b.y0, (int)b.y1) : 0x7fffffff;
@@ -155,28 +164,12 @@ __device__ inline void store_beam_and_box(const Beam &b, bool in_range, int i, B
         hi_x = max(hi_x, __shfl_xor(hi_x, off));
         hi_y = max(hi_y, __shfl_xor(hi_y, off));
     }
-    const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        red[0][wave] = lo_x;
-        red[1][wave] = lo_y;
-        red[2][wave] = hi_x;
-        red[3][wave] = hi_y;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < kTileWaves; ++w) {
-            lo_x = min(lo_x, red[0][w]);
-            lo_y = min(lo_y, red[1][w]);
-            hi_x = max(hi_x, red[2][w]);
-            hi_y = max(hi_y, red[3][w]);
-        }
-        chunk_box[blockIdx.x] = make_int4(lo_x, lo_y, hi_x, hi_y);
-    }
+    if ((threadIdx.x & 63) == 0) block_box[i >> 6] = make_int4(lo_x, lo_y, hi_x, hi_y);
 }
 
 __global__ __launch_bounds__(kChunk) void beams_from_rays_kernel(GridView g, const float2 *origin,
                                                                  const float2 *end, int n, Beam *beams,
-                                                                 int4 *chunk_box)
+                                                                 int4 *block_box)
 {
     const int  i = blockIdx.x * kChunk + threadIdx.x;
     const bool in = i < n;
@@ -187,13 +180,13 @@ __global__ __launch_bounds__(kChunk) void beams_from_rays_kernel(GridView g, con
         const float2 o = origin[i], e = end[i];
         b = make_beam(g, o.x, o.y, e.x, e.y);
     }
-    store_beam_and_box(b, in, i, beams, chunk_box);
+    store_beam_and_box(b, in, i, beams, block_box);
 }
 
 __global__ __launch_bounds__(kChunk) void beams_from_scans_kernel(GridView g, const double2 *pts,
                                                                   const int *scan_off, int n_scans,
                                                                   const double *R, const double *t, int n,
-                                                                  Beam *beams, int4 *chunk_box)
+                                                                  Beam *beams, int4 *block_box)
 {
     const int  i = blockIdx.x * kChunk + threadIdx.x;
     const bool in = i < n;
@@ -216,7 +209,7 @@ __global__ __launch_bounds__(kChunk) void beams_from_scans_kernel(GridView g, co
         const float ey = (float)__dadd_rn(__dadd_rn(__dmul_rn(Rs[2], P.x), __dmul_rn(Rs[3], P.y)), ts[1]);
         b = make_beam(g, (float)ts[0], (float)ts[1], ex, ey);
     }
-    store_beam_and_box(b, in, i, beams, chunk_box);
+    store_beam_and_box(b, in, i, beams, block_box);
 }
 
 // one global atomic per traversed cell (baseline implementation)
@@ -262,12 +255,11 @@ __global__ __launch_bounds__(256) void raycast_global_kernel(GridView g, const B
 }
 
 // Work list for the tiled raycast, built without atomics (so its order is
-// deterministic): for every tile the chunks whose bounding box overlaps it.
-//   tile_count : one wavefront per tile, ballot + popcount over the chunk boxes
+// deterministic): for every tile the 64-beam blocks whose bounding box overlaps it.
+//   tile_count : one wavefront per tile, ballot + popcount over the block boxes
 //   tile_scan  : exclusive prefix sums -> item_off[] (items) and seg_off[]
 //                (segments of <= kSeg items of ONE tile: the unit a workgroup takes)
-//   tile_fill  : same loop as tile_count, writes the chunk ids in chunk order
-constexpr int kSeg = 8;
+//   tile_fill  : same loop as tile_count, writes the block ids in beam order
 
 __device__ inline bool box_overlaps_tile(const int4 cb, int tx0, int ty0, int tx1, int ty1)
 {
@@ -275,7 +267,7 @@ __device__ inline bool box_overlaps_tile(const int4 cb, int tx0, int ty0, int tx
 }
 
 template <bool FILL>
-__global__ __launch_bounds__(256) void tile_items_kernel(const int4 *chunk_box, int n_chunks, int tiles_x,
+__global__ __launch_bounds__(256) void tile_items_kernel(const int4 *block_box, int n_blocks, int tiles_x,
                                                          int n_tiles, int sx, int sy, int *cnt,
                                                          const int *item_off, int *items)
 {
@@ -285,18 +277,26 @@ __global__ __launch_bounds__(256) void tile_items_kernel(const int4 *chunk_box, 
     const int tx1 = min(tx0 + kTile, sx) - 1, ty1 = min(ty0 + kTile, sy) - 1;
     int       c = 0;
     const int base_out = FILL ? item_off[t] : 0;
-    for (int base = 0; base < n_chunks; base += 64) {
-        const int  ch = base + lane;
-        const bool ov = ch < n_chunks && box_overlaps_tile(chunk_box[ch], tx0, ty0, tx1, ty1);
-        const unsigned long long m = __ballot(ov);
-        if (FILL && ov) items[base_out + c + __popcll(m & ((1ull << lane) - 1ull))] = ch;
-        c += __popcll(m);
+    for (int base = 0; base < n_blocks; base += 256) { // four independent box loads in flight per lane
+        int4 cb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = base + 64 * j + lane;
+            cb[j] = ch < n_blocks ? block_box[ch] : make_int4(0, 0, -1, -1);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool               ov = box_overlaps_tile(cb[j], tx0, ty0, tx1, ty1);
+            const unsigned long long m = __ballot(ov);
+            if (FILL && ov) items[base_out + c + __popcll(m & ((1ull << lane) - 1ull))] = base + 64 * j + lane;
+            c += __popcll(m);
+        }
     }
     if (!FILL && lane == 0) cnt[t] = c;
 }
 
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const int *cnt, int n_tiles, int *item_off, int *seg_off,
-                                                         int *queue)
+                                                         int *queue, int kSeg)
 {
     __shared__ int carry[2];
     __shared__ int wsum[2][16];
@@ -345,29 +345,46 @@ __global__ __launch_bounds__(1024) void tile_scan_kernel(const int *cnt, int n_t
     }
 }
 
+// floor(num / den) for 0 <= num < 2^31, 1 <= den < 2^16, when the quotient is
+// below 2^16 (larger quotients saturate to 65536: callers clamp against <= 32767).
+// One float multiply + an exact remainder fix instead of an integer division:
+// with rden within 1 ulp of 1/den the float quotient is off by < 2^16 * 2^-21,
+// so truncation lands on floor or floor +- 1 and the remainder test repairs it.
+__device__ inline int floor_div_small(int num, int den, float rden)
+{
+    const float qf = (float)num * rden;
+    if (qf >= 65536.0f) return 65536;
+    int       q = (int)qf;
+    const int r = (int)((unsigned)num - (unsigned)__mul24(q, den));
+    q += (r >= den) - (r < 0);
+    return q;
+}
+
 // Tiled raycast.  Persistent workgroups take SEGMENTS (<= kSeg chunks of one
 // tile) from a global queue.  For a segment the workgroup zeroes a 128x128
 // tile of packed (hits<<16 | misses) counters in LDS, its 16 wavefronts pull
 // (chunk, 64-beam block) pairs from an LDS counter, and the tile is written
-// back once with coalesced global atomics.  Within a block the lanes first
-// prepare "their" beam against the tile (clip along the major axis, pack the
-// line parameters), one ballot finds the beams that enter the tile, and the
-// wavefront then walks those beams one at a time with the 64 lanes on 64
-// CONSECUTIVE Bresenham steps, each from the closed form
-//   v_i = v0 + sv*floor((2*i*dv + du) / (2*du)),
-// so there is no per-lane walk and no divergence, and with the 129-word row
-// pitch x-major and y-major beams both spread over distinct LDS banks.
+// back once with coalesced global atomics.
+// Within a block every lane owns one beam: it clips the beam's Bresenham step
+// range [0, du] to the tile exactly -- the cell of step i has the closed form
+//   (u0 + su*i, v0 + sv*floor((2*i*dv + du) / (2*du))),
+// so the clipped range and the error term at its first step are two small
+// integer divisions, not a walk -- and then all lanes step their beams in
+// lock-step with the integer error update (4 integer ops + one ds_add per
+// cell).  Clipping by closed form is what makes the tiling invisible in the
+// result: the cells are exactly those of the unclipped line.
 __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView g, const Beam *beams, int n,
                                                                         const int *items, const int *item_off,
                                                                         const int *seg_off, int n_tiles,
-                                                                        int *queue, int tiles_x)
+                                                                        int *queue, int tiles_x, int kSeg,
+                                                                        int ablate)
 {
     __shared__ __attribute__((aligned(16))) unsigned tile[kTile * kTileStride];
     __shared__ int s_seg, s_pair;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int n_segs = queue[1];
-    unsigned  did = 0; // wave-uniform count, added once by lane 0
+    unsigned  did = 0;
 
     for (;;) {
         __syncthreads(); // the previous segment's write-back has read the tile
@@ -391,25 +408,35 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
         }
         const int t = lo;
         const int it0 = item_off[t] + (seg - seg_off[t]) * kSeg;
-        const int n_pairs = (min(it0 + kSeg, item_off[t + 1]) - it0) * kTileWaves;
+        const int n_pairs = (ablate & 8) ? 0 : min(it0 + kSeg, item_off[t + 1]) - it0; // 64-beam blocks in this segment
         const int tx0 = (t % tiles_x) * kTile, ty0 = (t / tiles_x) * kTile;
         const int tx1 = min(tx0 + kTile, g.sx) - 1, ty1 = min(ty0 + kTile, g.sy) - 1;
 
-        for (;;) {
+        // each wavefront pulls blocks from the segment; the next block's beams are
+        // requested before the current one is walked (hides the two dependent loads)
+        auto grab = [&](int2 *raw) {
             int p = 0;
             if (lane == 0) p = atomicAdd(&s_pair, 1);
             p = __builtin_amdgcn_readfirstlane(p);
-            if (p >= n_pairs) break;
-            const int bi = items[it0 + p / kTileWaves] * kChunk + (p % kTileWaves) * 64 + lane;
+            if (p < n_pairs) {
+                const int bi = items[it0 + p] * kBlock + lane;
+                *raw = bi < n ? *reinterpret_cast<const int2 *>(&beams[bi]) : make_int2(-1, 0);
+            }
+            return p;
+        };
+        int2 raw = make_int2(-1, 0), raw_next = make_int2(-1, 0);
+        int  p = grab(&raw);
+        while (p < n_pairs) {
+            const int p_next = grab(&raw_next);
 
-            // ---- per lane: prepare this lane's beam against the tile
-            int  W0 = 0, W1 = 0, W2 = 0, W3 = 0;
-            bool enters = false;
-            if (bi < n) {
-                const int2 raw = *reinterpret_cast<const int2 *>(&beams[bi]);
-                const int  x0 = (short)(raw.x & 0xffff), y0 = raw.x >> 16;
-                const int  x1 = (short)(raw.y & 0xffff), y1 = raw.y >> 16;
-                const int  dx = abs(x1 - x0), dy = abs(y1 - y0);
+            // ---- clip this lane's beam to the tile
+            int rem = 0, a = 0, e = 0, dv2 = 0, den = 1, step_u = 0, step_v = 0, to_end = 0;
+            const int x0 = (short)(raw.x & 0xffff), y0 = raw.x >> 16;
+            const int x1 = (short)(raw.y & 0xffff), y1 = raw.y >> 16;
+            const bool maybe = x0 >= 0 && max(x0, x1) >= tx0 && min(x0, x1) <= tx1 && max(y0, y1) >= ty0 &&
+                               min(y0, y1) <= ty1;
+            if (__any(maybe) && !(ablate & 16)) {
+                const int dx = abs(x1 - x0), dy = abs(y1 - y0);
                 // u = major axis, v = minor axis; step i in [0, du]; i == du is the end cell (hit)
                 const bool xm = dx >= dy;
                 const int  u0 = xm ? x0 : y0, v0 = xm ? y0 : x0, u1 = xm ? x1 : y1, v1 = xm ? y1 : x1;
@@ -417,49 +444,55 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
                 const int  tu0 = xm ? tx0 : ty0, tu1 = xm ? tx1 : ty1;
                 const int  tv0 = xm ? ty0 : tx0, tv1 = xm ? ty1 : tx1;
                 const bool up = u1 > u0, vp = v1 > v0;
-                const int  i_lo = max(0, up ? tu0 - u0 : u0 - tu1);
-                const int  i_hi = min(du, up ? tu1 - u0 : u0 - tu0);
-                enters = x0 >= 0 && i_lo <= i_hi && max(v0, v1) >= tv0 && min(v0, v1) <= tv1;
-                W0 = du | (dv << 15) | ((int)xm << 30);
-                W1 = ((u0 - tu0) & 0xffff) | ((v0 - tv0) << 16);
-                W2 = i_lo | (i_hi << 15) | ((int)up << 30) | ((int)vp << 31);
-                W3 = __float_as_int(1.0f / (float)max(2 * du, 1));
-            }
-            unsigned long long mask = __ballot(enters);
-
-            // ---- per entering beam: 64 lanes on 64 consecutive steps
-            while (mask) {
-                const int src = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                const int   w0 = __builtin_amdgcn_readlane(W0, src), w1 = __builtin_amdgcn_readlane(W1, src);
-                const int   w2 = __builtin_amdgcn_readlane(W2, src);
-                const float rden = __int_as_float(__builtin_amdgcn_readlane(W3, src));
-                const int   du = w0 & 0x7fff, dv = (w0 >> 15) & 0x7fff;
-                const bool  xm = (w0 >> 30) & 1;
-                const int   ub = (short)(w1 & 0xffff), vb = w1 >> 16;
-                const int   i_lo = w2 & 0x7fff, i_hi = (w2 >> 15) & 0x7fff;
-                const int   su = ((w2 >> 30) & 1) ? 1 : -1, sv = (w2 < 0) ? 1 : -1;
-                const int   den = max(2 * du, 1), dv2 = 2 * dv;
-                const int   tvn = xm ? ty1 - ty0 : tx1 - tx0;
-                const int   rs = xm ? kTileStride : 1, cs = xm ? 1 : kTileStride; // LDS pitch along v / along u
-                for (int i = i_lo + lane; i <= i_hi; i += 64) {
-                    const int num = __mul24(i, dv2) + du;   // < 2^31: i, dv < 2^15
-                    int       k = (int)((float)num * rden); // floor(num/den) up to +-1 ...
-                    const int r = num - __mul24(k, den);
-                    k += (r >= den) - (r < 0);              // ... fixed by the exact remainder
-                    const int  v = vb + __mul24(k, sv);
-                    const bool in = (unsigned)v <= (unsigned)tvn;
-                    if (in) {
-                        const int u = ub + __mul24(i, su);
-                        atomicAdd(&tile[__mul24(v, rs) + __mul24(u, cs)], i == du ? 0x10000u : 1u);
-                    }
-                    did += (unsigned)__popcll(__ballot(in));
+                int        i_lo = max(0, up ? tu0 - u0 : u0 - tu1);
+                int        i_hi = min(du, up ? tu1 - u0 : u0 - tu0);
+                den = max(2 * du, 1);
+                dv2 = 2 * dv;
+                const float rden = __builtin_amdgcn_rcpf((float)den); // 1 ulp is ample: see floor_div_small
+                // minor axis: v0 + sv*k in [tv0, tv1]  <=>  k in [k_lo, k_hi]
+                const int k_lo = vp ? tv0 - v0 : v0 - tv1;
+                const int k_hi = min(vp ? tv1 - v0 : v0 - tv0, dv);
+                bool      enters = maybe && k_hi >= 0 && k_lo <= dv;
+                if (enters && dv > 0 && !(ablate & 32)) {
+                    const float rdv2 = __builtin_amdgcn_rcpf((float)dv2);
+                    // k_i >= k_lo  <=>  i >= ceil((2*du*k_lo - du) / (2*dv))
+                    if (k_lo > 0) i_lo = max(i_lo, floor_div_small(__mul24(den, k_lo) - du + dv2 - 1, dv2, rdv2));
+                    // k_i <= k_hi  <=>  i <= floor((2*du*(k_hi+1) - du - 1) / (2*dv))
+                    i_hi = min(i_hi, floor_div_small(__mul24(den, k_hi + 1) - du - 1, dv2, rdv2));
+                }
+                enters = enters && i_lo <= i_hi;
+                if (enters && !(ablate & 64)) {
+                    const int num = __mul24(i_lo, dv2) + du; // < 2^31
+                    const int k = du ? floor_div_small(num, den, rden) : 0;
+                    e = num - __mul24(k, den); // running remainder in [0, den)
+                    const int ul = (up ? u0 + i_lo : u0 - i_lo) - tu0, vl = (vp ? v0 + k : v0 - k) - tv0;
+                    a = xm ? vl * kTileStride + ul : ul * kTileStride + vl;
+                    step_u = (up ? 1 : -1) * (xm ? 1 : kTileStride);
+                    step_v = (vp ? 1 : -1) * (xm ? kTileStride : 1);
+                    rem = i_hi - i_lo + 1;
+                    to_end = du - i_lo; // steps until the end cell
+                    did += (unsigned)rem;
                 }
             }
+            if (ablate & 1) rem = 0;
+            // ---- all lanes step their beams together
+            while (__any(rem > 0)) {
+                if (rem > 0) atomicAdd(&tile[a], to_end == 0 ? 0x10000u : 1u);
+                a += step_u;
+                e += dv2;
+                if (e >= den) {
+                    e -= den;
+                    a += step_v;
+                }
+                --rem;
+                --to_end;
+            }
+            p = p_next;
+            raw = raw_next;
         }
         __syncthreads();
         // coalesced write-back: consecutive lanes -> consecutive x of one row
-        for (int i = tid; i < kTile * kTile; i += kTileThreads) {
+        for (int i = (ablate & 2) ? kTile * kTile : tid; i < kTile * kTile; i += kTileThreads) {
             const int      lx = i & (kTile - 1), ly = i / kTile;
             const unsigned v = tile[ly * kTileStride + lx];
             if (!v) continue;
@@ -468,7 +501,7 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
             if (v >> 16) atomicAdd(&g.hits[s], (int)(v >> 16));
         }
     }
-    if (lane == 0 && did) atomicAdd(g.updates, (unsigned long long)did);
+    block_add_updates(g.updates, did);
 }
 
 // --------------------------------------------------------------- finalize
@@ -605,6 +638,9 @@ struct slam_grid {
     int             *d_items = nullptr;    // chunk ids bucketed by tile
     size_t           cap_items = 0;
     int              n_cu = 256;
+    int              seg_items = 32; // 64-beam blocks of one tile a workgroup accumulates before writing back
+    int              ablate = 0;     // debug: SLAM_RAYCAST_ABLATE bit mask (timing experiments only)
+    int              wg_per_cu = 2;
     void            *d_stage = nullptr;   // host-API staging
     size_t           cap_stage = 0;
     bool             state_from_inorder = false;
@@ -631,7 +667,7 @@ int reserve_beams(slam_grid *g, size_t n)
     SLAM_TRY(reserve(&p, &cb, n * sizeof(Beam)));
     g->d_beams = static_cast<Beam *>(p);
     g->cap_beams = cb / sizeof(Beam);
-    const size_t chunks = (n + kChunk - 1) / kChunk + 1;
+    const size_t chunks = (n + kBlock - 1) / kBlock + kChunk / kBlock;
     size_t       cc = g->cap_chunks * sizeof(int4);
     p = g->d_chunk_box;
     SLAM_TRY(reserve(&p, &cc, chunks * sizeof(int4)));
@@ -655,7 +691,7 @@ int reserve_beams(slam_grid *g, size_t n)
 
 int walk_beams(slam_grid *g, int n, hipStream_t st)
 {
-    const int n_chunks = (n + kChunk - 1) / kChunk;
+    const int n_chunks = (n + kBlock - 1) / kBlock; // culling blocks
     if (g->prm.raycast_impl == SLAM_RAYCAST_TILED) {
         const int tiles_x = (g->gv.sx + kTile - 1) / kTile, tiles_y = (g->gv.sy + kTile - 1) / kTile;
         const int n_tiles = tiles_x * tiles_y;
@@ -664,12 +700,12 @@ int walk_beams(slam_grid *g, int n, hipStream_t st)
         hipLaunchKernelGGL((tile_items_kernel<false>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
                            n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items);
         hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, g->d_tile_cnt, n_tiles, item_off, seg_off,
-                           g->d_queue);
+                           g->d_queue, g->seg_items);
         hipLaunchKernelGGL((tile_items_kernel<true>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
                            n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items);
         // persistent workgroups, two per CU (66 KB of LDS each); each drains the queue and exits
-        hipLaunchKernelGGL(raycast_tiled_kernel, dim3(2 * g->n_cu), dim3(kTileThreads), 0, st, g->gv, g->d_beams, n,
-                           g->d_items, item_off, seg_off, n_tiles, g->d_queue, tiles_x);
+        hipLaunchKernelGGL(raycast_tiled_kernel, dim3(g->wg_per_cu * g->n_cu), dim3(kTileThreads), 0, st, g->gv, g->d_beams, n,
+                           g->d_items, item_off, seg_off, n_tiles, g->d_queue, tiles_x, g->seg_items, g->ablate);
     } else {
         hipLaunchKernelGGL(raycast_global_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g->gv, g->d_beams, n);
     }
@@ -715,6 +751,9 @@ int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             g->n_cu = std::max(1, prop.multiProcessorCount);
     }
+    if (const char *e = getenv("SLAM_RAYCAST_SEG")) g->seg_items = std::max(1, atoi(e));
+    if (const char *e = getenv("SLAM_RAYCAST_ABLATE")) g->ablate = atoi(e);
+    if (const char *e = getenv("SLAM_RAYCAST_WGPCU")) g->wg_per_cu = std::max(1, atoi(e));
     int rc = SLAM_OK;
     auto alloc = [&](void **p, size_t bytes) {
         if (rc == SLAM_OK && hipMalloc(p, bytes) != hipSuccess) {
@@ -728,7 +767,7 @@ int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_
     alloc((void **)&g->d_occ_w, g->cells);
     alloc((void **)&g->d_num_s, g->cells * sizeof(double));
     alloc((void **)&g->d_occ_s, g->cells);
-    alloc((void **)&g->d_updates, sizeof(unsigned long long));
+    alloc((void **)&g->d_updates, kUpdateSlots * sizeof(unsigned long long));
     if (rc != SLAM_OK) {
         slam_grid_destroy(g);
         return rc;
@@ -774,7 +813,7 @@ int slam_grid_clear(slam_grid_t *g, slam_stream_t stream)
     SLAM_HIP(hipMemsetAsync(g->d_num_s, 0, g->cells * sizeof(double), st));
     SLAM_HIP(hipMemsetAsync(g->d_occ_w, 0xff, g->cells, st)); // -1 = unknown (mls.cpp:26)
     SLAM_HIP(hipMemsetAsync(g->d_occ_s, 0xff, g->cells, st));
-    SLAM_HIP(hipMemsetAsync(g->d_updates, 0, sizeof(unsigned long long), st));
+    SLAM_HIP(hipMemsetAsync(g->d_updates, 0, kUpdateSlots * sizeof(unsigned long long), st));
     g->state_from_inorder = false;
     return SLAM_OK;
 }
@@ -1006,9 +1045,11 @@ int slam_grid_total_updates(slam_grid_t *g, uint64_t *n)
 {
     SLAM_REQUIRE(g && n, SLAM_E_INVALID, "slam_grid_total_updates: bad arguments");
     SLAM_TRY(require_device());
-    unsigned long long v = 0;
-    SLAM_HIP(hipMemcpy(&v, g->d_updates, sizeof v, hipMemcpyDeviceToHost));
-    *n = (uint64_t)v;
+    std::vector<unsigned long long> v(kUpdateSlots, 0);
+    SLAM_HIP(hipMemcpy(v.data(), g->d_updates, kUpdateSlots * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    uint64_t sum = 0;
+    for (unsigned long long x : v) sum += x;
+    *n = sum;
     return SLAM_OK;
 }
 
@@ -1020,6 +1061,20 @@ int slam_grid_info(slam_grid_t *g, int *size_x, int *size_y, double *resolution,
     if (resolution) *resolution = g->gv.res;
     if (origin_x) *origin_x = g->gv.ox;
     if (origin_y) *origin_y = g->gv.oy;
+    return SLAM_OK;
+}
+
+int slam_grid_raycast_stats(slam_grid_t *g, int *n_tiles, int *n_items, int *n_segments)
+{
+    SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
+    const int tiles = ((g->gv.sx + kTile - 1) / kTile) * ((g->gv.sy + kTile - 1) / kTile);
+    if (n_tiles) *n_tiles = tiles;
+    if (n_items) *n_items = 0;
+    if (n_segments) *n_segments = 0;
+    if (!g->d_tile_fill) return SLAM_OK; // no tiled raycast has run yet
+    SLAM_HIP(hipDeviceSynchronize());
+    if (n_items) SLAM_HIP(hipMemcpy(n_items, g->d_tile_fill + tiles, sizeof(int), hipMemcpyDeviceToHost));
+    if (n_segments) SLAM_HIP(hipMemcpy(n_segments, g->d_queue + 1, sizeof(int), hipMemcpyDeviceToHost));
     return SLAM_OK;
 }
 
