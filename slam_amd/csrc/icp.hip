@@ -28,6 +28,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -41,6 +42,7 @@ constexpr int kBlock = 1024;          // threads per scan workgroup
 constexpr int kWaves = kBlock / 64;
 constexpr int kNumAcc = 9;            // doubles reduced per iteration
 constexpr unsigned kLdsTotal = 160u * 1024u;
+constexpr unsigned kScratchBytes = (2u * kWaves * kNumAcc + 2u * 8u) * sizeof(double); // reduction + broadcast
 
 struct Lattice {
     int   nx, ny;
@@ -84,18 +86,136 @@ __device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > 
 
 struct Best {
     float    d;    // squared float distance (kdtree.h:33)
-    unsigned oidx; // original index within the class (kdtree.h:34)
-    int      pos;  // position in the sorted pts array
+    unsigned oidx; // original index within the class (kdtree.h:34); filled by nn_search on return
+    int      pos;  // position in the sorted pts array, -1 = none
 };
+
+// kdtree.cpp:610-612: dis += squared(data[i][k]-qv[k]), k = 0 then 1, no FMA
+__device__ inline float dist2(const float2 m, float qx, float qy)
+{
+    const float dx = m.x - qx;
+    const float dy = m.y - qy;
+    return __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+}
+
+// Candidate i at squared distance d.  Ties go to the lowest ORIGINAL index (the
+// reference leaves ties to the kd-tree's visit order; this is the brute-force
+// arbiter's rule, kdtree.cpp:360-375): the index is only read when d == best.
+template <typename StartT>
+__device__ inline void consider(Best &b, float d, int i, const StartT *oidx)
+{
+    if (d < b.d) {
+        b.d = d;
+        b.pos = i;
+    } else if (d == b.d && b.pos >= 0) {
+        if ((unsigned)oidx[i] < (unsigned)oidx[b.pos]) b.pos = i;
+    }
+}
+
+// All points of cells [c0, c1] of one lattice row: they are contiguous in the
+// sorted array.  The G lanes of the group take consecutive points; four loads
+// are kept in flight per lane and their distances are independent chains.
+// EXACT = false is the fast form: branch-free minimum by (distance, position)
+// plus a flag that says whether an exact tie d == best was ever seen; the
+// caller then repeats the search with EXACT = true (ties by original index).
+template <int G, typename StartT, bool EXACT>
+__device__ inline void scan_span(Best &b, bool &tie, const StartT *start, const float2 *pts, const StartT *oidx,
+                                 int row_base, int c0, int c1, int sub, float qx, float qy)
+{
+    if (c0 > c1) return;
+    const int a = (int)start[row_base + c0];
+    const int e = (int)start[row_base + c1 + 1];
+    int       i = a + sub;
+    for (; i + 3 * G < e; i += 4 * G) {
+        const float2 m0 = pts[i], m1 = pts[i + G], m2 = pts[i + 2 * G], m3 = pts[i + 3 * G];
+        const float  d0 = dist2(m0, qx, qy), d1 = dist2(m1, qx, qy), d2 = dist2(m2, qx, qy), d3 = dist2(m3, qx, qy);
+        if (EXACT) {
+            if (fminf(fminf(d0, d1), fminf(d2, d3)) <= b.d) {
+                consider<StartT>(b, d0, i, oidx);
+                consider<StartT>(b, d1, i + G, oidx);
+                consider<StartT>(b, d2, i + 2 * G, oidx);
+                consider<StartT>(b, d3, i + 3 * G, oidx);
+            }
+        } else {
+            // min of the four (first position wins), then one compare against the running best
+            const bool  s01 = d1 < d0, s23 = d3 < d2;
+            const float m01 = s01 ? d1 : d0, m23 = s23 ? d3 : d2;
+            const int   p01 = s01 ? i + G : i, p23 = s23 ? i + 3 * G : i + 2 * G;
+            const bool  s = m23 < m01;
+            const float m = s ? m23 : m01;
+            const int   pm = s ? p23 : p01;
+            tie |= (d0 == d1) | (d2 == d3) | (m01 == m23) | (m == b.d);
+            const bool up = m < b.d;
+            b.d = up ? m : b.d;
+            b.pos = up ? pm : b.pos;
+        }
+    }
+    for (; i < e; i += G) {
+        const float d = dist2(pts[i], qx, qy);
+        if (EXACT) {
+            consider<StartT>(b, d, i, oidx);
+        } else {
+            tie |= (d == b.d);
+            const bool up = d < b.d;
+            b.d = up ? d : b.d;
+            b.pos = up ? i : b.pos;
+        }
+    }
+}
+
+template <int G, typename StartT>
+__device__ inline void group_min(Best &b, const StartT *oidx)
+{
+    b.oidx = b.pos >= 0 ? (unsigned)oidx[b.pos] : 0xffffffffu;
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) {
+        const float    od = __shfl_xor(b.d, off);
+        const unsigned oo = (unsigned)__shfl_xor((int)b.oidx, off);
+        const int      op = __shfl_xor(b.pos, off);
+        if (od < b.d || (od == b.d && oo < b.oidx)) {
+            b.d = od;
+            b.oidx = oo;
+            b.pos = op;
+        }
+    }
+}
+
+// The search proper: fast pass, and the exact pass only for a group that met an
+// exact distance tie (measure zero on noisy data, common on gridded maps).
+template <int G, typename StartT>
+__device__ inline Best nn_search(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls,
+                                 float qx, float qy, int sub, double gate)
+{
+    bool tie = false;
+    Best b = nn_search_impl<G, StartT, false>(ix, mv, cls, qx, qy, sub, gate, tie);
+    if (G > 1) {
+#pragma unroll
+        for (int off = 1; off < G; off <<= 1) tie |= (bool)__shfl_xor((int)tie, off);
+    }
+    if (tie) {
+        bool unused = false;
+        b = nn_search_impl<G, StartT, true>(ix, mv, cls, qx, qy, sub, gate, unused);
+    }
+    return b;
+}
 
 // Exact 1-NN of (qx,qy) among the points of class `cls`, searched by the G
 // lanes of a group (`sub` = lane within the group).  `gate` (double, squared
 // metres) lets the search stop once no unseen point can pass the inlier test
 // of icpPointToPoint.cpp:76; pass +inf for an ungated search.  On return all
 // G lanes hold the same result; pos < 0 when the class is empty.
-template <int G, typename StartT>
-__device__ inline Best nn_search(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls,
-                                 float qx, float qy, int sub, double gate)
+//
+// Order of visits: the query's own cell, then square rings of radius 1, 2, 4,
+// ... cells.  Inside a ring only the cells that intersect the disk of the
+// current best distance are read (a skipped cell lies entirely farther than
+// the best found so far, which only shrinks), and cells of the previous,
+// smaller square are not read again.  The search ends when the best distance
+// is below the distance to the ring's outer edge (minus a margin that absorbs
+// the f32 rounding of the cell assignment), when that edge is beyond the
+// inlier gate, or when the ring covers the whole lattice.
+template <int G, typename StartT, bool EXACT>
+__device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls,
+                                      float qx, float qy, int sub, double gate, bool &tie)
 {
     const Lattice &L = mv.lat;
     const StartT *start = ix.start[cls];
@@ -108,58 +228,70 @@ __device__ inline Best nn_search(const IndexPtrs<StartT> &ix, const ModelView &m
     b.pos = -1;
     if (mv.n_cls[cls] <= 0) return b;
 
-    const int cx = clampi((int)floorf((qx - L.x0) * L.inv_h), 0, L.nx - 1);
-    const int cy = clampi((int)floorf((qy - L.y0) * L.inv_h), 0, L.ny - 1);
+    const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
+    const int   cx = clampi((int)floorf(fx), 0, L.nx - 1);
+    const int   cy = clampi((int)floorf(fy), 0, L.ny - 1);
 
+    scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, cy * L.nx, cx, cx, sub, qx, qy);
+    if (G > 1) group_min<G, StartT>(b, oidx);
+
+    int rp = 0; // radius of the square already visited
     for (int r = 1;; r *= 2) {
-        const int y_lo = max(cy - r, 0), y_hi = min(cy + r, L.ny - 1);
-        const int x_lo = max(cx - r, 0), x_hi = min(cx + r, L.nx - 1);
+        // the ring's own extent, then the disk of the current best distance
+        int y_lo = max(cy - r, 0), y_hi = min(cy + r, L.ny - 1);
+        int x_lo = max(cx - r, 0), x_hi = min(cx + r, L.nx - 1);
+        const bool covers = (x_lo == 0) & (y_lo == 0) & (x_hi == L.nx - 1) & (y_hi == L.ny - 1);
+        if (b.d < FLT_MAX) {
+            // points of a column (row) above cell(q + R) have x (y) > q + R: the cell map is monotone
+            const float R = (__fsqrt_rn(b.d) + L.margin) * L.inv_h;
+            x_lo = max(x_lo, (int)floorf(fx - R));
+            x_hi = min(x_hi, (int)floorf(fx + R));
+            y_lo = max(y_lo, (int)floorf(fy - R));
+            y_hi = min(y_hi, (int)floorf(fy + R));
+        }
         for (int y = y_lo; y <= y_hi; ++y) {
             const int row = y * L.nx;
-            const int a = (int)start[row + x_lo];
-            const int e = (int)start[row + x_hi + 1];
-            for (int i = a + sub; i < e; i += G) {
-                const float2 m = pts[i];
-                const float dx = m.x - qx;
-                const float dy = m.y - qy;
-                // kdtree.cpp:610-612: dis += squared(data[i][k]-qv[k]), k = 0 then 1, no FMA
-                const float d = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-                if (d <= b.d) {
-                    const unsigned oi = (unsigned)oidx[i];
-                    if (d < b.d || oi < b.oidx) {
-                        b.d = d;
-                        b.oidx = oi;
-                        b.pos = i;
-                    }
-                }
+            if (y >= cy - rp && y <= cy + rp) {
+                scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, row, x_lo, min(x_hi, cx - rp - 1), sub, qx, qy);
+                scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, row, max(x_lo, cx + rp + 1), x_hi, sub, qx, qy);
+            } else {
+                scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, row, x_lo, x_hi, sub, qx, qy);
             }
         }
-        if (G > 1) {
-#pragma unroll
-            for (int off = 1; off < G; off <<= 1) {
-                const float    od = __shfl_xor(b.d, off);
-                const unsigned oo = (unsigned)__shfl_xor((int)b.oidx, off);
-                const int      op = __shfl_xor(b.pos, off);
-                if (od < b.d || (od == b.d && oo < b.oidx)) {
-                    b.d = od;
-                    b.oidx = oo;
-                    b.pos = op;
-                }
-            }
-        }
-        const bool  covers = (x_lo == 0) & (y_lo == 0) & (x_hi == L.nx - 1) & (y_hi == L.ny - 1);
+        if (G > 1) group_min<G, StartT>(b, oidx);
         const float bound = (float)r * L.h - L.margin;
         const float b2 = bound * bound;
-        // every unseen point is farther than `bound` in x or in y
+        // every point outside the ring's square is farther than `bound` in x or in y
         if (covers || b.d < b2 || (double)b2 >= gate) break;
+        rp = r;
     }
+    if (G == 1) b.oidx = b.pos >= 0 ? (unsigned)oidx[b.pos] : 0xffffffffu;
     return b;
 }
 
-__device__ inline double wave_sum(double v, int first_off)
+// Wavefront sum of a double on the VALU's DPP cross-lane path (no LDS
+// crossbar): a 16-lane prefix by row_shr 1,2,4,8, then row_bcast 15 and 31 fold
+// the four rows; lane 63 holds the total, which is returned to all lanes.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_shift_f64(double v)
 {
-    for (int off = first_off; off < 64; off <<= 1) v += __shfl_xor(v, off);
-    return v;
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double wave_sum(double v)
+{
+    v += dpp_shift_f64<0x111, 0xf>(v); // row_shr:1
+    v += dpp_shift_f64<0x112, 0xf>(v); // row_shr:2
+    v += dpp_shift_f64<0x114, 0xf>(v); // row_shr:4
+    v += dpp_shift_f64<0x118, 0xf>(v); // row_shr:8
+    v += dpp_shift_f64<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v += dpp_shift_f64<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 
 // icpPointToPoint.cpp:159-162, closed form of svd -> V*U^T (oracle: o_p2p_rotation)
@@ -251,22 +383,95 @@ struct FitArgs {
     int            max_iter;
     double         min_delta;
     double         indist;
+    long long     *stamps; // diagnostic only (SLAM_ICP_STAMPS=1): per scan, cycles in [search, reduce, barrier, solve]
 };
 
+struct Pose {
+    double r00, r01, r10, r11, t0, t1;
+};
+
+// One scene point, searched by GG lanes (sub = lane within that group); the
+// group's lane 0 adds the correspondence to its running sums.
+template <int GG, typename StartT, int MODE>
+__device__ inline void accumulate_point(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
+                                        const Pose &T, const double2 P, bool is_ga, int sub, double acc[kNumAcc])
+{
+    // icpPointToPoint.cpp:69-70: (r00*x + r01*y) + t0 in double, stored to float
+    const float qx = (float)__dadd_rn(__dadd_rn(__dmul_rn(T.r00, P.x), __dmul_rn(T.r01, P.y)), T.t0);
+    const float qy = (float)__dadd_rn(__dadd_rn(__dmul_rn(T.r10, P.x), __dmul_rn(T.r11, P.y)), T.t1);
+    if (MODE == SLAM_ICP_P2P) {
+        const int cls = is_ga ? 0 : 1;
+        if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
+            const Best b = nn_search<GG, StartT>(ix, mv, cls, qx, qy, sub, fa.indist);
+            if (sub == 0 && b.pos >= 0 && (double)b.d < fa.indist) { // :76
+                const float2 m = ix.pts[mv.base[cls] + b.pos];
+                const double ax = (double)m.x - mv.cx, ay = (double)m.y - mv.cy;
+                const double bx = (double)qx - mv.cx, by = (double)qy - mv.cy;
+                acc[0] += 1.0;
+                acc[1] += ax;
+                acc[2] += ay;
+                acc[3] += bx;
+                acc[4] += by;
+                acc[5] += bx * ax; // H[a][b] = sum q_t[a]*q_m[b]  (:159)
+                acc[6] += bx * ay;
+                acc[7] += by * ax;
+                acc[8] += by * ay;
+            }
+        }
+    } else {
+        // icpPointToPlane.cpp:55-77: single class, no inlier gate
+        const Best b0 = nn_search<GG, StartT>(ix, mv, 0, qx, qy, sub, INFINITY);
+        const Best b1 = nn_search<GG, StartT>(ix, mv, 1, qx, qy, sub, INFINITY);
+        const bool use1 = b0.pos < 0 || (b1.pos >= 0 && b1.d < b0.d);
+        const Best b = use1 ? b1 : b0;
+        if (sub == 0 && b.pos >= 0) {
+            const int    cls = use1 ? 1 : 0;
+            const float2 m = ix.pts[mv.base[cls] + b.pos];
+            const int    all = (cls ? mv.n_cls[0] : 0) + (int)b.oidx;
+            const double nx = mv.normals[2 * all], ny = mv.normals[2 * all + 1];
+            const double dx = (double)m.x, dy = (double)m.y;
+            const double sx = (double)qx, sy = (double)qy;
+            const double a0 = ny * sx - nx * sy, a1 = nx, a2 = ny;
+            const double bb = nx * dx + ny * dy - nx * sx - ny * sy;
+            acc[0] += a0 * a0;
+            acc[1] += a0 * a1;
+            acc[2] += a0 * a2;
+            acc[3] += a1 * a1;
+            acc[4] += a1 * a2;
+            acc[5] += a2 * a2;
+            acc[6] += a0 * bb;
+            acc[7] += a1 * bb;
+            acc[8] += a2 * bb;
+        }
+    }
+}
+
+// One pass of the workgroup over kBlock/GG consecutive scene points from p0.
+template <int GG, typename StartT, int MODE>
+__device__ inline void point_pass(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
+                                  const Pose &T, int off, int n, int nga, int p0, double acc[kNumAcc])
+{
+    const int p = p0 + (int)threadIdx.x / GG;
+    if (p < n) accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, fa.pts[off + p], p < nga, (int)threadIdx.x % GG, acc);
+}
+
 // One workgroup = one scan, all iterations.  MODE: SLAM_ICP_P2P / SLAM_ICP_P2L.
+// G = lanes per scene point; G = 0 picks it per pass: one lane per point while
+// more than half a workgroup of points is left, then the widest group that
+// still covers the rest in one pass (a 1081-point scan is 1024 points at G = 1
+// plus 57 points at G = 16), so no pass runs nearly empty.
 template <int G, bool LDS, typename StartT, int MODE>
 __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *partial = reinterpret_cast<double *>(smem); // [2][kWaves][kNumAcc]
-    constexpr unsigned kScratch = 2u * kWaves * kNumAcc * sizeof(double);
+    double *bcast = partial + 2 * kWaves * kNumAcc;     // [2][8] new pose, delta, n_corr
+    constexpr unsigned kScratch = kScratchBytes;
     static_assert(kScratch % 16 == 0, "scratch keeps the blob 16-B aligned");
 
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int sub = tid % G, group = tid / G;
-    constexpr int kGroups = kBlock / G;
 
     const int off = fa.scan_off[s];
     const int n = fa.scan_off[s + 1] - off;
@@ -294,132 +499,139 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
             double acc[kNumAcc];
 #pragma unroll
             for (int k = 0; k < kNumAcc; ++k) acc[k] = 0.0;
+            const Pose T = {r00, r01, r10, r11, t0, t1};
+            long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            if (fa.stamps) c0 = __builtin_amdgcn_s_memtime();
 
-            for (int p = group; p < n; p += kGroups) {
-                const double2 P = fa.pts[off + p];
-                // icpPointToPoint.cpp:69-70: (r00*x + r01*y) + t0 in double, stored to float
-                const float qx = (float)__dadd_rn(__dadd_rn(__dmul_rn(r00, P.x), __dmul_rn(r01, P.y)), t0);
-                const float qy = (float)__dadd_rn(__dadd_rn(__dmul_rn(r10, P.x), __dmul_rn(r11, P.y)), t1);
-                if (MODE == SLAM_ICP_P2P) {
-                    const int cls = p < nga ? 0 : 1;
-                    if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
-                        const Best b = nn_search<G, StartT>(ix, mv, cls, qx, qy, sub, fa.indist);
-                        if (sub == 0 && b.pos >= 0 && (double)b.d < fa.indist) { // :76
-                            const float2 m = ix.pts[mv.base[cls] + b.pos];
-                            const double ax = (double)m.x - mv.cx, ay = (double)m.y - mv.cy;
-                            const double bx = (double)qx - mv.cx, by = (double)qy - mv.cy;
-                            acc[0] += 1.0;
-                            acc[1] += ax;
-                            acc[2] += ay;
-                            acc[3] += bx;
-                            acc[4] += by;
-                            acc[5] += bx * ax; // H[a][b] = sum q_t[a]*q_m[b]  (:159)
-                            acc[6] += bx * ay;
-                            acc[7] += by * ax;
-                            acc[8] += by * ay;
-                        }
-                    }
+            for (int p0 = 0; p0 < n;) {
+                const int rem = n - p0;
+                if (G > 0) {
+                    point_pass<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+                    p0 += kBlock / (G > 0 ? G : 1);
+                } else if (rem * 2 > kBlock) {
+                    point_pass<1, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+                    p0 += kBlock;
+                } else if (rem * 4 > kBlock) {
+                    point_pass<2, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+                    p0 += kBlock / 2;
+                } else if (rem * 8 > kBlock) {
+                    point_pass<4, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+                    p0 += kBlock / 4;
+                } else if (rem * 16 > kBlock) {
+                    point_pass<8, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+                    p0 += kBlock / 8;
                 } else {
-                    // icpPointToPlane.cpp:55-77: single class, no inlier gate
-                    const Best b0 = nn_search<G, StartT>(ix, mv, 0, qx, qy, sub, INFINITY);
-                    const Best b1 = nn_search<G, StartT>(ix, mv, 1, qx, qy, sub, INFINITY);
-                    const bool use1 = b0.pos < 0 || (b1.pos >= 0 && b1.d < b0.d);
-                    const Best b = use1 ? b1 : b0;
-                    if (sub == 0 && b.pos >= 0) {
-                        const int    cls = use1 ? 1 : 0;
-                        const float2 m = ix.pts[mv.base[cls] + b.pos];
-                        const int    all = (cls ? mv.n_cls[0] : 0) + (int)b.oidx;
-                        const double nx = mv.normals[2 * all], ny = mv.normals[2 * all + 1];
-                        const double dx = (double)m.x, dy = (double)m.y;
-                        const double sx = (double)qx, sy = (double)qy;
-                        const double a0 = ny * sx - nx * sy, a1 = nx, a2 = ny;
-                        const double bb = nx * dx + ny * dy - nx * sx - ny * sy;
-                        acc[0] += a0 * a0;
-                        acc[1] += a0 * a1;
-                        acc[2] += a0 * a2;
-                        acc[3] += a1 * a1;
-                        acc[4] += a1 * a2;
-                        acc[5] += a2 * a2;
-                        acc[6] += a0 * bb;
-                        acc[7] += a1 * bb;
-                        acc[8] += a2 * bb;
-                    }
+                    point_pass<16, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+                    p0 += kBlock / 16;
                 }
             }
 
-            // wavefront reduction (lanes with sub != 0 hold zeros), then LDS across wavefronts
+            if (fa.stamps) c1 = __builtin_amdgcn_s_memtime();
+            // wavefront reduction on the DPP path, then LDS across the 16 wavefronts
             double *my = partial + ((iter & 1) * kWaves + wave) * kNumAcc;
 #pragma unroll
             for (int k = 0; k < kNumAcc; ++k) {
-                const double v = wave_sum(acc[k], G >= 64 ? 64 : G);
+                const double v = wave_sum(acc[k]);
                 if (lane == 0) my[k] = v;
             }
+            if (fa.stamps) c2 = __builtin_amdgcn_s_memtime();
             __syncthreads();
-            double S[kNumAcc];
-#pragma unroll
-            for (int k = 0; k < kNumAcc; ++k) S[k] = 0.0;
-            const double *all = partial + (iter & 1) * kWaves * kNumAcc;
-            for (int w = 0; w < kWaves; ++w)
-#pragma unroll
-                for (int k = 0; k < kNumAcc; ++k) S[k] += all[w * kNumAcc + k];
+            if (fa.stamps) c3 = __builtin_amdgcn_s_memtime();
 
-            double R_[4], t_[2];
-            bool   have = true;
-            if (MODE == SLAM_ICP_P2P) {
-                n_corr = (int)S[0];
-                if (n_corr == 0) { // icpPointToPoint.cpp:128-131
-                    delta = -1.0;
-                    have = false;
+            // wavefront 0 alone adds the 16 partials (fixed order: bitwise reproducible)
+            // and solves; the others wait at the barrier below and read the new pose.
+            double *bc = bcast + (iter & 1) * 8;
+            if (wave == 0) {
+                const double *all = partial + (iter & 1) * kWaves * kNumAcc;
+                double        mine = 0.0;
+                if (lane < kNumAcc)
+                    for (int w = 0; w < kWaves; ++w) mine += all[w * kNumAcc + lane];
+                double S[kNumAcc];
+#pragma unroll
+                for (int k = 0; k < kNumAcc; ++k)
+                    S[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), k),
+                                            __builtin_amdgcn_readlane(__double2loint(mine), k));
+
+                double R_[4], t_[2];
+                bool   have = true;
+                double d_out = 0.0;
+                int    nc_out = 0;
+                if (MODE == SLAM_ICP_P2P) {
+                    nc_out = (int)S[0];
+                    if (nc_out == 0) { // icpPointToPoint.cpp:128-131
+                        d_out = -1.0;
+                        have = false;
+                    } else {
+                        const double inv = 1.0 / S[0];
+                        const double ma0 = S[1] * inv, ma1 = S[2] * inv; // mean of (p_m - c)
+                        const double mb0 = S[3] * inv, mb1 = S[4] * inv; // mean of (p_t - c)
+                        double H[4];
+                        H[0] = S[5] - S[3] * ma0;
+                        H[1] = S[6] - S[3] * ma1;
+                        H[2] = S[7] - S[4] * ma0;
+                        H[3] = S[8] - S[4] * ma1;
+                        p2p_rotation(H, R_);
+                        const double mm0 = mv.cx + ma0, mm1 = mv.cy + ma1;
+                        const double mt0 = mv.cx + mb0, mt1 = mv.cy + mb1;
+                        t_[0] = mm0 - (R_[0] * mt0 + R_[1] * mt1); // :163
+                        t_[1] = mm1 - (R_[2] * mt0 + R_[3] * mt1);
+                    }
                 } else {
-                    const double inv = 1.0 / S[0];
-                    const double ma0 = S[1] * inv, ma1 = S[2] * inv; // mean of (p_m - c)
-                    const double mb0 = S[3] * inv, mb1 = S[4] * inv; // mean of (p_t - c)
-                    double H[4];
-                    H[0] = S[5] - S[3] * ma0;
-                    H[1] = S[6] - S[3] * ma1;
-                    H[2] = S[7] - S[4] * ma0;
-                    H[3] = S[8] - S[4] * ma1;
-                    p2p_rotation(H, R_);
-                    const double mm0 = mv.cx + ma0, mm1 = mv.cy + ma1;
-                    const double mt0 = mv.cx + mb0, mt1 = mv.cy + mb1;
-                    t_[0] = mm0 - (R_[0] * mt0 + R_[1] * mt1); // :163
-                    t_[1] = mm1 - (R_[2] * mt0 + R_[3] * mt1);
+                    nc_out = n;
+                    double A[9] = {S[0], S[1], S[2], S[1], S[3], S[4], S[2], S[4], S[5]};
+                    double b[3] = {S[6], S[7], S[8]};
+                    if (solve3(A, b)) { // icpPointToPlane.cpp:85
+                        const double w = b[0], nn = sqrt(1.0 + w * w); // :88-95 U*V^T
+                        R_[0] = 1.0 / nn;
+                        R_[1] = -w / nn;
+                        R_[2] = w / nn;
+                        R_[3] = 1.0 / nn;
+                        t_[0] = b[1];
+                        t_[1] = b[2];
+                    } else {
+                        d_out = 0.0; // falls out of the if at :85 and returns 0
+                        have = false;
+                    }
                 }
-            } else {
-                n_corr = n;
-                double A[9] = {S[0], S[1], S[2], S[1], S[3], S[4], S[2], S[4], S[5]};
-                double b[3] = {S[6], S[7], S[8]};
-                if (solve3(A, b)) { // icpPointToPlane.cpp:85
-                    const double w = b[0], nn = sqrt(1.0 + w * w); // :88-95 U*V^T
-                    R_[0] = 1.0 / nn;
-                    R_[1] = -w / nn;
-                    R_[2] = w / nn;
-                    R_[3] = 1.0 / nn;
-                    t_[0] = b[1];
-                    t_[1] = b[2];
-                } else {
-                    delta = 0.0; // falls out of the if at :85 and returns 0
-                    have = false;
+                double o[6] = {r00, r01, r10, r11, t0, t1};
+                if (have) {
+                    // :166-167 R = R_*R ; t = R_*t + t_
+                    o[0] = R_[0] * r00 + R_[1] * r10;
+                    o[1] = R_[0] * r01 + R_[1] * r11;
+                    o[2] = R_[2] * r00 + R_[3] * r10;
+                    o[3] = R_[2] * r01 + R_[3] * r11;
+                    o[4] = (R_[0] * t0 + R_[1] * t1) + t_[0];
+                    o[5] = (R_[2] * t0 + R_[3] * t1) + t_[1];
+                    const double a0 = R_[0] - 1.0, a3 = R_[3] - 1.0;
+                    const double nr = sqrt(a0 * a0 + R_[1] * R_[1] + R_[2] * R_[2] + a3 * a3);
+                    const double nt = sqrt(t_[0] * t_[0] + t_[1] * t_[1]);
+                    d_out = nr > nt ? nr : nt; // :170
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) bc[k] = o[k];
+                    bc[6] = d_out;
+                    bc[7] = (double)nc_out;
                 }
             }
-            if (have) {
-                // :166-167 R = R_*R ; t = R_*t + t_
-                const double n00 = R_[0] * r00 + R_[1] * r10, n01 = R_[0] * r01 + R_[1] * r11;
-                const double n10 = R_[2] * r00 + R_[3] * r10, n11 = R_[2] * r01 + R_[3] * r11;
-                const double nt0 = (R_[0] * t0 + R_[1] * t1) + t_[0];
-                const double nt1 = (R_[2] * t0 + R_[3] * t1) + t_[1];
-                r00 = n00;
-                r01 = n01;
-                r10 = n10;
-                r11 = n11;
-                t0 = nt0;
-                t1 = nt1;
-                const double a0 = R_[0] - 1.0, a3 = R_[3] - 1.0;
-                const double nr = sqrt(a0 * a0 + R_[1] * R_[1] + R_[2] * R_[2] + a3 * a3);
-                const double nt = sqrt(t_[0] * t_[0] + t_[1] * t_[1]);
-                delta = nr > nt ? nr : nt; // :170
-            }
+            __syncthreads();
+            r00 = bc[0];
+            r01 = bc[1];
+            r10 = bc[2];
+            r11 = bc[3];
+            t0 = bc[4];
+            t1 = bc[5];
+            delta = bc[6];
+            n_corr = (int)bc[7];
             ++iters;
+            if (fa.stamps && (tid & 63) == 0) {
+                const long long c4 = __builtin_amdgcn_s_memtime();
+                long long *st = fa.stamps + ((size_t)s * kWaves + wave) * 4;
+                st[0] += c1 - c0;
+                st[1] += c2 - c1;
+                st[2] += c3 - c2;
+                st[3] += c4 - c3;
+            }
             if (fa.trace && tid == 0) {
                 double *tr = fa.trace + ((size_t)s * fa.max_iter + iter) * 8;
                 tr[0] = r00;
@@ -500,7 +712,8 @@ struct slam_icp {
     size_t          lds_bytes = 0;
     void           *d_blob = nullptr;
     double         *d_normals = nullptr;
-    DevBuf          w_pts, w_off, w_nga, w_R, w_t, w_res;
+    DevBuf          w_pts, w_off, w_nga, w_R, w_t, w_res, w_stamps;
+    int             n_stamps = 0;
 };
 
 namespace {
@@ -566,7 +779,7 @@ int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, 
     SLAM_HIP(hipGetDevice(&dev));
     SLAM_HIP(hipDeviceGetAttribute(&lds_cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
     const unsigned lds_total = std::min<unsigned>((unsigned)lds_cap, kLdsTotal);
-    const unsigned scratch = 2u * kWaves * kNumAcc * sizeof(double);
+    const unsigned scratch = kScratchBytes;
 
     // LDS budget for the two start arrays (u16 entries) after points + original indices
     const long fixed16 = (long)scratch + align16(8u * n_all) + align16(2u * n_all) + 64;
@@ -598,7 +811,7 @@ int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, 
     mv.lat.y0 = lo[1];
     mv.lat.h = (float)hcell;
     mv.lat.inv_h = 1.0f / mv.lat.h;
-    mv.lat.margin = mv.lat.h * 0.0625f;
+    mv.lat.margin = mv.lat.h * 0.015625f; // h/64 >= 2 ulp(max|coordinate|) by the choice of h above
     mv.n_cls[0] = n_ga;
     mv.n_cls[1] = n_nga;
     mv.base[0] = 0;
@@ -675,6 +888,7 @@ template <int MODE>
 int launch_fit_m(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
 {
     switch (h->G) {
+    case 0: return launch_fit_g<0, MODE>(h, fa, n_scans, st);
     case 1: return launch_fit_g<1, MODE>(h, fa, n_scans, st);
     case 2: return launch_fit_g<2, MODE>(h, fa, n_scans, st);
     case 4: return launch_fit_g<4, MODE>(h, fa, n_scans, st);
@@ -683,7 +897,7 @@ int launch_fit_m(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
     case 32: return launch_fit_g<32, MODE>(h, fa, n_scans, st);
     case 64: return launch_fit_g<64, MODE>(h, fa, n_scans, st);
     }
-    set_error("lanes_per_point must be one of 1,2,4,8,16,32,64 (got %d)", h->G);
+    set_error("lanes_per_point must be 0 (per-pass choice) or one of 1,2,4,8,16,32,64 (got %d)", h->G);
     return SLAM_E_INVALID;
 }
 
@@ -730,7 +944,8 @@ int slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga
         h->prm = *params;
     else
         slam_icp_default_params(&h->prm);
-    h->G = h->prm.lanes_per_point > 0 ? h->prm.lanes_per_point : 8;
+    // 0 = library default (2: measured best on config 2); -1 = chosen per pass
+    h->G = h->prm.lanes_per_point > 0 ? h->prm.lanes_per_point : (h->prm.lanes_per_point < 0 ? 0 : 2);
     int rc = build_index(h, m_ga, n_ga, m_nga, n_nga);
     if (rc == SLAM_OK && (h->G & (h->G - 1) || h->G > 64)) {
         set_error("lanes_per_point must be one of 1,2,4,8,16,32,64 (got %d)", h->G);
@@ -796,6 +1011,13 @@ int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *
     fa.max_iter = icp->prm.max_iter;
     fa.min_delta = icp->prm.min_delta;
     fa.indist = indist;
+    fa.stamps = nullptr;
+    if (getenv("SLAM_ICP_STAMPS")) {
+        SLAM_TRY(icp->w_stamps.reserve((size_t)n_scans * kWaves * 4 * sizeof(long long)));
+        SLAM_HIP(hipMemsetAsync(icp->w_stamps.p, 0, (size_t)n_scans * kWaves * 4 * sizeof(long long), as_stream(stream)));
+        fa.stamps = static_cast<long long *>(icp->w_stamps.p);
+        icp->n_stamps = n_scans * kWaves;
+    }
     return launch_fit(icp, fa, n_scans, as_stream(stream));
 }
 
@@ -871,6 +1093,21 @@ int slam_icp_get_edge_weight(slam_icp_t *icp, double eW[9])
     SLAM_REQUIRE(icp && eW, SLAM_E_INVALID, "slam_icp_get_edge_weight: bad arguments");
     set_error("getEdgeWeight: not built yet (its only call site is commented out upstream, icpTools.cpp:191-192)");
     return SLAM_E_UNSUPPORTED;
+}
+
+// diagnostic (not in the public header): mean cycles per wavefront in the four
+// phases of the last batch launched with SLAM_ICP_STAMPS=1 in the environment
+int slam_icp_debug_stamps(slam_icp_t *icp, double out[4])
+{
+    SLAM_REQUIRE(icp && out && icp->n_stamps > 0, SLAM_E_INVALID, "no stamps collected");
+    SLAM_HIP(hipDeviceSynchronize());
+    std::vector<long long> v((size_t)icp->n_stamps * 4);
+    SLAM_HIP(hipMemcpy(v.data(), icp->w_stamps.p, v.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k) out[k] = 0;
+    for (int i = 0; i < icp->n_stamps; ++i)
+        for (int k = 0; k < 4; ++k) out[k] += (double)v[(size_t)i * 4 + k];
+    for (int k = 0; k < 4; ++k) out[k] /= icp->n_stamps;
+    return SLAM_OK;
 }
 
 int slam_icp_index_info(slam_icp_t *icp, int *nx, int *ny, double *cell, int *in_lds, size_t *lds_bytes,
