@@ -137,6 +137,10 @@ int slam_icp_nearest_dev(slam_icp_t *icp, int cls, const float *d_query_xy, int 
  * correspondences of the last slam_icp_fit() call. */
 int slam_icp_get_edge_weight(slam_icp_t *icp, double eW[9]);
 
+/* IcpPointToPlane::computeNormals, icpPointToPlane.cpp:340-349 (SLAM_ICP_P2L only): the unit
+ * normal of every model point, GA points first then NGA, 2 doubles each. */
+int slam_icp_get_normals(slam_icp_t *icp, double *normals_xy);
+
 /* what the index looks like (for DESIGN.md / bench reporting) */
 int slam_icp_index_info(slam_icp_t *icp, int *nx, int *ny, double *cell, int *in_lds,
                         size_t *lds_bytes, int *lanes_per_point);

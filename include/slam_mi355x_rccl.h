@@ -1,0 +1,41 @@
+/*
+ * slam_mi355x_rccl.h -- the one exchange step of the multi-GPU path: the
+ * per-GPU int32 hit/miss planes are summed over all ranks with a single RCCL
+ * all-reduce over xGMI.  Integer sums are order
+ * independent, so the merged counts are bit-identical to a single-GPU run
+ * over the union of the scans.  The reference has no counterpart (it is a
+ * single-process ROS node); a multi-GPU mapper calls this between
+ * slam_grid_raycast_*() and slam_grid_finalize().
+ *
+ * Lives in its own shared object (libslam_mi355x_rccl.so) so that the core
+ * library does not depend on RCCL.  One process per GPU; the communicator is
+ * either created here from an ncclUniqueId the host exchanges out of band
+ * (128 bytes from rank 0 to every rank), or adopted from an existing
+ * ncclComm_t.
+ */
+#ifndef SLAM_MI355X_RCCL_H
+#define SLAM_MI355X_RCCL_H
+
+#include "slam_mi355x.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct slam_comm slam_comm_t;
+
+#define SLAM_COMM_ID_BYTES 128
+
+int  slam_comm_unique_id(char id[SLAM_COMM_ID_BYTES]);                       /* rank 0: ncclGetUniqueId */
+int  slam_comm_create(const char id[SLAM_COMM_ID_BYTES], int rank, int n_ranks, slam_comm_t **out);
+int  slam_comm_adopt(void *nccl_comm, slam_comm_t **out);                     /* wrap an ncclComm_t (not owned) */
+void slam_comm_destroy(slam_comm_t *comm);
+int  slam_comm_info(slam_comm_t *comm, int *rank, int *n_ranks);
+
+/* ncclAllReduce(planes, planes, 2*size_x*size_y, ncclInt32, ncclSum) on `stream` */
+int  slam_grid_allreduce(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -58,6 +58,7 @@ EXPORTS = [
     "slam_icp_default_params", "slam_icp_create", "slam_icp_destroy",
     "slam_icp_set_max_iterations", "slam_icp_set_min_delta", "slam_icp_set_subsampling_step",
     "slam_icp_fit", "slam_icp_fit_batch_dev", "slam_icp_nearest_dev", "slam_icp_get_edge_weight",
+    "slam_icp_get_normals",
     "slam_icp_index_info",
     "slam_grid_default_params", "slam_grid_create", "slam_grid_destroy", "slam_grid_clear",
     "slam_grid_set_min_cluster_points", "slam_grid_set_max_range", "slam_grid_set_pose",
@@ -110,6 +111,7 @@ def lib():
                                          _vp, _vp]
     L.slam_icp_nearest_dev.argtypes = [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp]
     L.slam_icp_get_edge_weight.argtypes = [_vp, _vp]
+    L.slam_icp_get_normals.argtypes = [_vp, _vp]
     L.slam_icp_index_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_double), C.POINTER(C.c_int),
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
@@ -330,6 +332,17 @@ class Icp:
         synchronize()
         return d_R.download(), d_t.download(), d_res.download(), (d_tr.download() if trace else None)
 
+    def edge_weight(self):
+        """IcpPointToPoint::getEdgeWeight (icpPointToPoint.cpp:233-316) of the last fit()."""
+        out = np.zeros(9)
+        check(lib().slam_icp_get_edge_weight(self.h, _ptr(out)))
+        return out.reshape(3, 3)
+
+    def normals(self):
+        out = np.zeros((len(self.m_ga) + len(self.m_nga), 2))
+        check(lib().slam_icp_get_normals(self.h, _ptr(out)))
+        return out
+
     def nearest(self, cls, q_xy):
         """KDTree::n_nearest(q, 1) for every row of q_xy (f32): (dis[n], idx[n])."""
         q = np.ascontiguousarray(q_xy, dtype=np.float32).reshape(-1, 2)
@@ -463,6 +476,69 @@ class Grid:
     def close(self):
         if getattr(self, "h", None):
             lib().slam_grid_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------ RCCL merge
+_rccl = None
+RCCL_EXPORTS = ["slam_comm_unique_id", "slam_comm_create", "slam_comm_adopt", "slam_comm_destroy",
+                "slam_comm_info", "slam_grid_allreduce"]
+
+
+def rccl_lib():
+    """Loads slam_amd/lib/libslam_mi355x_rccl.so (include/slam_mi355x_rccl.h)."""
+    global _rccl
+    if _rccl is not None:
+        return _rccl
+    lib()  # the core library first: the RCCL object links against it
+    if not os.path.exists(RCCL_LIB_PATH):
+        raise SlamError(E_UNSUPPORTED, "RCCL merge library not built: %s is missing" % RCCL_LIB_PATH)
+    R = C.CDLL(RCCL_LIB_PATH, mode=C.RTLD_GLOBAL)
+    R.slam_comm_unique_id.argtypes = [C.c_char_p]
+    R.slam_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]
+    R.slam_comm_adopt.argtypes = [_vp, C.POINTER(_vp)]
+    R.slam_comm_destroy.argtypes = [_vp]
+    R.slam_comm_destroy.restype = None
+    R.slam_comm_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    R.slam_grid_allreduce.argtypes = [_vp, _vp, _vp]
+    _rccl = R
+    return R
+
+
+class Comm:
+    """One RCCL communicator per process/GPU.  `id_bytes` comes from Comm.unique_id()
+    on rank 0 and is handed to the other ranks out of band (e.g. a torch.distributed
+    broadcast or a file)."""
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        check(rccl_lib().slam_comm_unique_id(buf))
+        return buf.raw
+
+    def __init__(self, id_bytes, rank, n_ranks):
+        h = _vp()
+        check(rccl_lib().slam_comm_create(id_bytes, int(rank), int(n_ranks), C.byref(h)))
+        self.h = h.value
+
+    def info(self):
+        r, n = C.c_int(), C.c_int()
+        check(rccl_lib().slam_comm_info(self.h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def allreduce_grid(self, grid, stream=None):
+        check(rccl_lib().slam_grid_allreduce(grid.h, self.h, _sp(stream)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            rccl_lib().slam_comm_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -48,9 +48,11 @@ def build(force=False, verbose=False):
         built.append(LIB)
     rccl_srcs = [s for s in RCCL_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if rccl_srcs and (force or _stale(RCCL_LIB, _deps(rccl_srcs))):
+        # RCCL is resolved at load time: in a torch process torch's bundled librccl (same
+        # SONAME) is already mapped and is the one used; otherwise /opt/rocm/lib's.
         cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in rccl_srcs] + \
-              ["-o", RCCL_LIB, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-L" + LIBDIR,
-               "-l:libslam_mi355x.so"]
+              ["-o", RCCL_LIB, "-I/opt/rocm/include", "-L/opt/rocm/lib", "-lrccl",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib", "-L" + LIBDIR, "-l:libslam_mi355x.so"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

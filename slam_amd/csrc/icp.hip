@@ -383,6 +383,7 @@ struct FitArgs {
     int            max_iter;
     double         min_delta;
     double         indist;
+    double        *step_pose; // nullable; per scan 6 doubles: R,t as the last executed step found them
     long long     *stamps; // diagnostic only (SLAM_ICP_STAMPS=1): per scan, cycles in [search, reduce, barrier, solve]
 };
 
@@ -500,6 +501,15 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
 #pragma unroll
             for (int k = 0; k < kNumAcc; ++k) acc[k] = 0.0;
             const Pose T = {r00, r01, r10, r11, t0, t1};
+            if (fa.step_pose && tid == 0) {
+                double *sp = fa.step_pose + 6 * (size_t)s;
+                sp[0] = r00;
+                sp[1] = r01;
+                sp[2] = r10;
+                sp[3] = r11;
+                sp[4] = t0;
+                sp[5] = t1;
+            }
             long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
             if (fa.stamps) c0 = __builtin_amdgcn_s_memtime();
 
@@ -662,6 +672,160 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
     }
 }
 
+// Normals for the point-to-line mode, icpPointToPlane.cpp:279-305,340-349: for
+// every model point (GA then NGA, original order) the k nearest model points
+// (itself included, n_nearest_around_point(i, 0, k)), their scatter matrix, and
+// the direction of least spread.  Brute force with the model tiled through LDS:
+// it runs once per map.  Neighbours are kept ordered by (distance, index) with
+// a fully unrolled insertion so the list stays in registers.
+constexpr int kNormTile = 1024;
+constexpr int kMaxK = 16;
+
+template <int K>
+__global__ __launch_bounds__(256) void icp_normals_kernel(const float2 *all, int n, double *normals)
+{
+    __shared__ float2 tile[kNormTile];
+    const int    i = blockIdx.x * 256 + threadIdx.x;
+    const float2 q = i < n ? all[i] : make_float2(0.f, 0.f);
+    float        bd[K];
+    int          bi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        bd[j] = FLT_MAX;
+        bi[j] = -1;
+    }
+    for (int base = 0; base < n; base += kNormTile) {
+        __syncthreads();
+        for (int j = threadIdx.x; j < kNormTile; j += 256) tile[j] = base + j < n ? all[base + j] : make_float2(0.f, 0.f);
+        __syncthreads();
+        const int cnt = min(kNormTile, n - base);
+        for (int j = 0; j < cnt; ++j) {
+            float d = dist2(tile[j], q.x, q.y);
+            int   id = base + j;
+            if (d < bd[K - 1]) { // strict: among equals the lower index (seen first) stays ahead
+#pragma unroll
+                for (int s = 0; s < K; ++s) {
+                    const bool  take = d < bd[s];
+                    const float td = take ? bd[s] : d;
+                    const int   ti = take ? bi[s] : id;
+                    bd[s] = take ? d : bd[s];
+                    bi[s] = take ? id : bi[s];
+                    d = td;
+                    id = ti;
+                }
+            }
+        }
+    }
+    if (i >= n) return;
+    double mx = 0, my = 0;
+    int    k = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (bi[j] >= 0) {
+            const float2 p = all[bi[j]];
+            mx += (double)p.x;
+            my += (double)p.y;
+            ++k;
+        }
+    mx /= (double)k;
+    my /= (double)k;
+    double sxx = 0, sxy = 0, syy = 0;
+#pragma unroll
+    for (int j = 0; j < K; ++j)
+        if (bi[j] >= 0) {
+            const float2 p = all[bi[j]];
+            const double dx = (double)p.x - mx, dy = (double)p.y - my;
+            sxx += dx * dx;
+            sxy += dx * dy;
+            syy += dy * dy;
+        }
+    // eigenvector of the smaller eigenvalue of [[sxx,sxy],[sxy,syy]]
+    const double th = 0.5 * atan2(2.0 * sxy, sxx - syy);
+    normals[2 * i] = -sin(th);
+    normals[2 * i + 1] = cos(th);
+}
+
+// IcpPointToPoint::getEdgeWeight, icpPointToPoint.cpp:233-316 (with dy = ax - bx
+// of :262), over the correspondences of the last executed fitStep, i.e. those
+// found from `pose` = R,t as they stood when that step began.  One workgroup.
+template <typename StartT>
+__global__ __launch_bounds__(kBlock) void icp_edge_weight_kernel(ModelView mv, const double2 *pts, int n, int nga,
+                                                                 const double *pose, double indist, double *eW)
+{
+    __shared__ double red[kWaves][8];
+    __shared__ double D[3], tot[8];
+    const IndexPtrs<StartT> ix = make_ptrs<StartT>(mv.blob, mv);
+    const int  tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const Pose T = {pose[0], pose[1], pose[2], pose[3], pose[4], pose[5]};
+
+    auto block_sum = [&](double v[], int cnt) {
+        for (int k = 0; k < cnt; ++k) {
+            const double w = wave_sum(v[k]);
+            if (lane == 0) red[wave][k] = w;
+        }
+        __syncthreads();
+        if (tid < cnt) {
+            double s = 0.0;
+            for (int w = 0; w < kWaves; ++w) s += red[w][tid];
+            tot[tid] = s;
+        }
+        __syncthreads();
+    };
+
+    for (int phase = 0; phase < 2; ++phase) {
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int p = tid; p < n; p += kBlock) {
+            const double2 P = pts[p];
+            const float qx = (float)__dadd_rn(__dadd_rn(__dmul_rn(T.r00, P.x), __dmul_rn(T.r01, P.y)), T.t0);
+            const float qy = (float)__dadd_rn(__dadd_rn(__dmul_rn(T.r10, P.x), __dmul_rn(T.r11, P.y)), T.t1);
+            const int   cls = p < nga ? 0 : 1;
+            if (mv.n_cls[cls] <= 3) continue;
+            const Best b = nn_search<1, StartT>(ix, mv, cls, qx, qy, 0, indist);
+            if (b.pos < 0 || !((double)b.d < indist)) continue;
+            const float2 m = ix.pts[mv.base[cls] + b.pos];
+            const double ax = (double)m.x, ay = (double)m.y, bx = (double)qx, by = (double)qy;
+            const double x = (ax + bx) / 2.0, y = (ay + by) / 2.0;
+            if (phase == 0) {
+                const double dx = ax - bx, dy = ax - bx; // :261-262, as written there
+                acc[0] += 1.0;
+                acc[1] += x;
+                acc[2] += y;
+                acc[3] += x * x + y * y;
+                acc[4] += dx;
+                acc[5] += dy;
+                acc[6] += -y * dx + x * dy;
+            } else {
+                const double tx = (ax - bx - D[0] + y * D[2]);
+                const double ty = (ay - by - D[1] - x * D[2]);
+                acc[0] += tx * tx + ty * ty;
+            }
+        }
+        block_sum(acc, phase == 0 ? 7 : 1);
+        if (phase == 0) {
+            if (tid == 0) {
+                // D = inv(MM) * MZ through the Gauss-Jordan solve (Matrix::inv -> solve, matrix.cpp:393)
+                double A[9] = {tot[0], 0, -tot[2], 0, tot[0], tot[1], -tot[2], tot[1], tot[3]};
+                double b[3] = {tot[4], tot[5], tot[6]};
+                solve3(A, b);
+                D[0] = b[0];
+                D[1] = b[1];
+                D[2] = b[2];
+                eW[0] = tot[0]; // keep MM until ss is known
+                eW[1] = tot[1];
+                eW[2] = tot[2];
+                eW[3] = tot[3];
+            }
+            __syncthreads();
+        } else if (tid == 0) {
+            const double nc = eW[0], sx = eW[1], sy = eW[2], xpy = eW[3];
+            const double ss = tot[0] / (2 * nc - 3);
+            const double sconst = 1.0 / ss;
+            const double MM[9] = {nc, 0, -sy, 0, nc, sx, -sy, sx, xpy};
+            for (int k = 0; k < 9; ++k) eW[k] = MM[k] * sconst;
+        }
+    }
+}
+
 // KDTree::n_nearest(q, 1): G lanes per query, index read from HBM/L2.
 template <int G, typename StartT>
 __global__ __launch_bounds__(256) void icp_nearest_kernel(ModelView mv, int cls, const float2 *q, int n,
@@ -712,8 +876,12 @@ struct slam_icp {
     size_t          lds_bytes = 0;
     void           *d_blob = nullptr;
     double         *d_normals = nullptr;
-    DevBuf          w_pts, w_off, w_nga, w_R, w_t, w_res, w_stamps;
+    DevBuf          w_pts, w_off, w_nga, w_R, w_t, w_res, w_stamps, w_pose, w_ew;
     int             n_stamps = 0;
+    bool            want_step_pose = false; // set around slam_icp_fit()
+    int             last_n = 0, last_nga = 0; // template of the last slam_icp_fit()
+    double          last_indist = 0;
+    bool            have_last = false;
 };
 
 namespace {
@@ -863,6 +1031,36 @@ int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, 
     return SLAM_OK;
 }
 
+int compute_normals(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, int n_nga)
+{
+    const int n = n_ga + n_nga;
+    const int k = std::min(h->prm.normals_k > 0 ? h->prm.normals_k : 10, n);
+    SLAM_REQUIRE(k >= 2 && k <= kMaxK, SLAM_E_INVALID, "normals_k must be 2..%d (got %d)", kMaxK, k);
+    std::vector<float> all(2 * (size_t)n);
+    for (int i = 0; i < 2 * n_ga; ++i) all[i] = (float)m_ga[i]; // icp.cpp:54
+    for (int i = 0; i < 2 * n_nga; ++i) all[2 * (size_t)n_ga + i] = (float)m_nga[i];
+    float2 *d_all = nullptr;
+    SLAM_HIP(hipMalloc((void **)&d_all, sizeof(float2) * (size_t)n));
+    hipError_t e = hipMemcpy(d_all, all.data(), sizeof(float2) * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_normals, sizeof(double) * 2 * (size_t)n);
+    if (e != hipSuccess) {
+        (void)hipFree(d_all);
+        SLAM_HIP(e);
+    }
+    const dim3 grid((n + 255) / 256);
+    switch (k) {
+#define SLAM_K(KK) case KK: hipLaunchKernelGGL((icp_normals_kernel<KK>), grid, dim3(256), 0, nullptr, d_all, n, h->d_normals); break;
+        SLAM_K(2) SLAM_K(3) SLAM_K(4) SLAM_K(5) SLAM_K(6) SLAM_K(7) SLAM_K(8) SLAM_K(9) SLAM_K(10) SLAM_K(11)
+        SLAM_K(12) SLAM_K(13) SLAM_K(14) SLAM_K(15) SLAM_K(16)
+#undef SLAM_K
+    }
+    e = hipDeviceSynchronize();
+    (void)hipFree(d_all);
+    SLAM_HIP(e);
+    h->mv.normals = h->d_normals;
+    return SLAM_OK;
+}
+
 template <int G, bool LDS, typename StartT, int MODE>
 int launch_fit_t(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
 {
@@ -951,10 +1149,7 @@ int slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga
         set_error("lanes_per_point must be one of 1,2,4,8,16,32,64 (got %d)", h->G);
         rc = SLAM_E_INVALID;
     }
-    if (rc == SLAM_OK && h->prm.mode == SLAM_ICP_P2L) {
-        set_error("point-to-line mode: normals kernel not built yet");
-        rc = SLAM_E_UNSUPPORTED;
-    }
+    if (rc == SLAM_OK && h->prm.mode == SLAM_ICP_P2L) rc = compute_normals(h, m_ga, n_ga, m_nga, n_nga);
     if (rc != SLAM_OK) {
         slam_icp_destroy(h);
         return rc;
@@ -1011,6 +1206,7 @@ int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *
     fa.max_iter = icp->prm.max_iter;
     fa.min_delta = icp->prm.min_delta;
     fa.indist = indist;
+    fa.step_pose = icp->want_step_pose ? static_cast<double *>(icp->w_pose.p) : nullptr;
     fa.stamps = nullptr;
     if (getenv("SLAM_ICP_STAMPS")) {
         SLAM_TRY(icp->w_stamps.reserve((size_t)n_scans * kWaves * 4 * sizeof(long long)));
@@ -1044,6 +1240,7 @@ int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t
     SLAM_TRY(icp->w_R.reserve(32));
     SLAM_TRY(icp->w_t.reserve(16));
     SLAM_TRY(icp->w_res.reserve(sizeof(slam_icp_result)));
+    SLAM_TRY(icp->w_pose.reserve(6 * sizeof(double)));
     hipStream_t st = nullptr;
     double *dp = static_cast<double *>(icp->w_pts.p);
     if (n_tga) SLAM_HIP(hipMemcpyAsync(dp, t_ga, 16 * (size_t)n_tga, hipMemcpyHostToDevice, st));
@@ -1055,10 +1252,17 @@ int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t
     SLAM_HIP(hipMemcpyAsync(icp->w_nga.p, &nga, 4, hipMemcpyHostToDevice, st));
     SLAM_HIP(hipMemcpyAsync(icp->w_R.p, R, 32, hipMemcpyHostToDevice, st));
     SLAM_HIP(hipMemcpyAsync(icp->w_t.p, t, 16, hipMemcpyHostToDevice, st));
-    SLAM_TRY(slam_icp_fit_batch_dev(icp, dp, static_cast<int32_t *>(icp->w_off.p),
-                                    static_cast<int32_t *>(icp->w_nga.p), 1,
-                                    static_cast<double *>(icp->w_R.p), static_cast<double *>(icp->w_t.p),
-                                    indist, static_cast<slam_icp_result *>(icp->w_res.p), nullptr, st));
+    icp->want_step_pose = true;
+    const int rc_fit = slam_icp_fit_batch_dev(icp, dp, static_cast<int32_t *>(icp->w_off.p),
+                                              static_cast<int32_t *>(icp->w_nga.p), 1,
+                                              static_cast<double *>(icp->w_R.p), static_cast<double *>(icp->w_t.p),
+                                              indist, static_cast<slam_icp_result *>(icp->w_res.p), nullptr, st);
+    icp->want_step_pose = false;
+    SLAM_TRY(rc_fit);
+    icp->last_n = n;
+    icp->last_nga = n_tga;
+    icp->last_indist = indist;
+    icp->have_last = true;
     slam_icp_result res;
     SLAM_HIP(hipMemcpyAsync(R, icp->w_R.p, 32, hipMemcpyDeviceToHost, st));
     SLAM_HIP(hipMemcpyAsync(t, icp->w_t.p, 16, hipMemcpyDeviceToHost, st));
@@ -1088,11 +1292,34 @@ int slam_icp_nearest_dev(slam_icp_t *icp, int cls, const float *d_query_xy, int 
     return SLAM_OK;
 }
 
+int slam_icp_get_normals(slam_icp_t *icp, double *normals_xy)
+{
+    SLAM_REQUIRE(icp && normals_xy, SLAM_E_INVALID, "slam_icp_get_normals: bad arguments");
+    SLAM_REQUIRE(icp->d_normals, SLAM_E_INVALID, "normals exist only in SLAM_ICP_P2L mode");
+    const size_t n = (size_t)icp->mv.n_cls[0] + icp->mv.n_cls[1];
+    SLAM_HIP(hipMemcpy(normals_xy, icp->d_normals, 2 * n * sizeof(double), hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
 int slam_icp_get_edge_weight(slam_icp_t *icp, double eW[9])
 {
     SLAM_REQUIRE(icp && eW, SLAM_E_INVALID, "slam_icp_get_edge_weight: bad arguments");
-    set_error("getEdgeWeight: not built yet (its only call site is commented out upstream, icpTools.cpp:191-192)");
-    return SLAM_E_UNSUPPORTED;
+    SLAM_REQUIRE(icp->have_last, SLAM_E_INVALID, "getEdgeWeight: no slam_icp_fit() call to take correspondences from");
+    SLAM_REQUIRE(icp->prm.mode == SLAM_ICP_P2P, SLAM_E_UNSUPPORTED, "getEdgeWeight belongs to IcpPointToPoint");
+    SLAM_TRY(require_device());
+    SLAM_TRY(icp->w_ew.reserve(9 * sizeof(double)));
+    const double2 *pts = static_cast<const double2 *>(icp->w_pts.p);
+    const double  *pose = static_cast<const double *>(icp->w_pose.p);
+    double        *d_ew = static_cast<double *>(icp->w_ew.p);
+    if (icp->start32)
+        hipLaunchKernelGGL((icp_edge_weight_kernel<uint32_t>), dim3(1), dim3(kBlock), 0, nullptr, icp->mv, pts,
+                           icp->last_n, icp->last_nga, pose, icp->last_indist, d_ew);
+    else
+        hipLaunchKernelGGL((icp_edge_weight_kernel<uint16_t>), dim3(1), dim3(kBlock), 0, nullptr, icp->mv, pts,
+                           icp->last_n, icp->last_nga, pose, icp->last_indist, d_ew);
+    SLAM_HIP(hipGetLastError());
+    SLAM_HIP(hipMemcpy(eW, d_ew, 9 * sizeof(double), hipMemcpyDeviceToHost));
+    return SLAM_OK;
 }
 
 // diagnostic (not in the public header): mean cycles per wavefront in the four

@@ -239,3 +239,52 @@ def test_config2_full_size_properties(world):
     assert np.abs(t - batch.true_poses[:, :2]).max() < 0.03
     assert ang_diff(yaw(R), batch.true_poses[:, 2]).max() < 3e-3
     icp.close()
+
+
+def test_point_to_line_mode_matches_own_oracle():
+    """north-star 3x3 normal-equation step (icpPointToPlane.cpp:37-107, not compiled
+    upstream): normals and poses against the build's own scalar oracle."""
+    m_ga, m_nga = synth.make_map(5000)
+    model = O.IcpModel(m_ga, m_nga, normals_k=10)
+    icp = api.Icp(m_ga, m_nga, mode=api.ICP_P2L, normals_k=10, max_iter=15, min_delta=-1.0)
+    n_gpu, n_cpu = icp.normals(), model.normals()
+    # a normal and its negative are the same line: compare up to sign
+    dots = np.abs((n_gpu * n_cpu).sum(1))
+    assert dots.min() > 1 - 1e-9
+    batch = synth.make_batch(6, n_loop=256)
+    R, t, res, trace = icp.fit_batch(batch, trace=True)
+    for s in range(batch.n_scans):
+        t_ga, t_nga = batch.scan(s)
+        Ro, to, tr, steps = model.fit(t_ga, t_nga, batch.R[s], batch.t[s],
+                                      O.icp_params(15, -1.0, 5.0, O.NN_KDTREE, O.MODE_P2L))
+        assert steps == res["iters"][s] == 15
+        assert np.abs(t[s] - to).max() < POS_TOL
+        assert ang_diff(yaw(R[s]), yaw(Ro)).max() < ANG_TOL
+        assert np.abs(trace[s, :, 6] - tr[:, 6]).max() < 1e-7
+    assert np.abs(t - batch.true_poses[:, :2]).max() < 0.03
+    icp.close()
+
+
+def test_edge_weight_matches_oracle(world):
+    """getEdgeWeight (icpPointToPoint.cpp:233-316) over the correspondences of the
+    last executed fitStep, reference bug (dy = ax - bx) included."""
+    m_ga, m_nga, model = world
+    batch = synth.make_batch(1, n_loop=256)
+    t_ga, t_nga = batch.scan(0)
+    icp = api.Icp(m_ga, m_nga, max_iter=7, min_delta=-1.0)
+    R, t, res = icp.fit(t_ga, t_nga, batch.R[0], batch.t[0], 5.0)
+    eW = icp.edge_weight()
+    p = O.icp_params(7, -1.0, 5.0)
+    Ro, to, tr, steps = model.fit(t_ga, t_nga, batch.R[0], batch.t[0], p)
+    Rp, tp = tr[steps - 2, :4].reshape(2, 2), tr[steps - 2, 4:6]      # pose the last step started from
+    d, _, _, nc, corr = model.fit_step(t_ga, t_nga, Rp, tp, p)
+    q = np.concatenate([O.transform_points(t_ga, Rp, tp), O.transform_points(t_nga, Rp, tp)]).astype(np.float64)
+    mga32, mnga32 = m_ga.astype(np.float32).astype(np.float64), m_nga.astype(np.float32).astype(np.float64)
+    is_ga = np.arange(len(corr)) < len(t_ga)
+    sel = corr >= 0
+    pm = np.where(is_ga[sel, None], mga32[np.clip(corr[sel], 0, len(mga32) - 1)],
+                  mnga32[np.clip(corr[sel], 0, len(mnga32) - 1)])
+    ref = O.edge_weight(pm, q[sel])
+    assert nc == res.n_corr and ref[0, 0] == ref[1, 1] and ref[0, 1] == 0
+    assert np.allclose(eW, ref, rtol=1e-7, atol=1e-7 * np.abs(ref).max())
+    icp.close()

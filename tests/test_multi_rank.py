@@ -1,0 +1,114 @@
+"""The N > 1 path: scans are sharded contiguously by rank, every
+rank fills its own int32 hit/miss planes, one integer sum-all-reduce merges
+them, and finalize runs on the merged counts.
+
+CPU (gloo, world_size 2, runs anywhere): the sharding + merge logic with the
+planes produced by the oracle.  GPU: the RCCL entry point with one rank."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from slam_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GRID, RES = 400, 0.25
+
+
+def _planes_for(batch, poses):
+    g = O.grid_params(GRID, GRID, RES, min_cluster_points=20)
+    hits = np.zeros(GRID * GRID, np.int32)
+    misses = np.zeros(GRID * GRID, np.int32)
+    for s in range(batch.n_scans):
+        o, e = batch.scan_off[s], batch.scan_off[s + 1]
+        R, t = synth.pose_to_Rt(*poses[s])
+        end = O.transform_points(batch.pts[o:e], R, t)
+        O.grid_raycast(g, np.tile(t.astype(np.float32), (e - o, 1)), end, hits, misses)
+    return hits, misses
+
+
+def _worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = synth.make_batch(12, n_loop=64)
+    mine = full.shard(rank, world)
+    hits, misses = _planes_for(mine, mine.true_poses)
+    planes = torch.from_numpy(np.concatenate([hits, misses]))   # [hits | misses], one collective
+    dist.all_reduce(planes)                                      # integer sum: order independent
+    if rank == 0:
+        np.save(out, planes.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_covers_all_scans_once():
+    full = synth.make_batch(13, n_loop=64)
+    for world in (1, 2, 3, 8):
+        parts = [full.shard(r, world) for r in range(world)]
+        assert sum(p.n_scans for p in parts) == 13 and sum(p.n_points for p in parts) == full.n_points
+        assert np.array_equal(np.concatenate([p.pts for p in parts]), full.pts)
+        assert np.array_equal(np.concatenate([p.R for p in parts]), full.R)
+        for p in parts:
+            assert p.scan_off[0] == 0 and p.scan_off[-1] == p.n_points
+
+
+def test_two_rank_merge_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "merged.npy")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    merged = np.load(out)
+    full = synth.make_batch(12, n_loop=64)
+    hits, misses = _planes_for(full, full.true_poses)
+    assert np.array_equal(merged[:GRID * GRID], hits) and np.array_equal(merged[GRID * GRID:], misses)
+    # finalize on merged counts == finalize of the single-process counts
+    g = O.grid_params(GRID, GRID, RES, min_cluster_points=20)
+    n1, o1 = O.grid_finalize(g, merged[:GRID * GRID], merged[GRID * GRID:])
+    n2, o2 = O.grid_finalize(g, hits, misses)
+    assert np.array_equal(o1, o2) and np.array_equal(n1, n2)
+
+
+def test_rccl_library_exports_header_symbols():
+    import re
+    from slam_amd import api, build
+    build.build()
+    txt = open(os.path.join(ROOT, "include", "slam_mi355x_rccl.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    names = sorted(set(re.findall(r"\b(slam_[a-z0-9_]+)\s*\(", txt)))
+    assert names == sorted(api.RCCL_EXPORTS)
+    R = api.rccl_lib()
+    for n in names:
+        assert hasattr(R, n)
+
+
+@pytest.mark.gpu
+def test_rccl_allreduce_single_rank_is_identity():
+    from slam_amd import api
+    comm = api.Comm(api.Comm.unique_id(), 0, 1)
+    assert comm.info() == (0, 1)
+    g = api.Grid(GRID, GRID, RES, rolling=0, min_cluster_points=20)
+    full = synth.make_batch(3, n_loop=64)
+    R = np.stack([synth.pose_to_Rt(*p)[0].reshape(4) for p in full.true_poses])
+    t = np.stack([synth.pose_to_Rt(*p)[1] for p in full.true_poses])
+    d = [api.DeviceArray.from_host(a, dt) for a, dt in
+         ((full.pts, np.float64), (full.scan_off, np.int32), (R, np.float64), (t, np.float64))]
+    g.raycast_scans_dev(d[0], d[1], full.n_scans, full.n_points, d[2], d[3])
+    comm.allreduce_grid(g)
+    api.synchronize()
+    hits, misses = g.read_counts()
+    eh, em = _planes_for(full, full.true_poses)
+    assert np.array_equal(hits, eh) and np.array_equal(misses, em)
+    comm.close()
+    g.close()
