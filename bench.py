@@ -60,25 +60,47 @@ def cpu_baseline(m_ga, m_nga, batch, grid_size, res):
     g = O.grid_params(grid_size, grid_size, res, min_cluster_points=20)
     hits = np.zeros(grid_size * grid_size, np.int32)
     misses = np.zeros(grid_size * grid_size, np.int32)
-    t0 = time.perf_counter()
-    upd = 0
+    ends, origins = [], []
     for s in range(sub.n_scans):
         o, e = sub.scan_off[s], sub.scan_off[s + 1]
-        end = O.transform_points(sub.pts[o:e], R[s], t[s])
-        _, _, n = O.grid_raycast(g, np.tile(t[s].astype(np.float32), (e - o, 1)), end, hits, misses)
-        upd += n
+        ends.append(O.transform_points(sub.pts[o:e], R[s], t[s]))
+        origins.append(np.tile(t[s].astype(np.float32), (e - o, 1)))
+    ends, origins = np.concatenate(ends), np.concatenate(origins)
+    t0 = time.perf_counter()
+    _, _, upd = O.grid_raycast(g, origins, ends, hits, misses, n_threads=threads)
     t_grid = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    n1 = len(ends) // 8
+    _, _, upd1 = O.grid_raycast(g, origins[:n1], ends[:n1], hits, misses)
+    t_grid1 = time.perf_counter() - t0
     return {
         "value": sub.n_points / (t_icp + t_grid), "unit": "points/s", "cores": threads,
         "kind": "port",
         "sample": "%d of the %d scans x %d ICP iterations (kd-tree NN, OpenMP over scans, %d threads) "
-                  "+ single-thread Bresenham of the same scans into the %dx%d grid"
+                  "+ Bresenham of the same scans into the %dx%d grid (OpenMP over beams, atomic increments)"
                   % (sub.n_scans, batch.n_scans, N_ITERS, threads, grid_size, grid_size),
         "icp_points_per_s": sub.n_points / t_icp,
         "icp_points_per_s_1thread": one.n_points / t_icp1,
-        "grid_cell_updates_per_s_1thread": upd / t_grid,
+        "grid_cell_updates_per_s": upd / t_grid,
+        "grid_cell_updates_per_s_1thread": upd1 / t_grid1,
         "host_cores": cores,
     }
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary of this same
+    command (profiles/rNN_traffic.json, written by tools/summarize_profiles.py from
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes); None if not profiled."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        t = json.load(open(files[-1]))
+        key = kernel if kernel in t else ("raycast_tiled_kernel" if kernel.startswith("raycast") else None)
+        return t[key]["hbm_bytes_per_launch"] if key else None
+    except Exception:
+        return None
 
 
 def main():
@@ -225,14 +247,15 @@ def main():
         fin_bytes = GRID * GRID * 17                     # 2x4 B counts in, 8 B evidence + 1 B occupancy out
         kernels = {
             "icp_fit_kernel": {"ms": float(ms_icp), "alg_bytes": icp_bytes},
-            "raycast (beams + tiles)": {"ms": float(ms_ray), "alg_bytes": ray_bytes},
+            "raycast_tiled_kernel (+ beams, work list)": {"ms": float(ms_ray), "alg_bytes": ray_bytes},
             "finalize_kernel": {"ms": float(ms_fin), "alg_bytes": fin_bytes},
         }
         for k in kernels.values():
             k["GBps"] = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
         dom = max(kernels, key=lambda n: kernels[n]["ms"])
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS, "traffic": None,
+                "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,
+                "traffic": pmc_traffic(dom.split(" ")[0]),
                 "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "avg_launch_ms": kernels[dom]["ms"],
                 "note": "ICP is LDS/VALU-bound (exact 1-NN search in LDS), not HBM-bound: see DESIGN.md"}
         out = {

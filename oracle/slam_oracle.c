@@ -887,6 +887,47 @@ long ogrid_raycast(const ogrid_params *g, const float *origin_xy, const float *e
     return upd;
 }
 
+/* The same traversal with OpenMP over beams and atomic increments: the timed
+ * CPU baseline of bench.py (counts are sums, so the result equals ogrid_raycast). */
+long ogrid_raycast_mt(const ogrid_params *g, const float *origin_xy, const float *end_xy,
+                      int n, int32_t *hits, int32_t *misses, int n_threads)
+{
+    long upd = 0;
+    int  offset_x = g->size_x / 2, offset_y = g->size_y / 2;
+#ifdef _OPENMP
+    if (n_threads > 0) omp_set_num_threads(n_threads);
+#else
+    (void)n_threads;
+#endif
+#pragma omp parallel for schedule(static, 256) reduction(+ : upd)
+    for (int i = 0; i < n; i++) {
+        int x1, y1;
+        if (ogrid_cell(g, end_xy[2 * i], end_xy[2 * i + 1], &x1, &y1) < 0) continue;
+        double fx = (double)origin_xy[2 * i] / g->resolution + (double)offset_x;
+        double fy = (double)origin_xy[2 * i + 1] / g->resolution + (double)offset_y;
+        if (!(fx > -2147483648.0 && fx < 2147483648.0)) continue;
+        if (!(fy > -2147483648.0 && fy < 2147483648.0)) continue;
+        int x0 = (int)fx, y0 = (int)fy;
+        if (x0 < 0 || y0 < 0 || x0 >= g->size_x || y0 >= g->size_y) continue;
+        int dx = abs(x1 - x0), dy = abs(y1 - y0);
+        int sx = x1 > x0 ? 1 : -1, sy = y1 > y0 ? 1 : -1;
+        int x = x0, y = y0;
+        int du = dx >= dy ? dx : dy, dv = dx >= dy ? dy : dx, e = du;
+        for (int k = 0; k < du; k++) {
+            __atomic_fetch_add(&misses[x + g->size_x * y], 1, __ATOMIC_RELAXED);
+            if (dx >= dy) x += sx; else y += sy;
+            e += 2 * dv;
+            if (e >= 2 * du) {
+                if (dx >= dy) y += sy; else x += sx;
+                e -= 2 * du;
+            }
+        }
+        __atomic_fetch_add(&hits[x1 + g->size_x * y1], 1, __ATOMIC_RELAXED);
+        upd += du + 1;
+    }
+    return upd;
+}
+
 void o_transform_points(const double *pts, int n, const double R[4], const double t[2],
                         float *out_xy)
 {

@@ -143,6 +143,10 @@ long ogrid_add_endpoints(const ogrid_params *g, const float *obs, int n_obs,
 long ogrid_raycast(const ogrid_params *g, const float *origin_xy, const float *end_xy,
                    int n, int32_t *hits, int32_t *misses);
 
+/* ogrid_raycast with OpenMP over beams and atomic increments (CPU baseline). */
+long ogrid_raycast_mt(const ogrid_params *g, const float *origin_xy, const float *end_xy,
+                      int n, int32_t *hits, int32_t *misses, int n_threads);
+
 /* (float)(R*p+t) exactly as icpPointToPoint.cpp:69-70 forms its query:
  * double arithmetic, then a float store.  out_xy: n*2 floats. */
 void o_transform_points(const double *pts, int n, const double R[4], const double t[2],

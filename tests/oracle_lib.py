@@ -86,6 +86,8 @@ def lib():
                                       C.c_int, _i32p, _i32p, _ip]
     L.ogrid_raycast.restype = C.c_long
     L.ogrid_raycast.argtypes = [C.POINTER(OGridParams), _fp, _fp, C.c_int, _i32p, _i32p]
+    L.ogrid_raycast_mt.restype = C.c_long
+    L.ogrid_raycast_mt.argtypes = [C.POINTER(OGridParams), _fp, _fp, C.c_int, _i32p, _i32p, C.c_int]
     L.o_transform_points.argtypes = [_dp, C.c_int, _dp, _dp, _fp]
     L.ogrid_finalize.argtypes = [C.POINTER(OGridParams), _i32p, _i32p, _dp, _i8p]
     L.ogrid_add_scan_inorder.argtypes = [C.POINTER(OGridParams), _fp, C.c_int, _fp, C.c_int,
@@ -265,7 +267,7 @@ def grid_add_endpoints(g, obs, gnd, hits=None, misses=None):
     return hits, misses, cell_out[:n_obs + n_gnd], n
 
 
-def grid_raycast(g, origin_xy, end_xy, hits=None, misses=None):
+def grid_raycast(g, origin_xy, end_xy, hits=None, misses=None, n_threads=None):
     origin_xy = as_f32(origin_xy).reshape(-1, 2)
     end_xy = as_f32(end_xy).reshape(-1, 2)
     cells = g.size_x * g.size_y
@@ -273,8 +275,12 @@ def grid_raycast(g, origin_xy, end_xy, hits=None, misses=None):
         hits = np.zeros(cells, dtype=np.int32)
     if misses is None:
         misses = np.zeros(cells, dtype=np.int32)
-    n = lib().ogrid_raycast(C.byref(g), _f(origin_xy), _f(end_xy), len(end_xy),
-                            hits.ctypes.data_as(_i32p), misses.ctypes.data_as(_i32p))
+    if n_threads is None:
+        n = lib().ogrid_raycast(C.byref(g), _f(origin_xy), _f(end_xy), len(end_xy),
+                                hits.ctypes.data_as(_i32p), misses.ctypes.data_as(_i32p))
+    else:
+        n = lib().ogrid_raycast_mt(C.byref(g), _f(origin_xy), _f(end_xy), len(end_xy),
+                                   hits.ctypes.data_as(_i32p), misses.ctypes.data_as(_i32p), int(n_threads))
     return hits, misses, n
 
 

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): the default bench under rocprofv3
+# (kernel trace + stats), then the counter passes the roofline needs.  Counter
+# passes use --pmc with --kernel-trace only (no other trace domains).
+#   usage: bash tools/profile_round.sh r01
+# Output under gpurun_out/profile_<tag>/ ; tools/summarize_profiles.py turns it
+# into the committed files under profiles/.
+TAG=${1:-r01}
+OUT=gpurun_out/profile_$TAG
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rm -rf "$OUT" && mkdir -p "$OUT"
+BENCH="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.json 2> $OUT/stats.err || echo "stats pass failed"
+i=0
+for PMC in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM" \
+           "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc_$i -- $BENCH > $OUT/pmc_$i.json 2> $OUT/pmc_$i.err || echo "pmc pass $i failed"
+done
+# the un-profiled bench line, for reference beside the profiled one
+timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || echo "bench failed"
+ls $OUT
