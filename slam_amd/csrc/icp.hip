@@ -281,6 +281,12 @@ __device__ inline double dpp_shift_f64(double v)
     return __hiloint2double(hi, lo);
 }
 
+__device__ inline double uniform(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 __device__ inline double wave_sum(double v)
 {
     v += dpp_shift_f64<0x111, 0xf>(v); // row_shr:1
@@ -489,8 +495,9 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
     }
     const IndexPtrs<StartT> ix = make_ptrs<StartT>(base, mv);
 
-    double r00 = fa.R[4 * s + 0], r01 = fa.R[4 * s + 1], r10 = fa.R[4 * s + 2], r11 = fa.R[4 * s + 3];
-    double t0 = fa.t[2 * s + 0], t1 = fa.t[2 * s + 1];
+    double r00 = uniform(fa.R[4 * s + 0]), r01 = uniform(fa.R[4 * s + 1]), r10 = uniform(fa.R[4 * s + 2]),
+           r11 = uniform(fa.R[4 * s + 3]);
+    double t0 = uniform(fa.t[2 * s + 0]), t1 = uniform(fa.t[2 * s + 1]);
 
     int    iters = 0, n_corr = 0;
     double delta = 0.0;
@@ -625,14 +632,14 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                 }
             }
             __syncthreads();
-            r00 = bc[0];
-            r01 = bc[1];
-            r10 = bc[2];
-            r11 = bc[3];
-            t0 = bc[4];
-            t1 = bc[5];
-            delta = bc[6];
-            n_corr = (int)bc[7];
+            r00 = uniform(bc[0]); // the same in every lane: keep the pose in scalar registers
+            r01 = uniform(bc[1]);
+            r10 = uniform(bc[2]);
+            r11 = uniform(bc[3]);
+            t0 = uniform(bc[4]);
+            t1 = uniform(bc[5]);
+            delta = uniform(bc[6]);
+            n_corr = (int)uniform(bc[7]);
             ++iters;
             if (fa.stamps && (tid & 63) == 0) {
                 const long long c4 = __builtin_amdgcn_s_memtime();
