@@ -227,6 +227,49 @@ int slam_grid_raycast_stats(slam_grid_t *g, int *n_tiles, int *n_items, int *n_s
  * storage order) for a collective merge; see slam_mi355x_rccl.h */
 int slam_grid_counts_dev(slam_grid_t *g, int32_t **d_planes, size_t *n_ints);
 
+/* ------------------------------------------------------ ground segmentation
+ * Stands for class groundSegmentation (ground_segmentation/include/ground_segmentation/
+ * groundSegmentation.h:67-128), the GP-INSAC pre-filter both halves of the path run first
+ * (icpTools.cpp:114-115, mls.cpp:66-67): setupGroundSegmentation + segmentGround, with
+ * the constructor's parameters (groundSegmentation.cpp:31-55; field = reference setter). */
+typedef struct slam_gseg slam_gseg_t;
+
+typedef struct {
+    double rmax;                     /* set_rmax(100.0) */
+    int    num_seedpoints;           /* set_num_seedpoints(10) */
+    double gp_lengthparameter;       /* set_gp_lengthparameter(10) */
+    double gp_covariancescale;       /* set_gp_covariancescale(1.0) */
+    double gp_modelnoise;            /* set_gp_modelnoise(0.3) */
+    double gp_groundmodelconfidence; /* set_gp_groundmodelconfidence(5.0) */
+    double gp_grounddataconfidence;  /* set_gp_grounddataconfidence(5.0) */
+    double gp_groundthreshold;       /* set_gp_groundthreshold(0.3) */
+    double robotheight;              /* set_robotheight(1.2) */
+    double seeding_maxrange;         /* set_seeding_maxrange(50) */
+    double seeding_maxheight;        /* set_seeding_maxheight(15) */
+} slam_gseg_params;
+
+#define SLAM_GSEG_DROPPED  0 /* in no output cloud: beyond rmax, or in a bin with <= 5 points */
+#define SLAM_GSEG_GROUND   1 /* groundCloud */
+#define SLAM_GSEG_OBSTACLE 2 /* obsCloud and drvCloud (below robot height) */
+#define SLAM_GSEG_OVERHEAD 3 /* obsCloud only (drivable = 1) */
+
+void slam_gseg_default_params(slam_gseg_params *p);
+int  slam_gseg_create(const slam_gseg_params *params, slam_gseg_t **out);
+void slam_gseg_destroy(slam_gseg_t *h);
+int  slam_gseg_reserve(slam_gseg_t *h, int max_points);
+/* one label (SLAM_GSEG_*) per input point; points are `stride` floats apart (x, y, z first) */
+int  slam_gseg_segment(slam_gseg_t *h, const float *xyz, int n, int stride, uint8_t *labels);
+int  slam_gseg_segment_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, uint8_t *d_labels,
+                           slam_stream_t stream);
+/* the ground cloud and the drvCloud as (x, y, z, 0) records -- what slam_grid_add_endpoints_dev
+ * takes with stride 4; d_counts[0] = ground points, d_counts[1] = obstacle points written */
+int  slam_gseg_split_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, const uint8_t *d_labels,
+                         float *d_ground_xyz4, float *d_obstacle_xyz4, int32_t *d_counts,
+                         slam_stream_t stream);
+/* per polar bin (72 x 200): 1 = in the ground model (value = prototype height), 2 = candidate
+ * that stayed out (value = GP mean), 0 = no signal point; INSAC iterations per sector */
+int  slam_gseg_read_model(slam_gseg_t *h, uint8_t *bin_state, double *bin_value, int32_t *sector_iterations);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,6 +164,41 @@ void ogrid_add_scan_inorder(const ogrid_params *g, const float *obs, int n_obs,
                             const float *gnd, int n_gnd, int stride,
                             double *num_pts, int8_t *drivable, int8_t *occ);
 
+/* ------------------------------------------------- ground segmentation
+ * GP-INSAC ground segmentation, ground_segmentation/src/groundSegmentation.cpp:
+ * genPolarBinGrid :110-162, genGPModel :165-185, sectorINSAC :196-468, with the
+ * constructor's parameters (:31-55).  PARITY UNPINNED: the reference needs
+ * PCL/Eigen/ROS (absent here) and holds no test vectors; Eigen's dense
+ * inverse() (:303) is restated as an LU solve with partial pivoting, so values
+ * agree to rounding, not bitwise.  Ties of std::sort (:229) are broken by bin
+ * index here (unspecified there). */
+#define OGSEG_NUMBINSA 72  /* groundSegmentation.h:18 */
+#define OGSEG_NUMBINSL 200 /* groundSegmentation.h:19 */
+#define OGSEG_INVALID  1000 /* groundSegmentation.h:17 */
+
+typedef struct {
+    double rmax;           /* 100  */
+    int    num_seedpoints; /* 10   */
+    double p_l, p_sf, p_sn, p_tmodel, p_tdata, p_tg; /* 10, 1, 0.3, 5, 5, 0.3 */
+    double robot_height;   /* 1.2  */
+    double max_seed_range, max_seed_height; /* 50, 15 */
+} ogseg_params;
+
+void ogseg_default_params(ogseg_params *p);
+
+#define OGSEG_DROPPED   0 /* point appears in no output cloud */
+#define OGSEG_GROUND    1 /* gCloud */
+#define OGSEG_OBSTACLE  2 /* oCloud and dCloud (below robot height: blocks driving) */
+#define OGSEG_OVERHEAD  3 /* oCloud only (drivable = 1) */
+
+/* xyz: n points, `stride` floats apart.  labels: one OGSEG_* per point.
+ * Optional outputs (may be NULL): bin_of[n] = sector*200+bin or -1;
+ * sector_model[72*200] = 1 where the bin ended in the ground model, 2 where it
+ * stayed a candidate (value in sector_value = model height or GP mean f_s), 0
+ * otherwise. Returns the number of INSAC outer iterations summed over sectors. */
+int ogseg_segment(const ogseg_params *p, const float *xyz, int n, int stride, unsigned char *labels,
+                  int *bin_of, unsigned char *sector_model, double *sector_value);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,16 @@ class GridParams(C.Structure):
                 ("rolling", C.c_int), ("raycast_impl", C.c_int)]
 
 
+class GsegParams(C.Structure):
+    _fields_ = [("rmax", C.c_double), ("num_seedpoints", C.c_int), ("gp_lengthparameter", C.c_double),
+                ("gp_covariancescale", C.c_double), ("gp_modelnoise", C.c_double),
+                ("gp_groundmodelconfidence", C.c_double), ("gp_grounddataconfidence", C.c_double),
+                ("gp_groundthreshold", C.c_double), ("robotheight", C.c_double),
+                ("seeding_maxrange", C.c_double), ("seeding_maxheight", C.c_double)]
+
+
+GSEG_DROPPED, GSEG_GROUND, GSEG_OBSTACLE, GSEG_OVERHEAD = 0, 1, 2, 3
+
 RESULT_DTYPE = np.dtype([("iters", np.int32), ("n_corr", np.int32), ("delta", np.float64)])
 
 _vp = C.c_void_p
@@ -67,6 +77,8 @@ EXPORTS = [
     "slam_grid_finalize", "slam_grid_add_scan_inorder", "slam_grid_read_counts",
     "slam_grid_read_occupancy", "slam_grid_read_num_pts", "slam_grid_total_updates",
     "slam_grid_info", "slam_grid_counts_dev", "slam_grid_raycast_stats",
+    "slam_gseg_default_params", "slam_gseg_create", "slam_gseg_destroy", "slam_gseg_reserve",
+    "slam_gseg_segment", "slam_gseg_segment_dev", "slam_gseg_split_dev", "slam_gseg_read_model",
 ]
 
 
@@ -137,6 +149,16 @@ def lib():
     L.slam_grid_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.slam_grid_counts_dev.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]
+    L.slam_gseg_default_params.restype = None
+    L.slam_gseg_default_params.argtypes = [C.POINTER(GsegParams)]
+    L.slam_gseg_create.argtypes = [C.POINTER(GsegParams), C.POINTER(_vp)]
+    L.slam_gseg_destroy.restype = None
+    L.slam_gseg_destroy.argtypes = [_vp]
+    L.slam_gseg_reserve.argtypes = [_vp, C.c_int]
+    L.slam_gseg_segment.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp]
+    L.slam_gseg_segment_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp]
+    L.slam_gseg_split_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
+    L.slam_gseg_read_model.argtypes = [_vp, _vp, _vp, _vp]
     L.slam_grid_raycast_stats.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L
     return L
@@ -476,6 +498,52 @@ class Grid:
     def close(self):
         if getattr(self, "h", None):
             lib().slam_grid_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GroundSegmentation:
+    """groundSegmentation-shaped handle (groundSegmentation.h:67-128) over the C-ABI."""
+
+    def __init__(self, **kw):
+        self.params = GsegParams()
+        lib().slam_gseg_default_params(C.byref(self.params))
+        for k, v in kw.items():
+            setattr(self.params, k, v)
+        h = _vp()
+        check(lib().slam_gseg_create(C.byref(self.params), C.byref(h)))
+        self.h = h.value
+
+    def segment(self, xyz):
+        """setupGroundSegmentation + segmentGround: one GSEG_* label per point."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        n, stride = xyz.shape
+        labels = np.zeros(max(n, 1), dtype=np.uint8)
+        check(lib().slam_gseg_segment(self.h, _ptr(xyz), n, stride, _ptr(labels)))
+        return labels[:n]
+
+    def segment_dev(self, d_xyz, n, stride, d_labels, stream=None):
+        check(lib().slam_gseg_segment_dev(self.h, d_xyz.ptr, int(n), int(stride), d_labels.ptr, _sp(stream)))
+
+    def split_dev(self, d_xyz, n, stride, d_labels, d_ground, d_obstacle, d_counts, stream=None):
+        check(lib().slam_gseg_split_dev(self.h, d_xyz.ptr, int(n), int(stride), d_labels.ptr, d_ground.ptr,
+                                        d_obstacle.ptr, d_counts.ptr, _sp(stream)))
+
+    def read_model(self):
+        state = np.zeros(72 * 200, dtype=np.uint8)
+        value = np.zeros(72 * 200)
+        iters = np.zeros(72, dtype=np.int32)
+        check(lib().slam_gseg_read_model(self.h, _ptr(state), _ptr(value), _ptr(iters)))
+        return state, value, iters
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().slam_gseg_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -1,0 +1,467 @@
+// gseg.hip -- GP-INSAC ground segmentation on gfx950 behind the C-ABI: the
+// pre-filter both halves of the hot path run first (ccicp2d/src/icpTools.cpp:114-115,
+// mls/src/mls.cpp:66-67); SURVEY.md section 8(f) row 1.
+//
+// Reference: ground_segmentation/src/groundSegmentation.cpp
+//   genPolarBinGrid :110-162   72 sectors x 200 range bins, lowest-z prototype per bin
+//   genGPModel      :165-185   squared-exponential covariance
+//   sectorINSAC     :196-468   seeds, iterative GP inlier growth, per-point labels
+//
+// Three kernels.  (1) binning: one thread per point, integer count + one 64-bit
+// atomicMin of (orderable z, point index) per bin -- the reference's "first point
+// with the smallest z" is exactly that minimum.  (2) one workgroup per sector
+// runs the whole INSAC loop: the model Gram matrix is symmetric positive
+// definite (kernel + noise*I), so instead of Eigen's dense inverse (:303) it is
+// Cholesky-factored once per outer iteration and every candidate needs one
+// forward substitution: f = c^T A^-1 z, Vf = sf - |L^-1 c|^2 (values agree with
+// the inverse to rounding).  (3) labels: one thread per point.
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace slam;
+
+namespace {
+
+constexpr int NA = 72;   // groundSegmentation.h:18 NUMBINSA
+constexpr int NL = 200;  // groundSegmentation.h:19 NUMBINSL
+constexpr float kInvalid = 1000.0f; // groundSegmentation.h:17 INVALID
+constexpr int kSecThreads = 256;
+
+struct GsegParams {
+    double rmax;
+    int    num_seedpoints;
+    double p_l, p_sf, p_sn, p_tmodel, p_tdata, p_tg, robot_height, max_seed_range, max_seed_height;
+};
+
+__device__ inline unsigned orderable(float z)
+{
+    const unsigned u = __float_as_uint(z);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// :110-162.  bin_of[i] = sector*200 + bin, or -1 beyond RMAX
+__global__ __launch_bounds__(256) void gseg_bin_kernel(GsegParams p, const float *xyz, int n, int stride, int *bin_of,
+                                                       int *count, unsigned long long *proto)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *q = xyz + (size_t)i * stride;
+    const double px = q[0], py = q[1], pz = q[2];
+    int          b = -1;
+    if (sqrt(px * px + py * py + pz * pz) < p.rmax) { // :126
+        const double bsize_rad = 360.0 / NA, bsize_lin = p.rmax / NL;
+        double       ph = atan2(py, px) * (180 / M_PI);
+        if (ph < 0) ph = 360.0 + ph;
+        unsigned bind_rad = (unsigned)floor(ph / bsize_rad);
+        if (bind_rad >= (unsigned)NA) bind_rad = NA - 1; // the reference asserts (:136)
+        const double xy = sqrt(px * px + py * py);
+        unsigned     bind_lin = (unsigned)floor(xy / bsize_lin);
+        if (bind_lin >= (unsigned)NL) bind_lin = NL - 1;
+        b = (int)bind_rad * NL + (int)bind_lin;
+        atomicAdd(&count[b], 1);                                       // binPoints.push_back :145
+        if (q[2] < kInvalid)                                           // :149 against INVALID; NaN never passes
+            atomicMin(&proto[b], ((unsigned long long)orderable(q[2]) << 32) | (unsigned)i);
+    }
+    bin_of[i] = b;
+}
+
+// :165-185 with sig_f, p_l narrowed to float as the reference's signature does
+__device__ inline double gp_cov(double r1, double r2, float sig_f, float p_l)
+{
+    const float  coeff = (-1 / (2 * p_l * p_l));
+    const double diff = r1 - r2;
+    return (double)sig_f * exp((double)coeff * (diff * diff));
+}
+
+// One workgroup per sector: :196-468 up to the per-bin verdict
+//   state[b] = 1: bin is in the ground model, value = its prototype height
+//   state[b] = 2: bin stayed a candidate, value = GP mean f_s at its range
+//   state[b] = 0: bin holds no signal point (its points are dropped)
+__global__ __launch_bounds__(kSecThreads) void gseg_insac_kernel(GsegParams p, const float *xyz, int stride,
+                                                                 const int *count, const unsigned long long *proto,
+                                                                 unsigned char *state, double *value, double *scratch,
+                                                                 int *iters_out)
+{
+    __shared__ double s_range[NL], s_height[NL]; // candidates (sorted), compacted in place
+    __shared__ int    s_idx[NL];
+    __shared__ double m_range[NL], m_height[NL], alpha[NL], f_s[NL], v_f[NL];
+    __shared__ int    m_idx[NL];
+    __shared__ double t_range[NL], t_height[NL];
+    __shared__ int    t_idx[NL], t_valid[NL];
+    __shared__ int    s_ns, s_nm, s_keep, s_sufficient, s_iters;
+
+    const int    sec = blockIdx.x, tid = threadIdx.x;
+    const float  sf = (float)p.p_sf, pl = (float)p.p_l;
+    double      *Lm = scratch + (size_t)sec * NL * NL; // lower-triangular factor, row-major [i*NL + j]
+
+    // ---- signal points :205-219
+    for (int b = tid; b < NL; b += kSecThreads) {
+        const unsigned long long key = proto[sec * NL + b];
+        int                      ok = 0;
+        if (key != ~0ull && count[sec * NL + b] > 5) {
+            const float *q = xyz + (size_t)(unsigned)(key & 0xffffffffu) * stride;
+            const double px = q[0], py = q[1];
+            t_range[b] = (double)(float)sqrt(px * px + py * py); // pcl::PointXY stores floats
+            t_height[b] = (double)q[2];
+            ok = 1;
+        }
+        t_valid[b] = ok;
+        t_idx[b] = b;
+    }
+    __syncthreads();
+    // ---- sort by (height, bin) :229 : rank of every valid entry by counting
+    for (int b = tid; b < NL; b += kSecThreads) {
+        if (!t_valid[b]) continue;
+        int rank = 0;
+        for (int o = 0; o < NL; ++o)
+            if (t_valid[o] && (t_height[o] < t_height[b] || (t_height[o] == t_height[b] && o < b))) ++rank;
+        s_range[rank] = t_range[b];
+        s_height[rank] = t_height[b];
+        s_idx[rank] = b;
+    }
+    if (tid == 0) {
+        int ns = 0;
+        for (int b = 0; b < NL; ++b) ns += t_valid[b];
+        s_ns = ns;
+    }
+    __syncthreads();
+    // ---- seeds :235-277: the first npt sorted entries that pass the gates
+    if (tid == 0) {
+        int       ns = s_ns, nm = 0;
+        const int npt = ns < p.num_seedpoints ? ns : p.num_seedpoints;
+        int       w = 0; // write cursor of the compacted candidate list
+        for (int r = 0; r < ns; ++r) {
+            const bool take = nm < npt && s_range[r] < p.max_seed_range && fabs(s_height[r]) < p.max_seed_height;
+            if (take) {
+                m_range[nm] = s_range[r];
+                m_height[nm] = s_height[r];
+                m_idx[nm] = s_idx[r];
+                ++nm;
+            } else {
+                s_range[w] = s_range[r];
+                s_height[w] = s_height[r];
+                s_idx[w] = s_idx[r];
+                ++w;
+            }
+        }
+        s_ns = w;
+        s_nm = nm;
+        s_sufficient = nm >= 2; // :272-277
+        s_keep = (nm >= 2) && (w > 0); // :289-290
+        s_iters = 0;
+    }
+    __syncthreads();
+
+    while (s_keep) { // :295-377
+        const int nm = s_nm, ns = s_ns;
+        // A = C_XX + sn*I (lower triangle), then Cholesky in place, one column per step
+        for (int e = tid; e < nm * nm; e += kSecThreads) {
+            const int i = e / nm, j = e % nm;
+            if (j <= i) Lm[i * NL + j] = gp_cov(m_range[i], m_range[j], sf, pl) + (i == j ? p.p_sn : 0.0);
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int c = 0; c < nm; ++c) {
+            if (tid == 0) Lm[c * NL + c] = sqrt(Lm[c * NL + c]);
+            __threadfence_block();
+            __syncthreads();
+            const double d = Lm[c * NL + c];
+            for (int i = c + 1 + tid; i < nm; i += kSecThreads) Lm[i * NL + c] /= d;
+            __threadfence_block();
+            __syncthreads();
+            // trailing update of the lower triangle
+            const int rem = nm - c - 1;
+            for (int e = tid; e < rem * rem; e += kSecThreads) {
+                const int i = c + 1 + e / rem, j = c + 1 + e % rem;
+                if (j <= i) Lm[i * NL + j] -= Lm[i * NL + c] * Lm[j * NL + c];
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        // alpha = A^-1 z (thread 0: two triangular solves of length nm)
+        if (tid == 0) {
+            for (int i = 0; i < nm; ++i) {
+                double s = m_height[i];
+                for (int j = 0; j < i; ++j) s -= Lm[i * NL + j] * alpha[j];
+                alpha[i] = s / Lm[i * NL + i];
+            }
+            for (int i = nm - 1; i >= 0; --i) {
+                double s = alpha[i];
+                for (int j = i + 1; j < nm; ++j) s -= Lm[j * NL + i] * alpha[j];
+                alpha[i] = s / Lm[i * NL + i];
+            }
+        }
+        __syncthreads();
+        // every candidate: f = c . alpha ; Vf = sf - |L^-1 c|^2   (one thread per candidate, own scratch row)
+        double *Y = scratch + (size_t)NA * NL * NL + (size_t)sec * NL * NL; // [candidate][nm]
+        for (int k = tid; k < ns; k += kSecThreads) {
+            double *y = Y + (size_t)k * NL;
+            double  f = 0.0, q = 0.0;
+            for (int i = 0; i < nm; ++i) {
+                const double c = gp_cov(s_range[k], m_range[i], sf, pl);
+                f += c * alpha[i];
+                double s = c;
+                for (int j = 0; j < i; ++j) s -= Lm[i * NL + j] * y[j];
+                s /= Lm[i * NL + i];
+                y[i] = s;
+                q += s * s;
+            }
+            f_s[k] = f;
+            v_f[k] = gp_cov(s_range[k], s_range[k], sf, pl) - q;
+        }
+        __syncthreads();
+        // :331-369: all candidates are judged against THIS iteration's model; inliers join in order
+        if (tid == 0) {
+            int nm2 = nm, w = 0;
+            for (int k = 0; k < ns; ++k) {
+                const double met = (s_height[k] - f_s[k]) / sqrt(p.p_sn + v_f[k] * v_f[k]);
+                if (v_f[k] < p.p_tmodel && fabs(met) < p.p_tdata) {
+                    m_range[nm2] = s_range[k];
+                    m_height[nm2] = s_height[k];
+                    m_idx[nm2] = s_idx[k];
+                    ++nm2;
+                } else {
+                    s_range[w] = s_range[k];
+                    s_height[w] = s_height[k];
+                    s_idx[w] = s_idx[k];
+                    f_s[w] = f_s[k];
+                    ++w;
+                }
+            }
+            s_keep = !(nm2 == nm || w == 0); // :374-375
+            s_nm = nm2;
+            s_ns = w;
+            ++s_iters;
+        }
+        __syncthreads();
+    }
+
+    // ---- verdict per bin :385-454
+    for (int b = tid; b < NL; b += kSecThreads) state[sec * NL + b] = 0;
+    __syncthreads();
+    for (int i = tid; i < s_nm; i += kSecThreads) {
+        state[sec * NL + m_idx[i]] = 1;
+        value[sec * NL + m_idx[i]] = m_height[i];
+    }
+    if (s_sufficient)
+        for (int i = tid; i < s_ns; i += kSecThreads) {
+            state[sec * NL + s_idx[i]] = 2;
+            value[sec * NL + s_idx[i]] = f_s[i];
+        }
+    if (tid == 0 && iters_out) iters_out[sec] = s_iters;
+}
+
+__global__ __launch_bounds__(256) void gseg_label_kernel(GsegParams p, const float *xyz, int n, int stride,
+                                                         const int *bin_of, const unsigned char *state,
+                                                         const double *value, unsigned char *labels)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    unsigned char lab = 0; // dropped
+    const int     b = bin_of[i];
+    if (b >= 0) {
+        const unsigned char st = state[b];
+        if (st) {
+            const double z = (double)xyz[(size_t)i * stride + 2];
+            const float  h = (float)fabs(st == 1 ? value[b] - z : z - value[b]); // :397, :437
+            if (st == 1 && h < p.p_tg)
+                lab = 1; // ground
+            else
+                lab = h > p.robot_height ? 3 : 2; // :406-413, :439-446
+        }
+    }
+    labels[i] = lab;
+}
+
+// ground and drivability-blocking obstacle points as 4-float records (x, y, z, 0), the
+// two clouds mls.cpp:73-142 consumes; wave-aggregated append (output order is not input order)
+__global__ __launch_bounds__(256) void gseg_split_kernel(const float *xyz, int n, int stride,
+                                                         const unsigned char *labels, float4 *ground, float4 *obstacle,
+                                                         int *counts)
+{
+    const int  i = blockIdx.x * 256 + threadIdx.x;
+    const int  lab = i < n ? labels[i] : 0;
+    const int  lane = threadIdx.x & 63;
+    for (int which = 1; which <= 2; ++which) {
+        const bool               mine = lab == which;
+        const unsigned long long m = __ballot(mine);
+        if (!m) continue;
+        int base = 0;
+        if (lane == (__ffsll((long long)m) - 1)) base = atomicAdd(&counts[which - 1], __popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1);
+        if (mine) {
+            const float *q = xyz + (size_t)i * stride;
+            (which == 1 ? ground : obstacle)[base + __popcll(m & ((1ull << lane) - 1ull))] =
+                make_float4(q[0], q[1], q[2], 0.f);
+        }
+    }
+}
+
+} // namespace
+
+struct slam_gseg {
+    GsegParams prm;
+    int       *d_count = nullptr;
+    unsigned long long *d_proto = nullptr;
+    unsigned char *d_state = nullptr;
+    double    *d_value = nullptr;
+    double    *d_scratch = nullptr; // [2][72][200*200] Cholesky factor + forward-substitution rows
+    int       *d_iters = nullptr;
+    int       *d_bin_of = nullptr;
+    size_t     cap_points = 0;
+    void      *d_stage = nullptr; // host-API staging: points + labels
+    size_t     cap_stage = 0;
+};
+
+static int gseg_reserve(slam_gseg *h, size_t n)
+{
+    if (n <= h->cap_points) return SLAM_OK;
+    if (h->d_bin_of) (void)hipFree(h->d_bin_of);
+    h->d_bin_of = nullptr;
+    h->cap_points = 0;
+    SLAM_HIP(hipMalloc((void **)&h->d_bin_of, sizeof(int) * n));
+    h->cap_points = n;
+    return SLAM_OK;
+}
+
+extern "C" {
+
+void slam_gseg_default_params(slam_gseg_params *p)
+{ // groundSegmentation.cpp:31-55
+    if (!p) return;
+    p->rmax = 100.0;
+    p->num_seedpoints = 10;
+    p->gp_lengthparameter = 10;
+    p->gp_covariancescale = 1.0;
+    p->gp_modelnoise = 0.3;
+    p->gp_groundmodelconfidence = 5.0;
+    p->gp_grounddataconfidence = 5.0;
+    p->gp_groundthreshold = 0.3;
+    p->robotheight = 1.2;
+    p->seeding_maxrange = 50;
+    p->seeding_maxheight = 15;
+}
+
+int slam_gseg_create(const slam_gseg_params *params, slam_gseg_t **out)
+{
+    SLAM_REQUIRE(out, SLAM_E_INVALID, "slam_gseg_create: null out pointer");
+    *out = nullptr;
+    SLAM_TRY(require_device());
+    slam_gseg_params p;
+    if (params)
+        p = *params;
+    else
+        slam_gseg_default_params(&p);
+    SLAM_REQUIRE(p.rmax > 0 && p.num_seedpoints >= 0 && p.num_seedpoints <= NL, SLAM_E_INVALID,
+                 "slam_gseg_create: bad parameters");
+    slam_gseg *h = new (std::nothrow) slam_gseg();
+    SLAM_REQUIRE(h, SLAM_E_NOMEM, "slam_gseg_create: out of host memory");
+    h->prm = {p.rmax, p.num_seedpoints, p.gp_lengthparameter, p.gp_covariancescale, p.gp_modelnoise,
+              p.gp_groundmodelconfidence, p.gp_grounddataconfidence, p.gp_groundthreshold, p.robotheight,
+              p.seeding_maxrange, p.seeding_maxheight};
+    hipError_t e = hipMalloc((void **)&h->d_count, sizeof(int) * NA * NL);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_proto, sizeof(unsigned long long) * NA * NL);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_state, NA * NL);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_value, sizeof(double) * NA * NL);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_scratch, sizeof(double) * 2 * (size_t)NA * NL * NL);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_iters, sizeof(int) * NA);
+    if (e != hipSuccess) {
+        slam_gseg_destroy(h);
+        SLAM_HIP(e);
+    }
+    *out = h;
+    return SLAM_OK;
+}
+
+void slam_gseg_destroy(slam_gseg_t *h)
+{
+    if (!h) return;
+    void *ptrs[] = {h->d_count, h->d_proto, h->d_state, h->d_value, h->d_scratch, h->d_iters, h->d_bin_of, h->d_stage};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    delete h;
+}
+
+int slam_gseg_reserve(slam_gseg_t *h, int max_points)
+{
+    SLAM_REQUIRE(h && max_points >= 0, SLAM_E_INVALID, "slam_gseg_reserve: bad arguments");
+    return gseg_reserve(h, (size_t)max_points);
+}
+
+int slam_gseg_segment_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, uint8_t *d_labels,
+                          slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && n >= 0 && stride >= 3 && (n == 0 || (d_xyz && d_labels)), SLAM_E_INVALID,
+                 "slam_gseg_segment_dev: bad arguments");
+    SLAM_TRY(require_device());
+    SLAM_TRY(gseg_reserve(h, (size_t)(n > 0 ? n : 1)));
+    hipStream_t st = as_stream(stream);
+    SLAM_HIP(hipMemsetAsync(h->d_count, 0, sizeof(int) * NA * NL, st));
+    SLAM_HIP(hipMemsetAsync(h->d_proto, 0xff, sizeof(unsigned long long) * NA * NL, st));
+    if (n > 0)
+        hipLaunchKernelGGL(gseg_bin_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->prm, d_xyz, n, stride,
+                           h->d_bin_of, h->d_count, h->d_proto);
+    hipLaunchKernelGGL(gseg_insac_kernel, dim3(NA), dim3(kSecThreads), 0, st, h->prm, d_xyz, stride, h->d_count,
+                       h->d_proto, h->d_state, h->d_value, h->d_scratch, h->d_iters);
+    if (n > 0)
+        hipLaunchKernelGGL(gseg_label_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->prm, d_xyz, n, stride,
+                           h->d_bin_of, h->d_state, h->d_value, d_labels);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+int slam_gseg_segment(slam_gseg_t *h, const float *xyz, int n, int stride, uint8_t *labels)
+{
+    SLAM_REQUIRE(h && n >= 0 && stride >= 3 && (n == 0 || (xyz && labels)), SLAM_E_INVALID,
+                 "slam_gseg_segment: bad arguments");
+    SLAM_TRY(require_device());
+    if (n == 0) return SLAM_OK;
+    const size_t bytes = sizeof(float) * (size_t)n * stride;
+    if (bytes + (size_t)n > h->cap_stage) {
+        if (h->d_stage) (void)hipFree(h->d_stage);
+        h->d_stage = nullptr;
+        h->cap_stage = 0;
+        SLAM_HIP(hipMalloc(&h->d_stage, bytes + (size_t)n));
+        h->cap_stage = bytes + (size_t)n;
+    }
+    float   *d_xyz = static_cast<float *>(h->d_stage);
+    uint8_t *d_lab = reinterpret_cast<uint8_t *>(h->d_stage) + bytes;
+    SLAM_HIP(hipMemcpyAsync(d_xyz, xyz, bytes, hipMemcpyHostToDevice, nullptr));
+    SLAM_TRY(slam_gseg_segment_dev(h, d_xyz, n, stride, d_lab, nullptr));
+    SLAM_HIP(hipMemcpyAsync(labels, d_lab, (size_t)n, hipMemcpyDeviceToHost, nullptr));
+    SLAM_HIP(hipStreamSynchronize(nullptr));
+    return SLAM_OK;
+}
+
+int slam_gseg_split_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, const uint8_t *d_labels,
+                        float *d_ground_xyz4, float *d_obstacle_xyz4, int32_t *d_counts, slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && n >= 0 && stride >= 3 && d_counts && (n == 0 || (d_xyz && d_labels && d_ground_xyz4 && d_obstacle_xyz4)),
+                 SLAM_E_INVALID, "slam_gseg_split_dev: bad arguments");
+    hipStream_t st = as_stream(stream);
+    SLAM_HIP(hipMemsetAsync(d_counts, 0, 2 * sizeof(int32_t), st));
+    if (n > 0)
+        hipLaunchKernelGGL(gseg_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, stride, d_labels,
+                           reinterpret_cast<float4 *>(d_ground_xyz4), reinterpret_cast<float4 *>(d_obstacle_xyz4),
+                           d_counts);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+int slam_gseg_read_model(slam_gseg_t *h, uint8_t *bin_state, double *bin_value, int32_t *sector_iterations)
+{
+    SLAM_REQUIRE(h, SLAM_E_INVALID, "null handle");
+    SLAM_TRY(require_device());
+    SLAM_HIP(hipDeviceSynchronize());
+    if (bin_state) SLAM_HIP(hipMemcpy(bin_state, h->d_state, NA * NL, hipMemcpyDeviceToHost));
+    if (bin_value) SLAM_HIP(hipMemcpy(bin_value, h->d_value, sizeof(double) * NA * NL, hipMemcpyDeviceToHost));
+    if (sector_iterations) SLAM_HIP(hipMemcpy(sector_iterations, h->d_iters, sizeof(int) * NA, hipMemcpyDeviceToHost));
+    return SLAM_OK;
+}
+
+} // extern "C"

@@ -138,3 +138,42 @@ def make_batch(n_scans, n_loop=None, first=0, all_nga=False, n_beams=N_BEAMS):
                      np.ascontiguousarray(np.array(Rs)).reshape(n_scans, 4),
                      np.ascontiguousarray(np.array(ts)).reshape(n_scans, 2),
                      np.array(poses, dtype=np.float64).reshape(n_scans, 3))
+
+
+# ------------------------------------------------------------------ 3-D clouds
+# BASELINE config 3: a 64-ring spinning lidar (elevation -24.8..+2 deg, 2048
+# azimuth steps = 131 072 rays) in the same world, walls extruded to 3 m above a
+# ground plane 1.73 m below the sensor.
+GROUND_Z = -1.73
+WALL_HEIGHT = 3.0
+RING_EL_DEG = (-24.8, 2.0)
+
+
+def make_cloud3d(k, n_loop=50, rings=64, n_az=2048, seed_base=9000, max_range=100.0):
+    """Point cloud (sensor frame, f32 [n,3]) of the k-th pose of the loop; returns (xyz, pose)."""
+    segs, _ = world_segments()
+    x, y, th = true_pose(k, n_loop)
+    rs = np.random.RandomState(seed_base + k)
+    el = np.deg2rad(np.linspace(RING_EL_DEG[0], RING_EL_DEG[1], rings))
+    az = np.deg2rad(np.arange(n_az) * (360.0 / n_az))
+    EL, AZ = np.meshgrid(el, az, indexing="ij")
+    EL, AZ = EL.ravel(), AZ.ravel()
+    ce, se = np.cos(EL), np.sin(EL)
+    dx, dy = np.cos(AZ + th), np.sin(AZ + th)            # horizontal direction in the world
+    px, py = segs[:, 0][None, :], segs[:, 1][None, :]
+    ex, ey = (segs[:, 2] - segs[:, 0])[None, :], (segs[:, 3] - segs[:, 1])[None, :]
+    den = dx[:, None] * ey - dy[:, None] * ex
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rho = ((px - x) * ey - (py - y) * ex) / den      # horizontal distance to each wall line
+        s = ((px - x) * dy[:, None] - (py - y) * dx[:, None]) / den
+    r = rho / ce[:, None]
+    z = r * se[:, None]
+    ok = (np.abs(den) > 1e-12) & (rho > 1e-9) & (s >= 0) & (s <= 1) & (z >= GROUND_Z) & (z <= GROUND_Z + WALL_HEIGHT)
+    r_wall = np.where(ok, r, np.inf).min(axis=1)
+    with np.errstate(divide="ignore"):
+        r_ground = np.where(se < 0, GROUND_Z / se, np.inf)
+    rng = np.minimum(r_wall, r_ground) + rs.normal(0.0, NOISE_SIGMA, size=len(EL))
+    keep = np.isfinite(rng) & (rng > 0.5) & (rng < max_range)
+    rng, ce, se, AZ = rng[keep], ce[keep], se[keep], AZ[keep]
+    xyz = np.stack([rng * ce * np.cos(AZ), rng * ce * np.sin(AZ), rng * se], axis=1).astype(np.float32)
+    return np.ascontiguousarray(xyz), (x, y, th)

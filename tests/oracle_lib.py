@@ -23,9 +23,9 @@ _i8p = C.POINTER(C.c_int8)
 
 
 def build_oracle(force=False):
-    src = os.path.join(ORACLE_DIR, "slam_oracle.c")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("slam_oracle.c", "gseg_oracle.c", "slam_oracle.h")]
     if (force or not os.path.exists(ORACLE_SO)
-            or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src)):
+            or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in srcs)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
     return ORACLE_SO
 
@@ -33,6 +33,15 @@ def build_oracle(force=False):
 class OIcpParams(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("min_delta", C.c_double), ("indist", C.c_double),
                 ("nn_method", C.c_int), ("mode", C.c_int)]
+
+
+class OGsegParams(C.Structure):
+    _fields_ = [("rmax", C.c_double), ("num_seedpoints", C.c_int), ("p_l", C.c_double), ("p_sf", C.c_double),
+                ("p_sn", C.c_double), ("p_tmodel", C.c_double), ("p_tdata", C.c_double), ("p_tg", C.c_double),
+                ("robot_height", C.c_double), ("max_seed_range", C.c_double), ("max_seed_height", C.c_double)]
+
+
+GSEG_DROPPED, GSEG_GROUND, GSEG_OBSTACLE, GSEG_OVERHEAD = 0, 1, 2, 3
 
 
 class OGridParams(C.Structure):
@@ -92,6 +101,10 @@ def lib():
     L.ogrid_finalize.argtypes = [C.POINTER(OGridParams), _i32p, _i32p, _dp, _i8p]
     L.ogrid_add_scan_inorder.argtypes = [C.POINTER(OGridParams), _fp, C.c_int, _fp, C.c_int,
                                          C.c_int, _dp, _i8p, _i8p]
+    L.ogseg_default_params.argtypes = [C.POINTER(OGsegParams)]
+    L.ogseg_segment.restype = C.c_int
+    L.ogseg_segment.argtypes = [C.POINTER(OGsegParams), _fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte), _ip,
+                                C.POINTER(C.c_ubyte), _dp]
     _lib = L
     return L
 
@@ -313,6 +326,30 @@ def grid_add_scan_inorder(g, obs, gnd, num_pts, drivable, occ):
     lib().ogrid_add_scan_inorder(C.byref(g), _f(obs), obs.size // stride, _f(gnd),
                                  gnd.size // stride, stride, _d(num_pts),
                                  drivable.ctypes.data_as(_i8p), occ.ctypes.data_as(_i8p))
+
+
+# ------------------------------------------------------- ground segmentation
+def gseg_params(**kw):
+    p = OGsegParams()
+    lib().ogseg_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def gseg_segment(xyz, params=None):
+    """groundSegmentation::segmentGround on the oracle.  xyz: [n, stride>=3] f32.
+    Returns labels[n] (GSEG_*), bin_of[n], state[72*200], value[72*200], outer iterations."""
+    xyz = as_f32(xyz)
+    n, stride = xyz.shape
+    p = params or gseg_params()
+    labels = np.zeros(max(n, 1), dtype=np.uint8)
+    bin_of = np.zeros(max(n, 1), dtype=np.int32)
+    state = np.zeros(72 * 200, dtype=np.uint8)
+    value = np.zeros(72 * 200)
+    it = lib().ogseg_segment(C.byref(p), _f(xyz), n, stride, labels.ctypes.data_as(C.POINTER(C.c_ubyte)),
+                             _i(bin_of), state.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(value))
+    return labels[:n], bin_of[:n], state, value, it
 
 
 # --------------------------------------------------- compiled reference Matrix
