@@ -266,6 +266,11 @@ int  slam_gseg_segment_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride
 int  slam_gseg_split_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, const uint8_t *d_labels,
                          float *d_ground_xyz4, float *d_obstacle_xyz4, int32_t *d_counts,
                          slam_stream_t stream);
+/* CCICP::classifyPoints, icpTools.cpp:36-103: for every point of the obstacle cloud 1 = ground
+ * adjacent (GA), 0 = not (NGA), 255 = dropped there too (outside the 1200 x 1200 x 0.5 m lattice
+ * or in its outermost cells).  GA/NGA are the two classes the ICP matches separately. */
+int  slam_gseg_classify_ga_dev(slam_gseg_t *h, const float *d_obstacle_xyz, int n, int stride,
+                               uint8_t *d_flags, slam_stream_t stream);
 /* per polar bin (72 x 200): 1 = in the ground model (value = prototype height), 2 = candidate
  * that stayed out (value = GP mean), 0 = no signal point; INSAC iterations per sector */
 int  slam_gseg_read_model(slam_gseg_t *h, uint8_t *bin_state, double *bin_value, int32_t *sector_iterations);

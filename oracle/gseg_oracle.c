@@ -233,3 +233,38 @@ int ogseg_segment(const ogseg_params *p, const float *xyz, int n, int stride, un
     free(sig); free(model); free(A); free(Bm); free(fs); free(vf);
     return total_iters;
 }
+
+/* CCICP::classifyPoints, ccicp2d/src/icpTools.cpp:36-103 with icpTools.h:24-26
+ * (NUMBINSGA 1200, RESOLUTION 0.5, GRD_ADJ_THRESH 2): obstacle points are binned on a
+ * 1200 x 1200 lattice of 0.5 m cells centred on the sensor; a point is "ground adjacent"
+ * (GA) when at least 2 of the 8 cells around its cell are empty.  Points outside the
+ * lattice or in its outermost ring of cells are dropped (:60, :72-77). */
+void occicp_classify(const float *xyz, int n, int stride, unsigned char *flags)
+{
+    const int    NB = 1200;
+    const double RES = 0.5, offset = (double)NB * RES / 2;
+    unsigned char *occ = (unsigned char *)calloc((size_t)NB * NB, 1);
+    int           *bin = (int *)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < n; i++) {
+        const float cx = xyz[(size_t)i * stride], cy = xyz[(size_t)i * stride + 1];
+        /* :57-58  floor((curr_x + offset) / RESOLUTION): float + double -> double */
+        const double fx = floor(((double)cx + offset) / RES), fy = floor(((double)cy + offset) / RES);
+        bin[i] = -1;
+        if (!(fx >= 0 && fx < NB && fy >= 0 && fy < NB)) continue; /* :60 (NaN drops too) */
+        bin[i] = (int)fx * NB + (int)fy;
+        occ[bin[i]] = 1;
+    }
+    for (int i = 0; i < n; i++) {
+        flags[i] = 255;
+        if (bin[i] < 0) continue;
+        const int bi = bin[i] / NB, bj = bin[i] % NB;
+        if (bi == 0 || bi == NB - 1 || bj == 0 || bj == NB - 1) continue; /* :72-77 */
+        int ground = 0;
+        for (int q = bi - 1; q <= bi + 1; q++)
+            for (int r = bj - 1; r <= bj + 1; r++)
+                if (!(q == bi && r == bj) && !occ[q * NB + r]) ground++;
+        flags[i] = ground >= 2; /* :96 */
+    }
+    free(occ);
+    free(bin);
+}

@@ -199,6 +199,10 @@ void ogseg_default_params(ogseg_params *p);
 int ogseg_segment(const ogseg_params *p, const float *xyz, int n, int stride, unsigned char *labels,
                   int *bin_of, unsigned char *sector_model, double *sector_value);
 
+/* CCICP::classifyPoints (icpTools.cpp:36-103): per obstacle point 1 = ground adjacent,
+ * 0 = not, 255 = dropped (outside the 1200 x 1200 x 0.5 m lattice or in its edge cells). */
+void occicp_classify(const float *xyz, int n, int stride, unsigned char *flags);
+
 #ifdef __cplusplus
 }
 #endif

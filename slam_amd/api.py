@@ -79,6 +79,7 @@ EXPORTS = [
     "slam_grid_info", "slam_grid_counts_dev", "slam_grid_raycast_stats",
     "slam_gseg_default_params", "slam_gseg_create", "slam_gseg_destroy", "slam_gseg_reserve",
     "slam_gseg_segment", "slam_gseg_segment_dev", "slam_gseg_split_dev", "slam_gseg_read_model",
+    "slam_gseg_classify_ga_dev",
 ]
 
 
@@ -159,6 +160,7 @@ def lib():
     L.slam_gseg_segment_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp]
     L.slam_gseg_split_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
     L.slam_gseg_read_model.argtypes = [_vp, _vp, _vp, _vp]
+    L.slam_gseg_classify_ga_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp]
     L.slam_grid_raycast_stats.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L
     return L
@@ -533,6 +535,18 @@ class GroundSegmentation:
     def split_dev(self, d_xyz, n, stride, d_labels, d_ground, d_obstacle, d_counts, stream=None):
         check(lib().slam_gseg_split_dev(self.h, d_xyz.ptr, int(n), int(stride), d_labels.ptr, d_ground.ptr,
                                         d_obstacle.ptr, d_counts.ptr, _sp(stream)))
+
+    def classify_ga(self, obstacle_xyz):
+        """CCICP::classifyPoints over an obstacle cloud (host arrays): flags 1 GA / 0 NGA / 255 dropped."""
+        xyz = np.ascontiguousarray(obstacle_xyz, dtype=np.float32)
+        n, stride = xyz.shape
+        if n == 0:
+            return np.zeros(0, np.uint8)
+        d_xyz = DeviceArray.from_host(xyz)
+        d_f = DeviceArray((n,), np.uint8)
+        check(lib().slam_gseg_classify_ga_dev(self.h, d_xyz.ptr, n, stride, d_f.ptr, None))
+        synchronize()
+        return d_f.download()
 
     def read_model(self):
         state = np.zeros(72 * 200, dtype=np.uint8)

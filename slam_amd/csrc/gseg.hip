@@ -302,6 +302,47 @@ __global__ __launch_bounds__(256) void gseg_split_kernel(const float *xyz, int n
     }
 }
 
+// CCICP::classifyPoints, ccicp2d/src/icpTools.cpp:36-103 (icpTools.h:24-26): occupancy of a
+// 1200 x 1200 lattice of 0.5 m cells, then per point the number of empty cells among the 8
+// around its own: ground adjacent (GA) when >= 2.  flags: 1 GA, 0 NGA, 255 dropped.
+constexpr int kGaBins = 1200;
+
+__device__ inline int ga_bin(const float *q)
+{
+    const double RES = 0.5, offset = (double)kGaBins * RES / 2;
+    const double fx = floor(((double)q[0] + offset) / RES), fy = floor(((double)q[1] + offset) / RES); // :57-58
+    if (!(fx >= 0 && fx < kGaBins && fy >= 0 && fy < kGaBins)) return -1;                             // :60
+    return (int)fx * kGaBins + (int)fy;
+}
+
+__global__ __launch_bounds__(256) void ga_mark_kernel(const float *xyz, int n, int stride, unsigned char *occ)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int b = ga_bin(xyz + (size_t)i * stride);
+    if (b >= 0) occ[b] = 1;
+}
+
+__global__ __launch_bounds__(256) void ga_flag_kernel(const float *xyz, int n, int stride, const unsigned char *occ,
+                                                      unsigned char *flags)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int     b = ga_bin(xyz + (size_t)i * stride);
+    unsigned char f = 255;
+    if (b >= 0) {
+        const int bi = b / kGaBins, bj = b % kGaBins;
+        if (!(bi == 0 || bi == kGaBins - 1 || bj == 0 || bj == kGaBins - 1)) { // :72-77
+            int ground = 0;
+            for (int q = bi - 1; q <= bi + 1; ++q)
+                for (int r = bj - 1; r <= bj + 1; ++r)
+                    if (!(q == bi && r == bj) && !occ[q * kGaBins + r]) ++ground;
+            f = ground >= 2; // :96 GRD_ADJ_THRESH
+        }
+    }
+    flags[i] = f;
+}
+
 } // namespace
 
 struct slam_gseg {
@@ -314,6 +355,7 @@ struct slam_gseg {
     int       *d_iters = nullptr;
     int       *d_bin_of = nullptr;
     size_t     cap_points = 0;
+    unsigned char *d_ga_occ = nullptr; // 1200 x 1200 occupancy of classifyPoints
     void      *d_stage = nullptr; // host-API staging: points + labels
     size_t     cap_stage = 0;
 };
@@ -381,7 +423,8 @@ int slam_gseg_create(const slam_gseg_params *params, slam_gseg_t **out)
 void slam_gseg_destroy(slam_gseg_t *h)
 {
     if (!h) return;
-    void *ptrs[] = {h->d_count, h->d_proto, h->d_state, h->d_value, h->d_scratch, h->d_iters, h->d_bin_of, h->d_stage};
+    void *ptrs[] = {h->d_count, h->d_proto, h->d_state, h->d_value, h->d_scratch, h->d_iters, h->d_bin_of, h->d_stage,
+                    h->d_ga_occ};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete h;
@@ -449,6 +492,23 @@ int slam_gseg_split_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, c
         hipLaunchKernelGGL(gseg_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, stride, d_labels,
                            reinterpret_cast<float4 *>(d_ground_xyz4), reinterpret_cast<float4 *>(d_obstacle_xyz4),
                            d_counts);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+int slam_gseg_classify_ga_dev(slam_gseg_t *h, const float *d_obstacle_xyz, int n, int stride, uint8_t *d_flags,
+                              slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && n >= 0 && stride >= 2 && (n == 0 || (d_obstacle_xyz && d_flags)), SLAM_E_INVALID,
+                 "slam_gseg_classify_ga_dev: bad arguments");
+    SLAM_TRY(require_device());
+    if (n == 0) return SLAM_OK;
+    if (!h->d_ga_occ) SLAM_HIP(hipMalloc((void **)&h->d_ga_occ, (size_t)kGaBins * kGaBins));
+    hipStream_t st = as_stream(stream);
+    SLAM_HIP(hipMemsetAsync(h->d_ga_occ, 0, (size_t)kGaBins * kGaBins, st));
+    hipLaunchKernelGGL(ga_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_obstacle_xyz, n, stride, h->d_ga_occ);
+    hipLaunchKernelGGL(ga_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_obstacle_xyz, n, stride, h->d_ga_occ,
+                       d_flags);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }

@@ -105,6 +105,7 @@ def lib():
     L.ogseg_segment.restype = C.c_int
     L.ogseg_segment.argtypes = [C.POINTER(OGsegParams), _fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte), _ip,
                                 C.POINTER(C.c_ubyte), _dp]
+    L.occicp_classify.argtypes = [_fp, C.c_int, C.c_int, C.POINTER(C.c_ubyte)]
     _lib = L
     return L
 
@@ -350,6 +351,15 @@ def gseg_segment(xyz, params=None):
     it = lib().ogseg_segment(C.byref(p), _f(xyz), n, stride, labels.ctypes.data_as(C.POINTER(C.c_ubyte)),
                              _i(bin_of), state.ctypes.data_as(C.POINTER(C.c_ubyte)), _d(value))
     return labels[:n], bin_of[:n], state, value, it
+
+
+def classify_ga(xyz):
+    """CCICP::classifyPoints (icpTools.cpp:36-103): flags[n] in {0 NGA, 1 GA, 255 dropped}."""
+    xyz = as_f32(xyz)
+    n, stride = xyz.shape
+    flags = np.zeros(max(n, 1), dtype=np.uint8)
+    lib().occicp_classify(_f(xyz), n, stride, flags.ctypes.data_as(C.POINTER(C.c_ubyte)))
+    return flags[:n]
 
 
 # --------------------------------------------------- compiled reference Matrix

@@ -127,3 +127,33 @@ def test_config3_pipeline_segment_split_update():
     assert np.array_equal(hits, eh) and np.array_equal(misses, em)
     assert hits.sum() > 10000 and misses.sum() > 100000
     seg.close(); g.close()
+
+
+def test_oracle_ga_classification_rules():
+    # icpTools.cpp:36-103: 0.5 m cells, GA iff >= 2 of the 8 neighbour cells are empty
+    wall = np.stack([np.arange(0, 20, 0.1), np.full(200, 5.2), np.zeros(200)], 1).astype(np.float32)
+    f = O.classify_ga(wall)
+    assert (f == 1).all()                               # a thin wall: 6 empty neighbours
+    gx, gy = np.meshgrid(np.arange(0, 5, 0.25), np.arange(0, 5, 0.25))
+    blob = np.stack([gx.ravel(), gy.ravel(), np.zeros(gx.size)], 1).astype(np.float32) + np.float32(0.1)
+    f = O.classify_ga(blob)
+    inner = (blob[:, 0] > 0.6) & (blob[:, 0] < 4.4) & (blob[:, 1] > 0.6) & (blob[:, 1] < 4.4)
+    assert (f[inner] == 0).all() and (f[~inner] == 1).any()
+    far = np.array([[299.9, 0, 0], [300.1, 0, 0], [-300.0, 0, 0], [-299.4, 0, 0], [np.nan, 0, 0]], np.float32)
+    assert list(O.classify_ga(far)) == [255, 255, 255, 1, 255]   # edge ring and outside are dropped (:60, :72-77)
+
+
+@pytest.mark.gpu
+def test_gpu_ga_classification_matches_oracle():
+    from slam_amd import api
+    xyz = synth.make_cloud3d(9, n_loop=50)[0]
+    seg = api.GroundSegmentation()
+    lab = seg.segment(xyz)
+    obs = xyz[lab >= api.GSEG_OBSTACLE]                  # obsCloud (icpTools.cpp:114-117)
+    rs = np.random.RandomState(1)
+    extra = (rs.rand(2000, 3) * [700, 700, 1] - [350, 350, 0]).astype(np.float32)
+    pts = np.concatenate([obs, extra])
+    assert np.array_equal(seg.classify_ga(pts), O.classify_ga(pts))
+    f = seg.classify_ga(obs)
+    assert (f == 1).sum() > 100                          # thin walls: every obstacle cell has empty neighbours
+    seg.close()
