@@ -5,7 +5,7 @@
 // The reference takes PCL clouds and geometry_msgs poses and runs the ground
 // segmentation inside addToOccupancy (mls.cpp:66-67); this adapter starts just
 // below that: the caller hands over the already segmented obstacle ("drv") and
-// ground points as float arrays (PointXYZGD is 4 floats, x and y first).
+// ground points as float arrays (PointXYZGD is a 32-byte record = 8 floats, x, y, z first).
 // getDrivability() fills a struct laid out like nav_msgs/OccupancyGrid
 // (mls.h:167-175): data[x + size_x*y] in {-1, 0, 100}, origin -res*size/2.
 #pragma once
@@ -52,7 +52,7 @@ public:
     void clearMap() { if (h_) slam_grid_clear(h_, nullptr); }                                 // mls.cpp:18-31
     void setPose(double x, double y) { if (h_) slam_grid_set_pose(h_, x, y, nullptr); }      // mls.cpp:408-479
     // mls.cpp:59-150 below the segmentation: obstacle points +1.0, ground points -0.3, in that order
-    void addToOccupancy(const float *obstacle, int n_obstacle, const float *ground, int n_ground, int stride = 4)
+    void addToOccupancy(const float *obstacle, int n_obstacle, const float *ground, int n_ground, int stride = 8)
     {
         if (h_ && slam_grid_add_scan_inorder(h_, obstacle, n_obstacle, ground, n_ground, stride) != SLAM_OK)
             std::fprintf(stderr, "%s\n", slam_last_error());
@@ -60,7 +60,7 @@ public:
     // mls.cpp:34-53 (rolling branch): setPose, then the points (already rotated into the
     // global orientation and offset by the sub-cell residual, as mls.cpp:41-47 does with PCL)
     void addToMap(const float *obstacle, int n_obstacle, const float *ground, int n_ground, double pose_x,
-                  double pose_y, int stride = 4)
+                  double pose_y, int stride = 8)
     {
         setPose(pose_x, pose_y);
         addToOccupancy(obstacle, n_obstacle, ground, n_ground, stride);

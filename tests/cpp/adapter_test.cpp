@@ -64,7 +64,7 @@ int main(int argc, char **argv)
     // local_mapper.cpp:29,86: MLS local_map(200,200,0.2,true); setMinClusterPoints(20)
     MLS local_map(200, 200, 0.2, true);
     local_map.setMinClusterPoints(20);
-    for (int k = 0; k < 3; ++k) local_map.addToMap(obs.data(), (int)obs.size() / 4, gnd.data(), (int)gnd.size() / 4, 0.0, 0.0);
+    for (int k = 0; k < 3; ++k) local_map.addToMap(obs.data(), (int)obs.size() / 4, gnd.data(), (int)gnd.size() / 4, 0.0, 0.0, 4);
     const OccupancyGrid &g = local_map.getDrivability();
 
     FILE *f = std::fopen(out.c_str(), "wb");
