@@ -59,6 +59,13 @@ int slam_memset(void *dptr, int value, size_t bytes, slam_stream_t stream);
 int slam_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes, slam_stream_t stream);
 int slam_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes, slam_stream_t stream);
 int slam_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, slam_stream_t stream); /* asynchronous */
+/* pinned host memory and copies that only enqueue (for overlapping transfers with kernels on
+ * other streams; the host buffer must stay valid until the stream reaches the copy) */
+int slam_host_alloc(void **hptr, size_t bytes);
+int slam_host_free(void *hptr);
+int slam_memcpy_h2d_async(void *dst_dev, const void *src_pinned, size_t bytes, slam_stream_t stream);
+int slam_memcpy_d2h_async(void *dst_pinned, const void *src_dev, size_t bytes, slam_stream_t stream);
+int slam_stream_wait_event(slam_stream_t stream, slam_event_t ev);
 int slam_stream_create(slam_stream_t *stream);
 int slam_stream_destroy(slam_stream_t stream);
 int slam_stream_synchronize(slam_stream_t stream);
@@ -194,7 +201,9 @@ int slam_grid_raycast_dev(slam_grid_t *g, const float *d_origin_xy, const float 
                           int n, slam_stream_t stream);
 /* The same straight from registered scans: end = (float)(R_s * p + t_s) formed
  * as icpPointToPoint.cpp:69-70 forms its query, origin = (float)t_s.
- * n_points = d_scan_off[n_scans] (the host built that array and knows it). */
+ * n_points = d_scan_off[n_scans] (the host built that array and knows it).  With a rolling
+ * window the map-frame points are taken relative to the window centre (slam_grid_get_pose),
+ * as mls.cpp:36-47 shifts the cloud before addToOccupancy. */
 int slam_grid_raycast_scans_dev(slam_grid_t *g, const double *d_pts, const int32_t *d_scan_off,
                                 int n_scans, int n_points, const double *d_R, const double *d_t,
                                 slam_stream_t stream);

@@ -61,7 +61,8 @@ _lib = None
 EXPORTS = [
     "slam_last_error", "slam_version", "slam_device_count", "slam_set_device", "slam_device_info",
     "slam_malloc", "slam_free", "slam_memset", "slam_memcpy_h2d", "slam_memcpy_d2h",
-    "slam_memcpy_d2d",
+    "slam_memcpy_d2d", "slam_host_alloc", "slam_host_free", "slam_memcpy_h2d_async",
+    "slam_memcpy_d2h_async", "slam_stream_wait_event",
     "slam_stream_create", "slam_stream_destroy", "slam_stream_synchronize",
     "slam_device_synchronize", "slam_event_create", "slam_event_destroy", "slam_event_record",
     "slam_event_synchronize", "slam_event_elapsed_ms",
@@ -104,6 +105,11 @@ def lib():
     L.slam_memcpy_h2d.argtypes = [_vp, _vp, C.c_size_t, _vp]
     L.slam_memcpy_d2h.argtypes = [_vp, _vp, C.c_size_t, _vp]
     L.slam_memcpy_d2d.argtypes = [_vp, _vp, C.c_size_t, _vp]
+    L.slam_host_alloc.argtypes = [C.POINTER(_vp), C.c_size_t]
+    L.slam_host_free.argtypes = [_vp]
+    L.slam_memcpy_h2d_async.argtypes = [_vp, _vp, C.c_size_t, _vp]
+    L.slam_memcpy_d2h_async.argtypes = [_vp, _vp, C.c_size_t, _vp]
+    L.slam_stream_wait_event.argtypes = [_vp, _vp]
     L.slam_stream_create.argtypes = [C.POINTER(_vp)]
     L.slam_stream_destroy.argtypes = [_vp]
     L.slam_stream_synchronize.argtypes = [_vp]
@@ -224,6 +230,14 @@ class DeviceArray:
         check(lib().slam_memcpy_d2h(_ptr(out), self.ptr, self.nbytes, stream))
         return out
 
+    def upload_async(self, pinned, stream):
+        assert pinned.nbytes == self.nbytes
+        check(lib().slam_memcpy_h2d_async(self.ptr, pinned.ptr, self.nbytes, _sp(stream)))
+
+    def download_async(self, pinned, stream):
+        assert pinned.nbytes == self.nbytes
+        check(lib().slam_memcpy_d2h_async(pinned.ptr, self.ptr, self.nbytes, _sp(stream)))
+
     def copy_from(self, other, stream=None):
         assert other.nbytes == self.nbytes
         check(lib().slam_memcpy_d2d(self.ptr, other.ptr, self.nbytes, _sp(stream)))
@@ -243,6 +257,32 @@ class DeviceArray:
             pass
 
 
+class PinnedArray:
+    """A numpy view over pinned host memory (slam_host_alloc), for asynchronous copies."""
+
+    def __init__(self, shape, dtype):
+        self.shape = shape if isinstance(shape, tuple) else (int(shape),)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        p = _vp()
+        check(lib().slam_host_alloc(C.byref(p), max(self.nbytes, 1)))
+        self.ptr = p.value
+        buf = (C.c_char * max(self.nbytes, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=self.dtype, count=int(np.prod(self.shape))).reshape(self.shape)
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            lib().slam_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
 class Stream:
     def __init__(self):
         p = _vp()
@@ -251,6 +291,9 @@ class Stream:
 
     def synchronize(self):
         check(lib().slam_stream_synchronize(self.ptr))
+
+    def wait_event(self, ev):
+        check(lib().slam_stream_wait_event(self.ptr, ev.ptr))
 
     def __del__(self):
         if getattr(self, "ptr", None):

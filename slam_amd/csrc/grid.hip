@@ -204,10 +204,15 @@ __global__ __launch_bounds__(kChunk) void beams_from_scans_kernel(GridView g, co
         }
         const double *Rs = R + 4 * (size_t)lo, *ts = t + 2 * (size_t)lo;
         const double2 P = pts[i];
-        // end point formed as icpPointToPoint.cpp:69-70 forms its query
-        const float ex = (float)__dadd_rn(__dadd_rn(__dmul_rn(Rs[0], P.x), __dmul_rn(Rs[1], P.y)), ts[0]);
-        const float ey = (float)__dadd_rn(__dadd_rn(__dmul_rn(Rs[2], P.x), __dmul_rn(Rs[3], P.y)), ts[1]);
-        b = make_beam(g, (float)ts[0], (float)ts[1], ex, ey);
+        // end point formed as icpPointToPoint.cpp:69-70 forms its query; a rolling window is centred on
+        // curPose, so map-frame points are taken relative to it (mls.cpp:36-47 shifts the cloud the same way)
+        const double cx = g.rolling ? g.pose_x : 0.0, cy = g.rolling ? g.pose_y : 0.0;
+        const double gx = __dadd_rn(__dadd_rn(__dmul_rn(Rs[0], P.x), __dmul_rn(Rs[1], P.y)), ts[0]);
+        const double gy = __dadd_rn(__dadd_rn(__dmul_rn(Rs[2], P.x), __dmul_rn(Rs[3], P.y)), ts[1]);
+        const float  ex = (float)(g.rolling ? __dsub_rn(gx, cx) : gx), ey = (float)(g.rolling ? __dsub_rn(gy, cy) : gy);
+        const float  ox = (float)(g.rolling ? __dsub_rn(ts[0], cx) : ts[0]);
+        const float  oy = (float)(g.rolling ? __dsub_rn(ts[1], cy) : ts[1]);
+        b = make_beam(g, ox, oy, ex, ey);
     }
     store_beam_and_box(b, in, i, beams, block_box);
 }

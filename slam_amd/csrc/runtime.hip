@@ -127,6 +127,45 @@ int slam_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, slam_strea
     return SLAM_OK;
 }
 
+int slam_host_alloc(void **hptr, size_t bytes)
+{
+    SLAM_REQUIRE(hptr, SLAM_E_INVALID, "slam_host_alloc: null out pointer");
+    SLAM_TRY(require_device());
+    *hptr = nullptr;
+    SLAM_HIP(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return SLAM_OK;
+}
+
+int slam_host_free(void *hptr)
+{
+    if (!hptr) return SLAM_OK;
+    SLAM_HIP(hipHostFree(hptr));
+    return SLAM_OK;
+}
+
+int slam_memcpy_h2d_async(void *dst_dev, const void *src_pinned, size_t bytes, slam_stream_t stream)
+{
+    SLAM_TRY(require_device());
+    if (!bytes) return SLAM_OK;
+    SLAM_HIP(hipMemcpyAsync(dst_dev, src_pinned, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return SLAM_OK;
+}
+
+int slam_memcpy_d2h_async(void *dst_pinned, const void *src_dev, size_t bytes, slam_stream_t stream)
+{
+    SLAM_TRY(require_device());
+    if (!bytes) return SLAM_OK;
+    SLAM_HIP(hipMemcpyAsync(dst_pinned, src_dev, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    return SLAM_OK;
+}
+
+int slam_stream_wait_event(slam_stream_t stream, slam_event_t ev)
+{
+    SLAM_REQUIRE(ev, SLAM_E_INVALID, "slam_stream_wait_event: null event");
+    SLAM_HIP(hipStreamWaitEvent(as_stream(stream), (hipEvent_t)ev, 0));
+    return SLAM_OK;
+}
+
 int slam_stream_create(slam_stream_t *stream)
 {
     SLAM_REQUIRE(stream, SLAM_E_INVALID, "slam_stream_create: null out pointer");
