@@ -89,8 +89,10 @@ typedef struct {
     int    mode;            /* SLAM_ICP_P2P | SLAM_ICP_P2L */
     int    normals_k;       /* P2L: neighbours per normal (icpPointToPlane.h: 10) */
     int    lanes_per_point; /* lanes of a wavefront that share one scene point's
-                               search: 1,2,4,8,16,32,64; 0 = library default,
-                               -1 = chosen per pass from the points left */
+                               search: 1,2,4,8,16,32,64; 0 = library default (2),
+                               -1 = chosen per pass from the points left,
+                               -2 = experimental: one lane per point, ordered-cell
+                               sweeps + cooperative queue */
     double cell_size;       /* model lattice pitch in metres; 0 = sized to fit LDS */
     int    force_global;    /* 1 = keep the model index in HBM/L2 even if it fits LDS */
 } slam_icp_params;

@@ -41,8 +41,17 @@ namespace {
 constexpr int kBlock = 1024;          // threads per scan workgroup
 constexpr int kWaves = kBlock / 64;
 constexpr int kNumAcc = 9;            // doubles reduced per iteration
+constexpr int kStampSlots = 9;        // diagnostic stamps per wavefront
+constexpr int kHoist = 3;             // passes whose points stay in registers across iterations
 constexpr unsigned kLdsTotal = 160u * 1024u;
-constexpr unsigned kScratchBytes = (2u * kWaves * kNumAcc + 2u * 8u) * sizeof(double); // reduction + broadcast
+constexpr int kCoop = 16;                      // lanes per query in the cooperative ring search
+constexpr int kCoopPerWave = 64 / kCoop;       // queries a wavefront searches at a time
+constexpr int kCoopPerBlock = kWaves * kCoopPerWave;
+constexpr unsigned kReduceBytes = (2u * kWaves * kNumAcc + 2u * 8u) * sizeof(double); // reduction + broadcast
+constexpr unsigned kQueueBytes = 4u * kWaves + 2u * kBlock; // per-wavefront counts + 64 u16 entries per wavefront
+static_assert(kHoist == 3, "the pass loop selects Pc[0..2] explicitly");
+static_assert(kWaves == kCoop, "drain_queue keeps one wavefront count per lane of a DPP row");
+constexpr unsigned kScratchBytes = (kReduceBytes + kQueueBytes + 15u) & ~15u;
 
 struct Lattice {
     int   nx, ny;
@@ -57,6 +66,7 @@ struct ModelView {
     unsigned off_pts;       // float2[n_all]: class 0 (GA) sorted by cell, then class 1 (NGA)
     unsigned off_start[2];  // StartT[ncells+1] per class, positions relative to the class base
     unsigned off_oidx;      // StartT[n_all]: original index within the class
+    unsigned off_axis[2];   // u32 bit per cell and class: the cell's points are ordered by y (1) or by x (0)
     int      n_cls[2];
     int      base[2];       // first point of each class in pts
     Lattice  lat;
@@ -69,6 +79,7 @@ struct IndexPtrs {
     const float2 *pts;
     const StartT *start[2];
     const StartT *oidx;
+    const unsigned *axis[2];
 };
 
 template <typename StartT>
@@ -79,6 +90,8 @@ __device__ inline IndexPtrs<StartT> make_ptrs(const unsigned char *base, const M
     ix.start[0] = reinterpret_cast<const StartT *>(base + mv.off_start[0]);
     ix.start[1] = reinterpret_cast<const StartT *>(base + mv.off_start[1]);
     ix.oidx = reinterpret_cast<const StartT *>(base + mv.off_oidx);
+    ix.axis[0] = reinterpret_cast<const unsigned *>(base + mv.off_axis[0]);
+    ix.axis[1] = reinterpret_cast<const unsigned *>(base + mv.off_axis[1]);
     return ix;
 }
 
@@ -269,6 +282,118 @@ __device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelVi
     return b;
 }
 
+// ---------------------------------------------------------------- sweep search
+// Inside a cell the points are ordered along the axis of their larger extent
+// (walls are 1-D: the order follows the wall).  A query starts at the position
+// its own coordinate interpolates to and walks outwards in both directions
+// until it is past the query's own key AND the squared KEY distance alone
+// exceeds the best squared distance found: fl(dk*dk) <= fl(fl(dx*dx)+fl(dy*dy))
+// for every point, and beyond the query's key |dk| grows monotonically along the
+// order, so nothing further out can beat or tie the best.  One lane per query; two LDS reads (left, right) in flight per step.
+template <typename StartT>
+__device__ inline void sweep_cell(Best &b, bool &tie, const StartT *start, const unsigned *axis_bits,
+                                  const float2 *pts, int c, float rel_x, float rel_y, float qx, float qy)
+{
+    const int a = (int)start[c], e = (int)start[c + 1];
+    if (e <= a) return;
+    const bool  ay = (axis_bits[c >> 5] >> (c & 31)) & 1u;
+    const float kq = ay ? qy : qx;
+    const int   n = e - a;
+    // rel = position of the query along the axis in cell units relative to the cell's low edge
+    const int g = a + clampi((int)((ay ? rel_y : rel_x) * (float)n), 0, n - 1);
+    {
+        const float d = dist2(pts[g], qx, qy);
+        tie |= (d == b.d);
+        const bool up = d < b.d;
+        b.d = up ? d : b.d;
+        b.pos = up ? g : b.pos;
+    }
+    int  il = g - 1, ir = g + 1;
+    bool L = il >= a, R = ir < e;
+    while (L | R) {
+        const float2 ml = pts[max(il, a)], mr = pts[min(ir, e - 1)];
+        {
+            const float dk = (ay ? ml.y : ml.x) - kq;
+            const bool  in = L & !((dk < 0.f) & (__fmul_rn(dk, dk) > b.d)); // only past the query's key
+            const float d = dist2(ml, qx, qy);
+            tie |= in & (d == b.d);
+            const bool up = in & (d < b.d);
+            b.d = up ? d : b.d;
+            b.pos = up ? il : b.pos;
+            --il;
+            L = in & (il >= a);
+        }
+        {
+            const float dk = (ay ? mr.y : mr.x) - kq;
+            const bool  in = R & !((dk > 0.f) & (__fmul_rn(dk, dk) > b.d));
+            const float d = dist2(mr, qx, qy);
+            tie |= in & (d == b.d);
+            const bool up = in & (d < b.d);
+            b.d = up ? d : b.d;
+            b.pos = up ? ir : b.pos;
+            ++ir;
+            R = in & (ir < e);
+        }
+    }
+}
+
+// Exact 1-NN by sweeps: the query's cell, then those of its eight neighbours
+// that intersect the disk of the best distance.  Returns false when that is
+// not enough to decide (empty neighbourhood, best distance beyond the ring,
+// or an exact distance tie): the caller then runs nn_search(), which is exact
+// from any state.  Same stop rule as nn_search_impl at r = 1.
+template <typename StartT>
+__device__ inline bool sweep_search(Best &b, const IndexPtrs<StartT> &ix, const ModelView &mv, int cls,
+                                    float qx, float qy, double gate)
+{
+    const Lattice &L = mv.lat;
+    const StartT   *start = ix.start[cls];
+    const unsigned *axis_bits = ix.axis[cls];
+    const float2   *pts = ix.pts + mv.base[cls];
+    b.d = FLT_MAX;
+    b.oidx = 0xffffffffu;
+    b.pos = -1;
+    const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
+    const int   cx = clampi((int)floorf(fx), 0, L.nx - 1);
+    const int   cy = clampi((int)floorf(fy), 0, L.ny - 1);
+    bool tie = false;
+    sweep_cell<StartT>(b, tie, start, axis_bits, pts, cy * L.nx + cx, fx - (float)cx, fy - (float)cy, qx, qy);
+    // neighbours whose cell intersects the disk (the cell map is monotone, as in nn_search_impl);
+    // all eight when the query's own cell is empty
+    const float R = b.d < FLT_MAX ? (__fsqrt_rn(b.d) + L.margin) * L.inv_h : 2.0f;
+    const int   x_lo = max(max(cx - 1, 0), (int)floorf(fx - R)), x_hi = min(min(cx + 1, L.nx - 1), (int)floorf(fx + R));
+    const int   y_lo = max(max(cy - 1, 0), (int)floorf(fy - R)), y_hi = min(min(cy + 1, L.ny - 1), (int)floorf(fy + R));
+    // Which of those cells hold points: the start entries of the three rows are read together (one LDS
+    // round trip) and only non-empty cells are swept.  Clamped reads make out-of-lattice cells empty.
+    unsigned todo = 0; // bit 3*(dy+1)+(dx+1)
+    if ((x_lo < cx) | (x_hi > cx) | (y_lo < cy) | (y_hi > cy)) {
+        const int i0 = max(cx - 1, 0), i3 = min(cx + 2, L.nx);
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int y = cy + dy;
+            if (y >= y_lo && y <= y_hi) {
+                const StartT *row = start + y * L.nx;
+                const int s0 = (int)row[i0], s1 = (int)row[cx], s2 = (int)row[cx + 1], s3 = (int)row[i3];
+                if (s1 > s0 && cx - 1 >= x_lo) todo |= 1u << (3 * (dy + 1));
+                if (dy != 0 && s2 > s1) todo |= 1u << (3 * (dy + 1) + 1);
+                if (s3 > s2 && cx + 1 <= x_hi) todo |= 1u << (3 * (dy + 1) + 2);
+            }
+        }
+    }
+    while (todo) {
+        const int k = __ffs((int)todo) - 1;
+        todo &= todo - 1;
+        const int x = cx + k % 3 - 1, y = cy + k / 3 - 1;
+        sweep_cell<StartT>(b, tie, start, axis_bits, pts, y * L.nx + x, fx - (float)x, fy - (float)y, qx, qy);
+    }
+    const bool  covers = (cx - 1 <= 0) & (cy - 1 <= 0) & (cx + 1 >= L.nx - 1) & (cy + 1 >= L.ny - 1);
+    const float bound = L.h - L.margin;
+    const float b2 = bound * bound;
+    if (tie || !(covers || b.d < b2 || (double)b2 >= gate)) return false;
+    if (b.pos >= 0) b.oidx = (unsigned)(ix.oidx + mv.base[cls])[b.pos];
+    return true;
+}
+
 // Wavefront sum of a double on the VALU's DPP cross-lane path (no LDS
 // crossbar): a 16-lane prefix by row_shr 1,2,4,8, then row_bcast 15 and 31 fold
 // the four rows; lane 63 holds the total, which is returned to all lanes.
@@ -300,6 +425,31 @@ __device__ inline double wave_sum(double v)
     return __hiloint2double(hi, lo);
 }
 
+__device__ inline double shfl_xor_f64(double v, int mask)
+{
+    return __hiloint2double(__shfl_xor(__double2hiint(v), mask), __shfl_xor(__double2loint(v), mask));
+}
+
+// Wavefront sums of EIGHT doubles at once: each exchange step halves the number of values a lane
+// carries (lanes 0-31 keep values 0-3 and take the partner's, lanes 32-63 keep 4-7, and so on), so
+// 10 additions per lane replace 48.  On return every lane holds the total of value (lane >> 3).
+// Fixed order: bitwise reproducible.
+__device__ inline double wave_sum8(const double a[8])
+{
+    const int  lane = (int)threadIdx.x & 63;
+    const bool h32 = lane & 32, h16 = lane & 16, h8 = lane & 8;
+    double v4[4], v2[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v4[k] = (h32 ? a[k + 4] : a[k]) + shfl_xor_f64(h32 ? a[k] : a[k + 4], 32);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) v2[k] = (h16 ? v4[k + 2] : v4[k]) + shfl_xor_f64(h16 ? v4[k] : v4[k + 2], 16);
+    double v = (h8 ? v2[1] : v2[0]) + dpp_shift_f64<0x128, 0xf>(h8 ? v2[0] : v2[1]); // row_ror:8 = lane ^ 8
+    v += dpp_shift_f64<0x141, 0xf>(v); // row_half_mirror: lane ^ 7
+    v += dpp_shift_f64<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_shift_f64<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]: lane ^ 2
+    return v;
+}
+
 // icpPointToPoint.cpp:159-162, closed form of svd -> V*U^T (oracle: o_p2p_rotation)
 __device__ inline void p2p_rotation(const double H[4], double R_[4])
 {
@@ -315,8 +465,9 @@ __device__ inline void p2p_rotation(const double H[4], double R_[4])
     const double n = sqrt(a * a + b * b);
     double c = 1.0, s = 0.0;
     if (n > 0.0) {
-        c = a / n;
-        s = b / n;
+        const double inv_n = 1.0 / n;
+        c = a * inv_n;
+        s = b * inv_n;
     }
     if (det >= 0.0) {
         R_[0] = c;
@@ -397,33 +548,182 @@ struct Pose {
     double r00, r01, r10, r11, t0, t1;
 };
 
+// icpPointToPoint.cpp:69-70: (r00*x + r01*y) + t0 in double, stored to float
+__device__ inline void transform_query(const Pose &T, const double2 P, float &qx, float &qy)
+{
+    qx = (float)__dadd_rn(__dadd_rn(__dmul_rn(T.r00, P.x), __dmul_rn(T.r01, P.y)), T.t0);
+    qy = (float)__dadd_rn(__dadd_rn(__dmul_rn(T.r10, P.x), __dmul_rn(T.r11, P.y)), T.t1);
+}
+
+// icpPointToPoint.cpp:76,96-99,116-126,159: one inlier correspondence into the running sums
+template <typename StartT>
+__device__ inline void add_p2p(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, const Best &b, float qx,
+                               float qy, double acc[kNumAcc])
+{
+    const float2 m = ix.pts[mv.base[cls] + b.pos];
+    const double ax = (double)m.x - mv.cx, ay = (double)m.y - mv.cy;
+    const double bx = (double)qx - mv.cx, by = (double)qy - mv.cy;
+    acc[0] += 1.0;
+    acc[1] += ax;
+    acc[2] += ay;
+    acc[3] += bx;
+    acc[4] += by;
+    acc[5] += bx * ax; // H[a][b] = sum q_t[a]*q_m[b]  (:159)
+    acc[6] += bx * ay;
+    acc[7] += by * ax;
+    acc[8] += by * ay;
+}
+
+// Minimum of (d, pos) over the 16 lanes of a DPP row by rotations (no LDS); equal distances at different
+// positions raise `tie`.  All 16 lanes return the same result.
+__device__ inline void row16_min(float &d, int &pos, bool &tie)
+{
+#define SLAM_ROR_STEP(CTRL)                                                                              \
+    {                                                                                                    \
+        const float od = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), CTRL, 0xf, 0xf, false)); \
+        const int   op = __builtin_amdgcn_update_dpp(0, pos, CTRL, 0xf, 0xf, false);                     \
+        const int   ot = __builtin_amdgcn_update_dpp(0, (int)tie, CTRL, 0xf, 0xf, false);                \
+        tie |= (bool)ot | ((od == d) & (op != pos) & (pos >= 0) & (op >= 0));                            \
+        const bool take = (od < d) | ((od == d) & (op < pos));                                           \
+        d = take ? od : d;                                                                               \
+        pos = take ? op : pos;                                                                           \
+    }
+    SLAM_ROR_STEP(0x128) // row_ror:8
+    SLAM_ROR_STEP(0x124) // row_ror:4
+    SLAM_ROR_STEP(0x122) // row_ror:2
+    SLAM_ROR_STEP(0x121) // row_ror:1
+#undef SLAM_ROR_STEP
+}
+
+// Exact 1-NN by kCoop lanes scanning the 3x3 block of cells around the query (three row spans, start
+// entries read together, one DPP reduction): the cheap path for the scan's tail.  Same stop rule as
+// nn_search_impl at r = 1; returns false when that does not decide (then nn_search<kCoop> runs).
+template <typename StartT>
+__device__ inline bool block_search(Best &b, const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, float qx,
+                                    float qy, int sub, double gate)
+{
+    const Lattice &L = mv.lat;
+    const StartT *start = ix.start[cls];
+    const float2 *pts = ix.pts + mv.base[cls];
+    const float   fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
+    const int     cx = clampi((int)floorf(fx), 0, L.nx - 1);
+    const int     cy = clampi((int)floorf(fy), 0, L.ny - 1);
+    const int     xs = max(cx - 1, 0), xe = min(cx + 1, L.nx - 1);
+    int           a[3], e[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int  y = cy + k - 1;
+        const bool in = y >= 0 && y < L.ny;
+        const int  row = (in ? y : cy) * L.nx;
+        a[k] = (int)start[row + xs];
+        e[k] = in ? (int)start[row + xe + 1] : a[k];
+    }
+    float d = FLT_MAX;
+    int   pos = -1;
+    bool  tie = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int i = a[k] + sub; i < e[k]; i += kCoop) {
+            const float di = dist2(pts[i], qx, qy);
+            tie |= (di == d);
+            const bool up = di < d;
+            d = up ? di : d;
+            pos = up ? i : pos;
+        }
+    row16_min(d, pos, tie);
+    const bool  covers = (cx - 1 <= 0) & (cy - 1 <= 0) & (cx + 1 >= L.nx - 1) & (cy + 1 >= L.ny - 1);
+    const float bound = L.h - L.margin;
+    const float b2 = bound * bound;
+    if (tie || !(covers || d < b2 || (double)b2 >= gate)) return false;
+    b.d = d;
+    b.pos = pos;
+    b.oidx = pos >= 0 ? (unsigned)(ix.oidx + mv.base[cls])[pos] : 0xffffffffu;
+    return true;
+}
+
+// Sweep kernel, one pass over the kBlock points from p0, one lane per point.  A query the sweeps cannot
+// decide is not searched by its own lane (the whole wavefront, and at the barrier the whole workgroup,
+// would wait for a few lanes running the ring search): its offset goes to the wavefront's region of a
+// queue in LDS (fixed regions: the order does not depend on timing, so sums stay bitwise reproducible)
+// that all wavefronts drain together afterwards (drain_queue).
+template <typename StartT>
+__device__ inline void sweep_pass(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa, const Pose &T,
+                                  int n, int nga, int p0, const double2 P, double acc[kNumAcc], unsigned *wave_cnt,
+                                  unsigned short *queue, int &fell_back)
+{
+    const int  lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int  p = p0 + (int)threadIdx.x;
+    const int  cls = p < nga ? 0 : 1;
+    const bool valid = p < n && mv.n_cls[cls] > 3; // icpPointToPoint.cpp:59,93
+    bool       done = true;
+    if (valid) {
+        float qx, qy;
+        Best  b;
+        transform_query(T, P, qx, qy);
+        done = sweep_search<StartT>(b, ix, mv, cls, qx, qy, fa.indist);
+        if (done && b.pos >= 0 && (double)b.d < fa.indist) add_p2p<StartT>(ix, mv, cls, b, qx, qy, acc); // :76
+        fell_back += done ? 0 : 1;
+    }
+    const unsigned long long need = __ballot(!done);
+    if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(need);
+    if (!done) queue[wave * 64 + __popcll(need & ((1ull << lane) - 1ull))] = (unsigned short)threadIdx.x;
+}
+
+// All wavefronts take kCoopPerWave points at a time and search each with kCoop lanes: first the `tail`
+// points past the pass (block_search, then the ring search if that does not decide), then the queued
+// ones (ring search).  Entry e of the queue lives in the region of the wavefront whose inclusive count
+// prefix first exceeds e.
+template <typename StartT>
+__device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa, const Pose &T,
+                                   int off, int n, int nga, int p0, double acc[kNumAcc], int tail,
+                                   const unsigned *wave_cnt, const unsigned short *queue)
+{
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int mine = (int)wave_cnt[lane % kWaves];
+    int       incl = mine; // inclusive prefix over the 16 wavefronts, in every DPP row
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true); // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
+    const int queued = __builtin_amdgcn_readlane(incl, 15);
+    const int total = tail + queued;
+    for (int base = 0; base < total; base += kCoopPerBlock) {
+        const int g = lane / kCoop;
+        const int e = base + wave * kCoopPerWave + g;
+        // wavefront region holding queue entry e - tail
+        const unsigned long long le = __ballot(incl <= e - tail);
+        const int  w = __popcll((le >> (g * kCoop)) & 0xffffull);
+        const int  excl = __shfl(incl - mine, g * kCoop + min(w, kWaves - 1));
+        if (e < total) {
+            const bool is_tail = e < tail;
+            const int  p = p0 + (is_tail ? kBlock + e : (int)queue[w * 64 + (e - tail - excl)]);
+            const int  cls = p < nga ? 0 : 1;
+            if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
+                float qx, qy;
+                transform_query(T, fa.pts[off + p], qx, qy);
+                Best b;
+                if (!is_tail || !block_search<StartT>(b, ix, mv, cls, qx, qy, lane % kCoop, fa.indist))
+                    b = nn_search<kCoop, StartT>(ix, mv, cls, qx, qy, lane % kCoop, fa.indist);
+                if (lane % kCoop == 0 && b.pos >= 0 && (double)b.d < fa.indist)
+                    add_p2p<StartT>(ix, mv, cls, b, qx, qy, acc); // :76
+            }
+        }
+    }
+}
+
 // One scene point, searched by GG lanes (sub = lane within that group); the
 // group's lane 0 adds the correspondence to its running sums.
 template <int GG, typename StartT, int MODE>
 __device__ inline void accumulate_point(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
                                         const Pose &T, const double2 P, bool is_ga, int sub, double acc[kNumAcc])
 {
-    // icpPointToPoint.cpp:69-70: (r00*x + r01*y) + t0 in double, stored to float
-    const float qx = (float)__dadd_rn(__dadd_rn(__dmul_rn(T.r00, P.x), __dmul_rn(T.r01, P.y)), T.t0);
-    const float qy = (float)__dadd_rn(__dadd_rn(__dmul_rn(T.r10, P.x), __dmul_rn(T.r11, P.y)), T.t1);
+    float qx, qy;
+    transform_query(T, P, qx, qy);
     if (MODE == SLAM_ICP_P2P) {
         const int cls = is_ga ? 0 : 1;
         if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
             const Best b = nn_search<GG, StartT>(ix, mv, cls, qx, qy, sub, fa.indist);
-            if (sub == 0 && b.pos >= 0 && (double)b.d < fa.indist) { // :76
-                const float2 m = ix.pts[mv.base[cls] + b.pos];
-                const double ax = (double)m.x - mv.cx, ay = (double)m.y - mv.cy;
-                const double bx = (double)qx - mv.cx, by = (double)qy - mv.cy;
-                acc[0] += 1.0;
-                acc[1] += ax;
-                acc[2] += ay;
-                acc[3] += bx;
-                acc[4] += by;
-                acc[5] += bx * ax; // H[a][b] = sum q_t[a]*q_m[b]  (:159)
-                acc[6] += bx * ay;
-                acc[7] += by * ax;
-                acc[8] += by * ay;
-            }
+            if (sub == 0 && b.pos >= 0 && (double)b.d < fa.indist) add_p2p<StartT>(ix, mv, cls, b, qx, qy, acc); // :76
         }
     } else {
         // icpPointToPlane.cpp:55-77: single class, no inlier gate
@@ -462,17 +762,29 @@ __device__ inline void point_pass(const IndexPtrs<StartT> &ix, const ModelView &
     if (p < n) accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, fa.pts[off + p], p < nga, (int)threadIdx.x % GG, acc);
 }
 
+// The same with the lane's point already in registers (the first kHoist passes: a lane meets the same
+// points in every iteration, so they are loaded once per scan, not once per iteration).
+template <int GG, typename StartT, int MODE>
+__device__ inline void point_pass_reg(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
+                                      const Pose &T, int n, int nga, int p0, const double2 P, double acc[kNumAcc])
+{
+    const int p = p0 + (int)threadIdx.x / GG;
+    if (p < n) accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, P, p < nga, (int)threadIdx.x % GG, acc);
+}
+
 // One workgroup = one scan, all iterations.  MODE: SLAM_ICP_P2P / SLAM_ICP_P2L.
 // G = lanes per scene point; G = 0 picks it per pass: one lane per point while
 // more than half a workgroup of points is left, then the widest group that
 // still covers the rest in one pass (a 1081-point scan is 1024 points at G = 1
 // plus 57 points at G = 16), so no pass runs nearly empty.
-template <int G, bool LDS, typename StartT, int MODE>
+template <int G, bool LDS, typename StartT, int MODE, bool SWEEP>
 __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *partial = reinterpret_cast<double *>(smem); // [2][kWaves][kNumAcc]
     double *bcast = partial + 2 * kWaves * kNumAcc;     // [2][8] new pose, delta, n_corr
+    unsigned       *wave_cnt = reinterpret_cast<unsigned *>(smem + kReduceBytes); // [kWaves] undecided queries of the pass
+    unsigned short *queue = reinterpret_cast<unsigned short *>(smem + kReduceBytes + 4 * kWaves); // [kWaves][64]
     constexpr unsigned kScratch = kScratchBytes;
     static_assert(kScratch % 16 == 0, "scratch keeps the blob 16-B aligned");
 
@@ -502,6 +814,15 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
     int    iters = 0, n_corr = 0;
     double delta = 0.0;
 
+    // the lane's points of the first passes, loaded once
+    constexpr int kPerPass = kBlock / (G > 0 ? G : 1);
+    double2       Pc[kHoist];
+#pragma unroll
+    for (int k = 0; k < kHoist; ++k) {
+        const int p = k * kPerPass + tid / (G > 0 ? G : 1);
+        Pc[k] = (G > 0 && p < n) ? fa.pts[off + p] : make_double2(0.0, 0.0);
+    }
+
     if (n >= 5) { // icp.cpp:100-103
         for (int iter = 0; iter < fa.max_iter; ++iter) {
             double acc[kNumAcc];
@@ -517,13 +838,39 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                 sp[4] = t0;
                 sp[5] = t1;
             }
-            long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+            long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c_mid = 0;
+            int       fell_back = 0; // diagnostic: sweep queries of this lane that went to the ring search
             if (fa.stamps) c0 = __builtin_amdgcn_s_memtime();
 
-            for (int p0 = 0; p0 < n;) {
-                const int rem = n - p0;
-                if (G > 0) {
-                    point_pass<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+            int pass = 0;
+            for (int p0 = 0; p0 < n; ++pass) {
+                int rem = n - p0;
+                if (SWEEP && MODE == SLAM_ICP_P2P) {
+                    // a pass of kBlock points, then the cooperative rounds: the queries the pass left
+                    // undecided and, when fewer than kCoopPerBlock points remain after it, those too
+                    int tail = 0;
+                    if (rem > kCoopPerBlock) {
+                        const double2 P = pass == 0 ? Pc[0] : (p0 + tid < n ? fa.pts[off + p0 + tid] : Pc[0]);
+                        sweep_pass<StartT>(ix, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back);
+                        tail = rem - kBlock;
+                        tail = tail > 0 && tail <= kCoopPerBlock ? tail : 0;
+                    } else { // a scan shorter than one cooperative round
+                        if (lane == 0) wave_cnt[wave] = 0;
+                        tail = rem;
+                        p0 -= kBlock; // the tail is addressed as p0 + kBlock + i
+                    }
+                    __syncthreads();
+                    if (fa.stamps) c_mid = __builtin_amdgcn_s_memtime();
+                    drain_queue<StartT>(ix, mv, fa, T, off, n, nga, p0, acc, tail, wave_cnt, queue);
+                    p0 += kBlock + tail;
+                    if (p0 < n) __syncthreads(); // the queue is reused by the next pass
+                } else if (G > 0) {
+                    if (pass < kHoist) {
+                        const double2 P = pass == 0 ? Pc[0] : (pass == 1 ? Pc[1] : Pc[2]);
+                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc);
+                    } else {
+                        point_pass<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+                    }
                     p0 += kBlock / (G > 0 ? G : 1);
                 } else if (rem * 2 > kBlock) {
                     point_pass<1, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
@@ -546,10 +893,10 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
             if (fa.stamps) c1 = __builtin_amdgcn_s_memtime();
             // wavefront reduction on the DPP path, then LDS across the 16 wavefronts
             double *my = partial + ((iter & 1) * kWaves + wave) * kNumAcc;
-#pragma unroll
-            for (int k = 0; k < kNumAcc; ++k) {
-                const double v = wave_sum(acc[k]);
-                if (lane == 0) my[k] = v;
+            {
+                const double v8 = wave_sum8(acc), v9 = wave_sum(acc[8]);
+                if ((lane & 7) == 0) my[lane >> 3] = v8;
+                if (lane == 0) my[8] = v9;
             }
             if (fa.stamps) c2 = __builtin_amdgcn_s_memtime();
             __syncthreads();
@@ -620,9 +967,9 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                     o[4] = (R_[0] * t0 + R_[1] * t1) + t_[0];
                     o[5] = (R_[2] * t0 + R_[3] * t1) + t_[1];
                     const double a0 = R_[0] - 1.0, a3 = R_[3] - 1.0;
-                    const double nr = sqrt(a0 * a0 + R_[1] * R_[1] + R_[2] * R_[2] + a3 * a3);
-                    const double nt = sqrt(t_[0] * t_[0] + t_[1] * t_[1]);
-                    d_out = nr > nt ? nr : nt; // :170
+                    const double nr2 = a0 * a0 + R_[1] * R_[1] + R_[2] * R_[2] + a3 * a3;
+                    const double nt2 = t_[0] * t_[0] + t_[1] * t_[1];
+                    d_out = sqrt(nr2 > nt2 ? nr2 : nt2); // :170 max of the two norms (sqrt is monotone: same value)
                 }
                 if (lane == 0) {
 #pragma unroll
@@ -641,13 +988,19 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
             delta = uniform(bc[6]);
             n_corr = (int)uniform(bc[7]);
             ++iters;
-            if (fa.stamps && (tid & 63) == 0) {
-                const long long c4 = __builtin_amdgcn_s_memtime();
-                long long *st = fa.stamps + ((size_t)s * kWaves + wave) * 4;
-                st[0] += c1 - c0;
-                st[1] += c2 - c1;
-                st[2] += c3 - c2;
-                st[3] += c4 - c3;
+            if (fa.stamps) {
+                for (int o = 32; o > 0; o >>= 1) fell_back += __shfl_xor(fell_back, o);
+                if ((tid & 63) == 0) {
+                    const long long c4 = __builtin_amdgcn_s_memtime();
+                    long long *st = fa.stamps + ((size_t)s * kWaves + wave) * kStampSlots;
+                    st[0] += c1 - c0;
+                    st[1] += c2 - c1;
+                    st[2] += c3 - c2;
+                    st[3] += c4 - c3;
+                    st[4] += fell_back;
+                    if (iter < 3) st[5 + iter] += c1 - c0; // search time of the first iterations
+                    if (c_mid) st[8] += c1 - c_mid;        // of which the cooperative rounds (sweep kernel)
+                }
             }
             if (fa.trace && tid == 0) {
                 double *tr = fa.trace + ((size_t)s * fa.max_iter + iter) * 8;
@@ -880,6 +1233,7 @@ struct slam_icp {
     bool            in_lds = false;
     bool            start32 = false;
     int             G = 8;
+    bool            sweep = false; // P2P default: one lane per point, ordered-cell sweeps (sweep_search)
     size_t          lds_bytes = 0;
     void           *d_blob = nullptr;
     double         *d_normals = nullptr;
@@ -908,9 +1262,33 @@ void fill_index(std::vector<unsigned char> &blob, const ModelView &mv, const std
         for (int k = 0; k < ncells; ++k) count[k + 1] += count[k];
         for (int k = 0; k <= ncells; ++k) start[k] = (StartT)count[k];
         std::vector<int> fill(count.begin(), count.end() - 1);
-        for (int i = 0; i < n; ++i) { // stable: equal cells keep original order
-            const int pos = fill[cell_of[c][i]]++;
-            pts[mv.base[c] + pos] = make_float2(cls_xy[c][2 * i], cls_xy[c][2 * i + 1]);
+        std::vector<int> order(n);
+        for (int i = 0; i < n; ++i) order[fill[cell_of[c][i]]++] = i; // stable: equal cells keep original order
+        // inside a cell: by the coordinate of larger extent (sweep_search), non-finite points last
+        unsigned *axis = reinterpret_cast<unsigned *>(blob.data() + mv.off_axis[c]);
+        const float *xy = cls_xy[c].data();
+        for (int k = 0; k < ncells; ++k) {
+            const int a = count[k], e = count[k + 1];
+            if (e - a < 2) continue;
+            float lo[2] = {FLT_MAX, FLT_MAX}, hi[2] = {-FLT_MAX, -FLT_MAX};
+            for (int j = a; j < e; ++j)
+                for (int d = 0; d < 2; ++d) {
+                    const float v = xy[2 * order[j] + d];
+                    if (!std::isfinite(v)) continue;
+                    lo[d] = std::min(lo[d], v);
+                    hi[d] = std::max(hi[d], v);
+                }
+            const int ax = (hi[1] - lo[1]) > (hi[0] - lo[0]) ? 1 : 0;
+            if (ax) axis[k >> 5] |= 1u << (k & 31);
+            auto key = [&](int i) {
+                const float x = xy[2 * i], y = xy[2 * i + 1];
+                return std::isfinite(x) && std::isfinite(y) ? (ax ? y : x) : INFINITY;
+            };
+            std::stable_sort(order.begin() + a, order.begin() + e, [&](int p, int q) { return key(p) < key(q); });
+        }
+        for (int pos = 0; pos < n; ++pos) {
+            const int i = order[pos];
+            pts[mv.base[c] + pos] = make_float2(xy[2 * i], xy[2 * i + 1]);
             oidx[mv.base[c] + pos] = (StartT)i;
         }
     }
@@ -957,8 +1335,8 @@ int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, 
     const unsigned scratch = kScratchBytes;
 
     // LDS budget for the two start arrays (u16 entries) after points + original indices
-    const long fixed16 = (long)scratch + align16(8u * n_all) + align16(2u * n_all) + 64;
-    long       cells_lds = ((long)lds_total - fixed16) / (2 * 2) - 1;
+    const long fixed16 = (long)scratch + align16(8u * n_all) + align16(2u * n_all) + 128;
+    long       cells_lds = ((long)lds_total - fixed16) * 8 / (2 * 2 * 8 + 2) - 1; // + one axis bit per cell and class
     bool       lds = !h->prm.force_global && max_cls <= 65535 && cells_lds >= 256;
 
     const float w = std::max(hi[0] - lo[0], 1e-3f), ht = std::max(hi[1] - lo[1], 1e-3f);
@@ -986,7 +1364,10 @@ int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, 
     mv.lat.y0 = lo[1];
     mv.lat.h = (float)hcell;
     mv.lat.inv_h = 1.0f / mv.lat.h;
-    mv.lat.margin = mv.lat.h * 0.015625f; // h/64 >= 2 ulp(max|coordinate|) by the choice of h above
+    // the cell map floor(fl(fl(x-x0)*inv_h)) is monotone and off by at most ~3*2^-24*nx cells per evaluation,
+    // i.e. ~6*2^-24*maxabs metres for a model point and a query together; 2^-19*maxabs covers that 5x
+    // (and stays below h/8 by the choice of h above)
+    mv.lat.margin = std::max(mv.lat.h * 0.0009765625f, maxabs * 1.9073486328125e-06f);
     mv.n_cls[0] = n_ga;
     mv.n_cls[1] = n_nga;
     mv.base[0] = 0;
@@ -1006,6 +1387,10 @@ int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, 
     o = align16(o + esz * (unsigned)(ncells + 1));
     mv.off_oidx = o;
     o = align16(o + esz * (unsigned)n_all);
+    mv.off_axis[0] = o;
+    o = align16(o + 4u * (unsigned)(ncells / 32 + 1));
+    mv.off_axis[1] = o;
+    o = align16(o + 4u * (unsigned)(ncells / 32 + 1));
     mv.blob_bytes = o;
     if (lds && scratch + o > lds_total) lds = false, h->start32 = false; // keeps u16 entries, read from HBM
     h->in_lds = lds;
@@ -1068,10 +1453,10 @@ int compute_normals(slam_icp *h, const double *m_ga, int n_ga, const double *m_n
     return SLAM_OK;
 }
 
-template <int G, bool LDS, typename StartT, int MODE>
+template <int G, bool LDS, typename StartT, int MODE, bool SWEEP = false>
 int launch_fit_t(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
 {
-    auto kern = icp_fit_kernel<G, LDS, StartT, MODE>;
+    auto kern = icp_fit_kernel<G, LDS, StartT, MODE, SWEEP>;
     const size_t lds = h->lds_bytes;
     if (lds > 48 * 1024)
         SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
@@ -1079,6 +1464,14 @@ int launch_fit_t(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
     hipLaunchKernelGGL(kern, dim3(n_scans), dim3(kBlock), lds, st, h->mv, fa);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
+}
+
+template <int MODE>
+int launch_fit_sweep(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
+{
+    if (h->in_lds) return launch_fit_t<1, true, uint16_t, MODE, true>(h, fa, n_scans, st);
+    if (h->start32) return launch_fit_t<1, false, uint32_t, MODE, true>(h, fa, n_scans, st);
+    return launch_fit_t<1, false, uint16_t, MODE, true>(h, fa, n_scans, st);
 }
 
 template <int G, int MODE>
@@ -1092,6 +1485,7 @@ int launch_fit_g(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
 template <int MODE>
 int launch_fit_m(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
 {
+    if (h->sweep && MODE == SLAM_ICP_P2P) return launch_fit_sweep<SLAM_ICP_P2P>(h, fa, n_scans, st);
     switch (h->G) {
     case 0: return launch_fit_g<0, MODE>(h, fa, n_scans, st);
     case 1: return launch_fit_g<1, MODE>(h, fa, n_scans, st);
@@ -1149,8 +1543,10 @@ int slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga
         h->prm = *params;
     else
         slam_icp_default_params(&h->prm);
-    // 0 = library default (2: measured best on config 2); -1 = chosen per pass
-    h->G = h->prm.lanes_per_point > 0 ? h->prm.lanes_per_point : (h->prm.lanes_per_point < 0 ? 0 : 2);
+    // 0 = library default (sweep search, one lane per point; point-to-line: ring search with 2 lanes);
+    // N > 0 = ring search with N lanes per point; -1 = ring search, lanes chosen per pass
+    h->sweep = h->prm.lanes_per_point == -2;
+    h->G = h->prm.lanes_per_point > 0 ? h->prm.lanes_per_point : (h->prm.lanes_per_point == -1 ? 0 : 2);
     int rc = build_index(h, m_ga, n_ga, m_nga, n_nga);
     if (rc == SLAM_OK && (h->G & (h->G - 1) || h->G > 64)) {
         set_error("lanes_per_point must be one of 1,2,4,8,16,32,64 (got %d)", h->G);
@@ -1216,8 +1612,8 @@ int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *
     fa.step_pose = icp->want_step_pose ? static_cast<double *>(icp->w_pose.p) : nullptr;
     fa.stamps = nullptr;
     if (getenv("SLAM_ICP_STAMPS")) {
-        SLAM_TRY(icp->w_stamps.reserve((size_t)n_scans * kWaves * 4 * sizeof(long long)));
-        SLAM_HIP(hipMemsetAsync(icp->w_stamps.p, 0, (size_t)n_scans * kWaves * 4 * sizeof(long long), as_stream(stream)));
+        SLAM_TRY(icp->w_stamps.reserve((size_t)n_scans * kWaves * kStampSlots * sizeof(long long)));
+        SLAM_HIP(hipMemsetAsync(icp->w_stamps.p, 0, (size_t)n_scans * kWaves * kStampSlots * sizeof(long long), as_stream(stream)));
         fa.stamps = static_cast<long long *>(icp->w_stamps.p);
         icp->n_stamps = n_scans * kWaves;
     }
@@ -1329,18 +1725,18 @@ int slam_icp_get_edge_weight(slam_icp_t *icp, double eW[9])
     return SLAM_OK;
 }
 
-// diagnostic (not in the public header): mean cycles per wavefront in the four
-// phases of the last batch launched with SLAM_ICP_STAMPS=1 in the environment
-int slam_icp_debug_stamps(slam_icp_t *icp, double out[4])
+// diagnostic (not in the public header): per wavefront, mean cycles in the four phases, sweep
+// fall-backs, and the search cycles of iterations 0-3 of the last batch launched with SLAM_ICP_STAMPS=1 in the environment
+int slam_icp_debug_stamps(slam_icp_t *icp, double out[9])
 {
     SLAM_REQUIRE(icp && out && icp->n_stamps > 0, SLAM_E_INVALID, "no stamps collected");
     SLAM_HIP(hipDeviceSynchronize());
-    std::vector<long long> v((size_t)icp->n_stamps * 4);
+    std::vector<long long> v((size_t)icp->n_stamps * kStampSlots);
     SLAM_HIP(hipMemcpy(v.data(), icp->w_stamps.p, v.size() * sizeof(long long), hipMemcpyDeviceToHost));
-    for (int k = 0; k < 4; ++k) out[k] = 0;
+    for (int k = 0; k < kStampSlots; ++k) out[k] = 0;
     for (int i = 0; i < icp->n_stamps; ++i)
-        for (int k = 0; k < 4; ++k) out[k] += (double)v[(size_t)i * 4 + k];
-    for (int k = 0; k < 4; ++k) out[k] /= icp->n_stamps;
+        for (int k = 0; k < kStampSlots; ++k) out[k] += (double)v[(size_t)i * kStampSlots + k];
+    for (int k = 0; k < kStampSlots; ++k) out[k] /= icp->n_stamps;
     return SLAM_OK;
 }
 
