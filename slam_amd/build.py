@@ -41,7 +41,21 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     built = []
     if force or _stale(LIB, _deps(SOURCES)):
-        cmd = [HIPCC] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+        # one hipcc per source, side by side (icp.hip alone is most of the time), then one link
+        objdir = os.path.join(LIBDIR, "obj")
+        os.makedirs(objdir, exist_ok=True)
+        cflags = [f for f in FLAGS if f != "-shared"]
+        jobs = []
+        for s in SOURCES:
+            obj = os.path.join(objdir, s.replace(".hip", ".o"))
+            cmd = [HIPCC] + cflags + ["-c", os.path.join(CSRC, s), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            jobs.append((cmd, obj, subprocess.Popen(cmd)))
+        for cmd, obj, proc in jobs:
+            if proc.wait() != 0:
+                raise subprocess.CalledProcessError(proc.returncode, cmd)
+        cmd = [HIPCC, "--offload-arch=gfx950", "-fno-gpu-rdc", "-shared", "-fPIC"] + [j[1] for j in jobs] + ["-o", LIB]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

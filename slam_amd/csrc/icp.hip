@@ -176,6 +176,43 @@ __device__ inline void scan_span(Best &b, bool &tie, const StartT *start, const 
     }
 }
 
+// Fast-path minimum over the G lanes of a group: (distance, position) only, on the DPP cross-lane path for
+// the steps inside a row of 16 (no LDS round trip); equal distances at different positions raise `tie`,
+// which sends the group to the exact pass.  `tie` itself is OR-ed over the group.
+template <int CTRL>
+__device__ inline void lean_step_dpp(Best &b, bool &tie)
+{
+    const float od = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b.d), CTRL, 0xf, 0xf, false));
+    const int   op = __builtin_amdgcn_update_dpp(0, b.pos, CTRL, 0xf, 0xf, false);
+    const int   ot = __builtin_amdgcn_update_dpp(0, (int)tie, CTRL, 0xf, 0xf, false);
+    tie |= (bool)ot | ((od == b.d) & (op != b.pos) & (op >= 0) & (b.pos >= 0));
+    const bool take = (od < b.d) | ((od == b.d) & (op >= 0) & ((b.pos < 0) | (op < b.pos)));
+    b.d = take ? od : b.d;
+    b.pos = take ? op : b.pos;
+}
+
+__device__ inline void lean_step_shfl(Best &b, bool &tie, int mask)
+{
+    const float od = __shfl_xor(b.d, mask);
+    const int   op = __shfl_xor(b.pos, mask);
+    const int   ot = __shfl_xor((int)tie, mask);
+    tie |= (bool)ot | ((od == b.d) & (op != b.pos) & (op >= 0) & (b.pos >= 0));
+    const bool take = (od < b.d) | ((od == b.d) & (op >= 0) & ((b.pos < 0) | (op < b.pos)));
+    b.d = take ? od : b.d;
+    b.pos = take ? op : b.pos;
+}
+
+template <int G>
+__device__ inline void group_min_lean(Best &b, bool &tie)
+{
+    if (G >= 2) lean_step_dpp<0xB1>(b, tie);  // quad_perm [1,0,3,2]
+    if (G >= 4) lean_step_dpp<0x4E>(b, tie);  // quad_perm [2,3,0,1]
+    if (G >= 8) lean_step_dpp<0x141>(b, tie); // row_half_mirror
+    if (G >= 16) lean_step_dpp<0x140>(b, tie); // row_mirror
+    if (G >= 32) lean_step_shfl(b, tie, 16);
+    if (G >= 64) lean_step_shfl(b, tie, 32);
+}
+
 template <int G, typename StartT>
 __device__ inline void group_min(Best &b, const StartT *oidx)
 {
@@ -200,11 +237,7 @@ __device__ inline Best nn_search(const IndexPtrs<StartT> &ix, const ModelView &m
                                  float qx, float qy, int sub, double gate)
 {
     bool tie = false;
-    Best b = nn_search_impl<G, StartT, false>(ix, mv, cls, qx, qy, sub, gate, tie);
-    if (G > 1) {
-#pragma unroll
-        for (int off = 1; off < G; off <<= 1) tie |= (bool)__shfl_xor((int)tie, off);
-    }
+    Best b = nn_search_impl<G, StartT, false>(ix, mv, cls, qx, qy, sub, gate, tie); // `tie` is group-wide
     if (tie) {
         bool unused = false;
         b = nn_search_impl<G, StartT, true>(ix, mv, cls, qx, qy, sub, gate, unused);
@@ -246,7 +279,12 @@ __device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelVi
     const int   cy = clampi((int)floorf(fy), 0, L.ny - 1);
 
     scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, cy * L.nx, cx, cx, sub, qx, qy);
-    if (G > 1) group_min<G, StartT>(b, oidx);
+    if (G > 1) {
+        if (EXACT)
+            group_min<G, StartT>(b, oidx);
+        else
+            group_min_lean<G>(b, tie);
+    }
 
     int rp = 0; // radius of the square already visited
     for (int r = 1;; r *= 2) {
@@ -271,14 +309,19 @@ __device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelVi
                 scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, row, x_lo, x_hi, sub, qx, qy);
             }
         }
-        if (G > 1) group_min<G, StartT>(b, oidx);
+        if (G > 1) {
+            if (EXACT)
+                group_min<G, StartT>(b, oidx);
+            else
+                group_min_lean<G>(b, tie);
+        }
         const float bound = (float)r * L.h - L.margin;
         const float b2 = bound * bound;
         // every point outside the ring's square is farther than `bound` in x or in y
         if (covers || b.d < b2 || (double)b2 >= gate) break;
         rp = r;
     }
-    if (G == 1) b.oidx = b.pos >= 0 ? (unsigned)oidx[b.pos] : 0xffffffffu;
+    if (G == 1 || !EXACT) b.oidx = b.pos >= 0 ? (unsigned)oidx[b.pos] : 0xffffffffu;
     return b;
 }
 
@@ -865,12 +908,12 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                     p0 += kBlock + tail;
                     if (p0 < n) __syncthreads(); // the queue is reused by the next pass
                 } else if (G > 0) {
-                    if (pass < kHoist) {
-                        const double2 P = pass == 0 ? Pc[0] : (pass == 1 ? Pc[1] : Pc[2]);
-                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc);
-                    } else {
-                        point_pass<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+                    double2 P = pass == 0 ? Pc[0] : (pass == 1 ? Pc[1] : Pc[2]);
+                    if (pass >= kHoist) {
+                        const int p = p0 + tid / (G > 0 ? G : 1);
+                        P = fa.pts[off + min(p, n - 1)];
                     }
+                    point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc);
                     p0 += kBlock / (G > 0 ? G : 1);
                 } else if (rem * 2 > kBlock) {
                     point_pass<1, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
@@ -1485,16 +1528,22 @@ int launch_fit_g(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
 template <int MODE>
 int launch_fit_m(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
 {
-    if (h->sweep && MODE == SLAM_ICP_P2P) return launch_fit_sweep<SLAM_ICP_P2P>(h, fa, n_scans, st);
-    switch (h->G) {
-    case 0: return launch_fit_g<0, MODE>(h, fa, n_scans, st);
-    case 1: return launch_fit_g<1, MODE>(h, fa, n_scans, st);
-    case 2: return launch_fit_g<2, MODE>(h, fa, n_scans, st);
-    case 4: return launch_fit_g<4, MODE>(h, fa, n_scans, st);
-    case 8: return launch_fit_g<8, MODE>(h, fa, n_scans, st);
-    case 16: return launch_fit_g<16, MODE>(h, fa, n_scans, st);
-    case 32: return launch_fit_g<32, MODE>(h, fa, n_scans, st);
-    case 64: return launch_fit_g<64, MODE>(h, fa, n_scans, st);
+    // point-to-line (not what the reference builds) comes in the default width only; the other widths
+    // exist for the point-to-point measurements of DESIGN.md 4.1
+    if constexpr (MODE == SLAM_ICP_P2L) {
+        return launch_fit_g<2, MODE>(h, fa, n_scans, st);
+    } else {
+        if (h->sweep) return launch_fit_sweep<SLAM_ICP_P2P>(h, fa, n_scans, st);
+        switch (h->G) {
+        case 0: return launch_fit_g<0, MODE>(h, fa, n_scans, st);
+        case 1: return launch_fit_g<1, MODE>(h, fa, n_scans, st);
+        case 2: return launch_fit_g<2, MODE>(h, fa, n_scans, st);
+        case 4: return launch_fit_g<4, MODE>(h, fa, n_scans, st);
+        case 8: return launch_fit_g<8, MODE>(h, fa, n_scans, st);
+        case 16: return launch_fit_g<16, MODE>(h, fa, n_scans, st);
+        case 32: return launch_fit_g<32, MODE>(h, fa, n_scans, st);
+        case 64: return launch_fit_g<64, MODE>(h, fa, n_scans, st);
+        }
     }
     set_error("lanes_per_point must be 0 (per-pass choice) or one of 1,2,4,8,16,32,64 (got %d)", h->G);
     return SLAM_E_INVALID;
