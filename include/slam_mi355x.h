@@ -277,6 +277,11 @@ int  slam_gseg_segment_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride
 int  slam_gseg_split_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, const uint8_t *d_labels,
                          float *d_ground_xyz4, float *d_obstacle_xyz4, int32_t *d_counts,
                          slam_stream_t stream);
+/* the points whose label is in label_mask (bit (1 << SLAM_GSEG_x) per label) as (x, y, z, 0) records, e.g.
+ * (1 << SLAM_GSEG_OBSTACLE) | (1 << SLAM_GSEG_OVERHEAD) = the outcloud CCICP::segmentGround classifies
+ * (icpTools.cpp:114-117); *d_count = points written */
+int  slam_gseg_select_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, const uint8_t *d_labels,
+                          unsigned label_mask, float *d_out_xyz4, int32_t *d_count, slam_stream_t stream);
 /* CCICP::classifyPoints, icpTools.cpp:36-103: for every point of the obstacle cloud 1 = ground
  * adjacent (GA), 0 = not (NGA), 255 = dropped there too (outside the 1200 x 1200 x 0.5 m lattice
  * or in its outermost cells).  GA/NGA are the two classes the ICP matches separately. */
@@ -285,6 +290,42 @@ int  slam_gseg_classify_ga_dev(slam_gseg_t *h, const float *d_obstacle_xyz, int 
 /* per polar bin (72 x 200): 1 = in the ground model (value = prototype height), 2 = candidate
  * that stayed out (value = GP mean), 0 = no signal point; INSAC iterations per sector */
 int  slam_gseg_read_model(slam_gseg_t *h, uint8_t *bin_state, double *bin_value, int32_t *sector_iterations);
+
+/* ------------------------------------------------------------------------
+ * CCICP facade steps either side of the ICP call.  The reference does these
+ * with PCL (not part of its checkout): the published PCL 1.7 algorithms are restated; parity unpinned.
+ * All device-resident; every result is deterministic.
+ * ---------------------------------------------------------------------- */
+typedef struct slam_ccicp slam_ccicp_t;
+int  slam_ccicp_create(slam_ccicp_t **out);
+void slam_ccicp_destroy(slam_ccicp_t *h);
+
+/* CCICP::setSceneCloud / setTargetCloud voxel filter, icpTools.cpp:620-633 (pcl::VoxelGrid, leaf
+ * 0.5,0.5,2 for obstacles, 0.5,0.5,5 for ground): one output point per occupied voxel, x,y,z = centroid,
+ * [3] = ground_adj averaged as PCL averages every field (then stored to the uint16 field), in increasing
+ * voxel index (x fastest).  d_xyz: `stride` floats per point; the class comes from d_flag (1 = GA, as
+ * slam_gseg_classify_ga_dev writes it) or, when d_flag is null and stride > 3, from float [3] > 0.5.
+ * d_out: 4 floats per voxel, room for max_out; *n_out = voxels produced.  Synchronises the stream twice
+ * (lattice extent, count). */
+int slam_ccicp_voxel_downsample_dev(slam_ccicp_t *h, const float *d_xyz, const uint8_t *d_flag, int n, int stride,
+                                    float leaf_x, float leaf_y, float leaf_z, float *d_out, int max_out, int *n_out,
+                                    slam_stream_t stream);
+
+/* CCICP::doICPMatch(initPose) marshalling, icpTools.cpp:225-276: optional crop of +-crop_dist around
+ * (cur_x,cur_y) (pcl::PassThrough on x then y; the reference crops the target cloud only, 75 m), then the
+ * split by isGA(ground_adj) in cloud order with at most cap-1 points per class (ICP_MAX_PTS = 20000,
+ * icpTools.h:21) as f64 xy -- the arrays slam_icp_create / slam_icp_fit take.  d_xyzg: x,y,z,ground_adj
+ * with `stride` >= 4 floats per point (the voxel filter's output).  counts[0] = GA, counts[1] = NGA. */
+int slam_ccicp_split_dev(slam_ccicp_t *h, const float *d_xyzg, int n, int stride, int crop, double cur_x, double cur_y,
+                         double crop_dist, int cap, double *d_ga_xy, double *d_nga_xy, int counts[2],
+                         slam_stream_t stream);
+
+/* CCICP::doHeightInterpolate, icpTools.cpp:301-381: the four wheel points of the pose (x,y,z,qx,qy,qz,qw)
+ * find their nearest ground point (exact, squared distance < 9); with four of them the new z is
+ * n_z * 1.45 + mean z of the four (n = their plane normal, n_z >= 0); otherwise z stays.  nn_idx
+ * (optional) gets the four nearest indices. */
+int slam_ccicp_height_dev(slam_ccicp_t *h, const float *d_ground, int n, int stride, const double pose[7], double *z_out,
+                          int *n_corr, int nn_idx[4], slam_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -203,6 +203,16 @@ int ogseg_segment(const ogseg_params *p, const float *xyz, int n, int stride, un
  * 0 = not, 255 = dropped (outside the 1200 x 1200 x 0.5 m lattice or in its edge cells). */
 void occicp_classify(const float *xyz, int n, int stride, unsigned char *flags);
 
+/* ------------------------------------------------- CCICP facade steps (ccicp_oracle.c)
+ * crop, voxel grid, GA/NGA split and the height recovery around the ICP call
+ * (icpTools.cpp:222-381, 611-634).  PARITY UNPINNED: restated from the published PCL 1.7 algorithms the
+ * reference calls; see the header of ccicp_oracle.c. */
+int  occicp_crop(const float *xyz, int n, int stride, double cur_x, double cur_y, double crop, unsigned char *keep);
+int  ovoxel_downsample(const float *in, int n, int stride, float lx, float ly, float lz, float *out);
+void occicp_split(const float *xyzg, const unsigned char *keep, int n, int stride, int cap, double *ga, int *n_ga,
+                  double *nga, int *n_nga);
+int  occicp_height(const float *ground, int n, int stride, const double pose[7], double *z_out, int *nn_idx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,7 +80,9 @@ EXPORTS = [
     "slam_grid_info", "slam_grid_counts_dev", "slam_grid_raycast_stats",
     "slam_gseg_default_params", "slam_gseg_create", "slam_gseg_destroy", "slam_gseg_reserve",
     "slam_gseg_segment", "slam_gseg_segment_dev", "slam_gseg_split_dev", "slam_gseg_read_model",
-    "slam_gseg_classify_ga_dev",
+    "slam_gseg_classify_ga_dev", "slam_gseg_select_dev",
+    "slam_ccicp_create", "slam_ccicp_destroy", "slam_ccicp_voxel_downsample_dev", "slam_ccicp_split_dev",
+    "slam_ccicp_height_dev",
 ]
 
 
@@ -96,6 +98,14 @@ def lib():
     L.slam_last_error.restype = C.c_char_p
     L.slam_version.restype = C.c_char_p
     L.slam_icp_destroy.restype = None
+    L.slam_ccicp_destroy.restype = None
+    L.slam_ccicp_destroy.argtypes = [C.c_void_p]
+    L.slam_ccicp_voxel_downsample_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                                  C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.slam_ccicp_split_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                       C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.slam_ccicp_height_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
     L.slam_grid_destroy.restype = None
     L.slam_icp_default_params.restype = None
     L.slam_grid_default_params.restype = None
@@ -165,6 +175,7 @@ def lib():
     L.slam_gseg_segment.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp]
     L.slam_gseg_segment_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp]
     L.slam_gseg_split_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
+    L.slam_gseg_select_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, C.c_uint, _vp, _vp, _vp]
     L.slam_gseg_read_model.argtypes = [_vp, _vp, _vp, _vp]
     L.slam_gseg_classify_ga_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp]
     L.slam_grid_raycast_stats.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -601,6 +612,69 @@ class GroundSegmentation:
     def close(self):
         if getattr(self, "h", None):
             lib().slam_gseg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Ccicp:
+    """The CCICP facade steps either side of the ICP (icpTools.cpp:222-381, 611-634) over the C-ABI."""
+    ICP_MAX_PTS = 20000  # icpTools.h:21
+
+    def __init__(self):
+        h = _vp()
+        check(lib().slam_ccicp_create(C.byref(h)))
+        self.h = h.value
+
+    def voxel_downsample(self, xyz, flags=None, leaf=(0.5, 0.5, 2.0)):
+        """pcl::VoxelGrid as setSceneCloud uses it; returns [n_out, 4] = centroid x,y,z, ground_adj."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        n, stride = xyz.shape
+        if n == 0:
+            return np.zeros((0, 4), np.float32)
+        d_xyz = DeviceArray.from_host(xyz)
+        d_flag = DeviceArray.from_host(np.ascontiguousarray(flags, np.uint8)) if flags is not None else None
+        d_out = DeviceArray((n, 4), np.float32)
+        n_out = C.c_int(0)
+        check(lib().slam_ccicp_voxel_downsample_dev(self.h, d_xyz.ptr, d_flag.ptr if d_flag else None, n, stride,
+                                                    leaf[0], leaf[1], leaf[2], d_out.ptr, n, C.byref(n_out), None))
+        return d_out.download()[:n_out.value]
+
+    def split(self, xyzg, pose_xy=None, crop_dist=75.0, cap=ICP_MAX_PTS):
+        """doICPMatch marshalling: optional crop around pose_xy, then (ga_xy, nga_xy) f64 with the cap."""
+        xyzg = np.ascontiguousarray(xyzg, dtype=np.float32)
+        n, stride = xyzg.shape
+        if n == 0:
+            return np.zeros((0, 2)), np.zeros((0, 2))
+        d_in = DeviceArray.from_host(xyzg)
+        d_ga = DeviceArray((cap, 2), np.float64)
+        d_nga = DeviceArray((cap, 2), np.float64)
+        counts = (C.c_int * 2)()
+        cx, cy = pose_xy if pose_xy is not None else (0.0, 0.0)
+        check(lib().slam_ccicp_split_dev(self.h, d_in.ptr, n, stride, 1 if pose_xy is not None else 0, cx, cy,
+                                         crop_dist, cap, d_ga.ptr, d_nga.ptr, counts, None))
+        return d_ga.download()[:counts[0]], d_nga.download()[:counts[1]]
+
+    def height(self, ground_xyz, pose7):
+        """doHeightInterpolate: (z, n_corr, nn_idx[4])."""
+        g = np.ascontiguousarray(ground_xyz, dtype=np.float32)
+        n, stride = g.shape if g.ndim == 2 else (0, 3)
+        pose = (C.c_double * 7)(*pose7)
+        z = C.c_double(0.0)
+        nc = C.c_int(0)
+        idx = (C.c_int * 4)()
+        d_g = DeviceArray.from_host(g) if n else None
+        check(lib().slam_ccicp_height_dev(self.h, d_g.ptr if d_g else None, n, stride, pose, C.byref(z), C.byref(nc),
+                                          idx, None))
+        return z.value, nc.value, list(idx)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().slam_ccicp_destroy(self.h)
             self.h = None
 
     def __del__(self):

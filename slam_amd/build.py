@@ -12,7 +12,7 @@ LIB = os.path.join(LIBDIR, "libslam_mi355x.so")
 RCCL_LIB = os.path.join(LIBDIR, "libslam_mi355x_rccl.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-SOURCES = ["runtime.hip", "icp.hip", "grid.hip", "gseg.hip"]
+SOURCES = ["runtime.hip", "icp.hip", "grid.hip", "gseg.hip", "ccicp.hip"]
 RCCL_SOURCES = ["rccl.hip"]
 # -ffp-contract=off: the reference arithmetic (x86-64, no FMA) rounds every
 # product before the add; the kernels additionally spell the parity-critical

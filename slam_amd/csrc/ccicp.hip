@@ -1,0 +1,490 @@
+// ccicp.hip -- the CCICP facade steps either side of the ICP call:
+//   CCICP::setSceneCloud voxel filter     ccicp2d/src/icpTools.cpp:620-633  (pcl::VoxelGrid, leaf 0.5,0.5,2)
+//   CCICP::doICPMatch crop + split + cap  ccicp2d/src/icpTools.cpp:225-276  (pcl::PassThrough, isGA, ICP_MAX_PTS-1)
+//   CCICP::doHeightInterpolate            ccicp2d/src/icpTools.cpp:301-381  (KdTreeFLANN 1-NN, plane normal)
+// PCL is not part of the reference checkout: the published PCL 1.7 algorithms are restated
+// (oracle/ccicp_oracle.c); parity is unpinned there and tolerance-based where PCL's float sums are
+// order-dependent.  Everything stays on the device between ground segmentation (gseg.hip) and
+// slam_icp_create / slam_icp_fit_batch_dev; results are deterministic (integer sums, index-ordered output).
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace slam;
+
+namespace {
+
+constexpr int kItems = 4096; // cells / points per compaction block
+constexpr int kScanThreads = 256;
+constexpr double kFix = 16777216.0; // 2^24: coordinates summed as 64-bit fixed point (exact, order-free)
+
+struct Voxel { // 32 bytes
+    long long          sx, sy, sz;
+    unsigned           sflag, count;
+};
+
+struct VoxelGridView {
+    int       min_b[3], div_b[3];
+    float     inv[3];
+    long long n_vox;
+};
+
+__device__ inline unsigned order_f32(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float unorder_f32(unsigned u)
+{
+    const unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float          f;
+#ifdef __HIP_DEVICE_COMPILE__
+    f = __uint_as_float(v);
+#else
+    memcpy(&f, &v, 4);
+#endif
+    return f;
+}
+
+__device__ inline bool finite3(const float *p) { return isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]); }
+
+// getMinMax3D over finite points: wave reduction, one atomic per wavefront and bound
+__global__ __launch_bounds__(256) void minmax_kernel(const float *xyz, const unsigned char *flag, int n, int stride,
+                                                     unsigned *mm /*[6]*/)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned  lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+    if (i < n) {
+        const float *p = xyz + (size_t)i * stride;
+        if (finite3(p) && !(flag && flag[i] == 255)) // 255: dropped by classifyPoints (icpTools.cpp:60,72-77)
+            for (int d = 0; d < 3; ++d) lo[d] = hi[d] = order_f32(p[d]);
+    }
+    for (int d = 0; d < 3; ++d) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = min(lo[d], (unsigned)__shfl_xor((int)lo[d], off));
+            hi[d] = max(hi[d], (unsigned)__shfl_xor((int)hi[d], off));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            if (lo[d] != 0xffffffffu) atomicMin(&mm[d], lo[d]);
+            if (hi[d] != 0u) atomicMax(&mm[3 + d], hi[d]);
+        }
+    }
+}
+
+__device__ inline long long voxel_of(const VoxelGridView &g, const float *p)
+{
+    // static_cast<int>(floor(pt.x * inverse_leaf_size_[0]) - static_cast<float>(min_b_[0])), voxel_grid.hpp
+    const int i = (int)(floorf(p[0] * g.inv[0]) - (float)g.min_b[0]);
+    const int j = (int)(floorf(p[1] * g.inv[1]) - (float)g.min_b[1]);
+    const int k = (int)(floorf(p[2] * g.inv[2]) - (float)g.min_b[2]);
+    return (long long)i + (long long)j * g.div_b[0] + (long long)k * g.div_b[0] * g.div_b[1];
+}
+
+__global__ __launch_bounds__(256) void voxel_accumulate_kernel(VoxelGridView g, const float *xyz, const unsigned char *flag,
+                                                               int n, int stride, Voxel *vox)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *p = xyz + (size_t)i * stride;
+    if (!finite3(p) || (flag && flag[i] == 255)) return;
+    const long long v = voxel_of(g, p);
+    if (v < 0 || v >= g.n_vox) return;
+    Voxel *c = vox + v;
+    atomicAdd((unsigned long long *)&c->sx, (unsigned long long)llrint((double)p[0] * kFix));
+    atomicAdd((unsigned long long *)&c->sy, (unsigned long long)llrint((double)p[1] * kFix));
+    atomicAdd((unsigned long long *)&c->sz, (unsigned long long)llrint((double)p[2] * kFix));
+    const unsigned f = flag ? (flag[i] == 1 ? 1u : 0u) : (stride > 3 ? (p[3] > 0.5f ? 1u : 0u) : 0u);
+    if (f) atomicAdd(&c->sflag, 1u);
+    atomicAdd(&c->count, 1u);
+}
+
+// ---- stable compaction in three steps: per-block counts, scan of the block counts, ordered write
+template <class Pred>
+__global__ __launch_bounds__(kScanThreads) void count_kernel(Pred pred, long long n, int *block_cnt)
+{
+    const long long base = (long long)blockIdx.x * kItems;
+    int             c = 0;
+    for (int k = threadIdx.x; k < kItems; k += kScanThreads)
+        if (base + k < n && pred(base + k)) ++c;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    __shared__ int w[kScanThreads / 64];
+    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int k = 0; k < kScanThreads / 64; ++k) t += w[k];
+        block_cnt[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(1024) void scan_blocks_kernel(int *block_cnt, int n_blocks, int *total)
+{
+    __shared__ int carry, wsum[16];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n_blocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < n_blocks ? block_cnt[i] : 0;
+        int       x = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x, off);
+            if ((threadIdx.x & 63) >= off) x += y;
+        }
+        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+        __syncthreads();
+        int w = 0;
+        for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) w += wsum[k];
+        const int incl = carry + w + x;
+        if (i < n_blocks) block_cnt[i] = incl - v; // exclusive
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+// positions of the block's selected items in index order: thread t owns items [t*16, t*16+16)
+template <class Pred, class Emit>
+__global__ __launch_bounds__(kScanThreads) void write_kernel(Pred pred, Emit emit, long long n, const int *block_off,
+                                                            int limit)
+{
+    constexpr int   kPer = kItems / kScanThreads;
+    const long long base = (long long)blockIdx.x * kItems + (long long)threadIdx.x * kPer;
+    unsigned        mask = 0;
+    for (int k = 0; k < kPer; ++k)
+        if (base + k < n && pred(base + k)) mask |= 1u << k;
+    const int c = __popc(mask);
+    int       x = c;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off);
+        if ((threadIdx.x & 63) >= off) x += y;
+    }
+    __shared__ int wsum[kScanThreads / 64];
+    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
+    __syncthreads();
+    int w = 0;
+    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) w += wsum[k];
+    int pos = block_off[blockIdx.x] + w + x - c;
+    for (int k = 0; k < kPer; ++k)
+        if (mask & (1u << k)) {
+            if (pos < limit) emit(base + k, pos);
+            ++pos;
+        }
+}
+
+struct VoxelUsed {
+    const Voxel *vox;
+    __device__ bool operator()(long long v) const { return vox[v].count != 0; }
+};
+struct VoxelEmit {
+    const Voxel *vox;
+    float       *out;
+    __device__ void operator()(long long v, int pos) const
+    {
+        const Voxel  c = vox[v];
+        const double inv = 1.0 / ((double)c.count * kFix);
+        out[4 * (size_t)pos + 0] = (float)((double)c.sx * inv);
+        out[4 * (size_t)pos + 1] = (float)((double)c.sy * inv);
+        out[4 * (size_t)pos + 2] = (float)((double)c.sz * inv);
+        // PCL averages the uint16 ground_adj as a float and stores it back to the uint16 field (truncation)
+        out[4 * (size_t)pos + 3] = (float)(unsigned short)((float)c.sflag / (float)c.count);
+    }
+};
+
+// crop (pcl::PassThrough x then y) + class predicate of the split
+struct SplitPred {
+    const float *xyzg;
+    int          stride, want_ga;
+    float        x_lo, x_hi, y_lo, y_hi;
+    int          crop;
+    __device__ bool operator()(long long i) const
+    {
+        const float *p = xyzg + (size_t)i * stride;
+        if (crop && !(finite3(p) && p[0] >= x_lo && p[0] <= x_hi && p[1] >= y_lo && p[1] <= y_hi)) return false;
+        return (p[3] > 0.5f) == (want_ga != 0); // isGA, PointcloudXYZGD.h:28-30
+    }
+};
+struct SplitEmit {
+    const float *xyzg;
+    int          stride;
+    double      *out;
+    __device__ void operator()(long long i, int pos) const
+    {
+        const float *p = xyzg + (size_t)i * stride;
+        out[2 * (size_t)pos] = (double)p[0]; // icpTools.cpp:252, 267: float coordinates widened
+        out[2 * (size_t)pos + 1] = (double)p[1];
+    }
+};
+
+// four wheel points against all ground points: exact squared L2 in float (KdTreeFLANN, k = 1), packed
+// (distance bits, index) minimum -> lowest index on a tie
+__global__ __launch_bounds__(256) void height_nn_kernel(const float *ground, int n, int stride, float4 q0, float4 q1,
+                                                        float4 q2, float4 q3, unsigned long long *best /*[4]*/)
+{
+    const int          i = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long b[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    if (i < n) {
+        const float *c = ground + (size_t)i * stride;
+        const float4 q[4] = {q0, q1, q2, q3};
+        for (int k = 0; k < 4; ++k) {
+            const float dx = c[0] - q[k].x, dy = c[1] - q[k].y, dz = c[2] - q[k].z;
+            const float dd = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            if (dd == dd) b[k] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)i; // dd >= 0: bits order as values
+        }
+    }
+    for (int k = 0; k < 4; ++k) {
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(b[k], off);
+            b[k] = o < b[k] ? o : b[k];
+        }
+        if ((threadIdx.x & 63) == 0 && b[k] != ~0ull) atomicMin(&best[k], b[k]);
+    }
+}
+
+struct DevBuf {
+    void  *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return SLAM_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        SLAM_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+        return SLAM_OK;
+    }
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+};
+
+template <class Pred, class Emit>
+int compact(Pred pred, Emit emit, long long n, int limit, DevBuf &blocks, int *d_total, hipStream_t st)
+{
+    const int n_blocks = (int)((n + kItems - 1) / kItems);
+    SLAM_TRY(blocks.reserve(sizeof(int) * (size_t)(n_blocks + 1)));
+    int *bc = static_cast<int *>(blocks.p);
+    hipLaunchKernelGGL((count_kernel<Pred>), dim3(n_blocks), dim3(kScanThreads), 0, st, pred, n, bc);
+    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, bc, n_blocks, d_total);
+    hipLaunchKernelGGL((write_kernel<Pred, Emit>), dim3(n_blocks), dim3(kScanThreads), 0, st, pred, emit, n, bc, limit);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+} // namespace
+
+struct slam_ccicp {
+    DevBuf vox, blocks, blocks2, small; // small: 6 min/max words, totals, 4 packed NN results
+    long long max_voxels = 1ll << 26;
+};
+
+extern "C" {
+
+int slam_ccicp_create(slam_ccicp_t **out)
+{
+    SLAM_REQUIRE(out, SLAM_E_INVALID, "slam_ccicp_create: null out pointer");
+    *out = nullptr;
+    SLAM_TRY(require_device());
+    slam_ccicp *h = new (std::nothrow) slam_ccicp();
+    SLAM_REQUIRE(h, SLAM_E_NOMEM, "slam_ccicp_create: out of host memory");
+    int rc = h->small.reserve(256);
+    if (rc != SLAM_OK) {
+        delete h;
+        return rc;
+    }
+    *out = h;
+    return SLAM_OK;
+}
+
+void slam_ccicp_destroy(slam_ccicp_t *h) { delete h; }
+
+int slam_ccicp_voxel_downsample_dev(slam_ccicp_t *h, const float *d_xyz, const uint8_t *d_flag, int n, int stride,
+                                    float leaf_x, float leaf_y, float leaf_z, float *d_out, int max_out, int *n_out,
+                                    slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && n >= 0 && stride >= 3 && n_out && (d_xyz || n == 0) && (d_out || max_out == 0), SLAM_E_INVALID,
+                 "slam_ccicp_voxel_downsample_dev: bad arguments");
+    SLAM_REQUIRE(leaf_x > 0 && leaf_y > 0 && leaf_z > 0, SLAM_E_INVALID, "leaf size must be positive");
+    *n_out = 0;
+    if (n == 0) return SLAM_OK;
+    hipStream_t st = as_stream(stream);
+    unsigned   *mm = static_cast<unsigned *>(h->small.p);
+    const unsigned init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    SLAM_HIP(hipMemcpyAsync(mm, init, sizeof init, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(minmax_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, d_flag, n, stride, mm);
+    unsigned got[6];
+    SLAM_HIP(hipMemcpyAsync(got, mm, sizeof got, hipMemcpyDeviceToHost, st));
+    SLAM_HIP(hipStreamSynchronize(st)); // the lattice extent sizes the accumulator
+    if (got[0] == 0xffffffffu) return SLAM_OK; // no finite point
+    VoxelGridView g;
+    const float   leaf[3] = {leaf_x, leaf_y, leaf_z};
+    long long     nv = 1;
+    for (int d = 0; d < 3; ++d) {
+        g.inv[d] = 1.0f / leaf[d]; // Eigen::Array4f::Ones() / leaf_size_.array()
+        const double lo = std::floor((double)(unorder_f32(got[d]) * g.inv[d]));
+        const double hi = std::floor((double)(unorder_f32(got[3 + d]) * g.inv[d]));
+        SLAM_REQUIRE(std::fabs(lo) < 1e9 && hi - lo + 1.0 <= (double)h->max_voxels, SLAM_E_INVALID,
+                     "voxel lattice too large along axis %d: leaf too small for the extent", d);
+        g.min_b[d] = (int)lo;
+        g.div_b[d] = (int)(hi - lo) + 1;
+        nv *= g.div_b[d];
+        // PCL: "Leaf size is too small for the input dataset. Integer indices would overflow."
+        SLAM_REQUIRE(nv > 0 && nv <= h->max_voxels, SLAM_E_INVALID,
+                     "voxel lattice of %lld cells exceeds the accumulator limit (%lld): leaf too small for the extent",
+                     nv, h->max_voxels);
+    }
+    g.n_vox = nv;
+    SLAM_TRY(h->vox.reserve(sizeof(Voxel) * (size_t)nv));
+    Voxel *vox = static_cast<Voxel *>(h->vox.p);
+    SLAM_HIP(hipMemsetAsync(vox, 0, sizeof(Voxel) * (size_t)nv, st));
+    hipLaunchKernelGGL(voxel_accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, d_xyz, d_flag, n, stride, vox);
+    int *d_total = reinterpret_cast<int *>(mm + 8);
+    SLAM_TRY(compact(VoxelUsed{vox}, VoxelEmit{vox, d_out}, nv, max_out, h->blocks, d_total, st));
+    int total = 0;
+    SLAM_HIP(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
+    SLAM_HIP(hipStreamSynchronize(st));
+    *n_out = total;
+    SLAM_REQUIRE(total <= max_out, SLAM_E_INVALID, "output holds %d voxels, %d produced (first %d written)", max_out,
+                 total, max_out);
+    return SLAM_OK;
+}
+
+int slam_ccicp_split_dev(slam_ccicp_t *h, const float *d_xyzg, int n, int stride, int crop, double cur_x, double cur_y,
+                         double crop_dist, int cap, double *d_ga_xy, double *d_nga_xy, int counts[2],
+                         slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && n >= 0 && stride >= 4 && cap >= 1 && d_ga_xy && d_nga_xy && counts && (d_xyzg || n == 0),
+                 SLAM_E_INVALID, "slam_ccicp_split_dev: bad arguments");
+    counts[0] = counts[1] = 0;
+    if (n == 0) return SLAM_OK;
+    hipStream_t st = as_stream(stream);
+    int        *d_tot = reinterpret_cast<int *>(static_cast<unsigned *>(h->small.p) + 12);
+    SplitPred   p;
+    p.xyzg = d_xyzg;
+    p.stride = stride;
+    p.crop = crop;
+    p.x_lo = (float)(-crop_dist + cur_x); // setFilterLimits takes floats (icpTools.cpp:231,236)
+    p.x_hi = (float)(crop_dist + cur_x);
+    p.y_lo = (float)(-crop_dist + cur_y);
+    p.y_hi = (float)(crop_dist + cur_y);
+    p.want_ga = 1;
+    SLAM_TRY(compact(p, SplitEmit{d_xyzg, stride, d_ga_xy}, n, cap - 1, h->blocks, d_tot, st)); // ICP_MAX_PTS-1 (:256,:259)
+    p.want_ga = 0;
+    SLAM_TRY(compact(p, SplitEmit{d_xyzg, stride, d_nga_xy}, n, cap - 1, h->blocks2, d_tot + 1, st));
+    int tot[2];
+    SLAM_HIP(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st));
+    SLAM_HIP(hipStreamSynchronize(st));
+    counts[0] = tot[0] < cap - 1 ? tot[0] : cap - 1;
+    counts[1] = tot[1] < cap - 1 ? tot[1] : cap - 1;
+    return SLAM_OK;
+}
+
+// 3x3 symmetric: eigenvector of the smallest eigenvalue by Jacobi sweeps (four points: host side)
+static void smallest_eigvec3(double A[3][3], double v[3])
+{
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        if (std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]) < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (std::fabs(A[p][q]) < 1e-300) continue;
+                const double th = 0.5 * (A[q][q] - A[p][p]) / A[p][q];
+                const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int m = 0;
+    for (int k = 1; k < 3; ++k)
+        if (A[k][k] < A[m][m]) m = k;
+    for (int k = 0; k < 3; ++k) v[k] = V[k][m];
+}
+
+int slam_ccicp_height_dev(slam_ccicp_t *h, const float *d_ground, int n, int stride, const double pose[7], double *z_out,
+                          int *n_corr, int nn_idx[4], slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && pose && z_out && n >= 0 && stride >= 3 && (d_ground || n == 0), SLAM_E_INVALID,
+                 "slam_ccicp_height_dev: bad arguments");
+    const double ROBO_HEIGHT = 1.45, wheel = 0.5; // icpTools.cpp:303-305
+    *z_out = pose[2];
+    if (n_corr) *n_corr = 0;
+    if (nn_idx) nn_idx[0] = nn_idx[1] = nn_idx[2] = nn_idx[3] = -1;
+    if (n == 0) return SLAM_OK;
+    // tf::Matrix3x3(q) stored to an Eigen::Matrix4f (:321-329), then pcl::transformPointCloud in float (:332)
+    const double x = pose[3], y = pose[4], z = pose[5], w = pose[6];
+    const double d = x * x + y * y + z * z + w * w, s = 2.0 / d;
+    const double xs = x * s, ys = y * s, zs = z * s, wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys,
+                 xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+    const float M[3][4] = {{(float)(1.0 - (yy + zz)), (float)(xy - wz), (float)(xz + wy), (float)pose[0]},
+                           {(float)(xy + wz), (float)(1.0 - (xx + zz)), (float)(yz - wx), (float)pose[1]},
+                           {(float)(xz - wy), (float)(yz + wx), (float)(1.0 - (xx + yy)), (float)pose[2]}};
+    float4 q[4];
+    int    k = 0;
+    for (int i = -1; i <= 1; i += 2)
+        for (int j = -1; j <= 1; j += 2, ++k) { // :311-318
+            const float p[3] = {(float)(i * wheel), (float)(j * wheel), (float)(-1.0 * ROBO_HEIGHT)};
+            float       t[3];
+            for (int r = 0; r < 3; ++r) t[r] = M[r][0] * p[0] + M[r][1] * p[1] + M[r][2] * p[2] + M[r][3];
+            q[k] = make_float4(t[0], t[1], t[2], 0.f);
+        }
+    hipStream_t         st = as_stream(stream);
+    unsigned long long *best = reinterpret_cast<unsigned long long *>(static_cast<unsigned *>(h->small.p) + 16);
+    SLAM_HIP(hipMemsetAsync(best, 0xff, 4 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(height_nn_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_ground, n, stride, q[0], q[1], q[2],
+                       q[3], best);
+    unsigned long long got[4];
+    SLAM_HIP(hipMemcpyAsync(got, best, sizeof got, hipMemcpyDeviceToHost, st));
+    SLAM_HIP(hipStreamSynchronize(st));
+    float corr[4][3];
+    int   nc = 0;
+    for (k = 0; k < 4; ++k) {
+        if (got[k] == ~0ull) continue;
+        const unsigned idx = (unsigned)(got[k] & 0xffffffffu), bits = (unsigned)(got[k] >> 32);
+        float          dd;
+        memcpy(&dd, &bits, 4);
+        if (nn_idx) nn_idx[k] = (int)idx;
+        if (dd < 9.0f) { // :345
+            SLAM_HIP(hipMemcpyAsync(corr[nc], d_ground + (size_t)idx * stride, 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+            ++nc;
+        }
+    }
+    SLAM_HIP(hipStreamSynchronize(st));
+    if (n_corr) *n_corr = nc;
+    if (nc < 4) return SLAM_OK; // :351,:379 "Height could not be determined"
+    double mean[3] = {0, 0, 0};
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 3; ++r) mean[r] += (double)corr[i][r];
+    for (int r = 0; r < 3; ++r) mean[r] /= 4.0;
+    double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) C[r][c] += ((double)corr[i][r] - mean[r]) * ((double)corr[i][c] - mean[c]);
+    double nrm[3];
+    smallest_eigvec3(C, nrm); // computePointNormal -> solvePlaneParameters (:361-365)
+    if (std::isnan(nrm[0]) || std::isnan(nrm[1]) || std::isnan(nrm[2])) return SLAM_OK; // :367
+    if (nrm[2] < 0) nrm[2] = -nrm[2];                                                      // :369-372
+    *z_out = (double)(float)((float)nrm[2] * ROBO_HEIGHT + (float)mean[2]);                // :376
+    return SLAM_OK;
+}
+
+} // extern "C"

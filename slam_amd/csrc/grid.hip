@@ -128,7 +128,6 @@ struct Beam { // integer Bresenham endpoints in window cells; x0 < 0 marks a dro
 constexpr int kTile = 128;             // cells per tile side
 constexpr int kTileStride = kTile + 1; // LDS row pitch in words: vertical neighbours fall on adjacent banks
 constexpr int kTileThreads = 1024;
-constexpr int kTileWaves = kTileThreads / 64;
 constexpr int kChunk = 1024;           // beams per pre-pass workgroup
 constexpr int kBlock = 64;             // beams per culling block = one wavefront
 

@@ -230,6 +230,10 @@ __device__ inline void group_min(Best &b, const StartT *oidx)
     }
 }
 
+template <int G, typename StartT, bool EXACT>
+__device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, float qx, float qy,
+                                      int sub, double gate, bool &tie);
+
 // The search proper: fast pass, and the exact pass only for a group that met an
 // exact distance tie (measure zero on noisy data, common on gridded maps).
 template <int G, typename StartT>

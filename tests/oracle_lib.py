@@ -23,7 +23,7 @@ _i8p = C.POINTER(C.c_int8)
 
 
 def build_oracle(force=False):
-    srcs = [os.path.join(ORACLE_DIR, f) for f in ("slam_oracle.c", "gseg_oracle.c", "slam_oracle.h")]
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("slam_oracle.c", "gseg_oracle.c", "ccicp_oracle.c", "slam_oracle.h")]
     if (force or not os.path.exists(ORACLE_SO)
             or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in srcs)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
@@ -421,3 +421,46 @@ def ref_orthonormal_from_omega(w):
     out = np.zeros(4)
     ref().ref_orthonormal_from_omega(float(w), _d(out))
     return out.reshape(2, 2)
+
+
+# ------------------------------------------------------- CCICP facade steps
+def ccicp_crop(xyz, cur_x, cur_y, crop=75.0):
+    xyz = as_f32(xyz)
+    keep = np.zeros(max(len(xyz), 1), dtype=np.uint8)
+    lib().occicp_crop.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
+    lib().occicp_crop(xyz.ctypes.data, len(xyz), xyz.shape[1], cur_x, cur_y, crop, keep.ctypes.data)
+    return keep[:len(xyz)].astype(bool)
+
+
+def voxel_downsample(xyzg, leaf=(0.5, 0.5, 2.0)):
+    xyzg = as_f32(xyzg)
+    out = np.zeros((max(len(xyzg), 1), 4), dtype=np.float32)
+    f = lib().ovoxel_downsample
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+    n = f(xyzg.ctypes.data, len(xyzg), xyzg.shape[1], leaf[0], leaf[1], leaf[2], out.ctypes.data)
+    return out[:max(n, 0)], n
+
+
+def ccicp_split(xyzg, keep=None, cap=20000):
+    xyzg = as_f32(xyzg)
+    ga = np.zeros((cap, 2))
+    nga = np.zeros((cap, 2))
+    na, nb = C.c_int(0), C.c_int(0)
+    k = np.ascontiguousarray(keep, dtype=np.uint8) if keep is not None else None
+    f = lib().occicp_split
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f.restype = None
+    f(xyzg.ctypes.data, k.ctypes.data if k is not None else None, len(xyzg), xyzg.shape[1], cap, ga.ctypes.data,
+      C.addressof(na), nga.ctypes.data, C.addressof(nb))
+    return ga[:na.value], nga[:nb.value]
+
+
+def ccicp_height(ground, pose7):
+    g = as_f32(ground)
+    pose = (C.c_double * 7)(*pose7)
+    z = C.c_double(0.0)
+    idx = (C.c_int * 4)()
+    f = lib().occicp_height
+    f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    nc = f(g.ctypes.data if len(g) else None, len(g), g.shape[1] if g.ndim == 2 else 3, pose, C.addressof(z), idx)
+    return z.value, nc, list(idx)

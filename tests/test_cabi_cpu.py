@@ -78,3 +78,15 @@ def test_product_never_imports_the_oracle():
                     if re.match(r"\s*(#\s*include|import|from)\b", line):
                         assert "oracle" not in line, "%s: %s" % (f, line)
                 assert "CDLL" not in txt or f == "api.py", f
+
+
+def test_python_binding_declares_pointer_signatures():
+    """ctypes passes an undeclared Python int as a 32-bit C int: a device pointer handed to an entry point
+    without argtypes would be truncated (a GPU fault, not an error code).  Only calls that take no pointer
+    from Python, or a byref() struct, may go undeclared."""
+    from slam_amd import api
+    L = api.lib()
+    undeclared = {n for n in api.EXPORTS if getattr(L, n).argtypes is None}
+    assert undeclared <= {"slam_last_error", "slam_version", "slam_device_count", "slam_set_device",
+                          "slam_device_synchronize", "slam_icp_default_params", "slam_grid_default_params",
+                          "slam_ccicp_create"}
