@@ -277,11 +277,6 @@ int  slam_gseg_segment_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride
 int  slam_gseg_split_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, const uint8_t *d_labels,
                          float *d_ground_xyz4, float *d_obstacle_xyz4, int32_t *d_counts,
                          slam_stream_t stream);
-/* the points whose label is in label_mask (bit (1 << SLAM_GSEG_x) per label) as (x, y, z, 0) records, e.g.
- * (1 << SLAM_GSEG_OBSTACLE) | (1 << SLAM_GSEG_OVERHEAD) = the outcloud CCICP::segmentGround classifies
- * (icpTools.cpp:114-117); *d_count = points written */
-int  slam_gseg_select_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, const uint8_t *d_labels,
-                          unsigned label_mask, float *d_out_xyz4, int32_t *d_count, slam_stream_t stream);
 /* CCICP::classifyPoints, icpTools.cpp:36-103: for every point of the obstacle cloud 1 = ground
  * adjacent (GA), 0 = not (NGA), 255 = dropped there too (outside the 1200 x 1200 x 0.5 m lattice
  * or in its outermost cells).  GA/NGA are the two classes the ICP matches separately. */
@@ -300,6 +295,12 @@ typedef struct slam_ccicp slam_ccicp_t;
 int  slam_ccicp_create(slam_ccicp_t **out);
 void slam_ccicp_destroy(slam_ccicp_t *h);
 
+/* The points whose ground-segmentation label (SLAM_GSEG_*) is in label_mask (bit 1 << label), in cloud
+ * order, as (x, y, z, 0) records: (1 << SLAM_GSEG_OBSTACLE) | (1 << SLAM_GSEG_OVERHEAD) is the outcloud
+ * CCICP::segmentGround classifies, 1 << SLAM_GSEG_GROUND its ground cloud (icpTools.cpp:106-119). */
+int slam_ccicp_select_dev(slam_ccicp_t *h, const float *d_xyz, int n, int stride, const uint8_t *d_labels,
+                          unsigned label_mask, float *d_out_xyz4, int *n_out, slam_stream_t stream);
+
 /* CCICP::setSceneCloud / setTargetCloud voxel filter, icpTools.cpp:620-633 (pcl::VoxelGrid, leaf
  * 0.5,0.5,2 for obstacles, 0.5,0.5,5 for ground): one output point per occupied voxel, x,y,z = centroid,
  * [3] = ground_adj averaged as PCL averages every field (then stored to the uint16 field), in increasing
@@ -310,6 +311,14 @@ void slam_ccicp_destroy(slam_ccicp_t *h);
 int slam_ccicp_voxel_downsample_dev(slam_ccicp_t *h, const float *d_xyz, const uint8_t *d_flag, int n, int stride,
                                     float leaf_x, float leaf_y, float leaf_z, float *d_out, int max_out, int *n_out,
                                     slam_stream_t stream);
+
+/* The cloud as CCICP::classifyPoints leaves it (icpTools.cpp:64-101): points it keeps, bin by bin (x bin
+ * major, y bin minor), original order inside a bin, as x,y,z,ground_adj records -- the order in which
+ * doICPMatch applies the ICP_MAX_PTS cap to the target cloud (SCAN_TO_MAP: setTargetCloud classifies
+ * without a voxel filter, icpTools.cpp:591-595).  d_flag: the flags slam_gseg_classify_ga_dev wrote for
+ * the same points. */
+int slam_ccicp_bin_order_dev(slam_ccicp_t *h, const float *d_xyz, const uint8_t *d_flag, int n, int stride,
+                             float *d_out_xyzg, int *n_out, slam_stream_t stream);
 
 /* CCICP::doICPMatch(initPose) marshalling, icpTools.cpp:225-276: optional crop of +-crop_dist around
  * (cur_x,cur_y) (pcl::PassThrough on x then y; the reference crops the target cloud only, 75 m), then the

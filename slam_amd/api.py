@@ -80,9 +80,9 @@ EXPORTS = [
     "slam_grid_info", "slam_grid_counts_dev", "slam_grid_raycast_stats",
     "slam_gseg_default_params", "slam_gseg_create", "slam_gseg_destroy", "slam_gseg_reserve",
     "slam_gseg_segment", "slam_gseg_segment_dev", "slam_gseg_split_dev", "slam_gseg_read_model",
-    "slam_gseg_classify_ga_dev", "slam_gseg_select_dev",
+    "slam_gseg_classify_ga_dev",
     "slam_ccicp_create", "slam_ccicp_destroy", "slam_ccicp_voxel_downsample_dev", "slam_ccicp_split_dev",
-    "slam_ccicp_height_dev",
+    "slam_ccicp_height_dev", "slam_ccicp_bin_order_dev", "slam_ccicp_select_dev",
 ]
 
 
@@ -104,6 +104,10 @@ def lib():
                                                   C.c_float, C.c_float, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     L.slam_ccicp_split_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
                                        C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.slam_ccicp_select_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_uint, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
+    L.slam_ccicp_bin_order_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]
     L.slam_ccicp_height_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
     L.slam_grid_destroy.restype = None
@@ -175,7 +179,6 @@ def lib():
     L.slam_gseg_segment.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp]
     L.slam_gseg_segment_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp]
     L.slam_gseg_split_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
-    L.slam_gseg_select_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, C.c_uint, _vp, _vp, _vp]
     L.slam_gseg_read_model.argtypes = [_vp, _vp, _vp, _vp]
     L.slam_gseg_classify_ga_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp]
     L.slam_grid_raycast_stats.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -642,6 +645,19 @@ class Ccicp:
         n_out = C.c_int(0)
         check(lib().slam_ccicp_voxel_downsample_dev(self.h, d_xyz.ptr, d_flag.ptr if d_flag else None, n, stride,
                                                     leaf[0], leaf[1], leaf[2], d_out.ptr, n, C.byref(n_out), None))
+        return d_out.download()[:n_out.value]
+
+    def bin_order(self, xyz, flags):
+        """The cloud in classifyPoints order with its flags: [n_kept, 4]."""
+        xyz = np.ascontiguousarray(xyz, dtype=np.float32)
+        n, stride = xyz.shape
+        if n == 0:
+            return np.zeros((0, 4), np.float32)
+        d_xyz = DeviceArray.from_host(xyz)
+        d_flag = DeviceArray.from_host(np.ascontiguousarray(flags, np.uint8))
+        d_out = DeviceArray((n, 4), np.float32)
+        n_out = C.c_int(0)
+        check(lib().slam_ccicp_bin_order_dev(self.h, d_xyz.ptr, d_flag.ptr, n, stride, d_out.ptr, C.byref(n_out), None))
         return d_out.download()[:n_out.value]
 
     def split(self, xyzg, pose_xy=None, crop_dist=75.0, cap=ICP_MAX_PTS):

@@ -12,6 +12,8 @@
 #include <new>
 #include <vector>
 
+#include <rocprim/rocprim.hpp> // device radix sort (the stable bin order of classifyPoints)
+
 #include "common.hpp"
 
 using namespace slam;
@@ -195,6 +197,23 @@ struct VoxelEmit {
     }
 };
 
+// points whose label is in a mask, in cloud order, as (x, y, z, 0) records
+struct LabelPred {
+    const unsigned char *labels;
+    unsigned             mask;
+    __device__ bool operator()(long long i) const { return (mask >> labels[i]) & 1u; }
+};
+struct Xyz4Emit {
+    const float *xyz;
+    int          stride;
+    float4      *out;
+    __device__ void operator()(long long i, int pos) const
+    {
+        const float *q = xyz + (size_t)i * stride;
+        out[pos] = make_float4(q[0], q[1], q[2], 0.f);
+    }
+};
+
 // crop (pcl::PassThrough x then y) + class predicate of the split
 struct SplitPred {
     const float *xyzg;
@@ -245,6 +264,40 @@ __global__ __launch_bounds__(256) void height_nn_kernel(const float *ground, int
     }
 }
 
+// classifyPoints rebuilds the cloud bin by bin (x bin major, y bin minor, icpTools.cpp:64-101), points of a bin in
+// their original order: key = (bin << 32 | index), so sorted keys are that order.  Points it drops (outside the
+// 1200 x 1200 lattice :60, edge cells :72-77 -- flag 255 from slam_gseg_classify_ga_dev) get the last key.
+constexpr int kGaBins = 1200; // icpTools.h:24-26
+__global__ __launch_bounds__(256) void bin_keys_kernel(const float *xyz, const unsigned char *flag, int n, int stride,
+                                                       unsigned long long *keys)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float *q = xyz + (size_t)i * stride;
+    const double RES = 0.5, offset = (double)kGaBins * RES / 2;
+    const double fx = floor(((double)q[0] + offset) / RES), fy = floor(((double)q[1] + offset) / RES); // :57-58
+    unsigned long long bin = 0x1fffffull;
+    if (flag[i] != 255 && fx >= 0 && fx < kGaBins && fy >= 0 && fy < kGaBins) bin = (unsigned long long)((int)fx * kGaBins + (int)fy);
+    keys[i] = (bin << 32) | (unsigned)i;
+}
+
+__global__ __launch_bounds__(256) void bin_gather_kernel(const float *xyz, const unsigned char *flag, int stride,
+                                                         const unsigned long long *keys, int n, float4 *out, int *n_out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = keys[i];
+    const bool               kept = (k >> 32) != 0x1fffffull;
+    if (kept) {
+        const unsigned src = (unsigned)(k & 0xffffffffu);
+        const float   *q = xyz + (size_t)src * stride;
+        out[i] = make_float4(q[0], q[1], q[2], flag[src] == 1 ? 1.f : 0.f);
+    }
+    // kept points come first: the boundary is where the count stands
+    const bool next_kept = i + 1 < n && (keys[i + 1] >> 32) != 0x1fffffull;
+    if (kept && !next_kept) *n_out = i + 1;
+}
+
 struct DevBuf {
     void  *p = nullptr;
     size_t cap = 0;
@@ -281,6 +334,7 @@ int compact(Pred pred, Emit emit, long long n, int limit, DevBuf &blocks, int *d
 
 struct slam_ccicp {
     DevBuf vox, blocks, blocks2, small; // small: 6 min/max words, totals, 4 packed NN results
+    DevBuf keys, sort_tmp;
     long long max_voxels = 1ll << 26;
 };
 
@@ -352,6 +406,47 @@ int slam_ccicp_voxel_downsample_dev(slam_ccicp_t *h, const float *d_xyz, const u
     *n_out = total;
     SLAM_REQUIRE(total <= max_out, SLAM_E_INVALID, "output holds %d voxels, %d produced (first %d written)", max_out,
                  total, max_out);
+    return SLAM_OK;
+}
+
+int slam_ccicp_select_dev(slam_ccicp_t *h, const float *d_xyz, int n, int stride, const uint8_t *d_labels,
+                          unsigned label_mask, float *d_out_xyz4, int *n_out, slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && n >= 0 && stride >= 3 && n_out && (n == 0 || (d_xyz && d_labels && d_out_xyz4)), SLAM_E_INVALID,
+                 "slam_ccicp_select_dev: bad arguments");
+    *n_out = 0;
+    if (n == 0) return SLAM_OK;
+    hipStream_t st = as_stream(stream);
+    int        *d_tot = reinterpret_cast<int *>(static_cast<unsigned *>(h->small.p) + 26);
+    SLAM_TRY(compact(LabelPred{d_labels, label_mask}, Xyz4Emit{d_xyz, stride, reinterpret_cast<float4 *>(d_out_xyz4)}, n, n,
+                     h->blocks, d_tot, st));
+    SLAM_HIP(hipMemcpyAsync(n_out, d_tot, sizeof(int), hipMemcpyDeviceToHost, st));
+    SLAM_HIP(hipStreamSynchronize(st));
+    return SLAM_OK;
+}
+
+int slam_ccicp_bin_order_dev(slam_ccicp_t *h, const float *d_xyz, const uint8_t *d_flag, int n, int stride,
+                             float *d_out_xyzg, int *n_out, slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && n >= 0 && stride >= 3 && n_out && (n == 0 || (d_xyz && d_flag && d_out_xyzg)), SLAM_E_INVALID,
+                 "slam_ccicp_bin_order_dev: bad arguments");
+    *n_out = 0;
+    if (n == 0) return SLAM_OK;
+    hipStream_t st = as_stream(stream);
+    SLAM_TRY(h->keys.reserve(2 * sizeof(unsigned long long) * (size_t)n));
+    unsigned long long *k_in = static_cast<unsigned long long *>(h->keys.p), *k_out = k_in + n;
+    hipLaunchKernelGGL(bin_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, d_flag, n, stride, k_in);
+    size_t tmp = 0;
+    SLAM_HIP(rocprim::radix_sort_keys(nullptr, tmp, k_in, k_out, (size_t)n, 0u, 53u, st));
+    SLAM_TRY(h->sort_tmp.reserve(tmp));
+    SLAM_HIP(rocprim::radix_sort_keys(h->sort_tmp.p, tmp, k_in, k_out, (size_t)n, 0u, 53u, st));
+    int *d_n = reinterpret_cast<int *>(static_cast<unsigned *>(h->small.p) + 24);
+    SLAM_HIP(hipMemsetAsync(d_n, 0, sizeof(int), st));
+    hipLaunchKernelGGL(bin_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, d_flag, stride, k_out, n,
+                       reinterpret_cast<float4 *>(d_out_xyzg), d_n);
+    SLAM_HIP(hipGetLastError());
+    SLAM_HIP(hipMemcpyAsync(n_out, d_n, sizeof(int), hipMemcpyDeviceToHost, st));
+    SLAM_HIP(hipStreamSynchronize(st));
     return SLAM_OK;
 }
 

@@ -302,25 +302,6 @@ __global__ __launch_bounds__(256) void gseg_split_kernel(const float *xyz, int n
     }
 }
 
-// points whose label is in `mask` (bit per SLAM_GSEG_* value) as (x, y, z, 0) records
-__global__ __launch_bounds__(256) void gseg_select_kernel(const float *xyz, int n, int stride,
-                                                          const unsigned char *labels, unsigned mask, float4 *out,
-                                                          int *count)
-{
-    const int                i = blockIdx.x * 256 + threadIdx.x;
-    const int                lane = threadIdx.x & 63;
-    const bool               mine = i < n && ((mask >> labels[i]) & 1u);
-    const unsigned long long m = __ballot(mine);
-    if (!m) return;
-    int base = 0;
-    if (lane == (__ffsll((long long)m) - 1)) base = atomicAdd(count, __popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
-    if (mine) {
-        const float *q = xyz + (size_t)i * stride;
-        out[base + __popcll(m & ((1ull << lane) - 1ull))] = make_float4(q[0], q[1], q[2], 0.f);
-    }
-}
-
 // CCICP::classifyPoints, ccicp2d/src/icpTools.cpp:36-103 (icpTools.h:24-26): occupancy of a
 // 1200 x 1200 lattice of 0.5 m cells, then per point the number of empty cells among the 8
 // around its own: ground adjacent (GA) when >= 2.  flags: 1 GA, 0 NGA, 255 dropped.
@@ -511,20 +492,6 @@ int slam_gseg_split_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, c
         hipLaunchKernelGGL(gseg_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, stride, d_labels,
                            reinterpret_cast<float4 *>(d_ground_xyz4), reinterpret_cast<float4 *>(d_obstacle_xyz4),
                            d_counts);
-    SLAM_HIP(hipGetLastError());
-    return SLAM_OK;
-}
-
-int slam_gseg_select_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, const uint8_t *d_labels,
-                         unsigned label_mask, float *d_out_xyz4, int32_t *d_count, slam_stream_t stream)
-{
-    SLAM_REQUIRE(h && n >= 0 && stride >= 3 && d_count && (n == 0 || (d_xyz && d_labels && d_out_xyz4)), SLAM_E_INVALID,
-                 "slam_gseg_select_dev: bad arguments");
-    hipStream_t st = as_stream(stream);
-    SLAM_HIP(hipMemsetAsync(d_count, 0, sizeof(int32_t), st));
-    if (n > 0)
-        hipLaunchKernelGGL(gseg_select_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_xyz, n, stride, d_labels,
-                           label_mask, reinterpret_cast<float4 *>(d_out_xyz4), d_count);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }

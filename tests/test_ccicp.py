@@ -163,3 +163,55 @@ def test_gpu_height_matches_oracle():
     z, nc, idx = cc.height(np.zeros((0, 3), np.float32), [0, 0, 0.3, 0, 0, 0, 1])
     assert nc == 0 and z == 0.3 and idx == [-1] * 4
     cc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_bin_order_is_classify_points_order():
+    """classifyPoints rebuilds the cloud bin by bin (icpTools.cpp:64-101): x bin major, y bin minor, original
+    order inside a bin, edge cells and outside points dropped -- the order the ICP_MAX_PTS cap then cuts."""
+    from slam_amd import api
+    xyz, lab, obs = obstacle_cloud(6)
+    rs = np.random.RandomState(8)
+    pts = np.concatenate([obs, (rs.rand(3000, 3) * [700, 700, 2] - [350, 350, 1]).astype(np.float32)])
+    pts = pts[rs.permutation(len(pts))]
+    seg, cc = api.GroundSegmentation(), api.Ccicp()
+    flags = seg.classify_ga(pts)
+    assert np.array_equal(flags, O.classify_ga(pts))
+    out = cc.bin_order(pts, flags)
+    bx = np.floor((pts[:, 0].astype(np.float64) + 300.0) / 0.5).astype(np.int64)
+    by = np.floor((pts[:, 1].astype(np.float64) + 300.0) / 0.5).astype(np.int64)
+    kept = np.flatnonzero(flags != 255)
+    order = kept[np.argsort((bx * 1200 + by)[kept], kind="stable")]
+    assert len(out) == len(order) and 0 < len(out) < len(pts)
+    assert np.array_equal(out[:, :3], pts[order])
+    assert np.array_equal(out[:, 3], (flags[order] == 1).astype(np.float32))
+    # the cap cuts in that order
+    ga, nga = cc.split(out, None, cap=501)
+    sel = out[out[:, 3] > 0.5][:500, :2].astype(np.float64)
+    assert np.array_equal(ga, sel)
+    assert len(cc.bin_order(np.zeros((0, 3), np.float32), np.zeros(0, np.uint8))) == 0
+    seg.close(); cc.close()
+
+
+@pytest.mark.gpu
+def test_gpu_select_outcloud_in_cloud_order():
+    """labels -> the outcloud CCICP::segmentGround classifies (obstacle + overhead) and its ground cloud
+    (icpTools.cpp:106-119), cloud order kept."""
+    import ctypes as C
+    from slam_amd import api
+    xyz = synth.make_cloud3d(4, n_loop=50, rings=32, n_az=1024)[0]
+    n = len(xyz)
+    seg, cc = api.GroundSegmentation(), api.Ccicp()
+    d_xyz = api.DeviceArray.from_host(xyz)
+    d_lab = api.DeviceArray((n,), np.uint8)
+    d_out = api.DeviceArray((n, 4), np.float32)
+    seg.segment_dev(d_xyz, n, 3, d_lab)
+    api.synchronize()
+    lab = d_lab.download()
+    for mask, want in (((1 << api.GSEG_OBSTACLE) | (1 << api.GSEG_OVERHEAD), xyz[lab >= api.GSEG_OBSTACLE]),
+                       (1 << api.GSEG_GROUND, xyz[lab == api.GSEG_GROUND]), (0, xyz[:0])):
+        cnt = C.c_int(-1)
+        api.check(api.lib().slam_ccicp_select_dev(cc.h, d_xyz.ptr, n, 3, d_lab.ptr, mask, d_out.ptr, C.byref(cnt), None))
+        got = d_out.download()[:cnt.value]
+        assert cnt.value == len(want) and np.array_equal(got[:, :3], want) and (got[:, 3] == 0).all()
+    seg.close(); cc.close()

@@ -67,3 +67,81 @@ def test_adapters_match_oracle(tmp_path):
     for _ in range(3):
         O.grid_add_scan_inorder(gp, obs, gnd, num, drv, eocc)
     assert np.array_equal(occ, eocc)
+
+
+def compile_cpp(tmp, name):
+    build.build()
+    exe = os.path.join(tmp, name)
+    lib = os.path.join(ROOT, "slam_amd", "lib")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
+                           "-L" + lib, "-l:libslam_mi355x.so", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+def test_ccicp_adapter_compiles_against_the_cabi(tmp_path):
+    assert os.path.exists(compile_cpp(str(tmp_path), "ccicp_test"))
+
+
+def _quat_rpy(roll, pitch, yaw):
+    cy, sy, cp, sp, cr, sr = (np.cos(yaw / 2), np.sin(yaw / 2), np.cos(pitch / 2), np.sin(pitch / 2),
+                              np.cos(roll / 2), np.sin(roll / 2))
+    return [sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy,
+            cr * cp * cy + sr * sp * sy]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rtype", [0, 1])
+def test_ccicp_facade_matches_oracle_chain(tmp_path, rtype):
+    """CCICP::doICPMatch(initPose) end to end (icpTools.cpp:222-298): two 131 k-ray clouds in, pose out,
+    against the same chain made of oracle pieces."""
+    exe = compile_cpp(str(tmp_path), "ccicp_test")
+    d = str(tmp_path)
+    ka, kb = 3, 4
+    A, pa = synth.make_cloud3d(ka, n_loop=50)
+    B, pb = synth.make_cloud3d(kb, n_loop=50)
+    ca, sa = np.cos(pa[2]), np.sin(pa[2])
+    rel = np.array([ca * (pb[0] - pa[0]) + sa * (pb[1] - pa[1]), -sa * (pb[0] - pa[0]) + ca * (pb[1] - pa[1])])
+    rel_th = pb[2] - pa[2]
+    init = [rel[0] + 0.15, rel[1] - 0.1, 0.05] + _quat_rpy(0.0, 0.0, rel_th + 0.03)
+    lab_a, *_ = O.gseg_segment(A)
+    out_a, gnd_a = A[lab_a >= O.GSEG_OBSTACLE], A[lab_a == O.GSEG_GROUND]
+    target = out_a if rtype else A
+    for name, a in (("target.f32", target), ("scene.f32", B), ("target_ground.f32", gnd_a), ("init.f64", np.array(init))):
+        np.ascontiguousarray(a).tofile(os.path.join(d, name))
+    out = os.path.join(d, "out.bin")
+    subprocess.check_call([exe, d, out, str(rtype)])
+    got = np.fromfile(out, np.float64)
+
+    # the same chain from oracle pieces
+    fa = O.classify_ga(out_a)
+    kept = np.flatnonzero(fa != 255)
+    bx = np.floor((out_a[:, 0].astype(np.float64) + 300.0) / 0.5).astype(np.int64)
+    by = np.floor((out_a[:, 1].astype(np.float64) + 300.0) / 0.5).astype(np.int64)
+    order = kept[np.argsort((bx * 1200 + by)[kept], kind="stable")]
+    seg_target = np.concatenate([out_a[order], (fa[order] == 1).astype(np.float32)[:, None]], 1)
+    m_ga, m_nga = O.ccicp_split(seg_target, O.ccicp_crop(seg_target, init[0], init[1]))
+    lab_b, *_ = O.gseg_segment(B)
+    out_b = B[lab_b >= O.GSEG_OBSTACLE]
+    fb = O.classify_ga(out_b)
+    kb_ = fb != 255
+    seg_scene, n_vox = O.voxel_downsample(np.concatenate([out_b[kb_], fb[kb_, None].astype(np.float32)], 1))
+    s_ga, s_nga = O.ccicp_split(seg_scene, None)
+    gnd_scene, n_gvox = O.voxel_downsample(np.concatenate([B[lab_b == O.GSEG_GROUND], np.zeros((int((lab_b == O.GSEG_GROUND).sum()), 1), np.float32)], 1), (0.5, 0.5, 5.0))
+    assert list(got[8:16]) == [len(seg_target), n_vox, len(gnd_a), n_gvox, len(m_ga), len(m_nga), len(s_ga), len(s_nga)]
+    assert len(s_ga) + len(s_nga) > 300 and len(m_ga) + len(m_nga) > 5000
+
+    yaw0 = rel_th + 0.03
+    R0, t0 = synth.pose_to_Rt(init[0], init[1], yaw0)
+    # the voxel centroids differ in the last float bit between oracle and device: fit the oracle on the oracle's
+    model = O.IcpModel(m_ga, m_nga)
+    R, t, trace, steps = model.fit(s_ga, s_nga, R0, t0, O.icp_params(20, 1e-6, 5.0))
+    yaw = np.arctan2(R[1, 0], R[0, 0])
+    assert abs(got[0] - t[0]) < 1e-4 and abs(got[1] - t[1]) < 1e-4
+    q = _quat_rpy(0.0, 0.0, yaw)
+    assert np.abs(got[3:7] - q).max() < 1e-5
+    assert abs(got[7] - trace[-1, 7]) <= 2                                  # correspondences of the last step
+    z, nc, _ = O.ccicp_height(gnd_a, [got[0], got[1], init[2]] + list(got[3:7]))
+    assert abs(got[2] - z) < 1e-6            # (near the sensor the ring pattern leaves no ground within 3 m: z may stay)
+    # and the match is sane: B's pose in A's frame, to the 0.5 m voxel centroids the scene is reduced to
+    assert abs(got[0] - rel[0]) < 0.3 and abs(got[1] - rel[1]) < 0.3 and abs(yaw - rel_th) < 0.03

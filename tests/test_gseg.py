@@ -129,32 +129,6 @@ def test_config3_pipeline_segment_split_update():
     seg.close(); g.close()
 
 
-@pytest.mark.gpu
-def test_gpu_select_outcloud():
-    """labels -> the outcloud CCICP::segmentGround classifies (obstacle + overhead, icpTools.cpp:114-117)."""
-    from slam_amd import api
-    xyz = synth.make_cloud3d(4, n_loop=50, rings=32, n_az=1024)[0]
-    n = len(xyz)
-    seg = api.GroundSegmentation()
-    d_xyz = api.DeviceArray.from_host(xyz)
-    d_lab = api.DeviceArray((n,), np.uint8)
-    d_out = api.DeviceArray((n, 4), np.float32)
-    d_cnt = api.DeviceArray((1,), np.int32)
-    seg.segment_dev(d_xyz, n, 3, d_lab)
-    mask = (1 << api.GSEG_OBSTACLE) | (1 << api.GSEG_OVERHEAD)
-    api.check(api.lib().slam_gseg_select_dev(seg.h, d_xyz.ptr, n, 3, d_lab.ptr, mask, d_out.ptr, d_cnt.ptr, None))
-    api.synchronize()
-    lab = d_lab.download()
-    cnt = int(d_cnt.download()[0])
-    want = xyz[lab >= api.GSEG_OBSTACLE]
-    assert cnt == len(want) > 1000
-    got = d_out.download()[:cnt]
-    assert (got[:, 3] == 0).all()
-    key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]          # the order between wavefronts is free
-    assert np.array_equal(key(got[:, :3]), key(want))
-    seg.close()
-
-
 def test_oracle_ga_classification_rules():
     # icpTools.cpp:36-103: 0.5 m cells, GA iff >= 2 of the 8 neighbour cells are empty
     wall = np.stack([np.arange(0, 20, 0.1), np.full(200, 5.2), np.zeros(200)], 1).astype(np.float32)

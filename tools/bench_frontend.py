@@ -33,9 +33,10 @@ def chain(timing=None):
     t = [time.perf_counter()]
     seg.segment_dev(d_xyz, n, 3, d_lab)
     seg.split_dev(d_xyz, n, 3, d_lab, d_gnd, d_drv, d_cnt)               # ground cloud (+ drvCloud for the grid)
-    api.check(L.slam_gseg_select_dev(seg.h, d_xyz.ptr, n, 3, d_lab.ptr, (1 << 2) | (1 << 3), d_obs.ptr, d_cnt2.ptr, None))
-    api.synchronize(); t.append(time.perf_counter())
-    n_gnd = int(d_cnt.download()[0]); n_obs = int(d_cnt2.download()[0])
+    c_obs = C.c_int(0)
+    api.check(L.slam_ccicp_select_dev(cc.h, d_xyz.ptr, n, 3, d_lab.ptr, (1 << 2) | (1 << 3), d_obs.ptr, C.byref(c_obs), None))
+    t.append(time.perf_counter())
+    n_gnd = int(d_cnt.download()[0]); n_obs = c_obs.value
     api.check(L.slam_gseg_classify_ga_dev(seg.h, d_obs.ptr, n_obs, 4, d_flag.ptr, None))
     api.synchronize(); t.append(time.perf_counter())
     n_vox = C.c_int(0)
