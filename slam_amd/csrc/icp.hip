@@ -49,7 +49,7 @@ constexpr int kCoopPerWave = 64 / kCoop;       // queries a wavefront searches a
 constexpr int kCoopPerBlock = kWaves * kCoopPerWave;
 constexpr unsigned kReduceBytes = (2u * kWaves * kNumAcc + 2u * 8u) * sizeof(double); // reduction + broadcast
 constexpr unsigned kQueueBytes = 4u * kWaves + 2u * kBlock; // per-wavefront counts + 64 u16 entries per wavefront
-static_assert(kHoist == 3, "the pass loop selects Pc[0..2] explicitly");
+static_assert(kHoist == 3, "the pass loop selects Pc0, Pc1, Pc2 explicitly");
 static_assert(kWaves == kCoop, "drain_queue keeps one wavefront count per lane of a DPP row");
 constexpr unsigned kScratchBytes = (kReduceBytes + kQueueBytes + 15u) & ~15u;
 
@@ -863,12 +863,11 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
 
     // the lane's points of the first passes, loaded once
     constexpr int kPerPass = kBlock / (G > 0 ? G : 1);
-    double2       Pc[kHoist];
-#pragma unroll
-    for (int k = 0; k < kHoist; ++k) {
+    const auto    hoisted = [&](int k) {
         const int p = k * kPerPass + tid / (G > 0 ? G : 1);
-        Pc[k] = (G > 0 && p < n) ? fa.pts[off + p] : make_double2(0.0, 0.0);
-    }
+        return (G > 0 && p < n) ? fa.pts[off + p] : make_double2(0.0, 0.0);
+    };
+    const double2 Pc0 = hoisted(0), Pc1 = hoisted(1), Pc2 = hoisted(2); // named, not an array: stays in registers
 
     if (n >= 5) { // icp.cpp:100-103
         for (int iter = 0; iter < fa.max_iter; ++iter) {
@@ -897,7 +896,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                     // undecided and, when fewer than kCoopPerBlock points remain after it, those too
                     int tail = 0;
                     if (rem > kCoopPerBlock) {
-                        const double2 P = pass == 0 ? Pc[0] : (p0 + tid < n ? fa.pts[off + p0 + tid] : Pc[0]);
+                        const double2 P = pass == 0 ? Pc0 : (p0 + tid < n ? fa.pts[off + p0 + tid] : Pc0);
                         sweep_pass<StartT>(ix, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back);
                         tail = rem - kBlock;
                         tail = tail > 0 && tail <= kCoopPerBlock ? tail : 0;
@@ -912,7 +911,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                     p0 += kBlock + tail;
                     if (p0 < n) __syncthreads(); // the queue is reused by the next pass
                 } else if (G > 0) {
-                    double2 P = pass == 0 ? Pc[0] : (pass == 1 ? Pc[1] : Pc[2]);
+                    double2 P = pass == 0 ? Pc0 : (pass == 1 ? Pc1 : Pc2);
                     if (pass >= kHoist) {
                         const int p = p0 + tid / (G > 0 ? G : 1);
                         P = fa.pts[off + min(p, n - 1)];
