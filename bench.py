@@ -183,8 +183,10 @@ def main():
     ev = [[api.Event() for _ in range(5)] for _ in range(args.steps)]
 
     def step(e=None):
+        # one batch: initial poses in, a fresh local count map, register, ray-cast, merge over the GPUs, finalize
         d_R.copy_from(d_R0)
         d_t.copy_from(d_t0)
+        grid.reset_counts()
         if e: e[0].record()
         icp.fit_batch_dev(d_pts, d_off, d_nga, S, d_R, d_t, 5.0, d_res)
         if e: e[1].record()
@@ -224,6 +226,9 @@ def main():
         cnt = torch.tensor([P, upd_per_step], dtype=torch.int64, device="cuda")
         dist.all_reduce(cnt)
         total_pts, total_upd = int(cnt[0].item()), int(cnt[1].item())
+        # the merged planes of the last step hold every rank's updates of that step, once
+        merged = int(planes.to(torch.int64).sum().item())
+        assert merged == total_upd, "merged planes hold %d updates, the ranks made %d" % (merged, total_upd)
     else:
         total_pts, total_upd = P, upd_per_step
 

@@ -178,6 +178,9 @@ int  slam_grid_create(int size_x, int size_y, double resolution,
                       const slam_grid_params *params, slam_grid_t **out);
 void slam_grid_destroy(slam_grid_t *g);
 int  slam_grid_clear(slam_grid_t *g, slam_stream_t stream);            /* MLS::clearMap, mls.cpp:18-31 */
+/* zeroes the hit/miss count planes only (batch / multi-GPU mode: a fresh local map per batch, so that the
+ * all-reduce merges this batch's counts and not sums that were merged before) */
+int  slam_grid_reset_counts(slam_grid_t *g, slam_stream_t stream);
 int  slam_grid_set_min_cluster_points(slam_grid_t *g, int v);          /* mls.h:235 */
 int  slam_grid_set_max_range(slam_grid_t *g, double v);                /* mls.h:237 */
 /* MLS::setPose, mls.cpp:408-479.  Non-rolling: records curPose for the range

@@ -71,7 +71,7 @@ EXPORTS = [
     "slam_icp_fit", "slam_icp_fit_batch_dev", "slam_icp_nearest_dev", "slam_icp_get_edge_weight",
     "slam_icp_get_normals",
     "slam_icp_index_info",
-    "slam_grid_default_params", "slam_grid_create", "slam_grid_destroy", "slam_grid_clear",
+    "slam_grid_default_params", "slam_grid_create", "slam_grid_destroy", "slam_grid_clear", "slam_grid_reset_counts",
     "slam_grid_set_min_cluster_points", "slam_grid_set_max_range", "slam_grid_set_pose",
     "slam_grid_get_pose", "slam_grid_add_endpoints", "slam_grid_add_endpoints_dev",
     "slam_grid_raycast", "slam_grid_raycast_dev", "slam_grid_raycast_scans_dev",
@@ -152,6 +152,7 @@ def lib():
                                    C.POINTER(_vp)]
     L.slam_grid_destroy.argtypes = [_vp]
     L.slam_grid_clear.argtypes = [_vp, _vp]
+    L.slam_grid_reset_counts.argtypes = [_vp, _vp]
     L.slam_grid_set_min_cluster_points.argtypes = [_vp, C.c_int]
     L.slam_grid_set_max_range.argtypes = [_vp, C.c_double]
     L.slam_grid_set_pose.argtypes = [_vp, C.c_double, C.c_double, _vp]
@@ -468,6 +469,9 @@ class Grid:
 
     def clear(self, stream=None):
         check(lib().slam_grid_clear(self.h, _sp(stream)))
+
+    def reset_counts(self, stream=None):
+        check(lib().slam_grid_reset_counts(self.h, _sp(stream)))
 
     def set_pose(self, x, y, stream=None):
         check(lib().slam_grid_set_pose(self.h, float(x), float(y), _sp(stream)))

@@ -822,6 +822,13 @@ int slam_grid_clear(slam_grid_t *g, slam_stream_t stream)
     return SLAM_OK;
 }
 
+int slam_grid_reset_counts(slam_grid_t *g, slam_stream_t stream)
+{
+    SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
+    SLAM_HIP(hipMemsetAsync(g->d_planes, 0, 2 * g->cells * sizeof(int32_t), as_stream(stream)));
+    return SLAM_OK;
+}
+
 int slam_grid_set_min_cluster_points(slam_grid_t *g, int v)
 {
     SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
