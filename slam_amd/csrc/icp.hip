@@ -72,6 +72,18 @@ struct ModelView {
     Lattice  lat;
     double   cx, cy;        // shift origin for the running sums (model centroid)
     const double *normals;  // P2L: double2 per ORIGINAL all-index (GA then NGA), or null
+    // Halo lists (list-sweep mode): per class and cell of a second, coarser lattice, every point within the
+    // cell dilated by `pad` cells, ordered along the axis of larger extent.  A query whose best distance
+    // over its own cell's list is below cert2 has seen every point that close: no neighbour cells.
+    const unsigned char *lblob;
+    unsigned lblob_bytes;
+    unsigned loff_pts;      // float2[n_ent[0] + n_ent[1]]
+    unsigned loff_start[2]; // u16[lcells+1] per class, positions relative to the class base
+    unsigned loff_axis[2];  // bit per cell and class
+    int      lbase[2];      // first entry of each class
+    Lattice  llat;
+    float    lpad;          // halo in cell units
+    float    cert2;         // squared certified radius (metres^2)
 };
 
 template <typename StartT>
@@ -589,6 +601,14 @@ struct FitArgs {
     double         indist;
     double        *step_pose; // nullable; per scan 6 doubles: R,t as the last executed step found them
     long long     *stamps; // diagnostic only (SLAM_ICP_STAMPS=1): per scan, cycles in [search, reduce, barrier, solve]
+    // Two launches per batch: the ring-search kernel runs the first switch_iter iterations of every scan (by
+    // then a scan is normally within the certified radius of the halo lists) and the list-sweep kernel the
+    // rest.  The same count for every scan: a kernel boundary is a barrier over the whole batch, so a scan
+    // that handed over early would only lengthen the second launch.  state[scan] = iterations done, or -1
+    // when the scan finished (min_delta) in the first launch.
+    int           *state;
+    int            phase;  // 0 = single launch, 1 = first of two, 2 = second
+    int            switch_iter;
 };
 
 struct Pose {
@@ -602,12 +622,18 @@ __device__ inline void transform_query(const Pose &T, const double2 P, float &qx
     qy = (float)__dadd_rn(__dadd_rn(__dmul_rn(T.r10, P.x), __dmul_rn(T.r11, P.y)), T.t1);
 }
 
+__device__ inline void add_p2p_xy(const ModelView &mv, const float2 m, float qx, float qy, double acc[kNumAcc]);
+
 // icpPointToPoint.cpp:76,96-99,116-126,159: one inlier correspondence into the running sums
 template <typename StartT>
 __device__ inline void add_p2p(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, const Best &b, float qx,
                                float qy, double acc[kNumAcc])
 {
-    const float2 m = ix.pts[mv.base[cls] + b.pos];
+    add_p2p_xy(mv, ix.pts[mv.base[cls] + b.pos], qx, qy, acc);
+}
+
+__device__ inline void add_p2p_xy(const ModelView &mv, const float2 m, float qx, float qy, double acc[kNumAcc])
+{
     const double ax = (double)m.x - mv.cx, ay = (double)m.y - mv.cy;
     const double bx = (double)qx - mv.cx, by = (double)qy - mv.cy;
     acc[0] += 1.0;
@@ -716,13 +742,179 @@ __device__ inline void sweep_pass(const IndexPtrs<StartT> &ix, const ModelView &
     if (!done) queue[wave * 64 + __popcll(need & ((1ull << lane) - 1ull))] = (unsigned short)threadIdx.x;
 }
 
+// List-sweep mode: the query's own cell of the list lattice, one sweep over its halo list, certified when
+// the best distance is below the halo radius.  Returns false (undecided) otherwise.
+struct ListPtrs {
+    const float2         *pts;
+    const unsigned short *start[2];
+    const unsigned       *axis[2];
+};
+
+__device__ inline ListPtrs make_list_ptrs(const unsigned char *base, const ModelView &mv)
+{
+    ListPtrs lp;
+    lp.pts = reinterpret_cast<const float2 *>(base + mv.loff_pts);
+    lp.start[0] = reinterpret_cast<const unsigned short *>(base + mv.loff_start[0]);
+    lp.start[1] = reinterpret_cast<const unsigned short *>(base + mv.loff_start[1]);
+    lp.axis[0] = reinterpret_cast<const unsigned *>(base + mv.loff_axis[0]);
+    lp.axis[1] = reinterpret_cast<const unsigned *>(base + mv.loff_axis[1]);
+    return lp;
+}
+
+constexpr int kListWin = 3;  // entries examined on either side of the refined start
+constexpr int kListWalk = 3; // further steps on either side before the query is left to the cooperative round
+
+__device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const ModelView &mv, int cls, float qx, float qy)
+{
+    const Lattice &L = mv.llat;
+    b.d = FLT_MAX;
+    b.oidx = 0xffffffffu;
+    b.pos = -1;
+    const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
+    if (!(fx >= 0.f && fx < (float)L.nx && fy >= 0.f && fy < (float)L.ny)) return false; // outside (or NaN)
+    const int             cx = min((int)fx, L.nx - 1), cy = min((int)fy, L.ny - 1), c = cy * L.nx + cx;
+    const unsigned short *start = lp.start[cls];
+    const float2         *pts = lp.pts + mv.lbase[cls];
+    const int             a = (int)start[c], e = (int)start[c + 1], n = e - a;
+    if (n <= 0) return false;
+    const bool  ay = (lp.axis[cls][c >> 5] >> (c & 31)) & 1u;
+    const float kq = ay ? qy : qx;
+    // start: the first entry whose key is not below the query's (binary search: the keys of a list bent around
+    // a corner are far from evenly spaced, an interpolated start can be dozens of entries off)
+    int g;
+    {
+        int blo = a, bhi = e;
+        while (blo < bhi) {
+            const int    mid = (blo + bhi) >> 1;
+            const float2 pm = pts[mid];
+            if ((ay ? pm.y : pm.x) < kq)
+                blo = mid + 1;
+            else
+                bhi = mid;
+        }
+        g = min(blo, e - 1);
+    }
+    const int lo = max(a, g - kListWin), hi = min(e - 1, g + kListWin);
+    float     d = FLT_MAX, klo = 0.f, khi = 0.f;
+    int       pos = -1;
+    bool      tie = false;
+#pragma unroll
+    for (int j = 0; j <= 2 * kListWin; ++j) {
+        const int    i = lo + j;
+        const bool   ok = i <= hi;
+        const float2 p = pts[min(i, hi)];
+        const float  dj = ok ? dist2(p, qx, qy) : FLT_MAX;
+        const float  kj = ay ? p.y : p.x;
+        if (j == 0) klo = kj;
+        khi = ok ? kj : khi;
+        tie |= ok & (dj == d);
+        const bool up = dj < d;
+        d = up ? dj : d;
+        pos = up ? i : pos;
+    }
+    // beyond an end whose key distance alone exceeds the best (on the far side of the query) nothing can
+    // beat or tie it; otherwise walk on from that end
+    const float dl = klo - kq, dr = khi - kq;
+    bool        Lft = (lo > a) & !((dl < 0.f) & (__fmul_rn(dl, dl) > d));
+    bool        Rgt = (hi < e - 1) & !((dr > 0.f) & (__fmul_rn(dr, dr) > d));
+    int         il = lo - 1, ir = hi + 1;
+    // a bounded walk: a query that needs more (a list bent around a corner, a poor start) is left undecided
+    // rather than holding its wavefront -- and at the barrier its workgroup -- back
+    int budget = kListWalk;
+    while ((Lft | Rgt) & (budget > 0)) {
+        --budget;
+        const float2 ml = pts[max(il, a)], mr = pts[min(ir, e - 1)];
+        {
+            const float dk = (ay ? ml.y : ml.x) - kq;
+            const bool  in = Lft & !((dk < 0.f) & (__fmul_rn(dk, dk) > d));
+            const float dd = dist2(ml, qx, qy);
+            tie |= in & (dd == d);
+            const bool up = in & (dd < d);
+            d = up ? dd : d;
+            pos = up ? il : pos;
+            --il;
+            Lft = in & (il >= a);
+        }
+        {
+            const float dk = (ay ? mr.y : mr.x) - kq;
+            const bool  in = Rgt & !((dk > 0.f) & (__fmul_rn(dk, dk) > d));
+            const float dd = dist2(mr, qx, qy);
+            tie |= in & (dd == d);
+            const bool up = in & (dd < d);
+            d = up ? dd : d;
+            pos = up ? ir : pos;
+            ++ir;
+            Rgt = in & (ir < e);
+        }
+    }
+    b.d = d;
+    b.pos = pos;
+    if (tie || pos < 0 || (Lft | Rgt) || !(d < mv.cert2)) return false;
+    m = pts[pos];
+    return true;
+}
+
+// The whole halo list of the query's cell scanned by kCoop lanes (the list is in LDS; 2-6 entries a lane):
+// the cooperative round's first try for the scan's tail and for queries whose bounded walk gave up.
+__device__ inline bool list_scan16(Best &b, float2 &m, const ListPtrs &lp, const ModelView &mv, int cls, float qx, float qy,
+                                   int sub)
+{
+    const Lattice &L = mv.llat;
+    const float    fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
+    const bool     inside = fx >= 0.f && fx < (float)L.nx && fy >= 0.f && fy < (float)L.ny;
+    const int      cx = inside ? min((int)fx, L.nx - 1) : 0, cy = inside ? min((int)fy, L.ny - 1) : 0, c = cy * L.nx + cx;
+    const float2  *pts = lp.pts + mv.lbase[cls];
+    const int      a = (int)lp.start[cls][c], e = inside ? (int)lp.start[cls][c + 1] : a;
+    float          d = FLT_MAX;
+    int            pos = -1;
+    bool           tie = false;
+    for (int i = a + sub; i < e; i += kCoop) {
+        const float di = dist2(pts[i], qx, qy);
+        tie |= (di == d);
+        const bool up = di < d;
+        d = up ? di : d;
+        pos = up ? i : pos;
+    }
+    row16_min(d, pos, tie);
+    b.d = d;
+    b.pos = pos;
+    b.oidx = 0xffffffffu;
+    if (tie || pos < 0 || !(d < mv.cert2)) return false;
+    m = pts[pos];
+    return true;
+}
+
+// List-sweep kernel, one pass over kBlock points from p0; undecided queries are queued as in sweep_pass.
+__device__ inline void list_pass(const ListPtrs &lp, const ModelView &mv, const FitArgs &fa, const Pose &T, int n, int nga,
+                                 int p0, const double2 P, double acc[kNumAcc], unsigned *wave_cnt, unsigned short *queue,
+                                 int &fell_back)
+{
+    const int  lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int  p = p0 + (int)threadIdx.x;
+    const int  cls = p < nga ? 0 : 1;
+    const bool valid = p < n && mv.n_cls[cls] > 3; // icpPointToPoint.cpp:59,93
+    bool       done = true;
+    if (valid) {
+        float  qx, qy;
+        Best   b;
+        float2 m;
+        transform_query(T, P, qx, qy);
+        done = list_search(b, m, lp, mv, cls, qx, qy);
+        if (done && (double)b.d < fa.indist) add_p2p_xy(mv, m, qx, qy, acc); // :76
+        fell_back += done ? 0 : 1;
+    }
+    const unsigned long long need = __ballot(!done);
+    if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(need);
+    if (!done) queue[wave * 64 + __popcll(need & ((1ull << lane) - 1ull))] = (unsigned short)threadIdx.x;
+}
+
 // All wavefronts take kCoopPerWave points at a time and search each with kCoop lanes: first the `tail`
 // points past the pass (block_search, then the ring search if that does not decide), then the queued
 // ones (ring search).  Entry e of the queue lives in the region of the wavefront whose inclusive count
 // prefix first exceeds e.
-template <typename StartT>
-__device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa, const Pose &T,
-                                   int off, int n, int nga, int p0, double acc[kNumAcc], int tail,
+template <typename StartT, bool LISTS>
+__device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ListPtrs &lp, const ModelView &mv, const FitArgs &fa,
+                                   const Pose &T, int off, int n, int nga, int p0, double acc[kNumAcc], int tail,
                                    const unsigned *wave_cnt, const unsigned short *queue)
 {
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
@@ -748,11 +940,19 @@ __device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ModelView 
             if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
                 float qx, qy;
                 transform_query(T, fa.pts[off + p], qx, qy);
-                Best b;
-                if (!is_tail || !block_search<StartT>(b, ix, mv, cls, qx, qy, lane % kCoop, fa.indist))
+                Best   b;
+                float2 m;
+                bool   have_m = false;
+                if (LISTS) {
+                    have_m = list_scan16(b, m, lp, mv, cls, qx, qy, lane % kCoop);
+                    if (!have_m) b = nn_search<kCoop, StartT>(ix, mv, cls, qx, qy, lane % kCoop, fa.indist);
+                } else if (!is_tail || !block_search<StartT>(b, ix, mv, cls, qx, qy, lane % kCoop, fa.indist)) {
                     b = nn_search<kCoop, StartT>(ix, mv, cls, qx, qy, lane % kCoop, fa.indist);
-                if (lane % kCoop == 0 && b.pos >= 0 && (double)b.d < fa.indist)
-                    add_p2p<StartT>(ix, mv, cls, b, qx, qy, acc); // :76
+                }
+                if (lane % kCoop == 0 && b.pos >= 0 && (double)b.d < fa.indist) { // :76
+                    if (!have_m) m = ix.pts[mv.base[cls] + b.pos];
+                    add_p2p_xy(mv, m, qx, qy, acc);
+                }
             }
         }
     }
@@ -762,7 +962,8 @@ __device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ModelView 
 // group's lane 0 adds the correspondence to its running sums.
 template <int GG, typename StartT, int MODE>
 __device__ inline void accumulate_point(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
-                                        const Pose &T, const double2 P, bool is_ga, int sub, double acc[kNumAcc])
+                                        const Pose &T, const double2 P, bool is_ga, int sub, double acc[kNumAcc],
+                                        int &far)
 {
     float qx, qy;
     transform_query(T, P, qx, qy);
@@ -771,6 +972,7 @@ __device__ inline void accumulate_point(const IndexPtrs<StartT> &ix, const Model
         if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
             const Best b = nn_search<GG, StartT>(ix, mv, cls, qx, qy, sub, fa.indist);
             if (sub == 0 && b.pos >= 0 && (double)b.d < fa.indist) add_p2p<StartT>(ix, mv, cls, b, qx, qy, acc); // :76
+            far += (sub == 0 && !(b.pos >= 0 && b.d < mv.cert2)) ? 1 : 0; // beyond what the halo lists certify
         }
     } else {
         // icpPointToPlane.cpp:55-77: single class, no inlier gate
@@ -806,17 +1008,19 @@ __device__ inline void point_pass(const IndexPtrs<StartT> &ix, const ModelView &
                                   const Pose &T, int off, int n, int nga, int p0, double acc[kNumAcc])
 {
     const int p = p0 + (int)threadIdx.x / GG;
-    if (p < n) accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, fa.pts[off + p], p < nga, (int)threadIdx.x % GG, acc);
+    int       far = 0;
+    if (p < n) accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, fa.pts[off + p], p < nga, (int)threadIdx.x % GG, acc, far);
 }
 
 // The same with the lane's point already in registers (the first kHoist passes: a lane meets the same
 // points in every iteration, so they are loaded once per scan, not once per iteration).
 template <int GG, typename StartT, int MODE>
 __device__ inline void point_pass_reg(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
-                                      const Pose &T, int n, int nga, int p0, const double2 P, double acc[kNumAcc])
+                                      const Pose &T, int n, int nga, int p0, const double2 P, double acc[kNumAcc],
+                                      int &far)
 {
     const int p = p0 + (int)threadIdx.x / GG;
-    if (p < n) accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, P, p < nga, (int)threadIdx.x % GG, acc);
+    if (p < n) accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, P, p < nga, (int)threadIdx.x % GG, acc, far);
 }
 
 // One workgroup = one scan, all iterations.  MODE: SLAM_ICP_P2P / SLAM_ICP_P2L.
@@ -824,7 +1028,7 @@ __device__ inline void point_pass_reg(const IndexPtrs<StartT> &ix, const ModelVi
 // more than half a workgroup of points is left, then the widest group that
 // still covers the rest in one pass (a 1081-point scan is 1024 points at G = 1
 // plus 57 points at G = 16), so no pass runs nearly empty.
-template <int G, bool LDS, typename StartT, int MODE, bool SWEEP>
+template <int G, bool LDS, typename StartT, int MODE, int SWEEP>
 __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -842,6 +1046,11 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
     const int off = fa.scan_off[s];
     const int n = fa.scan_off[s + 1] - off;
     const int nga = fa.scan_nga[s];
+    int       iter_begin = 0;
+    if (fa.phase == 2) {
+        iter_begin = fa.state[s];
+        if (iter_begin < 0) return; // finished in the first launch (uniform for the workgroup)
+    }
 
     const unsigned char *base = mv.blob;
     if (LDS) {
@@ -853,6 +1062,15 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
         __syncthreads();
     }
     const IndexPtrs<StartT> ix = make_ptrs<StartT>(base, mv);
+    ListPtrs                lp = {};
+    if (SWEEP == 2) { // the halo lists live in LDS; the cell index above stays in HBM/L2 for the undecided few
+        unsigned char *dst = smem + kScratch;
+        const uint4   *src = reinterpret_cast<const uint4 *>(mv.lblob);
+        uint4         *d4 = reinterpret_cast<uint4 *>(dst);
+        for (unsigned i = tid; i < mv.lblob_bytes / 16u; i += kBlock) d4[i] = src[i];
+        lp = make_list_ptrs(dst, mv);
+        __syncthreads();
+    }
 
     double r00 = uniform(fa.R[4 * s + 0]), r01 = uniform(fa.R[4 * s + 1]), r10 = uniform(fa.R[4 * s + 2]),
            r11 = uniform(fa.R[4 * s + 3]);
@@ -869,8 +1087,10 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
     };
     const double2 Pc0 = hoisted(0), Pc1 = hoisted(1), Pc2 = hoisted(2); // named, not an array: stays in registers
 
+    bool hand_over = false;
+    iters = iter_begin;
     if (n >= 5) { // icp.cpp:100-103
-        for (int iter = 0; iter < fa.max_iter; ++iter) {
+        for (int iter = iter_begin; iter < fa.max_iter; ++iter) {
             double acc[kNumAcc];
 #pragma unroll
             for (int k = 0; k < kNumAcc; ++k) acc[k] = 0.0;
@@ -886,6 +1106,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
             }
             long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c_mid = 0;
             int       fell_back = 0; // diagnostic: sweep queries of this lane that went to the ring search
+            int       far = 0;       // queries of this lane whose neighbour is beyond the halo lists' certified radius
             if (fa.stamps) c0 = __builtin_amdgcn_s_memtime();
 
             int pass = 0;
@@ -897,7 +1118,10 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                     int tail = 0;
                     if (rem > kCoopPerBlock) {
                         const double2 P = pass == 0 ? Pc0 : (p0 + tid < n ? fa.pts[off + p0 + tid] : Pc0);
-                        sweep_pass<StartT>(ix, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back);
+                        if (SWEEP == 2)
+                            list_pass(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back);
+                        else
+                            sweep_pass<StartT>(ix, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back);
                         tail = rem - kBlock;
                         tail = tail > 0 && tail <= kCoopPerBlock ? tail : 0;
                     } else { // a scan shorter than one cooperative round
@@ -907,7 +1131,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                     }
                     __syncthreads();
                     if (fa.stamps) c_mid = __builtin_amdgcn_s_memtime();
-                    drain_queue<StartT>(ix, mv, fa, T, off, n, nga, p0, acc, tail, wave_cnt, queue);
+                    drain_queue<StartT, SWEEP == 2>(ix, lp, mv, fa, T, off, n, nga, p0, acc, tail, wave_cnt, queue);
                     p0 += kBlock + tail;
                     if (p0 < n) __syncthreads(); // the queue is reused by the next pass
                 } else if (G > 0) {
@@ -916,7 +1140,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                         const int p = p0 + tid / (G > 0 ? G : 1);
                         P = fa.pts[off + min(p, n - 1)];
                     }
-                    point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc);
+                    point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc, far);
                     p0 += kBlock / (G > 0 ? G : 1);
                 } else if (rem * 2 > kBlock) {
                     point_pass<1, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
@@ -936,6 +1160,11 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                 }
             }
 
+            const bool at_switch = fa.phase == 1 && iter + 1 >= fa.switch_iter && iter + 1 < fa.max_iter;
+            if (at_switch) { // how many queries the list-sweep launch could not certify right now
+                for (int o = 32; o > 0; o >>= 1) far += __shfl_xor(far, o);
+                if (lane == 0) wave_cnt[wave] = (unsigned)far;
+            }
             if (fa.stamps) c1 = __builtin_amdgcn_s_memtime();
             // wavefront reduction on the DPP path, then LDS across the 16 wavefronts
             double *my = partial + ((iter & 1) * kWaves + wave) * kNumAcc;
@@ -1043,8 +1272,10 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                     st[1] += c2 - c1;
                     st[2] += c3 - c2;
                     st[3] += c4 - c3;
-                    st[4] += fell_back;
-                    if (iter < 3) st[5 + iter] += c1 - c0; // search time of the first iterations
+                    if (iter >= 6) st[4] += fell_back; // queries the sweeps left undecided, late iterations
+                    if (iter >= 6 && c_mid) st[7] += c1 - c_mid; // cooperative rounds, late iterations
+                    if (iter == 0) st[5] += c1 - c0;  // search time of the first iteration
+                    if (iter >= 6) st[6] += c1 - c0;  // search time of the late iterations
                     if (c_mid) st[8] += c1 - c_mid;        // of which the cooperative rounds (sweep kernel)
                 }
             }
@@ -1060,6 +1291,16 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                 tr[7] = (double)n_corr;
             }
             if (delta < fa.min_delta) break; // icp.cpp:119-121
+            if (at_switch) {
+                // hand over unless too many queries are still far from the map (outliers, a scan that has not
+                // settled): each of them would cost the second launch a ring search from HBM per iteration
+                unsigned far_all = 0;
+                for (int w = 0; w < kWaves; ++w) far_all += wave_cnt[w];
+                if (far_all * 32u <= (unsigned)n) {
+                    hand_over = true; // the list-sweep launch continues from here
+                    break;
+                }
+            }
         }
     }
 
@@ -1075,6 +1316,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
             fa.result[s].n_corr = n_corr;
             fa.result[s].delta = delta;
         }
+        if (fa.phase == 1) fa.state[s] = hand_over ? iters : -1;
     }
 }
 
@@ -1279,11 +1521,16 @@ struct slam_icp {
     bool            in_lds = false;
     bool            start32 = false;
     int             G = 8;
-    bool            sweep = false; // P2P default: one lane per point, ordered-cell sweeps (sweep_search)
+    int             sweep = 0;     // 0 ring search, 1 ordered-cell sweeps (sweep_search), 2 halo-list sweeps (list_search)
+    void           *d_lblob = nullptr;
+    size_t          list_lds_bytes = 0;
+    bool            have_lists = false;
     size_t          lds_bytes = 0;
     void           *d_blob = nullptr;
     double         *d_normals = nullptr;
-    DevBuf          w_pts, w_off, w_nga, w_R, w_t, w_res, w_stamps, w_pose, w_ew;
+    DevBuf          w_pts, w_off, w_nga, w_R, w_t, w_res, w_stamps, w_pose, w_ew, w_state;
+    bool            two_phase = false;   // ring search, then list sweeps (the point-to-point default)
+    int             switch_iter = 10;    // iterations of the first launch (measured optimum on config 2: tools/switch_sweep.sh)
     int             n_stamps = 0;
     bool            want_step_pose = false; // set around slam_icp_fit()
     int             last_n = 0, last_nga = 0; // template of the last slam_icp_fit()
@@ -1341,6 +1588,9 @@ void fill_index(std::vector<unsigned char> &blob, const ModelView &mv, const std
 }
 
 inline unsigned align16(unsigned v) { return (v + 15u) & ~15u; }
+
+int build_lists(slam_icp *h, const std::vector<float> xy[2], const int cnt[2], const float lo[2], const float hi[2],
+                float maxabs, unsigned lds_total);
 
 int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, int n_nga)
 {
@@ -1466,6 +1716,123 @@ int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, 
     SLAM_HIP(hipMalloc(&h->d_blob, mv.blob_bytes));
     SLAM_HIP(hipMemcpy(h->d_blob, blob.data(), mv.blob_bytes, hipMemcpyHostToDevice));
     mv.blob = static_cast<const unsigned char *>(h->d_blob);
+    if (h->sweep == 2 || h->two_phase) SLAM_TRY(build_lists(h, xy, cnt, lo, hi, maxabs, lds_total));
+    return SLAM_OK;
+}
+
+// Halo lists for the list-sweep mode (ModelView::lblob): picks the smallest list-lattice pitch for which
+// points (with their halo copies), start arrays and axis bits fit LDS beside the scratch.  Leaves
+// have_lists false when nothing fits (the caller then keeps the ring search).
+int build_lists(slam_icp *h, const std::vector<float> xy[2], const int cnt[2], const float lo[2], const float hi[2],
+                float maxabs, unsigned lds_total)
+{
+    ModelView &mv = h->mv;
+    h->have_lists = false;
+    const double budget = (double)lds_total - (double)kScratchBytes - 64.0;
+    const float  margin_abs = maxabs * 1.9073486328125e-06f; // 2^-19 * maxabs, as for the cell lattice
+    struct Ent { int cell; float key; int pt; };
+    for (double frac : {0.25, 0.125}) {
+        for (double hs = 0.25; hs <= 64.0; hs *= 1.12) {
+            const double pad_m = hs * frac; // halo in metres
+            if (pad_m < 8.0 * margin_abs) continue;
+            const double x0 = (double)lo[0] - pad_m, y0 = (double)lo[1] - pad_m;
+            const long   nx = (long)std::floor(((double)hi[0] + pad_m - x0) / hs) + 1, ny = (long)std::floor(((double)hi[1] + pad_m - y0) / hs) + 1;
+            if (nx * ny > 60000) continue;
+            const int ncells = (int)(nx * ny);
+            // entries per class
+            size_t n_ent[2] = {0, 0};
+            bool   ok = true;
+            for (int c = 0; c < 2 && ok; ++c) {
+                for (int i = 0; i < cnt[c]; ++i) {
+                    const double px = xy[c][2 * i], py = xy[c][2 * i + 1];
+                    if (!std::isfinite(px) || !std::isfinite(py)) continue;
+                    const long ax = std::max(0L, (long)std::floor((px - pad_m - x0) / hs)), bx = std::min(nx - 1, (long)std::floor((px + pad_m - x0) / hs));
+                    const long ay = std::max(0L, (long)std::floor((py - pad_m - y0) / hs)), by = std::min(ny - 1, (long)std::floor((py + pad_m - y0) / hs));
+                    n_ent[c] += (size_t)((bx - ax + 1) * (by - ay + 1));
+                }
+                if (n_ent[c] > 65535) ok = false;
+            }
+            if (!ok) continue;
+            const size_t bytes = align16(8u * (unsigned)(n_ent[0] + n_ent[1])) + 2 * (size_t)align16(2u * (unsigned)(ncells + 1)) +
+                                 2 * (size_t)align16(4u * (unsigned)(ncells / 32 + 1));
+            if ((double)bytes > budget) continue;
+            // ---- build
+            unsigned o = 0;
+            mv.loff_pts = o;
+            o = align16(o + 8u * (unsigned)(n_ent[0] + n_ent[1]));
+            for (int c = 0; c < 2; ++c) {
+                mv.loff_start[c] = o;
+                o = align16(o + 2u * (unsigned)(ncells + 1));
+            }
+            for (int c = 0; c < 2; ++c) {
+                mv.loff_axis[c] = o;
+                o = align16(o + 4u * (unsigned)(ncells / 32 + 1));
+            }
+            mv.lblob_bytes = o;
+            mv.lbase[0] = 0;
+            mv.lbase[1] = (int)n_ent[0];
+            mv.llat.nx = (int)nx;
+            mv.llat.ny = (int)ny;
+            mv.llat.x0 = (float)x0;
+            mv.llat.y0 = (float)y0;
+            mv.llat.h = (float)hs;
+            mv.llat.inv_h = 1.0f / mv.llat.h;
+            mv.llat.margin = std::max(mv.llat.h * 0.0009765625f, margin_abs);
+            mv.lpad = (float)frac;
+            // a point within `cert` of a query lies within cert + (cell-map rounding) of the query's nominal cell
+            const double cert = pad_m - 4.0 * (double)mv.llat.margin - 2.0 * std::fabs((double)mv.llat.x0 - x0) - 2.0 * std::fabs((double)mv.llat.y0 - y0);
+            if (cert <= 0) continue;
+            mv.cert2 = (float)(cert * cert * 0.999);
+            std::vector<unsigned char> blob(o, 0);
+            float2 *lpts = reinterpret_cast<float2 *>(blob.data() + mv.loff_pts);
+            for (int c = 0; c < 2; ++c) {
+                std::vector<Ent> ent;
+                ent.reserve(n_ent[c]);
+                for (int i = 0; i < cnt[c]; ++i) {
+                    const double px = xy[c][2 * i], py = xy[c][2 * i + 1];
+                    if (!std::isfinite(px) || !std::isfinite(py)) continue;
+                    const long ax = std::max(0L, (long)std::floor((px - pad_m - x0) / hs)), bx = std::min(nx - 1, (long)std::floor((px + pad_m - x0) / hs));
+                    const long ay = std::max(0L, (long)std::floor((py - pad_m - y0) / hs)), by = std::min(ny - 1, (long)std::floor((py + pad_m - y0) / hs));
+                    for (long yy = ay; yy <= by; ++yy)
+                        for (long xx = ax; xx <= bx; ++xx) ent.push_back({(int)(yy * nx + xx), 0.f, i});
+                }
+                std::stable_sort(ent.begin(), ent.end(), [](const Ent &a, const Ent &b) { return a.cell < b.cell; });
+                unsigned short *start = reinterpret_cast<unsigned short *>(blob.data() + mv.loff_start[c]);
+                unsigned       *axis = reinterpret_cast<unsigned *>(blob.data() + mv.loff_axis[c]);
+                size_t          a = 0;
+                for (int k = 0; k < ncells; ++k) {
+                    start[k] = (unsigned short)a;
+                    size_t e = a;
+                    float  mn[2] = {FLT_MAX, FLT_MAX}, mx[2] = {-FLT_MAX, -FLT_MAX};
+                    while (e < ent.size() && ent[e].cell == k) {
+                        for (int d = 0; d < 2; ++d) {
+                            const float v = xy[c][2 * ent[e].pt + d];
+                            mn[d] = std::min(mn[d], v);
+                            mx[d] = std::max(mx[d], v);
+                        }
+                        ++e;
+                    }
+                    const int ax = (e - a >= 2 && (mx[1] - mn[1]) > (mx[0] - mn[0])) ? 1 : 0;
+                    if (ax) axis[k >> 5] |= 1u << (k & 31);
+                    for (size_t j = a; j < e; ++j) ent[j].key = xy[c][2 * ent[j].pt + ax];
+                    std::stable_sort(ent.begin() + a, ent.begin() + e, [](const Ent &p, const Ent &q) { return p.key < q.key; });
+                    a = e;
+                }
+                start[ncells] = (unsigned short)a;
+                for (size_t j = 0; j < ent.size(); ++j)
+                    lpts[mv.lbase[c] + j] = make_float2(xy[c][2 * ent[j].pt], xy[c][2 * ent[j].pt + 1]);
+            }
+            SLAM_HIP(hipMalloc(&h->d_lblob, mv.lblob_bytes));
+            SLAM_HIP(hipMemcpy(h->d_lblob, blob.data(), mv.lblob_bytes, hipMemcpyHostToDevice));
+            mv.lblob = static_cast<const unsigned char *>(h->d_lblob);
+            h->list_lds_bytes = kScratchBytes + mv.lblob_bytes;
+            h->have_lists = true;
+            if (getenv("SLAM_ICP_DEBUG"))
+                fprintf(stderr, "halo lists: pitch %.3f m, halo %.3f m, certified radius %.4f m, %d x %d cells, %zu + %zu entries, %u bytes\n", hs,
+                        pad_m, std::sqrt((double)mv.cert2), (int)nx, (int)ny, n_ent[0], n_ent[1], mv.lblob_bytes);
+            return SLAM_OK;
+        }
+    }
     return SLAM_OK;
 }
 
@@ -1499,7 +1866,7 @@ int compute_normals(slam_icp *h, const double *m_ga, int n_ga, const double *m_n
     return SLAM_OK;
 }
 
-template <int G, bool LDS, typename StartT, int MODE, bool SWEEP = false>
+template <int G, bool LDS, typename StartT, int MODE, int SWEEP = 0>
 int launch_fit_t(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
 {
     auto kern = icp_fit_kernel<G, LDS, StartT, MODE, SWEEP>;
@@ -1515,9 +1882,17 @@ int launch_fit_t(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
 template <int MODE>
 int launch_fit_sweep(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
 {
-    if (h->in_lds) return launch_fit_t<1, true, uint16_t, MODE, true>(h, fa, n_scans, st);
-    if (h->start32) return launch_fit_t<1, false, uint32_t, MODE, true>(h, fa, n_scans, st);
-    return launch_fit_t<1, false, uint16_t, MODE, true>(h, fa, n_scans, st);
+    if (h->sweep == 2 && h->have_lists) { // lists in LDS, cell index from HBM/L2
+        auto         kern = h->start32 ? icp_fit_kernel<1, false, uint32_t, MODE, 2> : icp_fit_kernel<1, false, uint16_t, MODE, 2>;
+        const size_t lds = h->list_lds_bytes;
+        SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(n_scans), dim3(kBlock), lds, st, h->mv, fa);
+        SLAM_HIP(hipGetLastError());
+        return SLAM_OK;
+    }
+    if (h->in_lds) return launch_fit_t<1, true, uint16_t, MODE, 1>(h, fa, n_scans, st);
+    if (h->start32) return launch_fit_t<1, false, uint32_t, MODE, 1>(h, fa, n_scans, st);
+    return launch_fit_t<1, false, uint16_t, MODE, 1>(h, fa, n_scans, st);
 }
 
 template <int G, int MODE>
@@ -1552,12 +1927,31 @@ int launch_fit_m(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
     return SLAM_E_INVALID;
 }
 
-int launch_fit(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
+int launch_fit(slam_icp *h, const FitArgs &fa_in, int n_scans, hipStream_t st)
 {
     if (n_scans <= 0) return SLAM_OK;
+    FitArgs fa = fa_in;
+    fa.state = nullptr;
+    fa.phase = 0;
+    fa.switch_iter = 0;
     if (h->prm.mode == SLAM_ICP_P2L) {
         SLAM_REQUIRE(h->d_normals, SLAM_E_INVALID, "point-to-line mode needs model normals");
         return launch_fit_m<SLAM_ICP_P2L>(h, fa, n_scans, st);
+    }
+    if (h->two_phase && h->have_lists) {
+        // first iterations by the ring search (index in LDS), the rest by the list sweeps (halo lists in LDS)
+        SLAM_TRY(h->w_state.reserve(sizeof(int) * (size_t)n_scans));
+        fa.state = static_cast<int *>(h->w_state.p);
+        fa.switch_iter = h->switch_iter;
+        fa.phase = 1;
+        const int keep = h->sweep;
+        h->sweep = 0;
+        int rc = launch_fit_m<SLAM_ICP_P2P>(h, fa, n_scans, st);
+        h->sweep = 2;
+        fa.phase = 2;
+        if (rc == SLAM_OK) rc = launch_fit_m<SLAM_ICP_P2P>(h, fa, n_scans, st);
+        h->sweep = keep;
+        return rc;
     }
     return launch_fit_m<SLAM_ICP_P2P>(h, fa, n_scans, st);
 }
@@ -1597,8 +1991,10 @@ int slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga
         slam_icp_default_params(&h->prm);
     // 0 = library default (sweep search, one lane per point; point-to-line: ring search with 2 lanes);
     // N > 0 = ring search with N lanes per point; -1 = ring search, lanes chosen per pass
-    h->sweep = h->prm.lanes_per_point == -2;
+    h->sweep = h->prm.lanes_per_point == -2 ? 1 : (h->prm.lanes_per_point == -3 ? 2 : 0);
     h->G = h->prm.lanes_per_point > 0 ? h->prm.lanes_per_point : (h->prm.lanes_per_point == -1 ? 0 : 2);
+    h->two_phase = h->prm.lanes_per_point == 0 && h->prm.mode == SLAM_ICP_P2P;
+    if (const char *e = getenv("SLAM_ICP_SWITCH_ITER")) h->switch_iter = atoi(e);
     int rc = build_index(h, m_ga, n_ga, m_nga, n_nga);
     if (rc == SLAM_OK && (h->G & (h->G - 1) || h->G > 64)) {
         set_error("lanes_per_point must be one of 1,2,4,8,16,32,64 (got %d)", h->G);
@@ -1617,6 +2013,7 @@ void slam_icp_destroy(slam_icp_t *icp)
 {
     if (!icp) return;
     if (icp->d_blob) (void)hipFree(icp->d_blob);
+    if (icp->d_lblob) (void)hipFree(icp->d_lblob);
     if (icp->d_normals) (void)hipFree(icp->d_normals);
     delete icp;
 }

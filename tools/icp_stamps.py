@@ -8,12 +8,14 @@ import numpy as np
 from slam_amd import api, synth
 m_ga, m_nga = synth.make_map(); batch = synth.make_batch(256)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-for lanes in (-2, 0, 1, 4):
+for lanes in (0, -3, 2):
     icp = api.Icp(m_ga, m_nga, max_iter=iters, min_delta=-1.0, lanes_per_point=lanes)
     icp.fit_batch(batch)
     out = (C.c_double * 9)()
     L = api.lib(); L.slam_icp_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
     api.check(L.slam_icp_debug_stamps(icp.h, out))
     v = np.array(out[:])
-    print("lanes=%d per iteration per wave: search %.0f reduce %.0f barrier %.0f solve %.0f | fell back %.1f queries/wave/iter"
-          " | search of iterations 0..2: %.0f %.0f %.0f | cooperative rounds %.0f per iteration" % ((lanes,) + tuple(v[:5] / iters) + tuple(v[5:8]) + (v[8] / iters,)))
+    late = max(iters - 6, 1)
+    print("lanes=%d per iteration per wave: search %.0f reduce %.0f barrier %.0f solve %.0f | search of iteration 0: %.0f"
+          " | iterations >= 6: search %.0f of which cooperative rounds %.0f, %.2f undecided queries/wave"
+          % ((lanes,) + tuple(v[:4] / iters) + (v[5], v[6] / late, v[7] / late, v[4] / late)))
