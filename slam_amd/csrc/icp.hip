@@ -44,13 +44,13 @@ constexpr int kNumAcc = 9;            // doubles reduced per iteration
 constexpr int kStampSlots = 9;        // diagnostic stamps per wavefront
 constexpr int kHoist = 3;             // passes whose points stay in registers across iterations
 constexpr unsigned kLdsTotal = 160u * 1024u;
-constexpr int kCoop = 16;                      // lanes per query in the cooperative ring search
+constexpr int kCoop = 8;                       // lanes per query in the cooperative rounds
 constexpr int kCoopPerWave = 64 / kCoop;       // queries a wavefront searches at a time
 constexpr int kCoopPerBlock = kWaves * kCoopPerWave;
 constexpr unsigned kReduceBytes = (2u * kWaves * kNumAcc + 2u * 8u) * sizeof(double); // reduction + broadcast
 constexpr unsigned kQueueBytes = 4u * kWaves + 2u * kBlock; // per-wavefront counts + 64 u16 entries per wavefront
 static_assert(kHoist == 3, "the pass loop selects Pc0, Pc1, Pc2 explicitly");
-static_assert(kWaves == kCoop, "drain_queue keeps one wavefront count per lane of a DPP row");
+static_assert(kWaves == 16 && 16 % kCoop == 0, "drain_queue keeps one wavefront count per lane of a 16-lane DPP row");
 constexpr unsigned kScratchBytes = (kReduceBytes + kQueueBytes + 15u) & ~15u;
 
 struct Lattice {
@@ -703,7 +703,15 @@ __device__ inline bool block_search(Best &b, const IndexPtrs<StartT> &ix, const 
             d = up ? di : d;
             pos = up ? i : pos;
         }
-    row16_min(d, pos, tie);
+    {
+        Best gb;
+        gb.d = d;
+        gb.pos = pos;
+        gb.oidx = 0;
+        group_min_lean<kCoop>(gb, tie);
+        d = gb.d;
+        pos = gb.pos;
+    }
     const bool  covers = (cx - 1 <= 0) & (cy - 1 <= 0) & (cx + 1 >= L.nx - 1) & (cy + 1 >= L.ny - 1);
     const float bound = L.h - L.margin;
     const float b2 = bound * bound;
@@ -854,9 +862,9 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
     return true;
 }
 
-// The whole halo list of the query's cell scanned by kCoop lanes (the list is in LDS; 2-6 entries a lane):
+// The whole halo list of the query's cell scanned by kCoop lanes (the list is in LDS; a handful of entries a lane):
 // the cooperative round's first try for the scan's tail and for queries whose bounded walk gave up.
-__device__ inline bool list_scan16(Best &b, float2 &m, const ListPtrs &lp, const ModelView &mv, int cls, float qx, float qy,
+__device__ inline bool list_scan_coop(Best &b, float2 &m, const ListPtrs &lp, const ModelView &mv, int cls, float qx, float qy,
                                    int sub)
 {
     const Lattice &L = mv.llat;
@@ -875,10 +883,12 @@ __device__ inline bool list_scan16(Best &b, float2 &m, const ListPtrs &lp, const
         d = up ? di : d;
         pos = up ? i : pos;
     }
-    row16_min(d, pos, tie);
     b.d = d;
     b.pos = pos;
     b.oidx = 0xffffffffu;
+    group_min_lean<kCoop>(b, tie);
+    d = b.d;
+    pos = b.pos;
     if (tie || pos < 0 || !(d < mv.cert2)) return false;
     m = pts[pos];
     return true;
@@ -924,18 +934,26 @@ __device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ListPtrs &
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
-    const int queued = __builtin_amdgcn_readlane(incl, 15);
+    int incl_w[kWaves]; // the same in every lane: scalar registers
+#pragma unroll
+    for (int j = 0; j < kWaves; ++j) incl_w[j] = __builtin_amdgcn_readlane(incl, j);
+    const int queued = incl_w[kWaves - 1];
     const int total = tail + queued;
     for (int base = 0; base < total; base += kCoopPerBlock) {
         const int g = lane / kCoop;
-        const int e = base + wave * kCoopPerWave + g;
-        // wavefront region holding queue entry e - tail
-        const unsigned long long le = __ballot(incl <= e - tail);
-        const int  w = __popcll((le >> (g * kCoop)) & 0xffffull);
-        const int  excl = __shfl(incl - mine, g * kCoop + min(w, kWaves - 1));
+        const int e = base + wave * kCoopPerWave + g; // wavefront-major: a short round keeps few wavefronts busy (measured
+                                                      // faster than dealing it round-robin over all sixteen)
+        // wavefront region holding queue entry e - tail: the first whose inclusive prefix exceeds it
+        int w = 0, excl = 0;
+#pragma unroll
+        for (int j = 0; j < kWaves; ++j) {
+            const bool below = incl_w[j] <= e - tail;
+            w += below ? 1 : 0;
+            excl = below ? incl_w[j] : excl;
+        }
         if (e < total) {
             const bool is_tail = e < tail;
-            const int  p = p0 + (is_tail ? kBlock + e : (int)queue[w * 64 + (e - tail - excl)]);
+            const int  p = p0 + (is_tail ? kBlock + e : (int)queue[min(w, kWaves - 1) * 64 + (e - tail - excl)]);
             const int  cls = p < nga ? 0 : 1;
             if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
                 float qx, qy;
@@ -944,7 +962,7 @@ __device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ListPtrs &
                 float2 m;
                 bool   have_m = false;
                 if (LISTS) {
-                    have_m = list_scan16(b, m, lp, mv, cls, qx, qy, lane % kCoop);
+                    have_m = list_scan_coop(b, m, lp, mv, cls, qx, qy, lane % kCoop);
                     if (!have_m) b = nn_search<kCoop, StartT>(ix, mv, cls, qx, qy, lane % kCoop, fa.indist);
                 } else if (!is_tail || !block_search<StartT>(b, ix, mv, cls, qx, qy, lane % kCoop, fa.indist)) {
                     b = nn_search<kCoop, StartT>(ix, mv, cls, qx, qy, lane % kCoop, fa.indist);
