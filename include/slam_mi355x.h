@@ -88,11 +88,11 @@ typedef struct {
     double min_delta;       /* icp.cpp:27 min_delta(1e-6); icp.h:54 setMinDeltaParam */
     int    mode;            /* SLAM_ICP_P2P | SLAM_ICP_P2L */
     int    normals_k;       /* P2L: neighbours per normal (icpPointToPlane.h: 10) */
-    int    lanes_per_point; /* lanes of a wavefront that share one scene point's
-                               search: 1,2,4,8,16,32,64; 0 = library default (2),
-                               -1 = chosen per pass from the points left,
-                               -2 = experimental: one lane per point, ordered-cell
-                               sweeps + cooperative queue */
+    int    lanes_per_point; /* 0 = library default: the ring search (2 lanes per scan point) for
+                               the first iterations of a scan, then the halo-list sweeps (one lane
+                               per point) in a second launch; N = 1,2,4,8,16,32,64:
+                               ring search only, N lanes per point; -1 = ring search, lanes chosen
+                               per pass; -2 = list sweeps for every iteration (measurements) */
     double cell_size;       /* model lattice pitch in metres; 0 = sized to fit LDS */
     int    force_global;    /* 1 = keep the model index in HBM/L2 even if it fits LDS */
 } slam_icp_params;

@@ -66,7 +66,6 @@ struct ModelView {
     unsigned off_pts;       // float2[n_all]: class 0 (GA) sorted by cell, then class 1 (NGA)
     unsigned off_start[2];  // StartT[ncells+1] per class, positions relative to the class base
     unsigned off_oidx;      // StartT[n_all]: original index within the class
-    unsigned off_axis[2];   // u32 bit per cell and class: the cell's points are ordered by y (1) or by x (0)
     int      n_cls[2];
     int      base[2];       // first point of each class in pts
     Lattice  lat;
@@ -91,7 +90,6 @@ struct IndexPtrs {
     const float2 *pts;
     const StartT *start[2];
     const StartT *oidx;
-    const unsigned *axis[2];
 };
 
 template <typename StartT>
@@ -102,8 +100,6 @@ __device__ inline IndexPtrs<StartT> make_ptrs(const unsigned char *base, const M
     ix.start[0] = reinterpret_cast<const StartT *>(base + mv.off_start[0]);
     ix.start[1] = reinterpret_cast<const StartT *>(base + mv.off_start[1]);
     ix.oidx = reinterpret_cast<const StartT *>(base + mv.off_oidx);
-    ix.axis[0] = reinterpret_cast<const unsigned *>(base + mv.off_axis[0]);
-    ix.axis[1] = reinterpret_cast<const unsigned *>(base + mv.off_axis[1]);
     return ix;
 }
 
@@ -341,118 +337,6 @@ __device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelVi
     return b;
 }
 
-// ---------------------------------------------------------------- sweep search
-// Inside a cell the points are ordered along the axis of their larger extent
-// (walls are 1-D: the order follows the wall).  A query starts at the position
-// its own coordinate interpolates to and walks outwards in both directions
-// until it is past the query's own key AND the squared KEY distance alone
-// exceeds the best squared distance found: fl(dk*dk) <= fl(fl(dx*dx)+fl(dy*dy))
-// for every point, and beyond the query's key |dk| grows monotonically along the
-// order, so nothing further out can beat or tie the best.  One lane per query; two LDS reads (left, right) in flight per step.
-template <typename StartT>
-__device__ inline void sweep_cell(Best &b, bool &tie, const StartT *start, const unsigned *axis_bits,
-                                  const float2 *pts, int c, float rel_x, float rel_y, float qx, float qy)
-{
-    const int a = (int)start[c], e = (int)start[c + 1];
-    if (e <= a) return;
-    const bool  ay = (axis_bits[c >> 5] >> (c & 31)) & 1u;
-    const float kq = ay ? qy : qx;
-    const int   n = e - a;
-    // rel = position of the query along the axis in cell units relative to the cell's low edge
-    const int g = a + clampi((int)((ay ? rel_y : rel_x) * (float)n), 0, n - 1);
-    {
-        const float d = dist2(pts[g], qx, qy);
-        tie |= (d == b.d);
-        const bool up = d < b.d;
-        b.d = up ? d : b.d;
-        b.pos = up ? g : b.pos;
-    }
-    int  il = g - 1, ir = g + 1;
-    bool L = il >= a, R = ir < e;
-    while (L | R) {
-        const float2 ml = pts[max(il, a)], mr = pts[min(ir, e - 1)];
-        {
-            const float dk = (ay ? ml.y : ml.x) - kq;
-            const bool  in = L & !((dk < 0.f) & (__fmul_rn(dk, dk) > b.d)); // only past the query's key
-            const float d = dist2(ml, qx, qy);
-            tie |= in & (d == b.d);
-            const bool up = in & (d < b.d);
-            b.d = up ? d : b.d;
-            b.pos = up ? il : b.pos;
-            --il;
-            L = in & (il >= a);
-        }
-        {
-            const float dk = (ay ? mr.y : mr.x) - kq;
-            const bool  in = R & !((dk > 0.f) & (__fmul_rn(dk, dk) > b.d));
-            const float d = dist2(mr, qx, qy);
-            tie |= in & (d == b.d);
-            const bool up = in & (d < b.d);
-            b.d = up ? d : b.d;
-            b.pos = up ? ir : b.pos;
-            ++ir;
-            R = in & (ir < e);
-        }
-    }
-}
-
-// Exact 1-NN by sweeps: the query's cell, then those of its eight neighbours
-// that intersect the disk of the best distance.  Returns false when that is
-// not enough to decide (empty neighbourhood, best distance beyond the ring,
-// or an exact distance tie): the caller then runs nn_search(), which is exact
-// from any state.  Same stop rule as nn_search_impl at r = 1.
-template <typename StartT>
-__device__ inline bool sweep_search(Best &b, const IndexPtrs<StartT> &ix, const ModelView &mv, int cls,
-                                    float qx, float qy, double gate)
-{
-    const Lattice &L = mv.lat;
-    const StartT   *start = ix.start[cls];
-    const unsigned *axis_bits = ix.axis[cls];
-    const float2   *pts = ix.pts + mv.base[cls];
-    b.d = FLT_MAX;
-    b.oidx = 0xffffffffu;
-    b.pos = -1;
-    const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
-    const int   cx = clampi((int)floorf(fx), 0, L.nx - 1);
-    const int   cy = clampi((int)floorf(fy), 0, L.ny - 1);
-    bool tie = false;
-    sweep_cell<StartT>(b, tie, start, axis_bits, pts, cy * L.nx + cx, fx - (float)cx, fy - (float)cy, qx, qy);
-    // neighbours whose cell intersects the disk (the cell map is monotone, as in nn_search_impl);
-    // all eight when the query's own cell is empty
-    const float R = b.d < FLT_MAX ? (__fsqrt_rn(b.d) + L.margin) * L.inv_h : 2.0f;
-    const int   x_lo = max(max(cx - 1, 0), (int)floorf(fx - R)), x_hi = min(min(cx + 1, L.nx - 1), (int)floorf(fx + R));
-    const int   y_lo = max(max(cy - 1, 0), (int)floorf(fy - R)), y_hi = min(min(cy + 1, L.ny - 1), (int)floorf(fy + R));
-    // Which of those cells hold points: the start entries of the three rows are read together (one LDS
-    // round trip) and only non-empty cells are swept.  Clamped reads make out-of-lattice cells empty.
-    unsigned todo = 0; // bit 3*(dy+1)+(dx+1)
-    if ((x_lo < cx) | (x_hi > cx) | (y_lo < cy) | (y_hi > cy)) {
-        const int i0 = max(cx - 1, 0), i3 = min(cx + 2, L.nx);
-#pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int y = cy + dy;
-            if (y >= y_lo && y <= y_hi) {
-                const StartT *row = start + y * L.nx;
-                const int s0 = (int)row[i0], s1 = (int)row[cx], s2 = (int)row[cx + 1], s3 = (int)row[i3];
-                if (s1 > s0 && cx - 1 >= x_lo) todo |= 1u << (3 * (dy + 1));
-                if (dy != 0 && s2 > s1) todo |= 1u << (3 * (dy + 1) + 1);
-                if (s3 > s2 && cx + 1 <= x_hi) todo |= 1u << (3 * (dy + 1) + 2);
-            }
-        }
-    }
-    while (todo) {
-        const int k = __ffs((int)todo) - 1;
-        todo &= todo - 1;
-        const int x = cx + k % 3 - 1, y = cy + k / 3 - 1;
-        sweep_cell<StartT>(b, tie, start, axis_bits, pts, y * L.nx + x, fx - (float)x, fy - (float)y, qx, qy);
-    }
-    const bool  covers = (cx - 1 <= 0) & (cy - 1 <= 0) & (cx + 1 >= L.nx - 1) & (cy + 1 >= L.ny - 1);
-    const float bound = L.h - L.margin;
-    const float b2 = bound * bound;
-    if (tie || !(covers || b.d < b2 || (double)b2 >= gate)) return false;
-    if (b.pos >= 0) b.oidx = (unsigned)(ix.oidx + mv.base[cls])[b.pos];
-    return true;
-}
-
 // Wavefront sum of a double on the VALU's DPP cross-lane path (no LDS
 // crossbar): a 16-lane prefix by row_shr 1,2,4,8, then row_bcast 15 and 31 fold
 // the four rows; lane 63 holds the total, which is returned to all lanes.
@@ -647,109 +531,6 @@ __device__ inline void add_p2p_xy(const ModelView &mv, const float2 m, float qx,
     acc[8] += by * ay;
 }
 
-// Minimum of (d, pos) over the 16 lanes of a DPP row by rotations (no LDS); equal distances at different
-// positions raise `tie`.  All 16 lanes return the same result.
-__device__ inline void row16_min(float &d, int &pos, bool &tie)
-{
-#define SLAM_ROR_STEP(CTRL)                                                                              \
-    {                                                                                                    \
-        const float od = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(d), CTRL, 0xf, 0xf, false)); \
-        const int   op = __builtin_amdgcn_update_dpp(0, pos, CTRL, 0xf, 0xf, false);                     \
-        const int   ot = __builtin_amdgcn_update_dpp(0, (int)tie, CTRL, 0xf, 0xf, false);                \
-        tie |= (bool)ot | ((od == d) & (op != pos) & (pos >= 0) & (op >= 0));                            \
-        const bool take = (od < d) | ((od == d) & (op < pos));                                           \
-        d = take ? od : d;                                                                               \
-        pos = take ? op : pos;                                                                           \
-    }
-    SLAM_ROR_STEP(0x128) // row_ror:8
-    SLAM_ROR_STEP(0x124) // row_ror:4
-    SLAM_ROR_STEP(0x122) // row_ror:2
-    SLAM_ROR_STEP(0x121) // row_ror:1
-#undef SLAM_ROR_STEP
-}
-
-// Exact 1-NN by kCoop lanes scanning the 3x3 block of cells around the query (three row spans, start
-// entries read together, one DPP reduction): the cheap path for the scan's tail.  Same stop rule as
-// nn_search_impl at r = 1; returns false when that does not decide (then nn_search<kCoop> runs).
-template <typename StartT>
-__device__ inline bool block_search(Best &b, const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, float qx,
-                                    float qy, int sub, double gate)
-{
-    const Lattice &L = mv.lat;
-    const StartT *start = ix.start[cls];
-    const float2 *pts = ix.pts + mv.base[cls];
-    const float   fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
-    const int     cx = clampi((int)floorf(fx), 0, L.nx - 1);
-    const int     cy = clampi((int)floorf(fy), 0, L.ny - 1);
-    const int     xs = max(cx - 1, 0), xe = min(cx + 1, L.nx - 1);
-    int           a[3], e[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int  y = cy + k - 1;
-        const bool in = y >= 0 && y < L.ny;
-        const int  row = (in ? y : cy) * L.nx;
-        a[k] = (int)start[row + xs];
-        e[k] = in ? (int)start[row + xe + 1] : a[k];
-    }
-    float d = FLT_MAX;
-    int   pos = -1;
-    bool  tie = false;
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-        for (int i = a[k] + sub; i < e[k]; i += kCoop) {
-            const float di = dist2(pts[i], qx, qy);
-            tie |= (di == d);
-            const bool up = di < d;
-            d = up ? di : d;
-            pos = up ? i : pos;
-        }
-    {
-        Best gb;
-        gb.d = d;
-        gb.pos = pos;
-        gb.oidx = 0;
-        group_min_lean<kCoop>(gb, tie);
-        d = gb.d;
-        pos = gb.pos;
-    }
-    const bool  covers = (cx - 1 <= 0) & (cy - 1 <= 0) & (cx + 1 >= L.nx - 1) & (cy + 1 >= L.ny - 1);
-    const float bound = L.h - L.margin;
-    const float b2 = bound * bound;
-    if (tie || !(covers || d < b2 || (double)b2 >= gate)) return false;
-    b.d = d;
-    b.pos = pos;
-    b.oidx = pos >= 0 ? (unsigned)(ix.oidx + mv.base[cls])[pos] : 0xffffffffu;
-    return true;
-}
-
-// Sweep kernel, one pass over the kBlock points from p0, one lane per point.  A query the sweeps cannot
-// decide is not searched by its own lane (the whole wavefront, and at the barrier the whole workgroup,
-// would wait for a few lanes running the ring search): its offset goes to the wavefront's region of a
-// queue in LDS (fixed regions: the order does not depend on timing, so sums stay bitwise reproducible)
-// that all wavefronts drain together afterwards (drain_queue).
-template <typename StartT>
-__device__ inline void sweep_pass(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa, const Pose &T,
-                                  int n, int nga, int p0, const double2 P, double acc[kNumAcc], unsigned *wave_cnt,
-                                  unsigned short *queue, int &fell_back)
-{
-    const int  lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-    const int  p = p0 + (int)threadIdx.x;
-    const int  cls = p < nga ? 0 : 1;
-    const bool valid = p < n && mv.n_cls[cls] > 3; // icpPointToPoint.cpp:59,93
-    bool       done = true;
-    if (valid) {
-        float qx, qy;
-        Best  b;
-        transform_query(T, P, qx, qy);
-        done = sweep_search<StartT>(b, ix, mv, cls, qx, qy, fa.indist);
-        if (done && b.pos >= 0 && (double)b.d < fa.indist) add_p2p<StartT>(ix, mv, cls, b, qx, qy, acc); // :76
-        fell_back += done ? 0 : 1;
-    }
-    const unsigned long long need = __ballot(!done);
-    if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(need);
-    if (!done) queue[wave * 64 + __popcll(need & ((1ull << lane) - 1ull))] = (unsigned short)threadIdx.x;
-}
-
 // List-sweep mode: the query's own cell of the list lattice, one sweep over its halo list, certified when
 // the best distance is below the halo radius.  Returns false (undecided) otherwise.
 struct ListPtrs {
@@ -894,7 +675,11 @@ __device__ inline bool list_scan_coop(Best &b, float2 &m, const ListPtrs &lp, co
     return true;
 }
 
-// List-sweep kernel, one pass over kBlock points from p0; undecided queries are queued as in sweep_pass.
+// List-sweep kernel, one pass over kBlock points from p0, one lane per point.  A query the list cannot
+// decide is not searched by its own lane (the whole wavefront, and at the barrier the whole workgroup,
+// would wait for a few lanes): its offset goes to the wavefront's region of a queue in LDS (fixed regions:
+// the order does not depend on timing, so sums stay bitwise reproducible) that all wavefronts drain
+// together afterwards (drain_queue).
 __device__ inline void list_pass(const ListPtrs &lp, const ModelView &mv, const FitArgs &fa, const Pose &T, int n, int nga,
                                  int p0, const double2 P, double acc[kNumAcc], unsigned *wave_cnt, unsigned short *queue,
                                  int &fell_back)
@@ -964,7 +749,7 @@ __device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ListPtrs &
                 if (LISTS) {
                     have_m = list_scan_coop(b, m, lp, mv, cls, qx, qy, lane % kCoop);
                     if (!have_m) b = nn_search<kCoop, StartT>(ix, mv, cls, qx, qy, lane % kCoop, fa.indist);
-                } else if (!is_tail || !block_search<StartT>(b, ix, mv, cls, qx, qy, lane % kCoop, fa.indist)) {
+                } else {
                     b = nn_search<kCoop, StartT>(ix, mv, cls, qx, qy, lane % kCoop, fa.indist);
                 }
                 if (lane % kCoop == 0 && b.pos >= 0 && (double)b.d < fa.indist) { // :76
@@ -1136,10 +921,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                     int tail = 0;
                     if (rem > kCoopPerBlock) {
                         const double2 P = pass == 0 ? Pc0 : (p0 + tid < n ? fa.pts[off + p0 + tid] : Pc0);
-                        if (SWEEP == 2)
-                            list_pass(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back);
-                        else
-                            sweep_pass<StartT>(ix, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back);
+                        list_pass(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back);
                         tail = rem - kBlock;
                         tail = tail > 0 && tail <= kCoopPerBlock ? tail : 0;
                     } else { // a scan shorter than one cooperative round
@@ -1539,7 +1321,7 @@ struct slam_icp {
     bool            in_lds = false;
     bool            start32 = false;
     int             G = 8;
-    int             sweep = 0;     // 0 ring search, 1 ordered-cell sweeps (sweep_search), 2 halo-list sweeps (list_search)
+    int             sweep = 0;     // 0 ring search, 2 halo-list sweeps (list_search) for every iteration
     void           *d_lblob = nullptr;
     size_t          list_lds_bytes = 0;
     bool            have_lists = false;
@@ -1573,33 +1355,9 @@ void fill_index(std::vector<unsigned char> &blob, const ModelView &mv, const std
         for (int k = 0; k < ncells; ++k) count[k + 1] += count[k];
         for (int k = 0; k <= ncells; ++k) start[k] = (StartT)count[k];
         std::vector<int> fill(count.begin(), count.end() - 1);
-        std::vector<int> order(n);
-        for (int i = 0; i < n; ++i) order[fill[cell_of[c][i]]++] = i; // stable: equal cells keep original order
-        // inside a cell: by the coordinate of larger extent (sweep_search), non-finite points last
-        unsigned *axis = reinterpret_cast<unsigned *>(blob.data() + mv.off_axis[c]);
-        const float *xy = cls_xy[c].data();
-        for (int k = 0; k < ncells; ++k) {
-            const int a = count[k], e = count[k + 1];
-            if (e - a < 2) continue;
-            float lo[2] = {FLT_MAX, FLT_MAX}, hi[2] = {-FLT_MAX, -FLT_MAX};
-            for (int j = a; j < e; ++j)
-                for (int d = 0; d < 2; ++d) {
-                    const float v = xy[2 * order[j] + d];
-                    if (!std::isfinite(v)) continue;
-                    lo[d] = std::min(lo[d], v);
-                    hi[d] = std::max(hi[d], v);
-                }
-            const int ax = (hi[1] - lo[1]) > (hi[0] - lo[0]) ? 1 : 0;
-            if (ax) axis[k >> 5] |= 1u << (k & 31);
-            auto key = [&](int i) {
-                const float x = xy[2 * i], y = xy[2 * i + 1];
-                return std::isfinite(x) && std::isfinite(y) ? (ax ? y : x) : INFINITY;
-            };
-            std::stable_sort(order.begin() + a, order.begin() + e, [&](int p, int q) { return key(p) < key(q); });
-        }
-        for (int pos = 0; pos < n; ++pos) {
-            const int i = order[pos];
-            pts[mv.base[c] + pos] = make_float2(xy[2 * i], xy[2 * i + 1]);
+        for (int i = 0; i < n; ++i) { // stable: equal cells keep original order
+            const int pos = fill[cell_of[c][i]]++;
+            pts[mv.base[c] + pos] = make_float2(cls_xy[c][2 * i], cls_xy[c][2 * i + 1]);
             oidx[mv.base[c] + pos] = (StartT)i;
         }
     }
@@ -1649,8 +1407,8 @@ int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, 
     const unsigned scratch = kScratchBytes;
 
     // LDS budget for the two start arrays (u16 entries) after points + original indices
-    const long fixed16 = (long)scratch + align16(8u * n_all) + align16(2u * n_all) + 128;
-    long       cells_lds = ((long)lds_total - fixed16) * 8 / (2 * 2 * 8 + 2) - 1; // + one axis bit per cell and class
+    const long fixed16 = (long)scratch + align16(8u * n_all) + align16(2u * n_all) + 64;
+    long       cells_lds = ((long)lds_total - fixed16) / (2 * 2) - 1;
     bool       lds = !h->prm.force_global && max_cls <= 65535 && cells_lds >= 256;
 
     const float w = std::max(hi[0] - lo[0], 1e-3f), ht = std::max(hi[1] - lo[1], 1e-3f);
@@ -1701,10 +1459,6 @@ int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, 
     o = align16(o + esz * (unsigned)(ncells + 1));
     mv.off_oidx = o;
     o = align16(o + esz * (unsigned)n_all);
-    mv.off_axis[0] = o;
-    o = align16(o + 4u * (unsigned)(ncells / 32 + 1));
-    mv.off_axis[1] = o;
-    o = align16(o + 4u * (unsigned)(ncells / 32 + 1));
     mv.blob_bytes = o;
     if (lds && scratch + o > lds_total) lds = false, h->start32 = false; // keeps u16 entries, read from HBM
     h->in_lds = lds;
@@ -1908,9 +1662,8 @@ int launch_fit_sweep(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st
         SLAM_HIP(hipGetLastError());
         return SLAM_OK;
     }
-    if (h->in_lds) return launch_fit_t<1, true, uint16_t, MODE, 1>(h, fa, n_scans, st);
-    if (h->start32) return launch_fit_t<1, false, uint32_t, MODE, 1>(h, fa, n_scans, st);
-    return launch_fit_t<1, false, uint16_t, MODE, 1>(h, fa, n_scans, st);
+    set_error("the list-sweep kernel needs halo lists, and they did not fit LDS for this model");
+    return SLAM_E_UNSUPPORTED;
 }
 
 template <int G, int MODE>
@@ -2009,7 +1762,7 @@ int slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga
         slam_icp_default_params(&h->prm);
     // 0 = library default (sweep search, one lane per point; point-to-line: ring search with 2 lanes);
     // N > 0 = ring search with N lanes per point; -1 = ring search, lanes chosen per pass
-    h->sweep = h->prm.lanes_per_point == -2 ? 1 : (h->prm.lanes_per_point == -3 ? 2 : 0);
+    h->sweep = h->prm.lanes_per_point == -2 ? 2 : 0;
     h->G = h->prm.lanes_per_point > 0 ? h->prm.lanes_per_point : (h->prm.lanes_per_point == -1 ? 0 : 2);
     h->two_phase = h->prm.lanes_per_point == 0 && h->prm.mode == SLAM_ICP_P2P;
     if (const char *e = getenv("SLAM_ICP_SWITCH_ITER")) h->switch_iter = atoi(e);

@@ -92,7 +92,7 @@ def test_config1_matches_golden_chain_and_oracle(world, golden_dir):
     icp.close()
 
 
-@pytest.mark.parametrize("lanes", [0, 1, 8, 64, -1, -2, -3])
+@pytest.mark.parametrize("lanes", [0, 1, 2, 8, 64, -1, -2])
 def test_batch_matches_oracle(world, lanes):
     """32 scans of the config-2 loop, 30 iterations, fixed count (min_delta -1)."""
     m_ga, m_nga, model = world
@@ -292,7 +292,7 @@ def test_edge_weight_matches_oracle(world):
     icp.close()
 
 
-@pytest.mark.parametrize("lanes", [0, -2, -3])
+@pytest.mark.parametrize("lanes", [0, 2, -2])
 def test_ragged_scan_sizes(world, lanes):
     """Scans from 5 to ~2600 points in one batch: the pass structure (full passes, short tails, the
     cooperative queue of the sweep mode, scans smaller than one cooperative round) against the oracle."""

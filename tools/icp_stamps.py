@@ -8,7 +8,7 @@ import numpy as np
 from slam_amd import api, synth
 m_ga, m_nga = synth.make_map(); batch = synth.make_batch(256)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-for lanes in (0, -3, 2):
+for lanes in (0, -2, 2):
     icp = api.Icp(m_ga, m_nga, max_iter=iters, min_delta=-1.0, lanes_per_point=lanes)
     icp.fit_batch(batch)
     out = (C.c_double * 9)()
