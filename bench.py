@@ -236,6 +236,26 @@ def main():
     seg = np.array([[e[i].elapsed_ms(e[i + 1]) for i in range(4)] for e in ev]) if args.steps else np.zeros((1, 4))
     ms_icp, ms_ray, ms_merge, ms_fin = seg.mean(axis=0)
 
+    # the default ICP schedule is two launches of icp_fit_kernel per batch (ring search for the first
+    # iterations, list sweeps for the rest): time them apart in a few extra, untimed steps
+    ms_ring = ms_list = None
+    if args.lanes == 0 and args.steps:
+        import ctypes as C
+        L = api.lib()
+        L.slam_icp_debug_phase_events.argtypes = [C.c_void_p, C.c_int]
+        L.slam_icp_debug_phase_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        api.check(L.slam_icp_debug_phase_events(icp.h, 1))
+        for _ in range(10):
+            step()
+        sync()
+        pm, calls = (C.c_double * 2)(), C.c_int(0)
+        api.check(L.slam_icp_debug_phase_ms(icp.h, pm, C.byref(calls)))
+        api.check(L.slam_icp_debug_phase_events(icp.h, 0))
+        if calls.value:
+            # scaled so that the two add up to the ICP time of the timed steps (events add a little)
+            f = float(ms_icp) / (pm[0] + pm[1]) if pm[0] + pm[1] > 0 else 1.0
+            ms_ring, ms_list = pm[0] * f, pm[1] * f
+
     # sanity on the result of the last step (not timed): all scans registered
     res = d_res.download()
     t_fin = d_t.download()
@@ -250,11 +270,17 @@ def main():
         icp_bytes = 16 * P + S * (8 * M + 96)
         ray_bytes = 8 * upd_per_step + 16 * P           # 8 B RMW per cell update + 16 B per beam
         fin_bytes = GRID * GRID * 17                     # 2x4 B counts in, 8 B evidence + 1 B occupancy out
-        kernels = {
-            "icp_fit_kernel": {"ms": float(ms_icp), "alg_bytes": icp_bytes},
+        kernels = {}
+        if ms_ring is not None:
+            # each launch reads the scans, its index (cell index 8 B/point + starts, or the halo lists) and the poses
+            kernels["icp_fit_kernel_ring (ring search, first iterations)"] = {"ms": float(ms_ring), "alg_bytes": icp_bytes}
+            kernels["icp_fit_kernel_list (list sweeps, remaining iterations)"] = {"ms": float(ms_list), "alg_bytes": 16 * P + S * (int(info.get("list_bytes", 8 * M)) + 96)}
+        else:
+            kernels["icp_fit_kernel"] = {"ms": float(ms_icp), "alg_bytes": icp_bytes}
+        kernels.update({
             "raycast_tiled_kernel (+ beams, work list)": {"ms": float(ms_ray), "alg_bytes": ray_bytes},
             "finalize_kernel": {"ms": float(ms_fin), "alg_bytes": fin_bytes},
-        }
+        })
         for k in kernels.values():
             k["GBps"] = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
         dom = max(kernels, key=lambda n: kernels[n]["ms"])

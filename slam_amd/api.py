@@ -70,7 +70,7 @@ EXPORTS = [
     "slam_icp_set_max_iterations", "slam_icp_set_min_delta", "slam_icp_set_subsampling_step",
     "slam_icp_fit", "slam_icp_fit_batch_dev", "slam_icp_nearest_dev", "slam_icp_get_edge_weight",
     "slam_icp_get_normals",
-    "slam_icp_index_info",
+    "slam_icp_index_info", "slam_icp_list_info",
     "slam_grid_default_params", "slam_grid_create", "slam_grid_destroy", "slam_grid_clear", "slam_grid_reset_counts",
     "slam_grid_set_min_cluster_points", "slam_grid_set_max_range", "slam_grid_set_pose",
     "slam_grid_get_pose", "slam_grid_add_endpoints", "slam_grid_add_endpoints_dev",
@@ -145,6 +145,7 @@ def lib():
     L.slam_icp_nearest_dev.argtypes = [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp]
     L.slam_icp_get_edge_weight.argtypes = [_vp, _vp]
     L.slam_icp_get_normals.argtypes = [_vp, _vp]
+    L.slam_icp_list_info.argtypes = [_vp] + [C.c_void_p] * 6
     L.slam_icp_index_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                       C.POINTER(C.c_double), C.POINTER(C.c_int),
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
@@ -374,8 +375,14 @@ class Icp:
         cell, lds = C.c_double(), C.c_size_t()
         check(lib().slam_icp_index_info(self.h, C.byref(nx), C.byref(ny), C.byref(cell),
                                         C.byref(in_lds), C.byref(lds), C.byref(lanes)))
+        two, first = C.c_int(), C.c_int()
+        pitch, halo, cert, lb = C.c_double(), C.c_double(), C.c_double(), C.c_size_t()
+        check(lib().slam_icp_list_info(self.h, C.byref(two), C.byref(first), C.byref(pitch), C.byref(halo),
+                                       C.byref(cert), C.byref(lb)))
         return dict(nx=nx.value, ny=ny.value, cell=cell.value, in_lds=bool(in_lds.value),
-                    lds_bytes=lds.value, lanes_per_point=lanes.value)
+                    lds_bytes=lds.value, lanes_per_point=lanes.value, two_launches=bool(two.value),
+                    first_iterations=first.value, list_pitch=pitch.value, list_halo=halo.value,
+                    list_certified_radius=cert.value, list_bytes=lb.value)
 
     def fit(self, t_ga, t_nga, R, t, indist=5.0):
         """Icp::fit (icp.cpp:80-114), host arrays; returns (R, t, IcpResult)."""

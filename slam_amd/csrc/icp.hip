@@ -1330,6 +1330,11 @@ struct slam_icp {
     double         *d_normals = nullptr;
     DevBuf          w_pts, w_off, w_nga, w_R, w_t, w_res, w_stamps, w_pose, w_ew, w_state;
     bool            two_phase = false;   // ring search, then list sweeps (the point-to-point default)
+    bool            phase_events = false; // diagnostic: time the two launches separately (slam_icp_debug_phase_ms)
+    hipEvent_t      ev[3] = {nullptr, nullptr, nullptr};
+    double          phase_ms[2] = {0, 0};
+    int             phase_calls = 0;
+    bool            ev_pending = false;
     int             switch_iter = 10;    // iterations of the first launch (measured optimum on config 2: tools/switch_sweep.sh)
     int             n_stamps = 0;
     bool            want_step_pose = false; // set around slam_icp_fit()
@@ -1716,11 +1721,31 @@ int launch_fit(slam_icp *h, const FitArgs &fa_in, int n_scans, hipStream_t st)
         fa.switch_iter = h->switch_iter;
         fa.phase = 1;
         const int keep = h->sweep;
+        if (h->phase_events) {
+            if (h->ev_pending) { // fold the previous call's times in before its events are reused
+                float a = 0, b = 0;
+                SLAM_HIP(hipEventSynchronize(h->ev[2]));
+                SLAM_HIP(hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+                SLAM_HIP(hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+                h->phase_ms[0] += a;
+                h->phase_ms[1] += b;
+                ++h->phase_calls;
+                h->ev_pending = false;
+            }
+            for (auto &e : h->ev)
+                if (!e) SLAM_HIP(hipEventCreate(&e));
+            SLAM_HIP(hipEventRecord(h->ev[0], st));
+        }
         h->sweep = 0;
         int rc = launch_fit_m<SLAM_ICP_P2P>(h, fa, n_scans, st);
+        if (h->phase_events) SLAM_HIP(hipEventRecord(h->ev[1], st));
         h->sweep = 2;
         fa.phase = 2;
         if (rc == SLAM_OK) rc = launch_fit_m<SLAM_ICP_P2P>(h, fa, n_scans, st);
+        if (h->phase_events) {
+            SLAM_HIP(hipEventRecord(h->ev[2], st));
+            h->ev_pending = true;
+        }
         h->sweep = keep;
         return rc;
     }
@@ -1785,6 +1810,8 @@ void slam_icp_destroy(slam_icp_t *icp)
     if (!icp) return;
     if (icp->d_blob) (void)hipFree(icp->d_blob);
     if (icp->d_lblob) (void)hipFree(icp->d_lblob);
+    for (auto &e : icp->ev)
+        if (e) (void)hipEventDestroy(e);
     if (icp->d_normals) (void)hipFree(icp->d_normals);
     delete icp;
 }
@@ -1947,6 +1974,39 @@ int slam_icp_get_edge_weight(slam_icp_t *icp, double eW[9])
 
 // diagnostic (not in the public header): per wavefront, mean cycles in the four phases, sweep
 // fall-backs, and the search cycles of iterations 0-3 of the last batch launched with SLAM_ICP_STAMPS=1 in the environment
+// diagnostic (not in the public header): with `on`, the two launches of the default schedule are timed
+// separately (three events per call); out = mean ms of the ring-search launch and of the list-sweep launch
+// over the calls since the last query
+int slam_icp_debug_phase_events(slam_icp_t *icp, int on)
+{
+    SLAM_REQUIRE(icp, SLAM_E_INVALID, "null handle");
+    icp->phase_events = on != 0;
+    icp->phase_ms[0] = icp->phase_ms[1] = 0;
+    icp->phase_calls = 0;
+    icp->ev_pending = false;
+    return SLAM_OK;
+}
+
+int slam_icp_debug_phase_ms(slam_icp_t *icp, double out[2], int *calls)
+{
+    SLAM_REQUIRE(icp && out, SLAM_E_INVALID, "null argument");
+    if (icp->ev_pending) {
+        float a = 0, b = 0;
+        SLAM_HIP(hipEventSynchronize(icp->ev[2]));
+        SLAM_HIP(hipEventElapsedTime(&a, icp->ev[0], icp->ev[1]));
+        SLAM_HIP(hipEventElapsedTime(&b, icp->ev[1], icp->ev[2]));
+        icp->phase_ms[0] += a;
+        icp->phase_ms[1] += b;
+        ++icp->phase_calls;
+        icp->ev_pending = false;
+    }
+    const int n = icp->phase_calls > 0 ? icp->phase_calls : 1;
+    out[0] = icp->phase_ms[0] / n;
+    out[1] = icp->phase_ms[1] / n;
+    if (calls) *calls = icp->phase_calls;
+    return SLAM_OK;
+}
+
 int slam_icp_debug_stamps(slam_icp_t *icp, double out[9])
 {
     SLAM_REQUIRE(icp && out && icp->n_stamps > 0, SLAM_E_INVALID, "no stamps collected");
@@ -1970,6 +2030,20 @@ int slam_icp_index_info(slam_icp_t *icp, int *nx, int *ny, double *cell, int *in
     if (in_lds) *in_lds = icp->in_lds ? 1 : 0;
     if (lds_bytes) *lds_bytes = icp->lds_bytes;
     if (lanes_per_point) *lanes_per_point = icp->G;
+    return SLAM_OK;
+}
+
+int slam_icp_list_info(slam_icp_t *icp, int *two_launches, int *first_iterations, double *pitch, double *halo,
+                       double *certified_radius, size_t *list_bytes)
+{
+    SLAM_REQUIRE(icp, SLAM_E_INVALID, "null handle");
+    const bool have = icp->have_lists;
+    if (two_launches) *two_launches = (icp->two_phase && have) ? 1 : 0;
+    if (first_iterations) *first_iterations = icp->switch_iter;
+    if (pitch) *pitch = have ? icp->mv.llat.h : 0.0;
+    if (halo) *halo = have ? (double)icp->mv.lpad * icp->mv.llat.h : 0.0;
+    if (certified_radius) *certified_radius = have ? std::sqrt((double)icp->mv.cert2) : 0.0;
+    if (list_bytes) *list_bytes = have ? icp->mv.lblob_bytes : 0;
     return SLAM_OK;
 }
 

@@ -26,7 +26,14 @@ os.makedirs(dst, exist_ok=True)
 
 def kname(k):
     m = re.search(r"(\w+_kernel)", k)
-    return m.group(1) if m else k.split("(")[0][:48]
+    if not m:
+        return k.split("(")[0][:48]
+    name = m.group(1)
+    if name == "icp_fit_kernel":  # two launches per batch: last template argument 0 = ring search, 2 = list sweeps
+        t = re.search(r"icp_fit_kernel<([^>]*)>", k)
+        if t:
+            name += "_list" if t.group(1).split(",")[-1].strip() == "2" else "_ring"
+    return name
 
 
 stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
