@@ -719,10 +719,7 @@ __device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ListPtrs &
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
-    int incl_w[kWaves]; // the same in every lane: scalar registers
-#pragma unroll
-    for (int j = 0; j < kWaves; ++j) incl_w[j] = __builtin_amdgcn_readlane(incl, j);
-    const int queued = incl_w[kWaves - 1];
+    const int queued = __builtin_amdgcn_readlane(incl, kWaves - 1);
     const int total = tail + queued;
     for (int base = 0; base < total; base += kCoopPerBlock) {
         const int g = lane / kCoop;
@@ -732,9 +729,10 @@ __device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ListPtrs &
         int w = 0, excl = 0;
 #pragma unroll
         for (int j = 0; j < kWaves; ++j) {
-            const bool below = incl_w[j] <= e - tail;
+            const int  incl_j = __builtin_amdgcn_readlane(incl, j); // the same in every lane: a scalar
+            const bool below = incl_j <= e - tail;
             w += below ? 1 : 0;
-            excl = below ? incl_w[j] : excl;
+            excl = below ? incl_j : excl;
         }
         if (e < total) {
             const bool is_tail = e < tail;
@@ -888,7 +886,8 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
         const int p = k * kPerPass + tid / (G > 0 ? G : 1);
         return (G > 0 && p < n) ? fa.pts[off + p] : make_double2(0.0, 0.0);
     };
-    const double2 Pc0 = hoisted(0), Pc1 = hoisted(1), Pc2 = hoisted(2); // named, not an array: stays in registers
+    // named, not an array: stays in registers (the list-sweep kernel has one full pass per 1024 points: one is enough)
+    const double2 Pc0 = hoisted(0), Pc1 = SWEEP ? Pc0 : hoisted(1), Pc2 = SWEEP ? Pc0 : hoisted(2);
 
     bool hand_over = false;
     iters = iter_begin;
