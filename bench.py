@@ -193,15 +193,34 @@ def main():
         grid.raycast_scans_dev(d_pts, d_off, S, P, d_R, d_t)
         if e: e[2].record()
         if multi:
-            dist.all_reduce(planes)   # RCCL sum of the int32 planes over xGMI
+            for part in merge_parts:  # RCCL sum of the int32 planes over xGMI (the touched rows of both planes)
+                dist.all_reduce(part)
         if e: e[3].record()
         grid.finalize()
         if e: e[4].record()
 
+    merge_parts = [planes] if multi else []
     grid.clear()
     for _ in range(args.warmup):
         step()
     sync()
+    merge_rows = None
+    if multi and args.warmup:
+        # The planes are row-major: the rows any rank touched are one contiguous slice of each plane.  The
+        # warm-up steps (full-plane merges) show which rows that is; the timed steps merge those rows only
+        # (room of 30 m in a 100 m grid: about a third of the bytes).  Checked after the timed loop: nothing
+        # outside the slice, and the merged total equals the ranks' updates.
+        both = planes.view(2, GRID, GRID)
+        rows = (both != 0).any(dim=2).any(dim=0).nonzero()
+        y0 = int(rows.min().item()) if rows.numel() else 0
+        y1 = int(rows.max().item()) + 1 if rows.numel() else 0
+        yr = torch.tensor([-y0, y1], dtype=torch.int64, device="cuda")
+        dist.all_reduce(yr, op=dist.ReduceOp.MAX)
+        y0, y1 = max(0, -int(yr[0].item()) - 16), min(GRID, int(yr[1].item()) + 16)
+        merge_rows = (y0, y1)
+        merge_parts = [both[0, y0:y1].reshape(-1), both[1, y0:y1].reshape(-1)]
+        assert all(p_.is_contiguous() and p_.data_ptr() == planes.data_ptr() + 4 * (k_ * GRID * GRID + y0 * GRID)
+                   for k_, p_ in enumerate(merge_parts))
     upd_per_step = None
     if args.warmup:
         upd_per_step = grid.total_updates() // args.warmup
@@ -229,6 +248,9 @@ def main():
         # the merged planes of the last step hold every rank's updates of that step, once
         merged = int(planes.to(torch.int64).sum().item())
         assert merged == total_upd, "merged planes hold %d updates, the ranks made %d" % (merged, total_upd)
+        if merge_rows is not None:
+            inside = int(sum(p_.to(torch.int64).sum().item() for p_ in merge_parts))
+            assert inside == merged, "updates outside the merged rows %s" % (merge_rows,)
     else:
         total_pts, total_upd = P, upd_per_step
 
@@ -298,10 +320,11 @@ def main():
             "config": {"workload": "BASELINE config 2 per GPU: %d x 1081-beam scans (%d points), %d ICP "
                                    "iterations vs %d-point map, Bresenham raycast into %dx%d @%.2f m, "
                                    "finalize%s" % (S, P, N_ITERS, M, GRID, GRID, RES,
-                                                   ", RCCL all-reduce of int32 planes" if multi else ""),
+                                                   ", RCCL all-reduce of the touched rows of the int32 planes" if multi else ""),
                        "scans_per_gpu": S, "icp_iters": N_ITERS, "grid": [GRID, GRID], "resolution": RES,
                        "map_points": M, "icp_index": info, "raycast": args.raycast,
-                       "raycast_worklist": grid.raycast_stats()},
+                       "raycast_worklist": grid.raycast_stats(),
+                       "merge_rows": list(merge_rows) if multi and merge_rows else None},
             "grid_cell_updates_per_s": total_upd * args.steps / elapsed,
             "cell_updates_per_step": total_upd,
             "point_iterations_per_s": total_pts * N_ITERS * args.steps / elapsed,
