@@ -319,3 +319,44 @@ def test_ragged_scan_sizes(world, lanes):
     R2, t2, _, _ = icp.fit_batch(batch, indist=5.0)
     assert np.array_equal(R, R2) and np.array_equal(t, t2)     # bitwise reproducible
     icp.close()
+
+
+@pytest.mark.parametrize("frac", [0.01, 0.1, 0.5])
+def test_outlier_scans_two_launch_schedule(world, frac):
+    """Scans with points far from the map (some inside the 5.0 gate, some beyond it): few of them and the scan is
+    handed to the list-sweep launch with a busy cooperative queue, many and it stays in the ring search (the
+    hand-over guard); either way the result is the oracle's."""
+    m_ga, m_nga, model = world
+    batch = synth.make_batch(6, n_loop=256)
+    rs = np.random.RandomState(int(frac * 1000))
+    pts = batch.pts.copy()
+    for s in range(batch.n_scans):
+        o, e = batch.scan_off[s], batch.scan_off[s + 1]
+        k = rs.choice(np.arange(o, e), int(frac * (e - o)), replace=False)
+        pts[k] += rs.uniform(-4.0, 4.0, (len(k), 2))           # up to 4 m off: neighbours at 0.2 .. 4 m
+    noisy = synth.ScanBatch(pts, batch.scan_off, batch.scan_nga, batch.R, batch.t, batch.true_poses)
+    Ro, to, iters, ncorr, delta = model.fit_batch(noisy.pts, noisy.scan_off, noisy.scan_nga, noisy.R, noisy.t,
+                                                  O.icp_params(25, 1e-7, 5.0))
+    for lanes in (0, 2, -2):
+        icp = api.Icp(m_ga, m_nga, max_iter=25, min_delta=1e-7, lanes_per_point=lanes)
+        R, t, res, _ = icp.fit_batch(noisy, indist=5.0)
+        assert np.array_equal(res["iters"], iters) and np.array_equal(res["n_corr"], ncorr), lanes
+        assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL, lanes
+        icp.close()
+
+
+def test_two_launch_schedule_edge_iteration_counts(world):
+    """max_iter below, at and just above the hand-over iteration; min_delta reached in either launch."""
+    m_ga, m_nga, model = world
+    batch = synth.make_batch(5, n_loop=256)
+    for max_iter, min_delta in ((1, -1.0), (9, -1.0), (10, -1.0), (11, -1.0), (40, 1e-2), (40, 1e-4), (40, 1e-9)):
+        Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R, batch.t,
+                                                      O.icp_params(max_iter, min_delta, 5.0))
+        icp = api.Icp(m_ga, m_nga, max_iter=max_iter, min_delta=min_delta)
+        assert icp.index_info()["two_launches"] and icp.index_info()["first_iterations"] == 10
+        R, t, res, _ = icp.fit_batch(batch, indist=5.0)
+        assert np.array_equal(res["iters"], iters), (max_iter, min_delta)
+        assert np.array_equal(res["n_corr"], ncorr)
+        assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL
+        assert np.abs(res["delta"] - delta).max() < 1e-9
+        icp.close()
