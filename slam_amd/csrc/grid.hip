@@ -260,27 +260,32 @@ __global__ __launch_bounds__(256) void raycast_global_kernel(GridView g, const B
 
 // Work list for the tiled raycast, built without atomics (so its order is
 // deterministic): for every tile the 64-beam blocks whose bounding box overlaps it.
-//   tile_count : one wavefront per tile, ballot + popcount over the block boxes
-//   tile_scan  : exclusive prefix sums -> item_off[] (items) and seg_off[]
-//                (segments of <= kSeg items of ONE tile: the unit a workgroup takes)
-//   tile_fill  : same loop as tile_count, writes the block ids in beam order
+//   tile_items : one wavefront per tile, ballot + popcount over the block boxes; the ids go to the tile's own
+//                row of `items` (n_blocks ids wide, so no prefix sum is needed first), the count to cnt[]
+//   the raycast workgroups turn cnt[] into segment offsets themselves (a prefix over a few hundred tiles
+//   in LDS): a segment = <= kSeg items of ONE tile, the unit a workgroup takes.
+//   Grids of more than kMaxLdsTiles tiles keep the three-kernel form (count, scan, fill).
 
 __device__ inline bool box_overlaps_tile(const int4 cb, int tx0, int ty0, int tx1, int ty1)
 {
     return cb.z >= tx0 && cb.x <= tx1 && cb.w >= ty0 && cb.y <= ty1; // empty boxes have z = w = -1
 }
 
-template <bool FILL>
+constexpr int kMaxLdsTiles = 2048; // segment offsets of that many tiles fit beside the LDS tile (8 KB)
+
+// FILL: 0 = count only, 1 = write the ids at item_off[t], 2 = single pass: ids at t * n_blocks, count to cnt[t]
+template <int FILL>
 __global__ __launch_bounds__(256) void tile_items_kernel(const int4 *block_box, int n_blocks, int tiles_x,
                                                          int n_tiles, int sx, int sy, int *cnt,
-                                                         const int *item_off, int *items)
+                                                         const int *item_off, int *items, int *queue)
 {
     const int t = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (FILL == 2 && blockIdx.x == 0 && threadIdx.x == 0) queue[0] = 0; // next segment to take
     if (t >= n_tiles) return;
     const int tx0 = (t % tiles_x) * kTile, ty0 = (t / tiles_x) * kTile;
     const int tx1 = min(tx0 + kTile, sx) - 1, ty1 = min(ty0 + kTile, sy) - 1;
     int       c = 0;
-    const int base_out = FILL ? item_off[t] : 0;
+    const int base_out = FILL == 1 ? item_off[t] : (FILL == 2 ? t * n_blocks : 0);
     for (int base = 0; base < n_blocks; base += 256) { // four independent box loads in flight per lane
         int4 cb[4];
 #pragma unroll
@@ -296,7 +301,7 @@ __global__ __launch_bounds__(256) void tile_items_kernel(const int4 *block_box, 
             c += __popcll(m);
         }
     }
-    if (!FILL && lane == 0) cnt[t] = c;
+    if (FILL != 1 && lane == 0) cnt[t] = c;
 }
 
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const int *cnt, int n_tiles, int *item_off, int *seg_off,
@@ -381,13 +386,40 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
                                                                         const int *items, const int *item_off,
                                                                         const int *seg_off, int n_tiles,
                                                                         int *queue, int tiles_x, int kSeg,
-                                                                        int ablate)
+                                                                        int ablate, const int *cnt, int item_stride)
 {
     __shared__ __attribute__((aligned(16))) unsigned tile[kTile * kTileStride];
     __shared__ int s_seg, s_pair;
+    __shared__ int s_segoff[kMaxLdsTiles + 1], s_wsum[kTileThreads / 64], s_carry;
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int n_segs = queue[1];
+    // single-pass work list (cnt != null): every workgroup turns the tile counts into segment offsets itself
+    const bool own_prefix = cnt != nullptr;
+    if (own_prefix) {
+        if (tid == 0) s_carry = 0;
+        __syncthreads();
+        for (int base = 0; base < n_tiles; base += kTileThreads) {
+            const int i = base + tid;
+            const int v = i < n_tiles ? (cnt[i] + kSeg - 1) / kSeg : 0;
+            int       x = v;
+            for (int off = 1; off < 64; off <<= 1) {
+                const int y = __shfl_up(x, off);
+                if (lane >= off) x += y;
+            }
+            if (lane == 63) s_wsum[tid >> 6] = x;
+            __syncthreads();
+            int w = 0;
+            for (int k = 0; k < (tid >> 6); ++k) w += s_wsum[k];
+            const int incl = s_carry + w + x;
+            if (i < n_tiles) s_segoff[i] = incl - v;
+            __syncthreads();
+            if (tid == kTileThreads - 1) s_carry = incl;
+            __syncthreads();
+        }
+        if (tid == 0) s_segoff[n_tiles] = s_carry;
+        __syncthreads();
+    }
+    const int n_segs = own_prefix ? s_segoff[n_tiles] : queue[1];
     unsigned  did = 0;
 
     for (;;) {
@@ -405,14 +437,16 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
         int lo = 0, hi = n_tiles - 1; // tile of the segment: last t with seg_off[t] <= seg
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (seg_off[mid] <= seg)
+            if ((own_prefix ? s_segoff[mid] : seg_off[mid]) <= seg)
                 lo = mid;
             else
                 hi = mid - 1;
         }
         const int t = lo;
-        const int it0 = item_off[t] + (seg - seg_off[t]) * kSeg;
-        const int n_pairs = (ablate & 8) ? 0 : min(it0 + kSeg, item_off[t + 1]) - it0; // 64-beam blocks in this segment
+        const int tile_base = own_prefix ? t * item_stride : item_off[t];
+        const int tile_end = own_prefix ? tile_base + cnt[t] : item_off[t + 1];
+        const int it0 = tile_base + (seg - (own_prefix ? s_segoff[t] : seg_off[t])) * kSeg;
+        const int n_pairs = (ablate & 8) ? 0 : min(it0 + kSeg, tile_end) - it0; // 64-beam blocks in this segment
         const int tx0 = (t % tiles_x) * kTile, ty0 = (t / tiles_x) * kTile;
         const int tx1 = min(tx0 + kTile, g.sx) - 1, ty1 = min(ty0 + kTile, g.sy) - 1;
 
@@ -643,6 +677,7 @@ struct slam_grid {
     size_t           cap_items = 0;
     int              n_cu = 256;
     int              seg_items = 32; // 64-beam blocks of one tile a workgroup accumulates before writing back
+    int              last_chunks = 0;
     int              ablate = 0;     // debug: SLAM_RAYCAST_ABLATE bit mask (timing experiments only)
     int              wg_per_cu = 2;
     void            *d_stage = nullptr;   // host-API staging
@@ -701,15 +736,26 @@ int walk_beams(slam_grid *g, int n, hipStream_t st)
         const int n_tiles = tiles_x * tiles_y;
         int      *item_off = g->d_tile_fill, *seg_off = g->d_tile_fill + (n_tiles + 1);
         const dim3 tgrid((n_tiles * 64 + 255) / 256);
-        hipLaunchKernelGGL((tile_items_kernel<false>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
-                           n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, g->d_tile_cnt, n_tiles, item_off, seg_off,
-                           g->d_queue, g->seg_items);
-        hipLaunchKernelGGL((tile_items_kernel<true>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
-                           n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items);
-        // persistent workgroups, two per CU (66 KB of LDS each); each drains the queue and exits
-        hipLaunchKernelGGL(raycast_tiled_kernel, dim3(g->wg_per_cu * g->n_cu), dim3(kTileThreads), 0, st, g->gv, g->d_beams, n,
-                           g->d_items, item_off, seg_off, n_tiles, g->d_queue, tiles_x, g->seg_items, g->ablate);
+        g->last_chunks = n_chunks;
+        if (n_tiles <= kMaxLdsTiles) {
+            // one pass over the block boxes; the raycast workgroups derive the segment offsets themselves
+            hipLaunchKernelGGL((tile_items_kernel<2>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
+                               n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items, g->d_queue);
+            hipLaunchKernelGGL(raycast_tiled_kernel, dim3(g->wg_per_cu * g->n_cu), dim3(kTileThreads), 0, st, g->gv, g->d_beams,
+                               n, g->d_items, item_off, seg_off, n_tiles, g->d_queue, tiles_x, g->seg_items, g->ablate,
+                               g->d_tile_cnt, n_chunks);
+        } else {
+            hipLaunchKernelGGL((tile_items_kernel<0>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
+                               n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items, g->d_queue);
+            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, g->d_tile_cnt, n_tiles, item_off, seg_off,
+                               g->d_queue, g->seg_items);
+            hipLaunchKernelGGL((tile_items_kernel<1>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
+                               n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items, g->d_queue);
+            // persistent workgroups, two per CU (66 KB of LDS each); each drains the queue and exits
+            hipLaunchKernelGGL(raycast_tiled_kernel, dim3(g->wg_per_cu * g->n_cu), dim3(kTileThreads), 0, st, g->gv, g->d_beams,
+                               n, g->d_items, item_off, seg_off, n_tiles, g->d_queue, tiles_x, g->seg_items, g->ablate,
+                               (const int *)nullptr, 0);
+        }
     } else {
         hipLaunchKernelGGL(raycast_global_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g->gv, g->d_beams, n);
     }
@@ -1084,6 +1130,18 @@ int slam_grid_raycast_stats(slam_grid_t *g, int *n_tiles, int *n_items, int *n_s
     if (n_segments) *n_segments = 0;
     if (!g->d_tile_fill) return SLAM_OK; // no tiled raycast has run yet
     SLAM_HIP(hipDeviceSynchronize());
+    if (tiles <= kMaxLdsTiles) { // single-pass work list: the counts are all there is
+        std::vector<int> cnt((size_t)tiles);
+        SLAM_HIP(hipMemcpy(cnt.data(), g->d_tile_cnt, sizeof(int) * (size_t)tiles, hipMemcpyDeviceToHost));
+        long items = 0, segs = 0;
+        for (int c : cnt) {
+            items += c;
+            segs += (c + g->seg_items - 1) / g->seg_items;
+        }
+        if (n_items) *n_items = (int)items;
+        if (n_segments) *n_segments = (int)segs;
+        return SLAM_OK;
+    }
     if (n_items) SLAM_HIP(hipMemcpy(n_items, g->d_tile_fill + tiles, sizeof(int), hipMemcpyDeviceToHost));
     if (n_segments) SLAM_HIP(hipMemcpy(n_segments, g->d_queue + 1, sizeof(int), hipMemcpyDeviceToHost));
     return SLAM_OK;

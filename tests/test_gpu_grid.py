@@ -211,9 +211,11 @@ def test_rolling_window_shift_and_clear():
     g.close()
 
 
-def test_config2_grid_full_size_properties():
-    """2000 x 2000 @ 0.05 m with 32 registered scans: tiled == global atomics,
-    counts are linear in the beam set, and one hit per kept beam."""
+@pytest.mark.parametrize("size,res", [(2000, 0.05), (4000, 0.05), (6000, 0.02)])
+def test_config2_grid_full_size_properties(size, res):
+    """2000 x 2000 @ 0.05 m (config 2), 4000 x 4000 (config 4: 1024 tiles, segment offsets computed by the raycast
+    workgroups) and 6000 x 6000 (2209 tiles: the three-kernel work list) with 32 registered scans: tiled ==
+    global atomics, counts are linear in the beam set, and one hit per kept beam."""
     batch = synth.make_batch(32, n_loop=256)
     Rt = [synth.pose_to_Rt(*p) for p in batch.true_poses]
     R = np.stack([r.reshape(4) for r, _ in Rt])
@@ -224,7 +226,7 @@ def test_config2_grid_full_size_properties():
     d_t = api.DeviceArray.from_host(t, np.float64)
     out = []
     for impl in (api.RAYCAST_TILED, api.RAYCAST_GLOBAL):
-        g = api.Grid(2000, 2000, 0.05, rolling=0, min_cluster_points=20, raycast_impl=impl)
+        g = api.Grid(size, size, res, rolling=0, min_cluster_points=20, raycast_impl=impl)
         g.raycast_scans_dev(d_pts, d_off, batch.n_scans, batch.n_points, d_R, d_t)
         api.synchronize()
         out.append(g.read_counts() + (g.total_updates(),))
