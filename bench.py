@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="lanes per scan point (0 = library default)")
     ap.add_argument("--raycast", choices=["tiled", "global"], default="tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="N=1: launch every step call by call instead of replaying one captured hipGraph")
     ap.add_argument("--no-torch", action="store_true", help="N=1 only: do not import torch at all")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearse the N>1 code path (process group + all-reduce) with one rank")
@@ -185,22 +187,27 @@ def main():
 
     ev = [[api.Event() for _ in range(5)] for _ in range(args.steps)]
 
+    # N=1: all calls go to one created stream, so that a step can be captured into a hipGraph and replayed
+    # with a single launch (about ten launches per step otherwise).  N>1: torch's collective runs on torch's
+    # current (null) stream, and so do the library's calls.
+    st = None if multi else api.Stream()
+
     def step(e=None):
         # one batch: initial poses in, a fresh local count map, register, ray-cast, merge over the GPUs, finalize
-        d_R.copy_from(d_R0)
-        d_t.copy_from(d_t0)
-        grid.reset_counts()
-        if e: e[0].record()
-        icp.fit_batch_dev(d_pts, d_off, d_nga, S, d_R, d_t, 5.0, d_res)
-        if e: e[1].record()
-        grid.raycast_scans_dev(d_pts, d_off, S, P, d_R, d_t)
-        if e: e[2].record()
+        d_R.copy_from(d_R0, st)
+        d_t.copy_from(d_t0, st)
+        grid.reset_counts(st)
+        if e: e[0].record(st)
+        icp.fit_batch_dev(d_pts, d_off, d_nga, S, d_R, d_t, 5.0, d_res, None, st)
+        if e: e[1].record(st)
+        grid.raycast_scans_dev(d_pts, d_off, S, P, d_R, d_t, st)
+        if e: e[2].record(st)
         if multi:
             for part in merge_parts:  # RCCL sum of the int32 planes over xGMI (the touched rows of both planes)
                 dist.all_reduce(part)
-        if e: e[3].record()
-        grid.finalize()
-        if e: e[4].record()
+        if e: e[3].record(st)
+        grid.finalize(st)
+        if e: e[4].record(st)
 
     merge_parts = [planes] if multi else []
     grid.clear()
@@ -231,13 +238,27 @@ def main():
     sync()
     barrier()
     sync()
+    graph = None
+    if st is not None and not args.no_graph and args.warmup:
+        graph = api.Graph(st)
+        with graph:          # the warm-up ran the same calls: every scratch buffer exists
+            step()
+        sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(ev[k])
+        if graph is not None:
+            graph.launch()
+        else:
+            step(ev[k])
     sync()
     barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    if graph is not None:    # per-kernel times from a few event-bracketed steps outside the timed region
+        ev = ev[:min(len(ev), 10)]
+        for e in ev:
+            step(e)
+        sync()
 
     if upd_per_step is None:
         upd_per_step = grid.total_updates() // max(args.steps, 1)
@@ -319,7 +340,7 @@ def main():
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 pose / f32 distance / int32 counts",
-            "data": "synthetic",
+            "data": "synthetic", "launch": "hipGraph replay of one captured step" if graph is not None else "call by call",
             "config": {"workload": "BASELINE config 2 per GPU: %d x 1081-beam scans (%d points), %d ICP "
                                    "iterations vs %d-point map, Bresenham raycast into %dx%d @%.2f m, "
                                    "finalize%s" % (S, P, N_ITERS, M, GRID, GRID, RES,

@@ -70,6 +70,13 @@ int slam_stream_create(slam_stream_t *stream);
 int slam_stream_destroy(slam_stream_t stream);
 int slam_stream_synchronize(slam_stream_t stream);
 int slam_device_synchronize(void);
+/* hipGraph capture of a sequence of this library's asynchronous calls on one (created) stream: record once
+ * after a warm-up call of the same sequence, replay with one launch. */
+typedef void *slam_graph_t;
+int slam_graph_begin_capture(slam_stream_t stream);
+int slam_graph_end_capture(slam_stream_t stream, slam_graph_t *out);
+int slam_graph_launch(slam_graph_t graph, slam_stream_t stream);
+int slam_graph_destroy(slam_graph_t graph);
 int slam_event_create(slam_event_t *ev);
 int slam_event_destroy(slam_event_t ev);
 int slam_event_record(slam_event_t ev, slam_stream_t stream);

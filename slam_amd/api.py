@@ -62,7 +62,8 @@ EXPORTS = [
     "slam_last_error", "slam_version", "slam_device_count", "slam_set_device", "slam_device_info",
     "slam_malloc", "slam_free", "slam_memset", "slam_memcpy_h2d", "slam_memcpy_d2h",
     "slam_memcpy_d2d", "slam_host_alloc", "slam_host_free", "slam_memcpy_h2d_async",
-    "slam_memcpy_d2h_async", "slam_stream_wait_event",
+    "slam_memcpy_d2h_async", "slam_stream_wait_event", "slam_graph_begin_capture", "slam_graph_end_capture",
+    "slam_graph_launch", "slam_graph_destroy",
     "slam_stream_create", "slam_stream_destroy", "slam_stream_synchronize",
     "slam_device_synchronize", "slam_event_create", "slam_event_destroy", "slam_event_record",
     "slam_event_synchronize", "slam_event_elapsed_ms",
@@ -124,6 +125,10 @@ def lib():
     L.slam_memcpy_h2d_async.argtypes = [_vp, _vp, C.c_size_t, _vp]
     L.slam_memcpy_d2h_async.argtypes = [_vp, _vp, C.c_size_t, _vp]
     L.slam_stream_wait_event.argtypes = [_vp, _vp]
+    L.slam_graph_begin_capture.argtypes = [_vp]
+    L.slam_graph_end_capture.argtypes = [_vp, C.POINTER(_vp)]
+    L.slam_graph_launch.argtypes = [_vp, _vp]
+    L.slam_graph_destroy.argtypes = [_vp]
     L.slam_stream_create.argtypes = [C.POINTER(_vp)]
     L.slam_stream_destroy.argtypes = [_vp]
     L.slam_stream_synchronize.argtypes = [_vp]
@@ -314,6 +319,33 @@ class Stream:
     def __del__(self):
         if getattr(self, "ptr", None):
             lib().slam_stream_destroy(self.ptr)
+            self.ptr = None
+
+
+class Graph:
+    """hipGraph of the library calls issued on `stream` inside the with-block (record once, replay)."""
+
+    def __init__(self, stream):
+        self.stream, self.ptr = stream, None
+
+    def __enter__(self):
+        check(lib().slam_graph_begin_capture(self.stream.ptr))
+        return self
+
+    def __exit__(self, *exc):
+        p = _vp()
+        rc = lib().slam_graph_end_capture(self.stream.ptr, C.byref(p))
+        if exc[0] is None:
+            check(rc)
+            self.ptr = p.value
+        return False
+
+    def launch(self, stream=None):
+        check(lib().slam_graph_launch(self.ptr, (stream or self.stream).ptr))
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            lib().slam_graph_destroy(self.ptr)
             self.ptr = None
 
 

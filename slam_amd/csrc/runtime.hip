@@ -197,6 +197,46 @@ int slam_device_synchronize(void)
     return SLAM_OK;
 }
 
+// A sequence of the library's asynchronous calls on one stream, recorded once and replayed with a single
+// launch (a hipGraph): for launch-bound loops such as one registration + map-update step per batch.  Every
+// call between begin and end must be stream-ordered on `stream` (no host buffers, no synchronising calls)
+// and must have run once before, so that scratch buffers exist.
+int slam_graph_begin_capture(slam_stream_t stream)
+{
+    SLAM_REQUIRE(stream, SLAM_E_INVALID, "slam_graph_begin_capture: a created stream is required");
+    SLAM_TRY(require_device());
+    SLAM_HIP(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
+    return SLAM_OK;
+}
+
+int slam_graph_end_capture(slam_stream_t stream, slam_graph_t *out)
+{
+    SLAM_REQUIRE(stream && out, SLAM_E_INVALID, "slam_graph_end_capture: bad arguments");
+    *out = nullptr;
+    hipGraph_t g = nullptr;
+    SLAM_HIP(hipStreamEndCapture(as_stream(stream), &g));
+    hipGraphExec_t  ex = nullptr;
+    const hipError_t e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    SLAM_HIP(e);
+    *out = (slam_graph_t)ex;
+    return SLAM_OK;
+}
+
+int slam_graph_launch(slam_graph_t graph, slam_stream_t stream)
+{
+    SLAM_REQUIRE(graph, SLAM_E_INVALID, "slam_graph_launch: null graph");
+    SLAM_HIP(hipGraphLaunch((hipGraphExec_t)graph, as_stream(stream)));
+    return SLAM_OK;
+}
+
+int slam_graph_destroy(slam_graph_t graph)
+{
+    if (!graph) return SLAM_OK;
+    SLAM_HIP(hipGraphExecDestroy((hipGraphExec_t)graph));
+    return SLAM_OK;
+}
+
 int slam_event_create(slam_event_t *ev)
 {
     SLAM_REQUIRE(ev, SLAM_E_INVALID, "slam_event_create: null out pointer");

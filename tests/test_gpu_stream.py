@@ -103,3 +103,51 @@ def test_stream_matches_oracle(tmp_path, n_scans, chunk, size, res):
     assert hits.sum() > 0.5 * batch.n_points and misses.sum() > 20 * hits.sum()
     O.grid_finalize(gp, H.reshape(-1), M.reshape(-1), num, eocc)
     assert np.array_equal(occ, eocc)
+
+
+@pytest.mark.gpu
+def test_graph_replay_equals_direct_calls():
+    """One registration + map-update step captured into a hipGraph through the C-ABI and replayed: the same
+    poses, counts and occupancy as the calls issued one by one."""
+    from slam_amd import api
+    m_ga, m_nga = synth.make_map(10000)
+    batch = synth.make_batch(24, n_loop=64)
+    S, P = batch.n_scans, batch.n_points
+    icp = api.Icp(m_ga, m_nga, max_iter=14, min_delta=-1.0)
+    grid = api.Grid(1200, 1200, 0.05, rolling=0)
+    st = api.Stream()
+    d_pts = api.DeviceArray.from_host(batch.pts, np.float64)
+    d_off = api.DeviceArray.from_host(batch.scan_off, np.int32)
+    d_nga = api.DeviceArray.from_host(batch.scan_nga, np.int32)
+    d_R0 = api.DeviceArray.from_host(batch.R, np.float64)
+    d_t0 = api.DeviceArray.from_host(batch.t, np.float64)
+    d_R = api.DeviceArray(batch.R.shape, np.float64)
+    d_t = api.DeviceArray(batch.t.shape, np.float64)
+    d_res = api.DeviceArray((S,), api.RESULT_DTYPE)
+
+    def step():
+        d_R.copy_from(d_R0, st)
+        d_t.copy_from(d_t0, st)
+        grid.reset_counts(st)
+        icp.fit_batch_dev(d_pts, d_off, d_nga, S, d_R, d_t, 5.0, d_res, None, st)
+        grid.raycast_scans_dev(d_pts, d_off, S, P, d_R, d_t, st)
+        grid.finalize(st)
+
+    step()                                   # direct (also creates every scratch buffer)
+    st.synchronize()
+    want = (d_R.download(), d_t.download(), d_res.download(), grid.read_counts(), grid.read_occupancy())
+    g = api.Graph(st)
+    with g:
+        step()
+    d_R.zero(); d_t.zero()
+    grid.clear()
+    api.synchronize()
+    for _ in range(3):
+        g.launch()
+    st.synchronize()
+    got = (d_R.download(), d_t.download(), d_res.download(), grid.read_counts(), grid.read_occupancy())
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(got[2]["iters"], want[2]["iters"]) and (got[2]["iters"] == 14).all()
+    assert np.array_equal(got[3][0], want[3][0]) and np.array_equal(got[3][1], want[3][1])
+    assert np.array_equal(got[4], want[4]) and want[3][0].sum() > 0.9 * P
+    icp.close(); grid.close()
