@@ -78,7 +78,8 @@ struct ModelView {
     unsigned lblob_bytes;
     unsigned loff_pts;      // float2[n_ent[0] + n_ent[1]]
     unsigned loff_start[2]; // u16[lcells+1] per class, positions relative to the class base
-    unsigned loff_axis[2];  // bit per cell and class
+    unsigned loff_axis[2];  // two bits per cell and class: the list's ordering key (list_key)
+    float    lkeps;         // rounding allowance of a diagonal key difference, metres
     int      lbase[2];      // first entry of each class
     Lattice  llat;
     float    lpad;          // halo in cell units
@@ -550,6 +551,16 @@ __device__ inline ListPtrs make_list_ptrs(const unsigned char *base, const Model
     return lp;
 }
 
+// Ordering key of a list: 0 = x, 1 = y, 2 = x + y, 3 = x - y (the diagonals serve lists bent around a corner,
+// where either axis would put a whole wall on one key).  Host and device evaluate the same float expression.
+__host__ __device__ inline float list_key(int dir, float x, float y)
+{
+    const float ux = dir == 1 ? 0.0f : 1.0f, uy = dir == 0 ? 0.0f : (dir == 3 ? -1.0f : 1.0f);
+    return ux * x + uy * y; // products by 0 and +-1 are exact: x, y, fl(x + y), fl(x - y); built without FMA contraction
+}
+// the same with the direction vector already in registers (one multiply-add pair per key, no selects)
+__device__ inline float list_key_u(float ux, float uy, float x, float y) { return __fadd_rn(__fmul_rn(ux, x), __fmul_rn(uy, y)); }
+
 constexpr int kListWin = 3;  // entries examined on either side of the refined start
 constexpr int kListWalk = 3; // further steps on either side before the query is left to the cooperative round
 
@@ -566,8 +577,17 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
     const float2         *pts = lp.pts + mv.lbase[cls];
     const int             a = (int)start[c], e = (int)start[c + 1], n = e - a;
     if (n <= 0) return false;
-    const bool  ay = (lp.axis[cls][c >> 5] >> (c & 31)) & 1u;
-    const float kq = ay ? qy : qx;
+    const int   dir = (int)((lp.axis[cls][c >> 4] >> (2 * (c & 15))) & 3u);
+    const float ux = dir == 1 ? 0.0f : 1.0f, uy = dir == 0 ? 0.0f : (dir == 3 ? -1.0f : 1.0f);
+    const float kq = list_key_u(ux, uy, qx, qy);
+    // A key difference dk bounds the distance from below: |p - q| >= |dk| along an axis, >= |dk| / sqrt(2) along
+    // a diagonal, where the rounded sums also cost a few ulp (keps).  far(dk) = "nothing at this key distance or
+    // beyond can beat or tie the best".
+    const float kscale = dir < 2 ? 1.0f : 0.4999f, keps = dir < 2 ? 0.0f : mv.lkeps;
+    auto        far = [&](float dk, float best) {
+        const float lb = fmaxf(fabsf(dk) - keps, 0.0f);
+        return __fmul_rn(__fmul_rn(lb, lb), kscale) > best;
+    };
     // start: the first entry whose key is not below the query's (binary search: the keys of a list bent around
     // a corner are far from evenly spaced, an interpolated start can be dozens of entries off)
     int g;
@@ -576,7 +596,7 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
         while (blo < bhi) {
             const int    mid = (blo + bhi) >> 1;
             const float2 pm = pts[mid];
-            if ((ay ? pm.y : pm.x) < kq)
+            if (list_key_u(ux, uy, pm.x, pm.y) < kq)
                 blo = mid + 1;
             else
                 bhi = mid;
@@ -593,7 +613,7 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
         const bool   ok = i <= hi;
         const float2 p = pts[min(i, hi)];
         const float  dj = ok ? dist2(p, qx, qy) : FLT_MAX;
-        const float  kj = ay ? p.y : p.x;
+        const float  kj = list_key_u(ux, uy, p.x, p.y);
         if (j == 0) klo = kj;
         khi = ok ? kj : khi;
         tie |= ok & (dj == d);
@@ -601,21 +621,21 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
         d = up ? dj : d;
         pos = up ? i : pos;
     }
-    // beyond an end whose key distance alone exceeds the best (on the far side of the query) nothing can
-    // beat or tie it; otherwise walk on from that end
+    // beyond an end whose key distance alone rules it out (on the far side of the query) nothing can beat or
+    // tie the best; otherwise walk on from that end
     const float dl = klo - kq, dr = khi - kq;
-    bool        Lft = (lo > a) & !((dl < 0.f) & (__fmul_rn(dl, dl) > d));
-    bool        Rgt = (hi < e - 1) & !((dr > 0.f) & (__fmul_rn(dr, dr) > d));
+    bool        Lft = (lo > a) & !((dl < 0.f) & far(dl, d));
+    bool        Rgt = (hi < e - 1) & !((dr > 0.f) & far(dr, d));
     int         il = lo - 1, ir = hi + 1;
-    // a bounded walk: a query that needs more (a list bent around a corner, a poor start) is left undecided
-    // rather than holding its wavefront -- and at the barrier its workgroup -- back
+    // a bounded walk: a query that needs more is left undecided rather than holding its wavefront -- and at the
+    // barrier its workgroup -- back
     int budget = kListWalk;
     while ((Lft | Rgt) & (budget > 0)) {
         --budget;
         const float2 ml = pts[max(il, a)], mr = pts[min(ir, e - 1)];
         {
-            const float dk = (ay ? ml.y : ml.x) - kq;
-            const bool  in = Lft & !((dk < 0.f) & (__fmul_rn(dk, dk) > d));
+            const float dk = list_key_u(ux, uy, ml.x, ml.y) - kq;
+            const bool  in = Lft & !((dk < 0.f) & far(dk, d));
             const float dd = dist2(ml, qx, qy);
             tie |= in & (dd == d);
             const bool up = in & (dd < d);
@@ -625,8 +645,8 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
             Lft = in & (il >= a);
         }
         {
-            const float dk = (ay ? mr.y : mr.x) - kq;
-            const bool  in = Rgt & !((dk > 0.f) & (__fmul_rn(dk, dk) > d));
+            const float dk = list_key_u(ux, uy, mr.x, mr.y) - kq;
+            const bool  in = Rgt & !((dk > 0.f) & far(dk, d));
             const float dd = dist2(mr, qx, qy);
             tie |= in & (dd == d);
             const bool up = in & (dd < d);
@@ -1530,7 +1550,7 @@ int build_lists(slam_icp *h, const std::vector<float> xy[2], const int cnt[2], c
             }
             if (!ok) continue;
             const size_t bytes = align16(8u * (unsigned)(n_ent[0] + n_ent[1])) + 2 * (size_t)align16(2u * (unsigned)(ncells + 1)) +
-                                 2 * (size_t)align16(4u * (unsigned)(ncells / 32 + 1));
+                                 2 * (size_t)align16(4u * (unsigned)(ncells / 16 + 1));
             if ((double)bytes > budget) continue;
             // ---- build
             unsigned o = 0;
@@ -1542,7 +1562,7 @@ int build_lists(slam_icp *h, const std::vector<float> xy[2], const int cnt[2], c
             }
             for (int c = 0; c < 2; ++c) {
                 mv.loff_axis[c] = o;
-                o = align16(o + 4u * (unsigned)(ncells / 32 + 1));
+                o = align16(o + 4u * (unsigned)(ncells / 16 + 1));
             }
             mv.lblob_bytes = o;
             mv.lbase[0] = 0;
@@ -1555,6 +1575,7 @@ int build_lists(slam_icp *h, const std::vector<float> xy[2], const int cnt[2], c
             mv.llat.inv_h = 1.0f / mv.llat.h;
             mv.llat.margin = std::max(mv.llat.h * 0.0009765625f, margin_abs);
             mv.lpad = (float)frac;
+            mv.lkeps = 8.0f * 2.0f * maxabs * 1.1920929e-07f; // 8 ulp of |x| + |y| <= 2 maxabs (query within the lattice)
             // a point within `cert` of a query lies within cert + (cell-map rounding) of the query's nominal cell
             const double cert = pad_m - 4.0 * (double)mv.llat.margin - 2.0 * std::fabs((double)mv.llat.x0 - x0) - 2.0 * std::fabs((double)mv.llat.y0 - y0);
             if (cert <= 0) continue;
@@ -1588,9 +1609,30 @@ int build_lists(slam_icp *h, const std::vector<float> xy[2], const int cnt[2], c
                         }
                         ++e;
                     }
-                    const int ax = (e - a >= 2 && (mx[1] - mn[1]) > (mx[0] - mn[0])) ? 1 : 0;
-                    if (ax) axis[k >> 5] |= 1u << (k & 31);
-                    for (size_t j = a; j < e; ++j) ent[j].key = xy[c][2 * ent[j].pt + ax];
+                    // ordering key: the direction (x, y, x+y, x-y) whose densest key window is the sparsest --
+                    // a window of the converged search radius must hold few entries, or the walk is long
+                    int best_dir = (mx[1] - mn[1]) > (mx[0] - mn[0]) ? 1 : 0;
+                    if (e - a >= 8) {
+                        size_t             best_metric = SIZE_MAX;
+                        std::vector<float> keys(e - a);
+                        for (int dir : {best_dir, 1 - best_dir, 2, 3}) {
+                            for (size_t j = a; j < e; ++j) keys[j - a] = list_key(dir, xy[c][2 * ent[j].pt], xy[c][2 * ent[j].pt + 1]);
+                            std::sort(keys.begin(), keys.end());
+                            const float win = (dir < 2 ? 1.0f : 1.41421356f) * 0.06f; // +-3 cm around the query
+                            size_t      metric = 0, lo_j = 0;
+                            for (size_t j = 0; j < keys.size(); ++j) {
+                                while (keys[j] - keys[lo_j] > win) ++lo_j;
+                                metric = std::max(metric, j - lo_j + 1);
+                            }
+                            if (dir >= 2) metric += metric / 4 + 1; // an axis key is cheaper and exact: prefer it when close
+                            if (metric < best_metric) {
+                                best_metric = metric;
+                                best_dir = dir;
+                            }
+                        }
+                    }
+                    axis[k >> 4] |= (unsigned)best_dir << (2 * (k & 15));
+                    for (size_t j = a; j < e; ++j) ent[j].key = list_key(best_dir, xy[c][2 * ent[j].pt], xy[c][2 * ent[j].pt + 1]);
                     std::stable_sort(ent.begin() + a, ent.begin() + e, [](const Ent &p, const Ent &q) { return p.key < q.key; });
                     a = e;
                 }
