@@ -1,3 +1,5 @@
+"""Cost of the first iterations of the ring-search launch as a function of the cell pitch and the lanes per
+point: one fit_batch of 256 scans with max_iter 2, 4, 10, timed with HIP events."""
 import sys; sys.path.insert(0, ".")
 import numpy as np
 from slam_amd import api, synth

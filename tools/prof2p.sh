@@ -1,3 +1,6 @@
+#!/bin/bash
+# Kernel trace of the default bench on the GPU box: duration of the two ICP launches of each step and the gap
+# between them (the hand-over is a barrier over the whole batch).  usage: bash tools/prof2p.sh
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof2p && mkdir -p gpurun_out/prof2p
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof2p -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-torch > gpurun_out/prof2p/out.json 2> gpurun_out/prof2p/err.txt
