@@ -112,11 +112,13 @@ def pmc_traffic(kernel):
 
 
 def main():
+    global GRID
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scans", type=int, default=N_SCANS, help="scans per GPU (default: config 2)")
+    ap.add_argument("--scans", type=int, default=N_SCANS, help="scans per GPU (default: config 2; config 4: 1024)")
+    ap.add_argument("--grid", type=int, default=GRID, help="grid side in cells (default: config 2; config 4: 4000)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per scan point (0 = library default)")
     ap.add_argument("--raycast", choices=["tiled", "global"], default="tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -126,6 +128,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearse the N>1 code path (process group + all-reduce) with one rank")
     args = ap.parse_args()
+    GRID = args.grid
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -346,9 +349,10 @@ def main():
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 pose / f32 distance / int32 counts",
             "data": "synthetic", "launch": "hipGraph replay of one captured step" if graph is not None else "call by call",
-            "config": {"workload": "BASELINE config 2 per GPU: %d x 1081-beam scans (%d points), %d ICP "
+            "config": {"workload": "BASELINE config %s per GPU: %d x 1081-beam scans (%d points), %d ICP "
                                    "iterations vs %d-point map, Bresenham raycast into %dx%d @%.2f m, "
-                                   "finalize%s" % (S, P, N_ITERS, M, GRID, GRID, RES,
+                                   "finalize%s" % ("2" if (S, GRID) == (256, 2000) else ("4" if (S, GRID) == (1024, 4000) else "2 (resized)"),
+                                                   S, P, N_ITERS, M, GRID, GRID, RES,
                                                    ", RCCL all-reduce of the touched rows of the int32 planes" if multi else ""),
                        "scans_per_gpu": S, "icp_iters": N_ITERS, "grid": [GRID, GRID], "resolution": RES,
                        "map_points": M, "icp_index": info, "raycast": args.raycast,
