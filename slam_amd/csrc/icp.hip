@@ -473,6 +473,39 @@ __device__ inline bool solve3(double A[9], double b[3])
     return true;
 }
 
+// One point-to-point step from the nine sums S = {n, sum(p_m - c), sum(p_t - c), sum (p_t - c)(p_m - c)^T}
+// (c = mv.cx, mv.cy): icpPointToPoint.cpp:128-171.  pose = r00 r01 r10 r11 t0 t1, updated in place when there
+// is a correspondence; returns the step's delta (-1 without correspondences, :128-131).
+__device__ inline double p2p_step(const double S[kNumAcc], const ModelView &mv, double pose[6], int &n_corr)
+{
+    n_corr = (int)S[0];
+    if (n_corr == 0) return -1.0;
+    const double inv = 1.0 / S[0];
+    const double ma0 = S[1] * inv, ma1 = S[2] * inv; // mean of (p_m - c)
+    const double mb0 = S[3] * inv, mb1 = S[4] * inv; // mean of (p_t - c)
+    double       H[4], R_[4], t_[2];
+    H[0] = S[5] - S[3] * ma0;
+    H[1] = S[6] - S[3] * ma1;
+    H[2] = S[7] - S[4] * ma0;
+    H[3] = S[8] - S[4] * ma1;
+    p2p_rotation(H, R_);
+    const double mm0 = mv.cx + ma0, mm1 = mv.cy + ma1;
+    const double mt0 = mv.cx + mb0, mt1 = mv.cy + mb1;
+    t_[0] = mm0 - (R_[0] * mt0 + R_[1] * mt1); // :163
+    t_[1] = mm1 - (R_[2] * mt0 + R_[3] * mt1);
+    const double r00 = pose[0], r01 = pose[1], r10 = pose[2], r11 = pose[3], t0 = pose[4], t1 = pose[5];
+    pose[0] = R_[0] * r00 + R_[1] * r10; // :166-167 R = R_*R ; t = R_*t + t_
+    pose[1] = R_[0] * r01 + R_[1] * r11;
+    pose[2] = R_[2] * r00 + R_[3] * r10;
+    pose[3] = R_[2] * r01 + R_[3] * r11;
+    pose[4] = (R_[0] * t0 + R_[1] * t1) + t_[0];
+    pose[5] = (R_[2] * t0 + R_[3] * t1) + t_[1];
+    const double a0 = R_[0] - 1.0, a3 = R_[3] - 1.0;
+    const double nr2 = a0 * a0 + R_[1] * R_[1] + R_[2] * R_[2] + a3 * a3;
+    const double nt2 = t_[0] * t_[0] + t_[1] * t_[1];
+    return sqrt(nr2 > nt2 ? nr2 : nt2); // :170 max of the two norms (sqrt is monotone: same value)
+}
+
 struct FitArgs {
     const double2 *pts;
     const int     *scan_off;
@@ -1010,60 +1043,30 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                     S[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), k),
                                             __builtin_amdgcn_readlane(__double2loint(mine), k));
 
-                double R_[4], t_[2];
-                bool   have = true;
+                double o[6] = {r00, r01, r10, r11, t0, t1};
                 double d_out = 0.0;
                 int    nc_out = 0;
                 if (MODE == SLAM_ICP_P2P) {
-                    nc_out = (int)S[0];
-                    if (nc_out == 0) { // icpPointToPoint.cpp:128-131
-                        d_out = -1.0;
-                        have = false;
-                    } else {
-                        const double inv = 1.0 / S[0];
-                        const double ma0 = S[1] * inv, ma1 = S[2] * inv; // mean of (p_m - c)
-                        const double mb0 = S[3] * inv, mb1 = S[4] * inv; // mean of (p_t - c)
-                        double H[4];
-                        H[0] = S[5] - S[3] * ma0;
-                        H[1] = S[6] - S[3] * ma1;
-                        H[2] = S[7] - S[4] * ma0;
-                        H[3] = S[8] - S[4] * ma1;
-                        p2p_rotation(H, R_);
-                        const double mm0 = mv.cx + ma0, mm1 = mv.cy + ma1;
-                        const double mt0 = mv.cx + mb0, mt1 = mv.cy + mb1;
-                        t_[0] = mm0 - (R_[0] * mt0 + R_[1] * mt1); // :163
-                        t_[1] = mm1 - (R_[2] * mt0 + R_[3] * mt1);
-                    }
+                    d_out = p2p_step(S, mv, o, nc_out);
                 } else {
                     nc_out = n;
                     double A[9] = {S[0], S[1], S[2], S[1], S[3], S[4], S[2], S[4], S[5]};
                     double b[3] = {S[6], S[7], S[8]};
                     if (solve3(A, b)) { // icpPointToPlane.cpp:85
                         const double w = b[0], nn = sqrt(1.0 + w * w); // :88-95 U*V^T
-                        R_[0] = 1.0 / nn;
-                        R_[1] = -w / nn;
-                        R_[2] = w / nn;
-                        R_[3] = 1.0 / nn;
-                        t_[0] = b[1];
-                        t_[1] = b[2];
-                    } else {
-                        d_out = 0.0; // falls out of the if at :85 and returns 0
-                        have = false;
-                    }
-                }
-                double o[6] = {r00, r01, r10, r11, t0, t1};
-                if (have) {
-                    // :166-167 R = R_*R ; t = R_*t + t_
-                    o[0] = R_[0] * r00 + R_[1] * r10;
-                    o[1] = R_[0] * r01 + R_[1] * r11;
-                    o[2] = R_[2] * r00 + R_[3] * r10;
-                    o[3] = R_[2] * r01 + R_[3] * r11;
-                    o[4] = (R_[0] * t0 + R_[1] * t1) + t_[0];
-                    o[5] = (R_[2] * t0 + R_[3] * t1) + t_[1];
-                    const double a0 = R_[0] - 1.0, a3 = R_[3] - 1.0;
-                    const double nr2 = a0 * a0 + R_[1] * R_[1] + R_[2] * R_[2] + a3 * a3;
-                    const double nt2 = t_[0] * t_[0] + t_[1] * t_[1];
-                    d_out = sqrt(nr2 > nt2 ? nr2 : nt2); // :170 max of the two norms (sqrt is monotone: same value)
+                        const double R_[4] = {1.0 / nn, -w / nn, w / nn, 1.0 / nn};
+                        const double t_[2] = {b[1], b[2]};
+                        o[0] = R_[0] * r00 + R_[1] * r10; // :166-167 R = R_*R ; t = R_*t + t_
+                        o[1] = R_[0] * r01 + R_[1] * r11;
+                        o[2] = R_[2] * r00 + R_[3] * r10;
+                        o[3] = R_[2] * r01 + R_[3] * r11;
+                        o[4] = (R_[0] * t0 + R_[1] * t1) + t_[0];
+                        o[5] = (R_[2] * t0 + R_[3] * t1) + t_[1];
+                        const double a0 = R_[0] - 1.0, a3 = R_[3] - 1.0;
+                        const double nr2 = a0 * a0 + R_[1] * R_[1] + R_[2] * R_[2] + a3 * a3;
+                        const double nt2 = t_[0] * t_[0] + t_[1] * t_[1];
+                        d_out = sqrt(nr2 > nt2 ? nr2 : nt2); // :170
+                    } // else: falls out of the if at :85 and returns 0, pose unchanged
                 }
                 if (lane == 0) {
 #pragma unroll
@@ -1136,6 +1139,109 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
             fa.result[s].delta = delta;
         }
         if (fa.phase == 1) fa.state[s] = hand_over ? iters : -1;
+    }
+}
+
+// ------------------------------------------------------------ one scan, low latency
+// A batch of ONE scan (the reference's own usage: scan_registration matches scan by scan) would keep a single
+// workgroup -- one CU of 256 -- busy for all iterations, with the index read from HBM/L2 when the model is
+// large.  Instead every iteration is two small launches: icp_step_kernel spreads the scan's points over as
+// many workgroups as it takes (kStepLanes lanes per point, ring search on the index in HBM/L2) and leaves one
+// row of nine partial sums per workgroup; icp_solve_kernel adds the rows in fixed order (bitwise reproducible),
+// solves and updates the pose in place.  A `done` flag turns the remaining launches into no-ops once
+// min_delta is reached.  ctrl: [0] iterations done, [1] done flag, [2] correspondences of the last step.
+constexpr int kStepLanes = 8, kStepBlock = 256, kStepPoints = kStepBlock / kStepLanes;
+
+template <typename StartT>
+__global__ __launch_bounds__(kStepBlock) void icp_step_kernel(ModelView mv, const double2 *pts, int n, int nga,
+                                                              const double *pose, double indist, double *partial,
+                                                              const int *ctrl)
+{
+    if (ctrl[1]) return;
+    __shared__ double wsum[kStepBlock / 64][kNumAcc];
+    const IndexPtrs<StartT> ix = make_ptrs<StartT>(mv.blob, mv);
+    const Pose T = {pose[0], pose[1], pose[2], pose[3], pose[4], pose[5]};
+    const int  tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int  p = blockIdx.x * kStepPoints + tid / kStepLanes, sub = tid % kStepLanes;
+    double     acc[kNumAcc];
+#pragma unroll
+    for (int k = 0; k < kNumAcc; ++k) acc[k] = 0.0;
+    if (p < n) {
+        const int cls = p < nga ? 0 : 1;
+        if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
+            float qx, qy;
+            transform_query(T, pts[p], qx, qy);
+            const Best b = nn_search<kStepLanes, StartT>(ix, mv, cls, qx, qy, sub, indist);
+            if (sub == 0 && b.pos >= 0 && (double)b.d < indist) add_p2p<StartT>(ix, mv, cls, b, qx, qy, acc); // :76
+        }
+    }
+    const double v8 = wave_sum8(acc), v9 = wave_sum(acc[8]);
+    if ((lane & 7) == 0) wsum[wave][lane >> 3] = v8;
+    if (lane == 0) wsum[wave][8] = v9;
+    __syncthreads();
+    if (tid < kNumAcc) {
+        double v = 0.0;
+        for (int w = 0; w < kStepBlock / 64; ++w) v += wsum[w][tid];
+        partial[(size_t)blockIdx.x * kNumAcc + tid] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void icp_solve_kernel(ModelView mv, const double *partial, int n_blocks, double *pose,
+                                                       int *ctrl, double *delta_out, int max_iter, double min_delta,
+                                                       double *trace, double *step_pose)
+{
+    if (ctrl[1]) return;
+    const int lane = threadIdx.x;
+    double    mine = 0.0;
+    if (lane < kNumAcc)
+        for (int b = 0; b < n_blocks; ++b) mine += partial[(size_t)b * kNumAcc + lane];
+    double S[kNumAcc];
+#pragma unroll
+    for (int k = 0; k < kNumAcc; ++k)
+        S[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), k),
+                                __builtin_amdgcn_readlane(__double2loint(mine), k));
+    double o[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = pose[k];
+    if (lane == 0 && step_pose)
+        for (int k = 0; k < 6; ++k) step_pose[k] = o[k]; // R,t as this step found them (edge weights)
+    int          nc = 0;
+    const double d = p2p_step(S, mv, o, nc);
+    if (lane == 0) {
+        const int it = ctrl[0];
+        for (int k = 0; k < 6; ++k) pose[k] = o[k];
+        *delta_out = d;
+        ctrl[0] = it + 1;
+        ctrl[2] = nc;
+        if (d < min_delta || it + 1 >= max_iter) ctrl[1] = 1; // icp.cpp:119-121
+        if (trace) {
+            double *tr = trace + (size_t)it * 8;
+            for (int k = 0; k < 6; ++k) tr[k] = o[k];
+            tr[6] = d;
+            tr[7] = (double)nc;
+        }
+    }
+}
+
+// copies the pose between the caller's R[4], t[2] and the contiguous six doubles the step kernels use, and
+// writes the result record at the end
+__global__ void icp_single_io_kernel(double *R, double *t, double *pose, const int *ctrl, const double *delta,
+                                     slam_icp_result *result, int to_pose)
+{
+    if (threadIdx.x != 0) return;
+    if (to_pose) {
+        for (int k = 0; k < 4; ++k) pose[k] = R[k];
+        pose[4] = t[0];
+        pose[5] = t[1];
+    } else {
+        for (int k = 0; k < 4; ++k) R[k] = pose[k];
+        t[0] = pose[4];
+        t[1] = pose[5];
+        if (result) {
+            result->iters = ctrl[0];
+            result->n_corr = ctrl[2];
+            result->delta = *delta;
+        }
     }
 }
 
@@ -1347,7 +1453,8 @@ struct slam_icp {
     size_t          lds_bytes = 0;
     void           *d_blob = nullptr;
     double         *d_normals = nullptr;
-    DevBuf          w_pts, w_off, w_nga, w_R, w_t, w_res, w_stamps, w_pose, w_ew, w_state;
+    DevBuf          w_pts, w_off, w_nga, w_R, w_t, w_res, w_stamps, w_pose, w_ew, w_state, w_single;
+    int             hint_n = -1, hint_nga = 0; // set by slam_icp_fit around its single-scan call
     bool            two_phase = false;   // ring search, then list sweeps (the point-to-point default)
     bool            phase_events = false; // diagnostic: time the two launches separately (slam_icp_debug_phase_ms)
     hipEvent_t      ev[3] = {nullptr, nullptr, nullptr};
@@ -1744,6 +1851,48 @@ int launch_fit_m(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
     return SLAM_E_INVALID;
 }
 
+// One scan: per iteration a step launch over ceil(n / 32) workgroups and a solve launch (see icp_step_kernel).
+// The scan's size has to be known on the host to size the grid: one 8-byte read of the offsets.
+int fit_single(slam_icp *h, const FitArgs &fa, hipStream_t st)
+{
+    int off[2] = {0, h->hint_n}, nga = h->hint_nga;
+    if (h->hint_n < 0) { // not called through slam_icp_fit: read the scan's size back (one synchronisation)
+        SLAM_HIP(hipMemcpyAsync(off, fa.scan_off, sizeof off, hipMemcpyDeviceToHost, st));
+        SLAM_HIP(hipMemcpyAsync(&nga, fa.scan_nga, sizeof nga, hipMemcpyDeviceToHost, st));
+        SLAM_HIP(hipStreamSynchronize(st));
+    }
+    const int n = off[1] - off[0];
+    const int n_blocks = (n + kStepPoints - 1) / kStepPoints;
+    SLAM_TRY(h->w_single.reserve(sizeof(double) * (8 + (size_t)std::max(n_blocks, 1) * kNumAcc) + 64));
+    double *pose = static_cast<double *>(h->w_single.p), *delta = pose + 6, *partial = pose + 8;
+    int    *ctrl = reinterpret_cast<int *>(partial + (size_t)std::max(n_blocks, 1) * kNumAcc);
+    SLAM_HIP(hipMemsetAsync(pose + 6, 0, 16, st));
+    SLAM_HIP(hipMemsetAsync(ctrl, 0, 16, st));
+    hipLaunchKernelGGL(icp_single_io_kernel, dim3(1), dim3(64), 0, st, fa.R, fa.t, pose, ctrl, delta, fa.result, 1);
+    if (n >= 5 && fa.max_iter > 0) { // icp.cpp:100-103
+        const double2 *pts = fa.pts + off[0];
+        for (int it = 0; it < fa.max_iter; ++it) {
+            if (h->start32)
+                hipLaunchKernelGGL((icp_step_kernel<uint32_t>), dim3(n_blocks), dim3(kStepBlock), 0, st, h->mv, pts, n, nga,
+                                   pose, fa.indist, partial, ctrl);
+            else
+                hipLaunchKernelGGL((icp_step_kernel<uint16_t>), dim3(n_blocks), dim3(kStepBlock), 0, st, h->mv, pts, n, nga,
+                                   pose, fa.indist, partial, ctrl);
+            hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, st, h->mv, partial, n_blocks, pose, ctrl, delta,
+                               fa.max_iter, fa.min_delta, fa.trace, fa.step_pose);
+            if ((it & 31) == 31 && it + 1 < fa.max_iter) { // long limits: stop issuing once the scan has converged
+                int done[2] = {0, 0};
+                SLAM_HIP(hipMemcpyAsync(done, ctrl, sizeof done, hipMemcpyDeviceToHost, st));
+                SLAM_HIP(hipStreamSynchronize(st));
+                if (done[1]) break;
+            }
+        }
+    }
+    hipLaunchKernelGGL(icp_single_io_kernel, dim3(1), dim3(64), 0, st, fa.R, fa.t, pose, ctrl, delta, fa.result, 0);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
 int launch_fit(slam_icp *h, const FitArgs &fa_in, int n_scans, hipStream_t st)
 {
     if (n_scans <= 0) return SLAM_OK;
@@ -1905,6 +2054,9 @@ int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *
         fa.stamps = static_cast<long long *>(icp->w_stamps.p);
         icp->n_stamps = n_scans * kWaves;
     }
+    // one scan against a model too large for LDS: many small workgroups per iteration instead of one
+    if (n_scans == 1 && !icp->in_lds && icp->prm.mode == SLAM_ICP_P2P && icp->prm.lanes_per_point == 0 && !fa.stamps)
+        return fit_single(icp, fa, as_stream(stream));
     return launch_fit(icp, fa, n_scans, as_stream(stream));
 }
 
@@ -1944,11 +2096,14 @@ int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t
     SLAM_HIP(hipMemcpyAsync(icp->w_R.p, R, 32, hipMemcpyHostToDevice, st));
     SLAM_HIP(hipMemcpyAsync(icp->w_t.p, t, 16, hipMemcpyHostToDevice, st));
     icp->want_step_pose = true;
+    icp->hint_n = n;
+    icp->hint_nga = n_tga;
     const int rc_fit = slam_icp_fit_batch_dev(icp, dp, static_cast<int32_t *>(icp->w_off.p),
                                               static_cast<int32_t *>(icp->w_nga.p), 1,
                                               static_cast<double *>(icp->w_R.p), static_cast<double *>(icp->w_t.p),
                                               indist, static_cast<slam_icp_result *>(icp->w_res.p), nullptr, st);
     icp->want_step_pose = false;
+    icp->hint_n = -1;
     SLAM_TRY(rc_fit);
     icp->last_n = n;
     icp->last_nga = n_tga;

@@ -10,6 +10,7 @@ import numpy as np
 from slam_amd import api, synth
 
 N_CLOUDS = int(sys.argv[1]) if len(sys.argv) > 1 else 50
+CELL = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0   # model lattice pitch (0 = library default)
 L = api.lib()
 seg, cc = api.GroundSegmentation(), api.Ccicp()
 clouds, poses = zip(*[synth.make_cloud3d(k, n_loop=50) for k in range(N_CLOUDS)])
@@ -56,7 +57,7 @@ def relative(pa, pb):
 def run():
     t0 = time.perf_counter()
     m_ga, m_nga, n_gnd_t = front_end(clouds[0], False, (0.0, 0.0))       # setTargetCloud (SCAN_TO_SCAN) + crop
-    icp = api.Icp(m_ga, m_nga)                                           # max_iter 20, min_delta 1e-6 (icp.cpp:27)
+    icp = api.Icp(m_ga, m_nga, cell_size=CELL)                           # max_iter 20, min_delta 1e-6 (icp.cpp:27)
     t_model = time.perf_counter() - t0
     # ground_target stays in d_gnd only until the next front_end: keep a copy for the height recovery
     d_gt = api.DeviceArray((max(n_gnd_t, 1), 4), np.float32)
