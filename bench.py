@@ -248,10 +248,19 @@ def main():
     sync()
     graph = None
     if st is not None and not args.no_graph and args.warmup:
-        graph = api.Graph(st)
-        with graph:          # the warm-up ran the same calls: every scratch buffer exists
+        try:
+            graph = api.Graph(st)
+            with graph:      # the warm-up ran the same calls: every scratch buffer exists
+                step()
+            sync()
+            graph.launch()   # one replay outside the timed region: a graph that cannot run must not cost the bench
+            sync()
+        except Exception as ex:   # fall back to launching call by call on a fresh stream
+            print("hipGraph capture/replay failed (%s); launching call by call" % ex, file=sys.stderr)
+            graph = None
+            st = api.Stream()
             step()
-        sync()
+            sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
         if graph is not None:
