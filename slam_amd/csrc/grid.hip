@@ -513,17 +513,22 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
                 }
             }
             if (ablate & 1) rem = 0;
-            // ---- all lanes step their beams together
-            while (__any(rem > 0)) {
-                if (rem > 0) atomicAdd(&tile[a], to_end == 0 ? 0x10000u : 1u);
-                a += step_u;
-                e += dv2;
-                if (e >= den) {
-                    e -= den;
-                    a += step_v;
-                }
-                --rem;
-                --to_end;
+            // ---- the end cell's hit if the beam ends in this tile (its last step here is then the end cell),
+            // then all lanes step their beams' misses together, two steps per trip of the loop
+            const bool hit_here = rem > 0 && to_end < rem;
+            if (hit_here) atomicAdd(&tile[(y1 - ty0) * kTileStride + (x1 - tx0)], 0x10000u);
+            int miss = rem - (hit_here ? 1 : 0);
+            while (__any(miss > 0)) {
+                if (miss > 0) atomicAdd(&tile[a], 1u);
+                const int  a1 = a + step_u, e1 = e + dv2;
+                const bool w1 = e1 >= den;
+                const int  a2 = w1 ? a1 + step_v : a1, e2 = w1 ? e1 - den : e1;
+                if (miss > 1) atomicAdd(&tile[a2], 1u);
+                const int  a3 = a2 + step_u, e3 = e2 + dv2;
+                const bool w2 = e3 >= den;
+                a = w2 ? a3 + step_v : a3; // a finished lane's a is not used again
+                e = w2 ? e3 - den : e3;
+                miss -= 2;
             }
             p = p_next;
             raw = raw_next;
