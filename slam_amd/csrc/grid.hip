@@ -126,6 +126,10 @@ struct Beam { // integer Bresenham endpoints in window cells; x0 < 0 marks a dro
 };
 
 constexpr int kTile = 128;             // cells per tile side
+#ifndef SLAM_WALK_UNROLL
+#define SLAM_WALK_UNROLL 4
+#endif
+constexpr int kWalkUnroll = SLAM_WALK_UNROLL; // steps per trip of the raycast walk loop
 constexpr int kTileStride = kTile + 1; // LDS row pitch in words: vertical neighbours fall on adjacent banks
 constexpr int kTileThreads = 1024;
 constexpr int kChunk = 1024;           // beams per pre-pass workgroup
@@ -519,16 +523,15 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
             if (hit_here) atomicAdd(&tile[(y1 - ty0) * kTileStride + (x1 - tx0)], 0x10000u);
             int miss = rem - (hit_here ? 1 : 0);
             while (__any(miss > 0)) {
-                if (miss > 0) atomicAdd(&tile[a], 1u);
-                const int  a1 = a + step_u, e1 = e + dv2;
-                const bool w1 = e1 >= den;
-                const int  a2 = w1 ? a1 + step_v : a1, e2 = w1 ? e1 - den : e1;
-                if (miss > 1) atomicAdd(&tile[a2], 1u);
-                const int  a3 = a2 + step_u, e3 = e2 + dv2;
-                const bool w2 = e3 >= den;
-                a = w2 ? a3 + step_v : a3; // a finished lane's a is not used again
-                e = w2 ? e3 - den : e3;
-                miss -= 2;
+#pragma unroll
+                for (int k = 0; k < kWalkUnroll; ++k) {
+                    if (miss > k) atomicAdd(&tile[a], 1u);
+                    const int  a1 = a + step_u, e1 = e + dv2;
+                    const bool w = e1 >= den;
+                    a = w ? a1 + step_v : a1; // a finished lane's a is not used again
+                    e = w ? e1 - den : e1;
+                }
+                miss -= kWalkUnroll;
             }
             p = p_next;
             raw = raw_next;
