@@ -299,8 +299,9 @@ def main():
     seg = np.array([[e[i].elapsed_ms(e[i + 1]) for i in range(4)] for e in ev]) if args.steps else np.zeros((1, 4))
     ms_icp, ms_ray, ms_merge, ms_fin = seg.mean(axis=0)
 
-    # the default ICP schedule is two launches of icp_fit_kernel per batch (ring search for the first
-    # iterations, list sweeps for the rest): time them apart in a few extra, untimed steps
+    # the default ICP schedule is ONE launch (icp_fit_fused_kernel): ring search for the first iterations of a
+    # scan, list sweeps for the rest.  For the record the two forms are timed apart in a few extra, untimed steps
+    # run as two launches (what slam_icp_debug_phase_events switches to)
     ms_ring = ms_list = None
     if args.lanes == 0 and args.steps:
         import ctypes as C
@@ -315,9 +316,7 @@ def main():
         api.check(L.slam_icp_debug_phase_ms(icp.h, pm, C.byref(calls)))
         api.check(L.slam_icp_debug_phase_events(icp.h, 0))
         if calls.value:
-            # scaled so that the two add up to the ICP time of the timed steps (events add a little)
-            f = float(ms_icp) / (pm[0] + pm[1]) if pm[0] + pm[1] > 0 else 1.0
-            ms_ring, ms_list = pm[0] * f, pm[1] * f
+            ms_ring, ms_list = pm[0], pm[1]   # averages over the calls
 
     # sanity on the result of the last step (not timed): all scans registered
     res = d_res.download()
@@ -334,10 +333,11 @@ def main():
         ray_bytes = 8 * upd_per_step + 16 * P           # 8 B RMW per cell update + 16 B per beam
         fin_bytes = GRID * GRID * 17                     # 2x4 B counts in, 8 B evidence + 1 B occupancy out
         kernels = {}
-        if ms_ring is not None:
-            # each launch reads the scans, its index (cell index 8 B/point + starts, or the halo lists) and the poses
-            kernels["icp_fit_kernel_ring (ring search, first iterations)"] = {"ms": float(ms_ring), "alg_bytes": icp_bytes}
-            kernels["icp_fit_kernel_list (list sweeps, remaining iterations)"] = {"ms": float(ms_list), "alg_bytes": 16 * P + S * (int(info.get("list_bytes", 8 * M)) + 96)}
+        fused = bool(info.get("two_forms")) and args.lanes == 0
+        if fused:
+            # one launch reads the scans, the cell index (8 B/point + starts), the halo lists and the poses
+            kernels["icp_fit_fused_kernel (ring search, then list sweeps)"] = {
+                "ms": float(ms_icp), "alg_bytes": icp_bytes + S * int(info.get("list_bytes", 0))}
         else:
             kernels["icp_fit_kernel"] = {"ms": float(ms_icp), "alg_bytes": icp_bytes}
         kernels.update({
@@ -373,6 +373,8 @@ def main():
             "kernel_ms": {"icp": float(ms_icp), "raycast": float(ms_ray), "merge": float(ms_merge),
                           "finalize": float(ms_fin)},
             "kernels": kernels,
+            "icp_forms_as_two_forms_ms": ({"ring_search_first_iterations": ms_ring, "list_sweeps_rest": ms_list}
+                                             if ms_ring is not None else None),
             "roofline": roof,
             "max_pose_error_m": pose_err,
             "device": api.device_info()[0],

@@ -160,10 +160,11 @@ int slam_icp_get_normals(slam_icp_t *icp, double *normals_xy);
 /* what the index looks like (for DESIGN.md / bench reporting) */
 int slam_icp_index_info(slam_icp_t *icp, int *nx, int *ny, double *cell, int *in_lds,
                         size_t *lds_bytes, int *lanes_per_point);
-/* The default point-to-point schedule: two_launches = 1 when the halo lists fit LDS for this model (the ring
- * search then runs the first `first_iterations` iterations and the list sweeps the rest); list lattice pitch,
- * halo and certified radius in metres, size of the list blob. */
-int slam_icp_list_info(slam_icp_t *icp, int *two_launches, int *first_iterations, double *pitch, double *halo,
+/* The default point-to-point schedule: two_forms = 1 when the halo lists fit LDS for this model (the ring
+ * search then runs at least the first `first_iterations` iterations of a scan and the list sweeps the rest, in
+ * one launch: the workgroup swaps its LDS contents); list lattice pitch, halo and certified radius in metres,
+ * size of the list blob. */
+int slam_icp_list_info(slam_icp_t *icp, int *two_forms, int *first_iterations, double *pitch, double *halo,
                        double *certified_radius, size_t *list_bytes);
 
 /* ------------------------------------------------------------------ grid

@@ -412,7 +412,7 @@ class Icp:
         check(lib().slam_icp_list_info(self.h, C.byref(two), C.byref(first), C.byref(pitch), C.byref(halo),
                                        C.byref(cert), C.byref(lb)))
         return dict(nx=nx.value, ny=ny.value, cell=cell.value, in_lds=bool(in_lds.value),
-                    lds_bytes=lds.value, lanes_per_point=lanes.value, two_launches=bool(two.value),
+                    lds_bytes=lds.value, lanes_per_point=lanes.value, two_forms=bool(two.value),
                     first_iterations=first.value, list_pitch=pitch.value, list_halo=halo.value,
                     list_certified_radius=cert.value, list_bytes=lb.value)
 

@@ -527,6 +527,7 @@ struct FitArgs {
     int           *state;
     int            phase;  // 0 = single launch, 1 = first of two, 2 = second
     int            switch_iter;
+    int            far_div;       // hand over once at most n / far_div queries are beyond the lists' certified radius
 };
 
 struct Pose {
@@ -882,56 +883,31 @@ __device__ inline void point_pass_reg(const IndexPtrs<StartT> &ix, const ModelVi
 // more than half a workgroup of points is left, then the widest group that
 // still covers the rest in one pass (a 1081-point scan is 1024 points at G = 1
 // plus 57 points at G = 16), so no pass runs nearly empty.
-template <int G, bool LDS, typename StartT, int MODE, int SWEEP>
-__global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs fa)
+// The state of one scan's fit that outlives a run of iterations: the pose (the same in every lane) and the
+// counters that go into slam_icp_result.
+struct FitState {
+    double r00, r01, r10, r11, t0, t1, delta;
+    int    iters, n_corr;
+    bool   hand_over;
+};
+
+// Iterations fs.iters .. max_iter-1 of the workgroup's scan in one search form (SWEEP 0: ring search with G lanes
+// per point on the cell index `ix`; SWEEP 2: list sweeps on the halo lists `lp`, the undecided few on `ix`).
+// phase 1 stops at fa.switch_iter with fs.hand_over set if the list form can take over (see launch_fit).
+template <int G, typename StartT, int MODE, int SWEEP>
+__device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArgs &fa, const IndexPtrs<StartT> &ix,
+                                               const ListPtrs &lp, unsigned char *smem, int s, int off, int n, int nga,
+                                               int phase, FitState &fs)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *partial = reinterpret_cast<double *>(smem); // [2][kWaves][kNumAcc]
     double *bcast = partial + 2 * kWaves * kNumAcc;     // [2][8] new pose, delta, n_corr
     unsigned       *wave_cnt = reinterpret_cast<unsigned *>(smem + kReduceBytes); // [kWaves] undecided queries of the pass
     unsigned short *queue = reinterpret_cast<unsigned short *>(smem + kReduceBytes + 4 * kWaves); // [kWaves][64]
-    constexpr unsigned kScratch = kScratchBytes;
-    static_assert(kScratch % 16 == 0, "scratch keeps the blob 16-B aligned");
-
-    const int s = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-
-    const int off = fa.scan_off[s];
-    const int n = fa.scan_off[s + 1] - off;
-    const int nga = fa.scan_nga[s];
-    int       iter_begin = 0;
-    if (fa.phase == 2) {
-        iter_begin = fa.state[s];
-        if (iter_begin < 0) return; // finished in the first launch (uniform for the workgroup)
-    }
-
-    const unsigned char *base = mv.blob;
-    if (LDS) {
-        unsigned char *dst = smem + kScratch;
-        const uint4 *src = reinterpret_cast<const uint4 *>(mv.blob);
-        uint4       *d4 = reinterpret_cast<uint4 *>(dst);
-        for (unsigned i = tid; i < mv.blob_bytes / 16u; i += kBlock) d4[i] = src[i];
-        base = dst;
-        __syncthreads();
-    }
-    const IndexPtrs<StartT> ix = make_ptrs<StartT>(base, mv);
-    ListPtrs                lp = {};
-    if (SWEEP == 2) { // the halo lists live in LDS; the cell index above stays in HBM/L2 for the undecided few
-        unsigned char *dst = smem + kScratch;
-        const uint4   *src = reinterpret_cast<const uint4 *>(mv.lblob);
-        uint4         *d4 = reinterpret_cast<uint4 *>(dst);
-        for (unsigned i = tid; i < mv.lblob_bytes / 16u; i += kBlock) d4[i] = src[i];
-        lp = make_list_ptrs(dst, mv);
-        __syncthreads();
-    }
-
-    double r00 = uniform(fa.R[4 * s + 0]), r01 = uniform(fa.R[4 * s + 1]), r10 = uniform(fa.R[4 * s + 2]),
-           r11 = uniform(fa.R[4 * s + 3]);
-    double t0 = uniform(fa.t[2 * s + 0]), t1 = uniform(fa.t[2 * s + 1]);
-
-    int    iters = 0, n_corr = 0;
-    double delta = 0.0;
+    const int iter_begin = fs.iters;
+    double    r00 = fs.r00, r01 = fs.r01, r10 = fs.r10, r11 = fs.r11, t0 = fs.t0, t1 = fs.t1, delta = fs.delta;
+    int       iters = fs.iters, n_corr = fs.n_corr;
 
     // the lane's points of the first passes, loaded once
     constexpr int kPerPass = kBlock / (G > 0 ? G : 1);
@@ -1012,7 +988,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                 }
             }
 
-            const bool at_switch = fa.phase == 1 && iter + 1 >= fa.switch_iter && iter + 1 < fa.max_iter;
+            const bool at_switch = phase == 1 && iter + 1 >= fa.switch_iter && iter + 1 < fa.max_iter;
             if (at_switch) { // how many queries the list-sweep launch could not certify right now
                 for (int o = 32; o > 0; o >>= 1) far += __shfl_xor(far, o);
                 if (lane == 0) wave_cnt[wave] = (unsigned)far;
@@ -1118,7 +1094,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
                 // settled): each of them would cost the second launch a ring search from HBM per iteration
                 unsigned far_all = 0;
                 for (int w = 0; w < kWaves; ++w) far_all += wave_cnt[w];
-                if (far_all * 32u <= (unsigned)n) {
+                if (far_all * (unsigned)fa.far_div <= (unsigned)n) {
                     hand_over = true; // the list-sweep launch continues from here
                     break;
                 }
@@ -1126,20 +1102,121 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
         }
     }
 
-    if (tid == 0) {
-        fa.R[4 * s + 0] = r00;
-        fa.R[4 * s + 1] = r01;
-        fa.R[4 * s + 2] = r10;
-        fa.R[4 * s + 3] = r11;
-        fa.t[2 * s + 0] = t0;
-        fa.t[2 * s + 1] = t1;
-        if (fa.result) {
-            fa.result[s].iters = iters;
-            fa.result[s].n_corr = n_corr;
-            fa.result[s].delta = delta;
-        }
-        if (fa.phase == 1) fa.state[s] = hand_over ? iters : -1;
+    fs.r00 = r00;
+    fs.r01 = r01;
+    fs.r10 = r10;
+    fs.r11 = r11;
+    fs.t0 = t0;
+    fs.t1 = t1;
+    fs.delta = delta;
+    fs.iters = iters;
+    fs.n_corr = n_corr;
+    fs.hand_over = hand_over;
+}
+
+// what a finished workgroup leaves behind: the pose in place, the result record, the hand-over state
+__device__ inline void store_fit(const FitArgs &fa, int s, const FitState &fs, int phase)
+{
+    fa.R[4 * s + 0] = fs.r00;
+    fa.R[4 * s + 1] = fs.r01;
+    fa.R[4 * s + 2] = fs.r10;
+    fa.R[4 * s + 3] = fs.r11;
+    fa.t[2 * s + 0] = fs.t0;
+    fa.t[2 * s + 1] = fs.t1;
+    if (fa.result) {
+        fa.result[s].iters = fs.iters;
+        fa.result[s].n_corr = fs.n_corr;
+        fa.result[s].delta = fs.delta;
     }
+    if (phase == 1) fa.state[s] = fs.hand_over ? fs.iters : -1;
+}
+
+__device__ inline FitState load_fit(const FitArgs &fa, int s, int iter_begin)
+{
+    FitState fs;
+    fs.r00 = uniform(fa.R[4 * s + 0]);
+    fs.r01 = uniform(fa.R[4 * s + 1]);
+    fs.r10 = uniform(fa.R[4 * s + 2]);
+    fs.r11 = uniform(fa.R[4 * s + 3]);
+    fs.t0 = uniform(fa.t[2 * s + 0]);
+    fs.t1 = uniform(fa.t[2 * s + 1]);
+    fs.delta = 0.0;
+    fs.iters = iter_begin;
+    fs.n_corr = 0;
+    fs.hand_over = false;
+    return fs;
+}
+
+__device__ inline void fill_lds(unsigned char *dst, const unsigned char *blob, unsigned bytes)
+{
+    const uint4 *src = reinterpret_cast<const uint4 *>(blob);
+    uint4       *d4 = reinterpret_cast<uint4 *>(dst);
+    for (unsigned i = threadIdx.x; i < bytes / 16u; i += kBlock) d4[i] = src[i];
+}
+
+template <int G, bool LDS, typename StartT, int MODE, int SWEEP>
+__global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs fa)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr unsigned kScratch = kScratchBytes;
+    static_assert(kScratch % 16 == 0, "scratch keeps the blob 16-B aligned");
+    const int s = blockIdx.x;
+    const int off = fa.scan_off[s];
+    const int n = fa.scan_off[s + 1] - off;
+    const int nga = fa.scan_nga[s];
+    int       iter_begin = 0;
+    if (fa.phase == 2) {
+        iter_begin = fa.state[s];
+        if (iter_begin < 0) return; // finished in the first launch (uniform for the workgroup)
+    }
+    const unsigned char *base = mv.blob;
+    if (LDS) {
+        fill_lds(smem + kScratch, mv.blob, mv.blob_bytes);
+        base = smem + kScratch;
+        __syncthreads();
+    }
+    const IndexPtrs<StartT> ix = make_ptrs<StartT>(base, mv);
+    ListPtrs                lp = {};
+    if (SWEEP == 2) { // the halo lists live in LDS; the cell index above stays in HBM/L2 for the undecided few
+        fill_lds(smem + kScratch, mv.lblob, mv.lblob_bytes);
+        lp = make_list_ptrs(smem + kScratch, mv);
+        __syncthreads();
+    }
+    FitState fs = load_fit(fa, s, iter_begin);
+    fit_iterations<G, StartT, MODE, SWEEP>(mv, fa, ix, lp, smem, s, off, n, nga, fa.phase, fs);
+    if (threadIdx.x == 0) store_fit(fa, s, fs, fa.phase);
+}
+
+// Both forms in one launch (the default for batches, point-to-point, index and lists each fitting LDS): the ring
+// search for the first fa.switch_iter iterations, then -- without a barrier over the batch -- the workgroup swaps
+// the halo lists into LDS over the cell index and carries on in list form; a scan the lists cannot take (see
+// fit_iterations) stays in ring form to the end.  StartT is the cell index's type in HBM (list form).
+template <typename StartT, int MODE>
+__global__ __launch_bounds__(kBlock) void icp_fit_fused_kernel(ModelView mv, FitArgs fa)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr unsigned kScratch = kScratchBytes;
+    const int s = blockIdx.x;
+    const int off = fa.scan_off[s];
+    const int n = fa.scan_off[s + 1] - off;
+    const int nga = fa.scan_nga[s];
+    fill_lds(smem + kScratch, mv.blob, mv.blob_bytes);
+    __syncthreads();
+    FitState fs = load_fit(fa, s, 0);
+    {
+        const IndexPtrs<uint16_t> ix = make_ptrs<uint16_t>(smem + kScratch, mv); // an index in LDS has 16-bit starts
+        const ListPtrs            none = {};
+        fit_iterations<2, uint16_t, MODE, 0>(mv, fa, ix, none, smem, s, off, n, nga, 1, fs);
+    }
+    if (fs.hand_over) { // uniform for the workgroup
+        __syncthreads();
+        fill_lds(smem + kScratch, mv.lblob, mv.lblob_bytes);
+        const ListPtrs          lp = make_list_ptrs(smem + kScratch, mv);
+        const IndexPtrs<StartT> ix = make_ptrs<StartT>(mv.blob, mv);
+        __syncthreads();
+        fit_iterations<1, StartT, MODE, 2>(mv, fa, ix, lp, smem, s, off, n, nga, 2, fs);
+    }
+    if (threadIdx.x == 0) store_fit(fa, s, fs, 0);
 }
 
 // ------------------------------------------------------------ one scan, low latency
@@ -1456,11 +1533,13 @@ struct slam_icp {
     DevBuf          w_pts, w_off, w_nga, w_R, w_t, w_res, w_stamps, w_pose, w_ew, w_state, w_single;
     int             hint_n = -1, hint_nga = 0; // set by slam_icp_fit around its single-scan call
     bool            two_phase = false;   // ring search, then list sweeps (the point-to-point default)
+    bool            split_launch = false; // SLAM_ICP_SPLIT=1: the two forms as two launches (measurements)
     bool            phase_events = false; // diagnostic: time the two launches separately (slam_icp_debug_phase_ms)
     hipEvent_t      ev[3] = {nullptr, nullptr, nullptr};
     double          phase_ms[2] = {0, 0};
     int             phase_calls = 0;
     bool            ev_pending = false;
+    int             far_div = 32;        // see FitArgs
     int             switch_iter = 10;    // iterations of the first launch (measured optimum on config 2: tools/switch_sweep.sh)
     int             n_stamps = 0;
     bool            want_step_pose = false; // set around slam_icp_fit()
@@ -1900,12 +1979,25 @@ int launch_fit(slam_icp *h, const FitArgs &fa_in, int n_scans, hipStream_t st)
     fa.state = nullptr;
     fa.phase = 0;
     fa.switch_iter = 0;
+    fa.far_div = h->far_div;
     if (h->prm.mode == SLAM_ICP_P2L) {
         SLAM_REQUIRE(h->d_normals, SLAM_E_INVALID, "point-to-line mode needs model normals");
         return launch_fit_m<SLAM_ICP_P2L>(h, fa, n_scans, st);
     }
+    if (h->two_phase && h->have_lists && h->in_lds && !h->phase_events && !h->split_launch) {
+        // first iterations by the ring search (index in LDS), the rest by the list sweeps (halo lists in LDS),
+        // one launch: every workgroup swaps its LDS contents when its own scan gets there
+        fa.switch_iter = h->switch_iter;
+        auto         kern = h->start32 ? icp_fit_fused_kernel<uint32_t, SLAM_ICP_P2P> : icp_fit_fused_kernel<uint16_t, SLAM_ICP_P2P>;
+        const size_t lds = std::max(h->lds_bytes, h->list_lds_bytes);
+        SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(n_scans), dim3(kBlock), lds, st, h->mv, fa);
+        SLAM_HIP(hipGetLastError());
+        return SLAM_OK;
+    }
     if (h->two_phase && h->have_lists) {
-        // first iterations by the ring search (index in LDS), the rest by the list sweeps (halo lists in LDS)
+        // the same schedule as two launches (SLAM_ICP_SPLIT=1, or while the phases are being timed): the second
+        // launch starts when the slowest scan of the first has handed over
         SLAM_TRY(h->w_state.reserve(sizeof(int) * (size_t)n_scans));
         fa.state = static_cast<int *>(h->w_state.p);
         fa.switch_iter = h->switch_iter;
@@ -1980,7 +2072,9 @@ int slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga
     h->sweep = h->prm.lanes_per_point == -2 ? 2 : 0;
     h->G = h->prm.lanes_per_point > 0 ? h->prm.lanes_per_point : (h->prm.lanes_per_point == -1 ? 0 : 2);
     h->two_phase = h->prm.lanes_per_point == 0 && h->prm.mode == SLAM_ICP_P2P;
+    if (const char *e = getenv("SLAM_ICP_SPLIT")) h->split_launch = atoi(e) != 0;
     if (const char *e = getenv("SLAM_ICP_SWITCH_ITER")) h->switch_iter = atoi(e);
+    if (const char *e = getenv("SLAM_ICP_FAR_DIV")) h->far_div = std::max(atoi(e), 1);
     int rc = build_index(h, m_ga, n_ga, m_nga, n_nga);
     if (rc == SLAM_OK && (h->G & (h->G - 1) || h->G > 64)) {
         set_error("lanes_per_point must be one of 1,2,4,8,16,32,64 (got %d)", h->G);
@@ -2203,6 +2297,17 @@ int slam_icp_debug_phase_ms(slam_icp_t *icp, double out[2], int *calls)
     return SLAM_OK;
 }
 
+// diagnostic: the raw stamps, [scan][wavefront][kStampSlots] ticks; returns the number of rows through *rows
+int slam_icp_debug_stamps_raw(slam_icp_t *icp, long long *out, int cap_rows, int *rows)
+{
+    SLAM_REQUIRE(icp && out && rows && icp->n_stamps > 0, SLAM_E_INVALID, "no stamps collected");
+    SLAM_HIP(hipDeviceSynchronize());
+    const int n = std::min(cap_rows, icp->n_stamps);
+    SLAM_HIP(hipMemcpy(out, icp->w_stamps.p, (size_t)n * kStampSlots * sizeof(long long), hipMemcpyDeviceToHost));
+    *rows = n;
+    return SLAM_OK;
+}
+
 int slam_icp_debug_stamps(slam_icp_t *icp, double out[9])
 {
     SLAM_REQUIRE(icp && out && icp->n_stamps > 0, SLAM_E_INVALID, "no stamps collected");
@@ -2229,12 +2334,12 @@ int slam_icp_index_info(slam_icp_t *icp, int *nx, int *ny, double *cell, int *in
     return SLAM_OK;
 }
 
-int slam_icp_list_info(slam_icp_t *icp, int *two_launches, int *first_iterations, double *pitch, double *halo,
+int slam_icp_list_info(slam_icp_t *icp, int *two_forms, int *first_iterations, double *pitch, double *halo,
                        double *certified_radius, size_t *list_bytes)
 {
     SLAM_REQUIRE(icp, SLAM_E_INVALID, "null handle");
     const bool have = icp->have_lists;
-    if (two_launches) *two_launches = (icp->two_phase && have) ? 1 : 0;
+    if (two_forms) *two_forms = (icp->two_phase && have) ? 1 : 0;
     if (first_iterations) *first_iterations = icp->switch_iter;
     if (pitch) *pitch = have ? icp->mv.llat.h : 0.0;
     if (halo) *halo = have ? (double)icp->mv.lpad * icp->mv.llat.h : 0.0;

@@ -345,15 +345,31 @@ def test_outlier_scans_two_launch_schedule(world, frac):
         icp.close()
 
 
-def test_two_launch_schedule_edge_iteration_counts(world):
-    """max_iter below, at and just above the hand-over iteration; min_delta reached in either launch."""
+def test_one_launch_and_two_launch_schedules_agree_bitwise(world, monkeypatch):
+    """The default runs both search forms in one launch (the workgroup swaps its LDS contents); SLAM_ICP_SPLIT=1
+    runs them as two launches with the hand-over state in HBM.  Same arithmetic, same order: identical bits."""
+    m_ga, m_nga, model = world
+    batch = synth.make_batch(24, n_loop=256)
+    out = []
+    for split in ("0", "1"):
+        monkeypatch.setenv("SLAM_ICP_SPLIT", split)
+        icp = api.Icp(m_ga, m_nga, max_iter=30, min_delta=1e-6)
+        R, t, res, _ = icp.fit_batch(batch, indist=5.0)
+        out.append((R.copy(), t.copy(), res.copy()))
+        icp.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    assert np.array_equal(out[0][2], out[1][2])
+
+
+def test_two_form_schedule_edge_iteration_counts(world):
+    """max_iter below, at and just above the hand-over iteration; min_delta reached in either form."""
     m_ga, m_nga, model = world
     batch = synth.make_batch(5, n_loop=256)
     for max_iter, min_delta in ((1, -1.0), (9, -1.0), (10, -1.0), (11, -1.0), (40, 1e-2), (40, 1e-4), (40, 1e-9)):
         Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R, batch.t,
                                                       O.icp_params(max_iter, min_delta, 5.0))
         icp = api.Icp(m_ga, m_nga, max_iter=max_iter, min_delta=min_delta)
-        assert icp.index_info()["two_launches"] and icp.index_info()["first_iterations"] == 10
+        assert icp.index_info()["two_forms"] and icp.index_info()["first_iterations"] == 10
         R, t, res, _ = icp.fit_batch(batch, indist=5.0)
         assert np.array_equal(res["iters"], iters), (max_iter, min_delta)
         assert np.array_equal(res["n_corr"], ncorr)
