@@ -95,10 +95,11 @@ def cpu_baseline(m_ga, m_nga, batch, grid_size, res):
     }
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, field="hbm_bytes_per_launch"):
     """HBM bytes per launch of `kernel` from the committed PMC summary of this same
     command (profiles/rNN_traffic.json, written by tools/summarize_profiles.py from
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes); None if not profiled."""
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes); None if not profiled.
+    field "valu_busy_frac": share of SIMD cycles that issued a VALU instruction (same file)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
@@ -106,7 +107,7 @@ def pmc_traffic(kernel):
     try:
         t = json.load(open(files[-1]))
         key = kernel if kernel in t else ("raycast_tiled_kernel" if kernel.startswith("raycast") else None)
-        return t[key]["hbm_bytes_per_launch"] if key else None
+        return t[key].get(field) if key else None
     except Exception:
         return None
 
@@ -351,7 +352,10 @@ def main():
                 "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(dom.split(" ")[0]),
                 "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "avg_launch_ms": kernels[dom]["ms"],
-                "note": "ICP is LDS/VALU-bound (exact 1-NN search in LDS), not HBM-bound: see DESIGN.md"}
+                "valu_busy_frac": pmc_traffic(dom.split(" ")[0], "valu_busy_frac"),
+                "note": "the ICP kernel is VALU-issue bound (exact 1-NN search in LDS, one workgroup per scan, "
+                        "launch time = slowest scan), not HBM-bound: valu_busy_frac (PMC) is the share of SIMD "
+                        "cycles that issued a VALU instruction; see DESIGN.md 4.1"}
         out = {
             "metric": "registered_scan_points_per_s", "value": total_pts * args.steps / elapsed,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

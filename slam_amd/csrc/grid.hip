@@ -386,6 +386,16 @@ __device__ inline int floor_div_small(int num, int den, float rden)
 // lock-step with the integer error update (4 integer ops + one ds_add per
 // cell).  Clipping by closed form is what makes the tiling invisible in the
 // result: the cells are exactly those of the unclipped line.
+// Blocks of one tile a workgroup accumulates before it writes the tile back (a segment), when the caller leaves the
+// choice to the library: about five segments per persistent workgroup, at least 20 blocks -- fewer segments leave
+// workgroups idle at the end, shorter ones pay the tile's zeroing and write-back too often (SLAM_RAYCAST_SEG sweeps
+// on configs 2 and 4).
+__host__ __device__ inline int adaptive_seg(long total_items, int n_workgroups)
+{
+    const long per = (total_items + 5L * n_workgroups - 1) / (5L * n_workgroups);
+    return (int)(per < 20 ? 20 : (per > 128 ? 128 : per));
+}
+
 __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView g, const Beam *beams, int n,
                                                                         const int *items, const int *item_off,
                                                                         const int *seg_off, int n_tiles,
@@ -400,6 +410,17 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
     // single-pass work list (cnt != null): every workgroup turns the tile counts into segment offsets itself
     const bool own_prefix = cnt != nullptr;
     if (own_prefix) {
+        if (kSeg <= 0) { // segment length from the total number of (tile, block) items
+            int v = 0;
+            for (int i = tid; i < n_tiles; i += kTileThreads) v += cnt[i];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0) s_wsum[tid >> 6] = v;
+            __syncthreads();
+            long total = 0;
+            for (int k = 0; k < kTileThreads / 64; ++k) total += s_wsum[k];
+            kSeg = adaptive_seg(total, (int)gridDim.x);
+            __syncthreads();
+        }
         if (tid == 0) s_carry = 0;
         __syncthreads();
         for (int base = 0; base < n_tiles; base += kTileThreads) {
@@ -684,7 +705,7 @@ struct slam_grid {
     int             *d_items = nullptr;    // chunk ids bucketed by tile
     size_t           cap_items = 0;
     int              n_cu = 256;
-    int              seg_items = 32; // 64-beam blocks of one tile a workgroup accumulates before writing back
+    int              seg_items = 0;  // 64-beam blocks of one tile a workgroup accumulates before writing back; 0 = adaptive_seg
     int              last_chunks = 0;
     int              ablate = 0;     // debug: SLAM_RAYCAST_ABLATE bit mask (timing experiments only)
     int              wg_per_cu = 2;
@@ -755,13 +776,14 @@ int walk_beams(slam_grid *g, int n, hipStream_t st)
         } else {
             hipLaunchKernelGGL((tile_items_kernel<0>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
                                n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items, g->d_queue);
+            const int seg_items = g->seg_items > 0 ? g->seg_items : 32; // the total is not known on the host here
             hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, g->d_tile_cnt, n_tiles, item_off, seg_off,
-                               g->d_queue, g->seg_items);
+                               g->d_queue, seg_items);
             hipLaunchKernelGGL((tile_items_kernel<1>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
                                n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items, g->d_queue);
             // persistent workgroups, two per CU (66 KB of LDS each); each drains the queue and exits
             hipLaunchKernelGGL(raycast_tiled_kernel, dim3(g->wg_per_cu * g->n_cu), dim3(kTileThreads), 0, st, g->gv, g->d_beams,
-                               n, g->d_items, item_off, seg_off, n_tiles, g->d_queue, tiles_x, g->seg_items, g->ablate,
+                               n, g->d_items, item_off, seg_off, n_tiles, g->d_queue, tiles_x, seg_items, g->ablate,
                                (const int *)nullptr, 0);
         }
     } else {
@@ -809,7 +831,7 @@ int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             g->n_cu = std::max(1, prop.multiProcessorCount);
     }
-    if (const char *e = getenv("SLAM_RAYCAST_SEG")) g->seg_items = std::max(1, atoi(e));
+    if (const char *e = getenv("SLAM_RAYCAST_SEG")) g->seg_items = std::max(0, atoi(e));
     if (const char *e = getenv("SLAM_RAYCAST_ABLATE")) g->ablate = atoi(e);
     if (const char *e = getenv("SLAM_RAYCAST_WGPCU")) g->wg_per_cu = std::max(1, atoi(e));
     int rc = SLAM_OK;
@@ -1142,10 +1164,9 @@ int slam_grid_raycast_stats(slam_grid_t *g, int *n_tiles, int *n_items, int *n_s
         std::vector<int> cnt((size_t)tiles);
         SLAM_HIP(hipMemcpy(cnt.data(), g->d_tile_cnt, sizeof(int) * (size_t)tiles, hipMemcpyDeviceToHost));
         long items = 0, segs = 0;
-        for (int c : cnt) {
-            items += c;
-            segs += (c + g->seg_items - 1) / g->seg_items;
-        }
+        for (int c : cnt) items += c;
+        const int seg = g->seg_items > 0 ? g->seg_items : adaptive_seg(items, g->wg_per_cu * g->n_cu);
+        for (int c : cnt) segs += (c + seg - 1) / seg;
         if (n_items) *n_items = (int)items;
         if (n_segments) *n_segments = (int)segs;
         return SLAM_OK;
