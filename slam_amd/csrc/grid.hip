@@ -539,20 +539,38 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
             }
             if (ablate & 1) rem = 0;
             // ---- the end cell's hit if the beam ends in this tile (its last step here is then the end cell),
-            // then all lanes step their beams' misses together, two steps per trip of the loop
+            // then all lanes step their beams' misses together.  Per step: one ds_add and five integer
+            // instructions -- the cell is kept as a byte offset, the error term biased by 2^32 - den so that the
+            // carry of `+= dv2` is the test `e + dv2 >= den` -- in trips of kWalkUnroll steps for the lanes that
+            // have that many left (no per-step predicate), then the remainders.
             const bool hit_here = rem > 0 && to_end < rem;
             if (hit_here) atomicAdd(&tile[(y1 - ty0) * kTileStride + (x1 - tx0)], 0x10000u);
-            int miss = rem - (hit_here ? 1 : 0);
-            while (__any(miss > 0)) {
+            int            miss = rem - (hit_here ? 1 : 0);
+            unsigned char *tb = reinterpret_cast<unsigned char *>(tile);
+            int            a4 = a * 4;
+            const int      su4 = step_u * 4, sv4 = step_v * 4;
+            const unsigned bias = 0u - (unsigned)den, udv2 = (unsigned)dv2;
+            unsigned       eu = (unsigned)e + bias;
+            const auto     advance = [&]() {
+                const unsigned e2 = eu + udv2;
+                const bool     carry = e2 < eu; // e + dv2 >= den
+                a4 += su4 + (carry ? sv4 : 0);
+                eu = e2 + (carry ? bias : 0u);
+            };
+            while (__any(miss >= kWalkUnroll)) {
+                if (miss >= kWalkUnroll) {
 #pragma unroll
-                for (int k = 0; k < kWalkUnroll; ++k) {
-                    if (miss > k) atomicAdd(&tile[a], 1u);
-                    const int  a1 = a + step_u, e1 = e + dv2;
-                    const bool w = e1 >= den;
-                    a = w ? a1 + step_v : a1; // a finished lane's a is not used again
-                    e = w ? e1 - den : e1;
+                    for (int k = 0; k < kWalkUnroll; ++k) {
+                        atomicAdd(reinterpret_cast<unsigned *>(tb + a4), 1u);
+                        advance();
+                    }
+                    miss -= kWalkUnroll;
                 }
-                miss -= kWalkUnroll;
+            }
+#pragma unroll
+            for (int k = 0; k < kWalkUnroll - 1; ++k) {
+                if (miss > k) atomicAdd(reinterpret_cast<unsigned *>(tb + a4), 1u);
+                advance(); // a finished lane's cell is not used again
             }
             p = p_next;
             raw = raw_next;
