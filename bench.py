@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--scans", type=int, default=N_SCANS, help="scans per GPU (default: config 2; config 4: 1024)")
     ap.add_argument("--grid", type=int, default=GRID, help="grid side in cells (default: config 2; config 4: 4000)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per scan point (0 = library default)")
+    ap.add_argument("--cell", type=float, default=0.0, help="ICP cell pitch in metres (0 = library default)")
     ap.add_argument("--raycast", choices=["tiled", "global"], default="tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true",
@@ -162,7 +163,7 @@ def main():
     m_ga, m_nga = synth.make_map(MAP_POINTS)
     batch = synth.make_batch(S, n_loop=S * world, first=rank * S)
     P = batch.n_points
-    icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, lanes_per_point=args.lanes)
+    icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, lanes_per_point=args.lanes, cell_size=args.cell)
     grid = api.Grid(GRID, GRID, RES, rolling=0, min_cluster_points=20,
                     raycast_impl=api.RAYCAST_TILED if args.raycast == "tiled" else api.RAYCAST_GLOBAL)
     d_pts = api.DeviceArray.from_host(batch.pts, np.float64)
@@ -377,7 +378,7 @@ def main():
             "kernel_ms": {"icp": float(ms_icp), "raycast": float(ms_ray), "merge": float(ms_merge),
                           "finalize": float(ms_fin)},
             "kernels": kernels,
-            "icp_forms_as_two_forms_ms": ({"ring_search_first_iterations": ms_ring, "list_sweeps_rest": ms_list}
+            "icp_forms_as_two_launches_ms": ({"ring_search_first_iterations": ms_ring, "list_sweeps_rest": ms_list}
                                              if ms_ring is not None else None),
             "roofline": roof,
             "max_pose_error_m": pose_err,

@@ -345,6 +345,30 @@ def test_outlier_scans_two_launch_schedule(world, frac):
         icp.close()
 
 
+@pytest.mark.parametrize("cell", [0.33, 0.5, 1.3])
+def test_cell_pitch_is_only_a_cost_parameter(world, cell):
+    """The lattice pitch changes the cost of the exact search, never its result: nearest neighbours bit-exact,
+    batch fit as the oracle (tools/cell_sweep.sh measures the cost side)."""
+    m_ga, m_nga, model = world
+    icp = api.Icp(m_ga, m_nga, max_iter=30, min_delta=1e-6, cell_size=cell)
+    assert abs(icp.index_info()["cell"] - cell) < 1e-6
+    rs = np.random.RandomState(3)
+    xy = m_nga.astype(np.float32)
+    q = xy[rs.randint(0, len(xy), 200)] + rs.randn(200, 2).astype(np.float32) * \
+        rs.choice([0.01, 0.3, 3.0], size=(200, 1)).astype(np.float32)
+    dis, idx = icp.nearest(1, q)
+    for k in range(len(q)):
+        d, i = O.brute_nn1(xy, q[k, 0], q[k, 1])
+        assert dis[k] == np.float32(d) and idx[k] == i, (k, q[k])
+    batch = synth.make_batch(12, n_loop=256)
+    Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R, batch.t,
+                                                  O.icp_params(30, 1e-6, 5.0))
+    R, t, res, _ = icp.fit_batch(batch, indist=5.0)
+    assert np.array_equal(res["iters"], iters) and np.array_equal(res["n_corr"], ncorr)
+    assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL
+    icp.close()
+
+
 def test_one_launch_and_two_launch_schedules_agree_bitwise(world, monkeypatch):
     """The default runs both search forms in one launch (the workgroup swaps its LDS contents); SLAM_ICP_SPLIT=1
     runs them as two launches with the hand-over state in HBM.  Same arithmetic, same order: identical bits."""
