@@ -97,7 +97,7 @@ typedef struct {
     int    normals_k;       /* P2L: neighbours per normal (icpPointToPlane.h: 10) */
     int    lanes_per_point; /* 0 = library default: the ring search (2 lanes per scan point) for
                                the first iterations of a scan, then the halo-list sweeps (one lane
-                               per point) in a second launch; N = 1,2,4,8,16,32,64:
+                               per point), both in one launch; N = 1,2,4,8,16,32,64:
                                ring search only, N lanes per point; -1 = ring search, lanes chosen
                                per pass; -2 = list sweeps for every iteration (measurements) */
     double cell_size;       /* model lattice pitch in metres; 0 = sized to fit LDS */

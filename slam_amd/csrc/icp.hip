@@ -519,13 +519,12 @@ struct FitArgs {
     double         indist;
     double        *step_pose; // nullable; per scan 6 doubles: R,t as the last executed step found them
     long long     *stamps; // diagnostic only (SLAM_ICP_STAMPS=1): per scan, cycles in [search, reduce, barrier, solve]
-    // Two launches per batch: the ring-search kernel runs the first switch_iter iterations of every scan (by
-    // then a scan is normally within the certified radius of the halo lists) and the list-sweep kernel the
-    // rest.  The same count for every scan: a kernel boundary is a barrier over the whole batch, so a scan
-    // that handed over early would only lengthen the second launch.  state[scan] = iterations done, or -1
-    // when the scan finished (min_delta) in the first launch.
+    // Two search forms per scan: the ring search runs at least the first switch_iter iterations (by then a scan
+    // is normally within the certified radius of the halo lists), the list sweeps the rest.  One launch does
+    // both (icp_fit_fused_kernel); as two launches of icp_fit_kernel (SLAM_ICP_SPLIT=1, measurements) the
+    // hand-over goes through state[scan] = iterations done, or -1 when the scan finished in the ring search.
     int           *state;
-    int            phase;  // 0 = single launch, 1 = first of two, 2 = second
+    int            phase;  // icp_fit_kernel: 0 = the only launch, 1 = ring search of two launches, 2 = list sweeps of two
     int            switch_iter;
     int            far_div;       // hand over once at most n / far_div queries are beyond the lists' certified radius
 };
@@ -893,7 +892,7 @@ struct FitState {
 
 // Iterations fs.iters .. max_iter-1 of the workgroup's scan in one search form (SWEEP 0: ring search with G lanes
 // per point on the cell index `ix`; SWEEP 2: list sweeps on the halo lists `lp`, the undecided few on `ix`).
-// phase 1 stops at fa.switch_iter with fs.hand_over set if the list form can take over (see launch_fit).
+// phase 1 stops from fa.switch_iter on with fs.hand_over set as soon as the list form can take over (see the guard).
 template <int G, typename StartT, int MODE, int SWEEP>
 __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArgs &fa, const IndexPtrs<StartT> &ix,
                                                const ListPtrs &lp, unsigned char *smem, int s, int off, int n, int nga,
@@ -989,7 +988,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
             }
 
             const bool at_switch = phase == 1 && iter + 1 >= fa.switch_iter && iter + 1 < fa.max_iter;
-            if (at_switch) { // how many queries the list-sweep launch could not certify right now
+            if (at_switch) { // how many queries the list sweeps could not certify right now
                 for (int o = 32; o > 0; o >>= 1) far += __shfl_xor(far, o);
                 if (lane == 0) wave_cnt[wave] = (unsigned)far;
             }
@@ -1091,11 +1090,11 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
             if (delta < fa.min_delta) break; // icp.cpp:119-121
             if (at_switch) {
                 // hand over unless too many queries are still far from the map (outliers, a scan that has not
-                // settled): each of them would cost the second launch a ring search from HBM per iteration
+                // settled): each of them would cost the list form a ring search from HBM per iteration
                 unsigned far_all = 0;
                 for (int w = 0; w < kWaves; ++w) far_all += wave_cnt[w];
                 if (far_all * (unsigned)fa.far_div <= (unsigned)n) {
-                    hand_over = true; // the list-sweep launch continues from here
+                    hand_over = true; // the list sweeps continue from here
                     break;
                 }
             }
@@ -1167,7 +1166,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
     int       iter_begin = 0;
     if (fa.phase == 2) {
         iter_begin = fa.state[s];
-        if (iter_begin < 0) return; // finished in the first launch (uniform for the workgroup)
+        if (iter_begin < 0) return; // finished in the ring-search launch (uniform for the workgroup)
     }
     const unsigned char *base = mv.blob;
     if (LDS) {
@@ -1540,7 +1539,7 @@ struct slam_icp {
     int             phase_calls = 0;
     bool            ev_pending = false;
     int             far_div = 32;        // see FitArgs
-    int             switch_iter = 10;    // iterations of the first launch (measured optimum on config 2: tools/switch_sweep.sh)
+    int             switch_iter = 10;    // ring-search iterations before a scan may change to list sweeps (tools/switch_sweep.sh)
     int             n_stamps = 0;
     bool            want_step_pose = false; // set around slam_icp_fit()
     int             last_n = 0, last_nga = 0; // template of the last slam_icp_fit()
@@ -2067,7 +2066,7 @@ int slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga
         h->prm = *params;
     else
         slam_icp_default_params(&h->prm);
-    // 0 = library default (sweep search, one lane per point; point-to-line: ring search with 2 lanes);
+    // 0 = library default (ring search with 2 lanes per point, then list sweeps; point-to-line: ring search only);
     // N > 0 = ring search with N lanes per point; -1 = ring search, lanes chosen per pass
     h->sweep = h->prm.lanes_per_point == -2 ? 2 : 0;
     h->G = h->prm.lanes_per_point > 0 ? h->prm.lanes_per_point : (h->prm.lanes_per_point == -1 ? 0 : 2);
@@ -2264,9 +2263,9 @@ int slam_icp_get_edge_weight(slam_icp_t *icp, double eW[9])
 
 // diagnostic (not in the public header): per wavefront, mean cycles in the four phases, sweep
 // fall-backs, and the search cycles of iterations 0-3 of the last batch launched with SLAM_ICP_STAMPS=1 in the environment
-// diagnostic (not in the public header): with `on`, the two launches of the default schedule are timed
-// separately (three events per call); out = mean ms of the ring-search launch and of the list-sweep launch
-// over the calls since the last query
+// diagnostic (not in the public header): with `on`, the default schedule runs as two launches (ring search,
+// list sweeps) timed separately (three events per call); out = mean ms of either over the calls since the
+// last query
 int slam_icp_debug_phase_events(slam_icp_t *icp, int on)
 {
     SLAM_REQUIRE(icp, SLAM_E_INVALID, "null handle");

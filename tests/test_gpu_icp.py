@@ -322,9 +322,9 @@ def test_ragged_scan_sizes(world, lanes):
 
 
 @pytest.mark.parametrize("frac", [0.01, 0.1, 0.5])
-def test_outlier_scans_two_launch_schedule(world, frac):
+def test_outlier_scans_two_form_schedule(world, frac):
     """Scans with points far from the map (some inside the 5.0 gate, some beyond it): few of them and the scan is
-    handed to the list-sweep launch with a busy cooperative queue, many and it stays in the ring search (the
+    handed to the list sweeps with a busy cooperative queue, many and it stays in the ring search (the
     hand-over guard); either way the result is the oracle's."""
     m_ga, m_nga, model = world
     batch = synth.make_batch(6, n_loop=256)

@@ -29,7 +29,7 @@ def kname(k):
     if not m:
         return k.split("(")[0][:48]
     name = m.group(1)
-    if name == "icp_fit_kernel":  # two launches per batch: last template argument 0 = ring search, 2 = list sweeps
+    if name == "icp_fit_kernel":  # SLAM_ICP_SPLIT / phase timing: last template argument 0 = ring search, 2 = list sweeps
         t = re.search(r"icp_fit_kernel<([^>]*)>", k)
         if t:
             name += "_list" if t.group(1).split(",")[-1].strip() == "2" else "_ring"
