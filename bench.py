@@ -198,26 +198,42 @@ def main():
     ev = [[api.Event() for _ in range(5)] for _ in range(args.steps)]
 
     # N=1: all calls go to one created stream, so that a step can be captured into a hipGraph and replayed
-    # with a single launch (about ten launches per step otherwise).  N>1: torch's collective runs on torch's
-    # current (null) stream, and so do the library's calls.
+    # with a single launch (about nine launches per step otherwise).
+    # N>1: two streams.  A: poses in, ICP, then -- once the previous step's finalize has released the planes --
+    # count reset and raycast.  B: the RCCL sum of the planes and finalize.  The registration of step k+1 (which
+    # does not touch the planes) runs while step k's planes are merged over xGMI and finalized.
     st = None if multi else api.Stream()
+    if multi:
+        s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
+        a, b = s_a.cuda_stream, s_b.cuda_stream
+        ev_ray, ev_fin = api.Event(), api.Event()      # planes written by the raycast / released by finalize
+        L = api.lib()
+    else:
+        a = b = st
 
     def step(e=None):
         # one batch: initial poses in, a fresh local count map, register, ray-cast, merge over the GPUs, finalize
-        d_R.copy_from(d_R0, st)
-        d_t.copy_from(d_t0, st)
-        grid.reset_counts(st)
-        if e: e[0].record(st)
-        icp.fit_batch_dev(d_pts, d_off, d_nga, S, d_R, d_t, 5.0, d_res, None, st)
-        if e: e[1].record(st)
-        grid.raycast_scans_dev(d_pts, d_off, S, P, d_R, d_t, st)
-        if e: e[2].record(st)
+        d_R.copy_from(d_R0, a)
+        d_t.copy_from(d_t0, a)
+        if e: e[0].record(a)
+        icp.fit_batch_dev(d_pts, d_off, d_nga, S, d_R, d_t, 5.0, d_res, None, a)
+        if e: e[1].record(a)
         if multi:
-            for part in merge_parts:  # RCCL sum of the int32 planes over xGMI (the touched rows of both planes)
-                dist.all_reduce(part)
-        if e: e[3].record(st)
-        grid.finalize(st)
-        if e: e[4].record(st)
+            api.check(L.slam_stream_wait_event(a, ev_fin.ptr))   # no-op before the first finalize
+        grid.reset_counts(a)
+        grid.raycast_scans_dev(d_pts, d_off, S, P, d_R, d_t, a)
+        if e: e[2].record(a)
+        if multi:
+            ev_ray.record(a)
+            api.check(L.slam_stream_wait_event(b, ev_ray.ptr))
+            with torch.cuda.stream(s_b):
+                for part in merge_parts:  # RCCL sum of the int32 planes over xGMI (the touched rows of both planes)
+                    dist.all_reduce(part)
+        if e: e[3].record(b)
+        grid.finalize(b)
+        if e: e[4].record(b)
+        if multi:
+            ev_fin.record(b)
 
     merge_parts = [planes] if multi else []
     grid.clear()
