@@ -127,13 +127,17 @@ def main():
     ap.add_argument("--no-graph", action="store_true",
                     help="N=1: launch every step call by call instead of replaying one captured hipGraph")
     ap.add_argument("--no-torch", action="store_true", help="N=1 only: do not import torch at all")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the N>1 path "
+                         "with several ranks on ONE GPU: --one-device)")
+    ap.add_argument("--one-device", action="store_true", help="all ranks use GPU 0 (rehearsal with --backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearse the N>1 code path (process group + all-reduce) with one rank")
     args = ap.parse_args()
     GRID = args.grid
 
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
@@ -156,7 +160,10 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     # ---- synthetic inputs of BASELINE config 2 (per rank: its own 256 scans of the loop)
     S = args.scans
@@ -383,7 +390,7 @@ def main():
                                    "iterations vs %d-point map, Bresenham raycast into %dx%d @%.2f m, "
                                    "finalize%s" % ("2" if (S, GRID) == (256, 2000) else ("4" if (S, GRID) == (1024, 4000) else "2 (resized)"),
                                                    S, P, N_ITERS, M, GRID, GRID, RES,
-                                                   ", RCCL all-reduce of the touched rows of the int32 planes" if multi else ""),
+                                                   ", %s all-reduce of the touched rows of the int32 planes" % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)") if multi else ""),
                        "scans_per_gpu": S, "icp_iters": N_ITERS, "grid": [GRID, GRID], "resolution": RES,
                        "map_points": M, "icp_index": info, "raycast": args.raycast,
                        "raycast_worklist": grid.raycast_stats(),
