@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void raycast_global_kernel(GridView g, const B
 
 // Work list for the tiled raycast, built without atomics (so its order is
 // deterministic): for every tile the 64-beam blocks whose bounding box overlaps it.
-//   tile_items : one wavefront per tile, ballot + popcount over the block boxes; the ids go to the tile's own
+//   tile_items_wg : one workgroup per tile, ballot + popcount over the block boxes; the ids go to the tile's own
 //                row of `items` (n_blocks ids wide, so no prefix sum is needed first), the count to cnt[]
 //   the raycast workgroups turn cnt[] into segment offsets themselves (a prefix over a few hundred tiles
 //   in LDS): a segment = <= kSeg items of ONE tile, the unit a workgroup takes.
@@ -277,19 +277,18 @@ __device__ inline bool box_overlaps_tile(const int4 cb, int tx0, int ty0, int tx
 
 constexpr int kMaxLdsTiles = 2048; // segment offsets of that many tiles fit beside the LDS tile (8 KB)
 
-// FILL: 0 = count only, 1 = write the ids at item_off[t], 2 = single pass: ids at t * n_blocks, count to cnt[t]
+// Grids of more than kMaxLdsTiles tiles.  FILL: 0 = count only, 1 = write the ids at item_off[t]
 template <int FILL>
 __global__ __launch_bounds__(256) void tile_items_kernel(const int4 *block_box, int n_blocks, int tiles_x,
                                                          int n_tiles, int sx, int sy, int *cnt,
                                                          const int *item_off, int *items, int *queue)
 {
     const int t = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    if (FILL == 2 && blockIdx.x == 0 && threadIdx.x == 0) queue[0] = 0; // next segment to take
     if (t >= n_tiles) return;
     const int tx0 = (t % tiles_x) * kTile, ty0 = (t / tiles_x) * kTile;
     const int tx1 = min(tx0 + kTile, sx) - 1, ty1 = min(ty0 + kTile, sy) - 1;
     int       c = 0;
-    const int base_out = FILL == 1 ? item_off[t] : (FILL == 2 ? t * n_blocks : 0);
+    const int base_out = FILL == 1 ? item_off[t] : 0;
     for (int base = 0; base < n_blocks; base += 256) { // four independent box loads in flight per lane
         int4 cb[4];
 #pragma unroll
@@ -306,6 +305,59 @@ __global__ __launch_bounds__(256) void tile_items_kernel(const int4 *block_box, 
         }
     }
     if (FILL != 1 && lane == 0) cnt[t] = c;
+}
+
+// The single-pass form with one workgroup of 16 wavefronts per tile: every lane looks at up to four block boxes per
+// trip (all loads in flight at once), the wavefronts' match counts go through LDS, and the ids land in the tile's row
+// in ascending block order as before (17 dependent trips of one wavefront per tile took 11 us on config 2).
+__global__ __launch_bounds__(1024) void tile_items_wg_kernel(const int4 *block_box, int n_blocks, int tiles_x, int sx,
+                                                             int sy, int *cnt, int *items, int *queue)
+{
+    __shared__ int s_cnt[4][16], s_base;
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (t == 0 && tid == 0) queue[0] = 0; // next segment to take
+    if (tid == 0) s_base = 0;
+    const int tx0 = (t % tiles_x) * kTile, ty0 = (t / tiles_x) * kTile;
+    const int tx1 = min(tx0 + kTile, sx) - 1, ty1 = min(ty0 + kTile, sy) - 1;
+    const int base_out = t * n_blocks;
+    for (int base = 0; base < n_blocks; base += 4096) {
+        int4 cb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = base + 1024 * j + tid;
+            cb[j] = ch < n_blocks ? block_box[ch] : make_int4(0, 0, -1, -1);
+        }
+        unsigned long long m[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            m[j] = __ballot(box_overlaps_tile(cb[j], tx0, ty0, tx1, ty1));
+            if (lane == 0) s_cnt[j][wave] = __popcll(m[j]);
+        }
+        __syncthreads(); // the counts of this trip (and s_base of the previous one) are visible
+        int total = 0; // ids are ordered by (j, wave, lane) = ascending block id
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            for (int w = 0; w < 16; ++w) {
+                const int c = s_cnt[j][w];
+                total += c;
+            }
+        int run = s_base;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int mine = run;
+            for (int w = 0; w < 16; ++w) {
+                const int c = s_cnt[j][w];
+                mine += w < wave ? c : 0;
+                run += c;
+            }
+            if ((m[j] >> lane) & 1ull)
+                items[base_out + mine + __popcll(m[j] & ((1ull << lane) - 1ull))] = base + 1024 * j + tid;
+        }
+        __syncthreads(); // everyone has read s_cnt and s_base
+        if (tid == 0) s_base += total;
+    }
+    __syncthreads();
+    if (tid == 0) cnt[t] = s_base;
 }
 
 __global__ __launch_bounds__(1024) void tile_scan_kernel(const int *cnt, int n_tiles, int *item_off, int *seg_off,
@@ -786,8 +838,8 @@ int walk_beams(slam_grid *g, int n, hipStream_t st)
         g->last_chunks = n_chunks;
         if (n_tiles <= kMaxLdsTiles) {
             // one pass over the block boxes; the raycast workgroups derive the segment offsets themselves
-            hipLaunchKernelGGL((tile_items_kernel<2>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
-                               n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items, g->d_queue);
+            hipLaunchKernelGGL(tile_items_wg_kernel, dim3(n_tiles), dim3(1024), 0, st, g->d_chunk_box, n_chunks, tiles_x,
+                               g->gv.sx, g->gv.sy, g->d_tile_cnt, g->d_items, g->d_queue);
             hipLaunchKernelGGL(raycast_tiled_kernel, dim3(g->wg_per_cu * g->n_cu), dim3(kTileThreads), 0, st, g->gv, g->d_beams,
                                n, g->d_items, item_off, seg_off, n_tiles, g->d_queue, tiles_x, g->seg_items, g->ablate,
                                g->d_tile_cnt, n_chunks);
