@@ -176,10 +176,10 @@ def main():
     d_pts = api.DeviceArray.from_host(batch.pts, np.float64)
     d_off = api.DeviceArray.from_host(batch.scan_off, np.int32)
     d_nga = api.DeviceArray.from_host(batch.scan_nga, np.int32)
-    d_R0 = api.DeviceArray.from_host(batch.R, np.float64)
-    d_t0 = api.DeviceArray.from_host(batch.t, np.float64)
-    d_R = api.DeviceArray(batch.R.shape, np.float64)
-    d_t = api.DeviceArray(batch.t.shape, np.float64)
+    # the batch's initial poses arrive as one block [R (4 per scan) | t (2 per scan)]: one copy per step
+    d_pose0 = api.DeviceArray.from_host(np.concatenate([batch.R.ravel(), batch.t.ravel()]), np.float64)
+    d_pose = api.DeviceArray(d_pose0.shape, np.float64)
+    d_R, d_t = d_pose.view(0, batch.R.shape), d_pose.view(batch.R.size, batch.t.shape)
     d_res = api.DeviceArray((S,), api.RESULT_DTYPE)
 
     planes = None
@@ -220,8 +220,7 @@ def main():
 
     def step(e=None):
         # one batch: initial poses in, a fresh local count map, register, ray-cast, merge over the GPUs, finalize
-        d_R.copy_from(d_R0, a)
-        d_t.copy_from(d_t0, a)
+        d_pose.copy_from(d_pose0, a)
         if e: e[0].record(a)
         icp.fit_batch_dev(d_pts, d_off, d_nga, S, d_R, d_t, 5.0, d_res, None, a)
         if e: e[1].record(a)

@@ -266,10 +266,21 @@ class DeviceArray:
     def zero(self, stream=None):
         check(lib().slam_memset(self.ptr, 0, self.nbytes, stream))
 
+    def view(self, first, shape):
+        """`shape` elements of this block from element `first` on: shares the memory, does not own it."""
+        v = object.__new__(DeviceArray)
+        v.shape = tuple(shape)
+        v.dtype = self.dtype
+        v.nbytes = int(np.prod(v.shape)) * self.dtype.itemsize
+        assert first >= 0 and first * self.dtype.itemsize + v.nbytes <= self.nbytes
+        v.ptr = self.ptr + first * self.dtype.itemsize
+        v.owner = self   # keeps the block alive
+        return v
+
     def free(self):
-        if getattr(self, "ptr", None):
+        if getattr(self, "ptr", None) and getattr(self, "owner", None) is None:
             lib().slam_free(self.ptr)
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
