@@ -197,13 +197,24 @@ __global__ __launch_bounds__(kChunk) void beams_from_scans_kernel(GridView g, co
     b.x0 = -1;
     b.y0 = b.x1 = b.y1 = 0;
     if (in) {
-        int lo = 0, hi = n_scans - 1; // scan of point i: last s with scan_off[s] <= i
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (scan_off[mid] <= i)
-                lo = mid;
-            else
-                hi = mid - 1;
+        // scan of point i: the last s with scan_off[s] <= i.  Scans of a batch are about the same size, so the
+        // proportional guess is right or one off: a few steps from there instead of log2(n_scans) dependent loads
+        // (the bisection below takes over for ragged batches)
+        int lo = (int)(((long long)i * n_scans) / max(n, 1));
+        lo = min(max(lo, 0), n_scans - 1);
+        int steps = 0;
+        while (steps < 4 && scan_off[lo] > i) --lo, ++steps;
+        while (steps < 4 && lo + 1 < n_scans && scan_off[lo + 1] <= i) ++lo, ++steps;
+        if (scan_off[lo] > i || (lo + 1 < n_scans && scan_off[lo + 1] <= i)) {
+            lo = 0;
+            int hi = n_scans - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (scan_off[mid] <= i)
+                    lo = mid;
+                else
+                    hi = mid - 1;
+            }
         }
         const double *Rs = R + 4 * (size_t)lo, *ts = t + 2 * (size_t)lo;
         const double2 P = pts[i];

@@ -147,6 +147,44 @@ def test_raycast_scans_equals_explicit_rays():
     g.close()
 
 
+def test_raycast_scans_ragged_batch():
+    """Scans of very different sizes, empty ones among them: the point -> scan lookup of the pre-pass starts from a
+    proportional guess and has to fall back to bisection here."""
+    full = synth.make_batch(12, n_loop=256)
+    sizes = [5, 1081, 0, 1, 700, 0, 0, 1081, 33, 2, 900, 64]
+    pts, off = [], [0]
+    for s, k in enumerate(sizes):
+        o = full.scan_off[s]
+        pts.append(full.pts[o:o + k])
+        off.append(off[-1] + k)
+    pts = np.concatenate(pts)
+    off = np.array(off, np.int32)
+    Rt = [synth.pose_to_Rt(*p) for p in full.true_poses]
+    R = np.stack([r.reshape(4) for r, _ in Rt])
+    t = np.stack([tt for _, tt in Rt])
+    g = api.Grid(1000, 1000, 0.05, rolling=0)
+    d_pts = api.DeviceArray.from_host(pts, np.float64)
+    d_off = api.DeviceArray.from_host(off, np.int32)
+    d_R = api.DeviceArray.from_host(R, np.float64)
+    d_t = api.DeviceArray.from_host(t, np.float64)
+    g.raycast_scans_dev(d_pts, d_off, len(sizes), len(pts), d_R, d_t)
+    api.synchronize()
+    hits, misses = g.read_counts()
+    eh = np.zeros(g.cells, np.int32)
+    em = np.zeros(g.cells, np.int32)
+    total = 0
+    for s in range(len(sizes)):
+        o, e = off[s], off[s + 1]
+        if e == o:
+            continue
+        end = O.transform_points(pts[o:e], R[s], t[s])
+        origin = np.tile(t[s].astype(np.float32), (e - o, 1))
+        _, _, n = O.grid_raycast(og(g), origin, end, eh, em)
+        total += n
+    assert np.array_equal(hits, eh) and np.array_equal(misses, em) and g.total_updates() == total
+    g.close()
+
+
 def test_finalize_matches_oracle_rule():
     rs = np.random.RandomState(11)
     g = api.Grid(80, 60, 0.5, min_cluster_points=3, rolling=1)
