@@ -243,6 +243,34 @@ def test_config2_full_size_properties(world):
     icp.close()
 
 
+def test_config4_share_1024_scans_properties(world):
+    """One GPU's share of BASELINE config 4: 1024 scans in one launch, four workgroups per CU in turn.  The same
+    size-independent checks: determinism, independence of the batch it runs in (each quarter alone gives the same
+    bits), convergence; and the early-exit form (min_delta 1e-6) against the oracle on a sample of the scans."""
+    m_ga, m_nga, model = world
+    batch = synth.make_batch(1024)
+    icp = api.Icp(m_ga, m_nga, max_iter=30, min_delta=-1.0)
+    R, t, res, _ = icp.fit_batch(batch)
+    R2, t2, _, _ = icp.fit_batch(batch)
+    assert np.array_equal(R, R2) and np.array_equal(t, t2)
+    for q in range(4):
+        Rq, tq, _, _ = icp.fit_batch(batch.shard(q, 4))
+        assert np.array_equal(Rq, R[256 * q:256 * (q + 1)]) and np.array_equal(tq, t[256 * q:256 * (q + 1)]), q
+    assert (res["iters"] == 30).all() and (res["n_corr"] > 900).all()
+    assert np.abs(t - batch.true_poses[:, :2]).max() < 0.03
+    assert ang_diff(yaw(R), batch.true_poses[:, 2]).max() < 3e-3
+    icp.close()
+    icp = api.Icp(m_ga, m_nga, max_iter=30, min_delta=1e-6)
+    R, t, res, _ = icp.fit_batch(batch)
+    for s in range(0, 1024, 97):
+        o, e, g = batch.scan_off[s], batch.scan_off[s + 1], batch.scan_nga[s]
+        Ro, to, trace, steps = model.fit(batch.pts[o:o + g], batch.pts[o + g:e], batch.R[s].reshape(2, 2), batch.t[s],
+                                         O.icp_params(30, 1e-6, 5.0))
+        assert res["iters"][s] == steps, s
+        assert np.abs(t[s] - to).max() < POS_TOL and abs(ang_diff(yaw(R[s:s + 1]), yaw(Ro.reshape(1, 4)))[0]) < ANG_TOL, s
+    icp.close()
+
+
 def test_point_to_line_mode_matches_own_oracle():
     """north-star 3x3 normal-equation step (icpPointToPlane.cpp:37-107, not compiled
     upstream): normals and poses against the build's own scalar oracle."""
