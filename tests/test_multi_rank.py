@@ -112,3 +112,22 @@ def test_rccl_allreduce_single_rank_is_identity():
     assert np.array_equal(hits, eh) and np.array_equal(misses, em)
     comm.close()
     g.close()
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """The N > 1 path of bench.py -- two streams per rank, touched-row merge, the checks that the merged planes
+    hold every rank's updates exactly once -- with two ranks sharing this one GPU (gloo stands in for RCCL, which
+    does not put two ranks on one device)."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--scans", "64",
+           "--backend", "gloo", "--one-device", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["merge_rows"] is not None
+    assert d["config"]["scans_per_gpu"] == 64
