@@ -2072,6 +2072,7 @@ int slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga
     h->G = h->prm.lanes_per_point > 0 ? h->prm.lanes_per_point : (h->prm.lanes_per_point == -1 ? 0 : 2);
     h->two_phase = h->prm.lanes_per_point == 0 && h->prm.mode == SLAM_ICP_P2P;
     if (const char *e = getenv("SLAM_ICP_SPLIT")) h->split_launch = atoi(e) != 0;
+    if (const char *e = getenv("SLAM_ICP_CELL")) h->prm.cell_size = atof(e); // measurements: overrides the pitch
     if (const char *e = getenv("SLAM_ICP_SWITCH_ITER")) h->switch_iter = atoi(e);
     if (const char *e = getenv("SLAM_ICP_FAR_DIV")) h->far_div = std::max(atoi(e), 1);
     int rc = build_index(h, m_ga, n_ga, m_nga, n_nga);
