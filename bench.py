@@ -323,25 +323,6 @@ def main():
     seg = np.array([[e[i].elapsed_ms(e[i + 1]) for i in range(4)] for e in ev]) if args.steps else np.zeros((1, 4))
     ms_icp, ms_ray, ms_merge, ms_fin = seg.mean(axis=0)
 
-    # the default ICP schedule is ONE launch (icp_fit_fused_kernel): ring search for the first iterations of a
-    # scan, list sweeps for the rest.  For the record the two forms are timed apart in a few extra, untimed steps
-    # run as two launches (what slam_icp_debug_phase_events switches to)
-    ms_ring = ms_list = None
-    if args.lanes == 0 and args.steps:
-        import ctypes as C
-        L = api.lib()
-        L.slam_icp_debug_phase_events.argtypes = [C.c_void_p, C.c_int]
-        L.slam_icp_debug_phase_ms.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        api.check(L.slam_icp_debug_phase_events(icp.h, 1))
-        for _ in range(10):
-            step()
-        sync()
-        pm, calls = (C.c_double * 2)(), C.c_int(0)
-        api.check(L.slam_icp_debug_phase_ms(icp.h, pm, C.byref(calls)))
-        api.check(L.slam_icp_debug_phase_events(icp.h, 0))
-        if calls.value:
-            ms_ring, ms_list = pm[0], pm[1]   # averages over the calls
-
     # sanity on the result of the last step (not timed): all scans registered
     res = d_res.download()
     t_fin = d_t.download()
@@ -400,8 +381,6 @@ def main():
             "kernel_ms": {"icp": float(ms_icp), "raycast": float(ms_ray), "merge": float(ms_merge),
                           "finalize": float(ms_fin)},
             "kernels": kernels,
-            "icp_forms_as_two_launches_ms": ({"ring_search_first_iterations": ms_ring, "list_sweeps_rest": ms_list}
-                                             if ms_ring is not None else None),
             "roofline": roof,
             "max_pose_error_m": pose_err,
             "device": api.device_info()[0],

@@ -102,6 +102,13 @@ typedef struct {
                                per pass; -2 = list sweeps for every iteration (measurements) */
     double cell_size;       /* model lattice pitch in metres; 0 = sized to fit LDS */
     int    force_global;    /* 1 = keep the model index in HBM/L2 even if it fits LDS */
+    int    build_on_host;   /* 1 = build the model index with the single-threaded host code instead of the
+                               device kernels (the reference the device build is verified against: same bytes) */
+    int    first_iterations;/* default schedule: ring-search iterations before a scan may change to list sweeps
+                               (0 = library default, 10) */
+    int    far_div;         /* default schedule: hand over once at most n / far_div queries are beyond the lists'
+                               certified radius (0 = library default, 32) */
+    int    split_launch;    /* 1 = the two search forms as two launches instead of one (same results) */
 } slam_icp_params;
 
 typedef struct {
@@ -117,6 +124,10 @@ void slam_icp_default_params(slam_icp_params *p);
  * index replaces the two kd-trees; the exact-1-NN-in-float contract is kept. */
 int  slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga,
                      const slam_icp_params *params, slam_icp_t **out);
+/* The same with the model arrays resident in HBM (a target built from registered scans: the sliding local
+ * map of a streaming mapper).  Synchronises the default stream; the arrays must be complete before the call. */
+int  slam_icp_create_dev(const double *d_m_ga, int n_ga, const double *d_m_nga, int n_nga,
+                         const slam_icp_params *params, slam_icp_t **out);
 void slam_icp_destroy(slam_icp_t *icp);
 int  slam_icp_set_max_iterations(slam_icp_t *icp, int val);  /* icp.h:51 */
 int  slam_icp_set_min_delta(slam_icp_t *icp, double val);    /* icp.h:54 */
@@ -160,6 +171,13 @@ int slam_icp_get_normals(slam_icp_t *icp, double *normals_xy);
 /* what the index looks like (for DESIGN.md / bench reporting) */
 int slam_icp_index_info(slam_icp_t *icp, int *nx, int *ny, double *cell, int *in_lds,
                         size_t *lds_bytes, int *lanes_per_point);
+/* How the index was built: on_device = 1 for the device kernels; ms[0..3] = host wall time of the model
+ * upload and extent, the cell-index kernels' enqueue, the list plan (the build's one read-back) and the list
+ * kernels' enqueue. */
+int slam_icp_build_info(slam_icp_t *icp, int *on_device, double ms[4]);
+/* The index as it lies in HBM: which = 0 the cell index, 1 the halo lists (0 bytes when the model has
+ * none).  bytes (optional) receives the size; buf (optional, cap bytes) the content.  Synchronous. */
+int slam_icp_index_blob(slam_icp_t *icp, int which, void *buf, size_t cap, size_t *bytes);
 /* The default point-to-point schedule: two_forms = 1 when the halo lists fit LDS for this model (the ring
  * search then runs at least the first `first_iterations` iterations of a scan and the list sweeps the rest, in
  * one launch: the workgroup swaps its LDS contents); list lattice pitch, halo and certified radius in metres,
@@ -182,6 +200,9 @@ typedef struct {
     int    min_cluster_points;  /* mls.h:165 (10); local_mapper.cpp:86 sets 20 */
     int    rolling;             /* MLS(..., bool roll) mls.h:154 */
     int    raycast_impl;        /* SLAM_RAYCAST_* */
+    int    raycast_seg_items;   /* tiled raycast: 64-beam blocks of one tile a workgroup accumulates before it
+                                   writes the tile back; 0 = sized from the work list; at most 1023 */
+    int    raycast_wg_per_cu;   /* tiled raycast: persistent workgroups per CU; 0 = library default (2) */
 } slam_grid_params;
 
 void slam_grid_default_params(slam_grid_params *p);

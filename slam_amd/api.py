@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libslam_mi355x.so")
+# SLAM_AMD_MEASURE=1 loads the measurement build (python -m slam_amd.build --measure) for the tools/ scripts
+LIB_PATH = os.path.join(HERE, "lib", "libslam_mi355x_measure.so" if os.environ.get("SLAM_AMD_MEASURE") == "1"
+                        else "libslam_mi355x.so")
 RCCL_LIB_PATH = os.path.join(HERE, "lib", "libslam_mi355x_rccl.so")
 
 SLAM_OK = 0
@@ -29,7 +31,8 @@ class SlamError(RuntimeError):
 class IcpParams(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("min_delta", C.c_double), ("mode", C.c_int),
                 ("normals_k", C.c_int), ("lanes_per_point", C.c_int), ("cell_size", C.c_double),
-                ("force_global", C.c_int)]
+                ("force_global", C.c_int), ("build_on_host", C.c_int), ("first_iterations", C.c_int),
+                ("far_div", C.c_int), ("split_launch", C.c_int)]
 
 
 class IcpResult(C.Structure):
@@ -39,7 +42,8 @@ class IcpResult(C.Structure):
 class GridParams(C.Structure):
     _fields_ = [("max_range", C.c_double), ("occupancy_increment", C.c_double),
                 ("occupancy_decrement", C.c_double), ("min_cluster_points", C.c_int),
-                ("rolling", C.c_int), ("raycast_impl", C.c_int)]
+                ("rolling", C.c_int), ("raycast_impl", C.c_int), ("raycast_seg_items", C.c_int),
+                ("raycast_wg_per_cu", C.c_int)]
 
 
 class GsegParams(C.Structure):
@@ -67,7 +71,8 @@ EXPORTS = [
     "slam_stream_create", "slam_stream_destroy", "slam_stream_synchronize",
     "slam_device_synchronize", "slam_event_create", "slam_event_destroy", "slam_event_record",
     "slam_event_synchronize", "slam_event_elapsed_ms",
-    "slam_icp_default_params", "slam_icp_create", "slam_icp_destroy",
+    "slam_icp_default_params", "slam_icp_create", "slam_icp_create_dev", "slam_icp_destroy",
+    "slam_icp_build_info", "slam_icp_index_blob",
     "slam_icp_set_max_iterations", "slam_icp_set_min_delta", "slam_icp_set_subsampling_step",
     "slam_icp_fit", "slam_icp_fit_batch_dev", "slam_icp_nearest_dev", "slam_icp_get_edge_weight",
     "slam_icp_get_normals",
@@ -139,6 +144,9 @@ def lib():
     L.slam_event_elapsed_ms.argtypes = [_vp, _vp, C.POINTER(C.c_float)]
     L.slam_device_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
     L.slam_icp_create.argtypes = [_vp, C.c_int, _vp, C.c_int, C.POINTER(IcpParams), C.POINTER(_vp)]
+    L.slam_icp_create_dev.argtypes = [_vp, C.c_int, _vp, C.c_int, C.POINTER(IcpParams), C.POINTER(_vp)]
+    L.slam_icp_build_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.slam_icp_index_blob.argtypes = [_vp, C.c_int, _vp, C.c_size_t, C.POINTER(C.c_size_t)]
     L.slam_icp_destroy.argtypes = [_vp]
     L.slam_icp_set_max_iterations.argtypes = [_vp, C.c_int]
     L.slam_icp_set_min_delta.argtypes = [_vp, C.c_double]
@@ -406,6 +414,33 @@ class Icp:
         check(lib().slam_icp_create(_ptr(self.m_ga), len(self.m_ga), _ptr(self.m_nga),
                                     len(self.m_nga), C.byref(self.params), C.byref(h)))
         self.h = h.value
+
+    @classmethod
+    def from_device(cls, d_ga, n_ga, d_nga, n_nga, params=None, **kw):
+        """slam_icp_create_dev: the model arrays (f64 xy) are DeviceArrays / device pointers."""
+        self = object.__new__(cls)
+        self.m_ga = self.m_nga = None
+        self.n_model = (int(n_ga), int(n_nga))
+        self.params = params or icp_default_params(**kw)
+        h = _vp()
+        check(lib().slam_icp_create_dev(getattr(d_ga, "ptr", d_ga), int(n_ga), getattr(d_nga, "ptr", d_nga), int(n_nga),
+                                        C.byref(self.params), C.byref(h)))
+        self.h = h.value
+        return self
+
+    def build_info(self):
+        on, ms = C.c_int(0), (C.c_double * 4)()
+        check(lib().slam_icp_build_info(self.h, C.byref(on), ms))
+        return bool(on.value), list(ms)
+
+    def index_blob(self, which):
+        """The cell index (which = 0) or the halo lists (1) as they lie in HBM, as bytes."""
+        n = C.c_size_t(0)
+        check(lib().slam_icp_index_blob(self.h, int(which), None, 0, C.byref(n)))
+        buf = np.zeros(n.value, np.uint8)
+        if n.value:
+            check(lib().slam_icp_index_blob(self.h, int(which), _ptr(buf), n.value, None))
+        return buf
 
     def set_max_iterations(self, v):
         check(lib().slam_icp_set_max_iterations(self.h, int(v)))

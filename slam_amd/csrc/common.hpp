@@ -17,6 +17,14 @@ int  require_device();
 
 inline hipStream_t as_stream(slam_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Device-memory pool for the short-lived buffers of a handle (the reference constructs its matcher per
+// scan, icpTools.cpp:187: a hipMalloc/hipFree pair per buffer would cost more than the match).  pool_alloc
+// returns a cached block of at least `bytes` or allocates one; pool_free puts it back -- the caller guarantees
+// that no enqueued work still uses it (hipFree would have synchronised; the pool does not).
+void *pool_alloc(size_t bytes);
+void  pool_free(void *p);
+void  pool_trim(); // hipFree of everything cached
+
 } // namespace slam
 
 #define SLAM_HIP(expr)                                                          \

@@ -463,8 +463,14 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
                                                                         const int *items, const int *item_off,
                                                                         const int *seg_off, int n_tiles,
                                                                         int *queue, int tiles_x, int kSeg,
-                                                                        int ablate, const int *cnt, int item_stride)
+                                                                        int ablate_arg, const int *cnt, int item_stride)
 {
+#ifdef SLAM_MEASURE // timing experiments only (tools/ablate.sh): bits switch parts of the kernel off -- wrong counts
+    const int ablate = ablate_arg;
+#else
+    constexpr int ablate = 0;
+    (void)ablate_arg;
+#endif
     __shared__ __attribute__((aligned(16))) unsigned tile[kTile * kTileStride];
     __shared__ int s_seg, s_pair;
     __shared__ int s_segoff[kMaxLdsTiles + 1], s_wsum[kTileThreads / 64], s_carry;
@@ -889,6 +895,8 @@ void slam_grid_default_params(slam_grid_params *p)
     p->min_cluster_points = 10;   // mls.h:165
     p->rolling = 1;               // local_mapper.cpp:29 MLS(200,200,0.2,true)
     p->raycast_impl = SLAM_RAYCAST_TILED;
+    p->raycast_seg_items = 0;
+    p->raycast_wg_per_cu = 0;
 }
 
 int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_params *params,
@@ -912,9 +920,15 @@ int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             g->n_cu = std::max(1, prop.multiProcessorCount);
     }
-    if (const char *e = getenv("SLAM_RAYCAST_SEG")) g->seg_items = std::max(0, atoi(e));
+    // a segment adds up to 64 * seg_items misses to one 16-bit packed LDS counter (the sensor cell): 1023 is the
+    // most that cannot carry into the hit half
+    g->seg_items = std::min(std::max(g->prm.raycast_seg_items, 0), 1023);
+    if (g->prm.raycast_wg_per_cu > 0) g->wg_per_cu = std::min(g->prm.raycast_wg_per_cu, 8);
+#ifdef SLAM_MEASURE
+    if (const char *e = getenv("SLAM_RAYCAST_SEG")) g->seg_items = std::min(std::max(0, atoi(e)), 1023);
     if (const char *e = getenv("SLAM_RAYCAST_ABLATE")) g->ablate = atoi(e);
     if (const char *e = getenv("SLAM_RAYCAST_WGPCU")) g->wg_per_cu = std::max(1, atoi(e));
+#endif
     int rc = SLAM_OK;
     auto alloc = [&](void **p, size_t bytes) {
         if (rc == SLAM_OK && hipMalloc(p, bytes) != hipSuccess) {

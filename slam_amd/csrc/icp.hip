@@ -34,477 +34,21 @@
 
 #include "common.hpp"
 
+#include "icp_search.hpp"
+
 using namespace slam;
+using namespace slam::icp;
+
+// In-kernel stamps, the two-launch schedule with events and the environment knobs of the round-1 sweeps exist
+// only in a measurement build (python -m slam_amd.build --measure: -DSLAM_MEASURE, a library of its own that
+// the tools/ scripts load); the shipped library reads no environment variable and executes no stamp.
+#ifdef SLAM_MEASURE
+#define SLAM_STAMPS(fa) ((fa).stamps != nullptr)
+#else
+#define SLAM_STAMPS(fa) false
+#endif
 
 namespace {
-
-constexpr int kBlock = 1024;          // threads per scan workgroup
-constexpr int kWaves = kBlock / 64;
-constexpr int kNumAcc = 9;            // doubles reduced per iteration
-constexpr int kStampSlots = 9;        // diagnostic stamps per wavefront
-constexpr int kHoist = 3;             // passes whose points stay in registers across iterations
-constexpr unsigned kLdsTotal = 160u * 1024u;
-constexpr int kCoop = 8;                       // lanes per query in the cooperative rounds
-constexpr int kCoopPerWave = 64 / kCoop;       // queries a wavefront searches at a time
-constexpr int kCoopPerBlock = kWaves * kCoopPerWave;
-constexpr unsigned kReduceBytes = (2u * kWaves * kNumAcc + 2u * 8u) * sizeof(double); // reduction + broadcast
-constexpr unsigned kQueueBytes = 4u * kWaves + 2u * kBlock; // per-wavefront counts + 64 u16 entries per wavefront
-static_assert(kHoist == 3, "the pass loop selects Pc0, Pc1, Pc2 explicitly");
-static_assert(kWaves == 16 && 16 % kCoop == 0, "drain_queue keeps one wavefront count per lane of a 16-lane DPP row");
-constexpr unsigned kScratchBytes = (kReduceBytes + kQueueBytes + 15u) & ~15u;
-
-struct Lattice {
-    int   nx, ny;
-    float x0, y0, h, inv_h;
-    float margin; // subtracted from r*h before squaring: absorbs f32 rounding of the cell assignment
-};
-
-// Device view of the model index.  All offsets are bytes into `blob`.
-struct ModelView {
-    const unsigned char *blob;
-    unsigned blob_bytes;
-    unsigned off_pts;       // float2[n_all]: class 0 (GA) sorted by cell, then class 1 (NGA)
-    unsigned off_start[2];  // StartT[ncells+1] per class, positions relative to the class base
-    unsigned off_oidx;      // StartT[n_all]: original index within the class
-    int      n_cls[2];
-    int      base[2];       // first point of each class in pts
-    Lattice  lat;
-    double   cx, cy;        // shift origin for the running sums (model centroid)
-    const double *normals;  // P2L: double2 per ORIGINAL all-index (GA then NGA), or null
-    // Halo lists (list-sweep mode): per class and cell of a second, coarser lattice, every point within the
-    // cell dilated by `pad` cells, ordered along the axis of larger extent.  A query whose best distance
-    // over its own cell's list is below cert2 has seen every point that close: no neighbour cells.
-    const unsigned char *lblob;
-    unsigned lblob_bytes;
-    unsigned loff_pts;      // float2[n_ent[0] + n_ent[1]]
-    unsigned loff_start[2]; // u16[lcells+1] per class, positions relative to the class base
-    unsigned loff_axis[2];  // two bits per cell and class: the list's ordering key (list_key)
-    float    lkeps;         // rounding allowance of a diagonal key difference, metres
-    int      lbase[2];      // first entry of each class
-    Lattice  llat;
-    float    lpad;          // halo in cell units
-    float    cert2;         // squared certified radius (metres^2)
-};
-
-template <typename StartT>
-struct IndexPtrs {
-    const float2 *pts;
-    const StartT *start[2];
-    const StartT *oidx;
-};
-
-template <typename StartT>
-__device__ inline IndexPtrs<StartT> make_ptrs(const unsigned char *base, const ModelView &mv)
-{
-    IndexPtrs<StartT> ix;
-    ix.pts = reinterpret_cast<const float2 *>(base + mv.off_pts);
-    ix.start[0] = reinterpret_cast<const StartT *>(base + mv.off_start[0]);
-    ix.start[1] = reinterpret_cast<const StartT *>(base + mv.off_start[1]);
-    ix.oidx = reinterpret_cast<const StartT *>(base + mv.off_oidx);
-    return ix;
-}
-
-__device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-struct Best {
-    float    d;    // squared float distance (kdtree.h:33)
-    unsigned oidx; // original index within the class (kdtree.h:34); filled by nn_search on return
-    int      pos;  // position in the sorted pts array, -1 = none
-};
-
-// kdtree.cpp:610-612: dis += squared(data[i][k]-qv[k]), k = 0 then 1, no FMA
-__device__ inline float dist2(const float2 m, float qx, float qy)
-{
-    const float dx = m.x - qx;
-    const float dy = m.y - qy;
-    return __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-}
-
-// Candidate i at squared distance d.  Ties go to the lowest ORIGINAL index (the
-// reference leaves ties to the kd-tree's visit order; this is the brute-force
-// arbiter's rule, kdtree.cpp:360-375): the index is only read when d == best.
-template <typename StartT>
-__device__ inline void consider(Best &b, float d, int i, const StartT *oidx)
-{
-    if (d < b.d) {
-        b.d = d;
-        b.pos = i;
-    } else if (d == b.d && b.pos >= 0) {
-        if ((unsigned)oidx[i] < (unsigned)oidx[b.pos]) b.pos = i;
-    }
-}
-
-// All points of cells [c0, c1] of one lattice row: they are contiguous in the
-// sorted array.  The G lanes of the group take consecutive points; four loads
-// are kept in flight per lane and their distances are independent chains.
-// EXACT = false is the fast form: branch-free minimum by (distance, position)
-// plus a flag that says whether an exact tie d == best was ever seen; the
-// caller then repeats the search with EXACT = true (ties by original index).
-template <int G, typename StartT, bool EXACT>
-__device__ inline void scan_span(Best &b, bool &tie, const StartT *start, const float2 *pts, const StartT *oidx,
-                                 int row_base, int c0, int c1, int sub, float qx, float qy)
-{
-    if (c0 > c1) return;
-    const int a = (int)start[row_base + c0];
-    const int e = (int)start[row_base + c1 + 1];
-    int       i = a + sub;
-    for (; i + 3 * G < e; i += 4 * G) {
-        const float2 m0 = pts[i], m1 = pts[i + G], m2 = pts[i + 2 * G], m3 = pts[i + 3 * G];
-        const float  d0 = dist2(m0, qx, qy), d1 = dist2(m1, qx, qy), d2 = dist2(m2, qx, qy), d3 = dist2(m3, qx, qy);
-        if (EXACT) {
-            if (fminf(fminf(d0, d1), fminf(d2, d3)) <= b.d) {
-                consider<StartT>(b, d0, i, oidx);
-                consider<StartT>(b, d1, i + G, oidx);
-                consider<StartT>(b, d2, i + 2 * G, oidx);
-                consider<StartT>(b, d3, i + 3 * G, oidx);
-            }
-        } else {
-            // min of the four (first position wins), then one compare against the running best
-            const bool  s01 = d1 < d0, s23 = d3 < d2;
-            const float m01 = s01 ? d1 : d0, m23 = s23 ? d3 : d2;
-            const int   p01 = s01 ? i + G : i, p23 = s23 ? i + 3 * G : i + 2 * G;
-            const bool  s = m23 < m01;
-            const float m = s ? m23 : m01;
-            const int   pm = s ? p23 : p01;
-            tie |= (d0 == d1) | (d2 == d3) | (m01 == m23) | (m == b.d);
-            const bool up = m < b.d;
-            b.d = up ? m : b.d;
-            b.pos = up ? pm : b.pos;
-        }
-    }
-    for (; i < e; i += G) {
-        const float d = dist2(pts[i], qx, qy);
-        if (EXACT) {
-            consider<StartT>(b, d, i, oidx);
-        } else {
-            tie |= (d == b.d);
-            const bool up = d < b.d;
-            b.d = up ? d : b.d;
-            b.pos = up ? i : b.pos;
-        }
-    }
-}
-
-// Fast-path minimum over the G lanes of a group: (distance, position) only, on the DPP cross-lane path for
-// the steps inside a row of 16 (no LDS round trip); equal distances at different positions raise `tie`,
-// which sends the group to the exact pass.  `tie` itself is OR-ed over the group.
-template <int CTRL>
-__device__ inline void lean_step_dpp(Best &b, bool &tie)
-{
-    const float od = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b.d), CTRL, 0xf, 0xf, false));
-    const int   op = __builtin_amdgcn_update_dpp(0, b.pos, CTRL, 0xf, 0xf, false);
-    const int   ot = __builtin_amdgcn_update_dpp(0, (int)tie, CTRL, 0xf, 0xf, false);
-    tie |= (bool)ot | ((od == b.d) & (op != b.pos) & (op >= 0) & (b.pos >= 0));
-    const bool take = (od < b.d) | ((od == b.d) & (op >= 0) & ((b.pos < 0) | (op < b.pos)));
-    b.d = take ? od : b.d;
-    b.pos = take ? op : b.pos;
-}
-
-__device__ inline void lean_step_shfl(Best &b, bool &tie, int mask)
-{
-    const float od = __shfl_xor(b.d, mask);
-    const int   op = __shfl_xor(b.pos, mask);
-    const int   ot = __shfl_xor((int)tie, mask);
-    tie |= (bool)ot | ((od == b.d) & (op != b.pos) & (op >= 0) & (b.pos >= 0));
-    const bool take = (od < b.d) | ((od == b.d) & (op >= 0) & ((b.pos < 0) | (op < b.pos)));
-    b.d = take ? od : b.d;
-    b.pos = take ? op : b.pos;
-}
-
-template <int G>
-__device__ inline void group_min_lean(Best &b, bool &tie)
-{
-    if (G >= 2) lean_step_dpp<0xB1>(b, tie);  // quad_perm [1,0,3,2]
-    if (G >= 4) lean_step_dpp<0x4E>(b, tie);  // quad_perm [2,3,0,1]
-    if (G >= 8) lean_step_dpp<0x141>(b, tie); // row_half_mirror
-    if (G >= 16) lean_step_dpp<0x140>(b, tie); // row_mirror
-    if (G >= 32) lean_step_shfl(b, tie, 16);
-    if (G >= 64) lean_step_shfl(b, tie, 32);
-}
-
-template <int G, typename StartT>
-__device__ inline void group_min(Best &b, const StartT *oidx)
-{
-    b.oidx = b.pos >= 0 ? (unsigned)oidx[b.pos] : 0xffffffffu;
-#pragma unroll
-    for (int off = 1; off < G; off <<= 1) {
-        const float    od = __shfl_xor(b.d, off);
-        const unsigned oo = (unsigned)__shfl_xor((int)b.oidx, off);
-        const int      op = __shfl_xor(b.pos, off);
-        if (od < b.d || (od == b.d && oo < b.oidx)) {
-            b.d = od;
-            b.oidx = oo;
-            b.pos = op;
-        }
-    }
-}
-
-template <int G, typename StartT, bool EXACT>
-__device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, float qx, float qy,
-                                      int sub, double gate, bool &tie);
-
-// The search proper: fast pass, and the exact pass only for a group that met an
-// exact distance tie (measure zero on noisy data, common on gridded maps).
-template <int G, typename StartT>
-__device__ inline Best nn_search(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls,
-                                 float qx, float qy, int sub, double gate)
-{
-    bool tie = false;
-    Best b = nn_search_impl<G, StartT, false>(ix, mv, cls, qx, qy, sub, gate, tie); // `tie` is group-wide
-    if (tie) {
-        bool unused = false;
-        b = nn_search_impl<G, StartT, true>(ix, mv, cls, qx, qy, sub, gate, unused);
-    }
-    return b;
-}
-
-// Exact 1-NN of (qx,qy) among the points of class `cls`, searched by the G
-// lanes of a group (`sub` = lane within the group).  `gate` (double, squared
-// metres) lets the search stop once no unseen point can pass the inlier test
-// of icpPointToPoint.cpp:76; pass +inf for an ungated search.  On return all
-// G lanes hold the same result; pos < 0 when the class is empty.
-//
-// Order of visits: the query's own cell, then square rings of radius 1, 2, 4,
-// ... cells.  Inside a ring only the cells that intersect the disk of the
-// current best distance are read (a skipped cell lies entirely farther than
-// the best found so far, which only shrinks), and cells of the previous,
-// smaller square are not read again.  The search ends when the best distance
-// is below the distance to the ring's outer edge (minus a margin that absorbs
-// the f32 rounding of the cell assignment), when that edge is beyond the
-// inlier gate, or when the ring covers the whole lattice.
-template <int G, typename StartT, bool EXACT>
-__device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls,
-                                      float qx, float qy, int sub, double gate, bool &tie)
-{
-    const Lattice &L = mv.lat;
-    const StartT *start = ix.start[cls];
-    const float2 *pts = ix.pts + mv.base[cls];
-    const StartT *oidx = ix.oidx + mv.base[cls];
-
-    Best b;
-    b.d = FLT_MAX;
-    b.oidx = 0xffffffffu;
-    b.pos = -1;
-    if (mv.n_cls[cls] <= 0) return b;
-
-    const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
-    const int   cx = clampi((int)floorf(fx), 0, L.nx - 1);
-    const int   cy = clampi((int)floorf(fy), 0, L.ny - 1);
-
-    scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, cy * L.nx, cx, cx, sub, qx, qy);
-    if (G > 1) {
-        if (EXACT)
-            group_min<G, StartT>(b, oidx);
-        else
-            group_min_lean<G>(b, tie);
-    }
-
-    int rp = 0; // radius of the square already visited
-    for (int r = 1;; r *= 2) {
-        // the ring's own extent, then the disk of the current best distance
-        int y_lo = max(cy - r, 0), y_hi = min(cy + r, L.ny - 1);
-        int x_lo = max(cx - r, 0), x_hi = min(cx + r, L.nx - 1);
-        const bool covers = (x_lo == 0) & (y_lo == 0) & (x_hi == L.nx - 1) & (y_hi == L.ny - 1);
-        if (b.d < FLT_MAX) {
-            // points of a column (row) above cell(q + R) have x (y) > q + R: the cell map is monotone
-            const float R = (__fsqrt_rn(b.d) + L.margin) * L.inv_h;
-            x_lo = max(x_lo, (int)floorf(fx - R));
-            x_hi = min(x_hi, (int)floorf(fx + R));
-            y_lo = max(y_lo, (int)floorf(fy - R));
-            y_hi = min(y_hi, (int)floorf(fy + R));
-        }
-        for (int y = y_lo; y <= y_hi; ++y) {
-            const int row = y * L.nx;
-            if (y >= cy - rp && y <= cy + rp) {
-                scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, row, x_lo, min(x_hi, cx - rp - 1), sub, qx, qy);
-                scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, row, max(x_lo, cx + rp + 1), x_hi, sub, qx, qy);
-            } else {
-                scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, row, x_lo, x_hi, sub, qx, qy);
-            }
-        }
-        if (G > 1) {
-            if (EXACT)
-                group_min<G, StartT>(b, oidx);
-            else
-                group_min_lean<G>(b, tie);
-        }
-        const float bound = (float)r * L.h - L.margin;
-        const float b2 = bound * bound;
-        // every point outside the ring's square is farther than `bound` in x or in y
-        if (covers || b.d < b2 || (double)b2 >= gate) break;
-        rp = r;
-    }
-    if (G == 1 || !EXACT) b.oidx = b.pos >= 0 ? (unsigned)oidx[b.pos] : 0xffffffffu;
-    return b;
-}
-
-// Wavefront sum of a double on the VALU's DPP cross-lane path (no LDS
-// crossbar): a 16-lane prefix by row_shr 1,2,4,8, then row_bcast 15 and 31 fold
-// the four rows; lane 63 holds the total, which is returned to all lanes.
-template <int CTRL, int ROW_MASK>
-__device__ inline double dpp_shift_f64(double v)
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ inline double uniform(double v)
-{
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
-                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-
-__device__ inline double wave_sum(double v)
-{
-    v += dpp_shift_f64<0x111, 0xf>(v); // row_shr:1
-    v += dpp_shift_f64<0x112, 0xf>(v); // row_shr:2
-    v += dpp_shift_f64<0x114, 0xf>(v); // row_shr:4
-    v += dpp_shift_f64<0x118, 0xf>(v); // row_shr:8
-    v += dpp_shift_f64<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
-    v += dpp_shift_f64<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ inline double shfl_xor_f64(double v, int mask)
-{
-    return __hiloint2double(__shfl_xor(__double2hiint(v), mask), __shfl_xor(__double2loint(v), mask));
-}
-
-// Wavefront sums of EIGHT doubles at once: each exchange step halves the number of values a lane
-// carries (lanes 0-31 keep values 0-3 and take the partner's, lanes 32-63 keep 4-7, and so on), so
-// 10 additions per lane replace 48.  On return every lane holds the total of value (lane >> 3).
-// Fixed order: bitwise reproducible.
-__device__ inline double wave_sum8(const double a[8])
-{
-    const int  lane = (int)threadIdx.x & 63;
-    const bool h32 = lane & 32, h16 = lane & 16, h8 = lane & 8;
-    double v4[4], v2[2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v4[k] = (h32 ? a[k + 4] : a[k]) + shfl_xor_f64(h32 ? a[k] : a[k + 4], 32);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) v2[k] = (h16 ? v4[k + 2] : v4[k]) + shfl_xor_f64(h16 ? v4[k] : v4[k + 2], 16);
-    double v = (h8 ? v2[1] : v2[0]) + dpp_shift_f64<0x128, 0xf>(h8 ? v2[0] : v2[1]); // row_ror:8 = lane ^ 8
-    v += dpp_shift_f64<0x141, 0xf>(v); // row_half_mirror: lane ^ 7
-    v += dpp_shift_f64<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]: lane ^ 1
-    v += dpp_shift_f64<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]: lane ^ 2
-    return v;
-}
-
-// icpPointToPoint.cpp:159-162, closed form of svd -> V*U^T (oracle: o_p2p_rotation)
-__device__ inline void p2p_rotation(const double H[4], double R_[4])
-{
-    const double det = H[0] * H[3] - H[1] * H[2];
-    double a, b;
-    if (det >= 0.0) {
-        a = H[0] + H[3];
-        b = H[1] - H[2];
-    } else {
-        a = H[0] - H[3];
-        b = H[1] + H[2];
-    }
-    const double n = sqrt(a * a + b * b);
-    double c = 1.0, s = 0.0;
-    if (n > 0.0) {
-        const double inv_n = 1.0 / n;
-        c = a * inv_n;
-        s = b * inv_n;
-    }
-    if (det >= 0.0) {
-        R_[0] = c;
-        R_[1] = -s;
-        R_[2] = s;
-        R_[3] = c;
-    } else {
-        R_[0] = c;
-        R_[1] = s;
-        R_[2] = s;
-        R_[3] = -c;
-    }
-}
-
-// matrix.cpp:420-508 Gauss-Jordan with full pivoting, 3x3, one rhs (oracle: o_solve3)
-__device__ inline bool solve3(double A[9], double b[3])
-{
-    int indxc[3], indxr[3], ipiv[3] = {0, 0, 0};
-    int irow = 0, icol = 0;
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        double big = 0.0;
-        for (int j = 0; j < 3; j++)
-            if (ipiv[j] != 1)
-                for (int k = 0; k < 3; k++)
-                    if (ipiv[k] == 0 && fabs(A[3 * j + k]) >= big) {
-                        big = fabs(A[3 * j + k]);
-                        irow = j;
-                        icol = k;
-                    }
-        ++ipiv[icol];
-        if (irow != icol) {
-            for (int l = 0; l < 3; l++) {
-                const double tmp = A[3 * irow + l];
-                A[3 * irow + l] = A[3 * icol + l];
-                A[3 * icol + l] = tmp;
-            }
-            const double tmp = b[irow];
-            b[irow] = b[icol];
-            b[icol] = tmp;
-        }
-        indxr[i] = irow;
-        indxc[i] = icol;
-        if (fabs(A[3 * icol + icol]) < 1e-20) return false;
-        const double pivinv = 1.0 / A[3 * icol + icol];
-        A[3 * icol + icol] = 1.0;
-        for (int l = 0; l < 3; l++) A[3 * icol + l] *= pivinv;
-        b[icol] *= pivinv;
-        for (int ll = 0; ll < 3; ll++)
-            if (ll != icol) {
-                const double dum = A[3 * ll + icol];
-                A[3 * ll + icol] = 0.0;
-                for (int l = 0; l < 3; l++) A[3 * ll + l] -= A[3 * icol + l] * dum;
-                b[ll] -= b[icol] * dum;
-            }
-    }
-    (void)indxr;
-    (void)indxc; // column unscrambling only affects the inverse, not the solution vector
-    return true;
-}
-
-// One point-to-point step from the nine sums S = {n, sum(p_m - c), sum(p_t - c), sum (p_t - c)(p_m - c)^T}
-// (c = mv.cx, mv.cy): icpPointToPoint.cpp:128-171.  pose = r00 r01 r10 r11 t0 t1, updated in place when there
-// is a correspondence; returns the step's delta (-1 without correspondences, :128-131).
-__device__ inline double p2p_step(const double S[kNumAcc], const ModelView &mv, double pose[6], int &n_corr)
-{
-    n_corr = (int)S[0];
-    if (n_corr == 0) return -1.0;
-    const double inv = 1.0 / S[0];
-    const double ma0 = S[1] * inv, ma1 = S[2] * inv; // mean of (p_m - c)
-    const double mb0 = S[3] * inv, mb1 = S[4] * inv; // mean of (p_t - c)
-    double       H[4], R_[4], t_[2];
-    H[0] = S[5] - S[3] * ma0;
-    H[1] = S[6] - S[3] * ma1;
-    H[2] = S[7] - S[4] * ma0;
-    H[3] = S[8] - S[4] * ma1;
-    p2p_rotation(H, R_);
-    const double mm0 = mv.cx + ma0, mm1 = mv.cy + ma1;
-    const double mt0 = mv.cx + mb0, mt1 = mv.cy + mb1;
-    t_[0] = mm0 - (R_[0] * mt0 + R_[1] * mt1); // :163
-    t_[1] = mm1 - (R_[2] * mt0 + R_[3] * mt1);
-    const double r00 = pose[0], r01 = pose[1], r10 = pose[2], r11 = pose[3], t0 = pose[4], t1 = pose[5];
-    pose[0] = R_[0] * r00 + R_[1] * r10; // :166-167 R = R_*R ; t = R_*t + t_
-    pose[1] = R_[0] * r01 + R_[1] * r11;
-    pose[2] = R_[2] * r00 + R_[3] * r10;
-    pose[3] = R_[2] * r01 + R_[3] * r11;
-    pose[4] = (R_[0] * t0 + R_[1] * t1) + t_[0];
-    pose[5] = (R_[2] * t0 + R_[3] * t1) + t_[1];
-    const double a0 = R_[0] - 1.0, a3 = R_[3] - 1.0;
-    const double nr2 = a0 * a0 + R_[1] * R_[1] + R_[2] * R_[2] + a3 * a3;
-    const double nt2 = t_[0] * t_[0] + t_[1] * t_[1];
-    return sqrt(nr2 > nt2 ? nr2 : nt2); // :170 max of the two norms (sqrt is monotone: same value)
-}
 
 struct FitArgs {
     const double2 *pts;
@@ -529,42 +73,6 @@ struct FitArgs {
     int            far_div;       // hand over once at most n / far_div queries are beyond the lists' certified radius
 };
 
-struct Pose {
-    double r00, r01, r10, r11, t0, t1;
-};
-
-// icpPointToPoint.cpp:69-70: (r00*x + r01*y) + t0 in double, stored to float
-__device__ inline void transform_query(const Pose &T, const double2 P, float &qx, float &qy)
-{
-    qx = (float)__dadd_rn(__dadd_rn(__dmul_rn(T.r00, P.x), __dmul_rn(T.r01, P.y)), T.t0);
-    qy = (float)__dadd_rn(__dadd_rn(__dmul_rn(T.r10, P.x), __dmul_rn(T.r11, P.y)), T.t1);
-}
-
-__device__ inline void add_p2p_xy(const ModelView &mv, const float2 m, float qx, float qy, double acc[kNumAcc]);
-
-// icpPointToPoint.cpp:76,96-99,116-126,159: one inlier correspondence into the running sums
-template <typename StartT>
-__device__ inline void add_p2p(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, const Best &b, float qx,
-                               float qy, double acc[kNumAcc])
-{
-    add_p2p_xy(mv, ix.pts[mv.base[cls] + b.pos], qx, qy, acc);
-}
-
-__device__ inline void add_p2p_xy(const ModelView &mv, const float2 m, float qx, float qy, double acc[kNumAcc])
-{
-    const double ax = (double)m.x - mv.cx, ay = (double)m.y - mv.cy;
-    const double bx = (double)qx - mv.cx, by = (double)qy - mv.cy;
-    acc[0] += 1.0;
-    acc[1] += ax;
-    acc[2] += ay;
-    acc[3] += bx;
-    acc[4] += by;
-    acc[5] += bx * ax; // H[a][b] = sum q_t[a]*q_m[b]  (:159)
-    acc[6] += bx * ay;
-    acc[7] += by * ax;
-    acc[8] += by * ay;
-}
-
 // List-sweep mode: the query's own cell of the list lattice, one sweep over its halo list, certified when
 // the best distance is below the halo radius.  Returns false (undecided) otherwise.
 struct ListPtrs {
@@ -584,13 +92,6 @@ __device__ inline ListPtrs make_list_ptrs(const unsigned char *base, const Model
     return lp;
 }
 
-// Ordering key of a list: 0 = x, 1 = y, 2 = x + y, 3 = x - y (the diagonals serve lists bent around a corner,
-// where either axis would put a whole wall on one key).  Host and device evaluate the same float expression.
-__host__ __device__ inline float list_key(int dir, float x, float y)
-{
-    const float ux = dir == 1 ? 0.0f : 1.0f, uy = dir == 0 ? 0.0f : (dir == 3 ? -1.0f : 1.0f);
-    return ux * x + uy * y; // products by 0 and +-1 are exact: x, y, fl(x + y), fl(x - y); built without FMA contraction
-}
 // the same with the direction vector already in registers (one multiply-add pair per key, no selects)
 __device__ inline float list_key_u(float ux, float uy, float x, float y) { return __fadd_rn(__fmul_rn(ux, x), __fmul_rn(uy, y)); }
 
@@ -937,7 +438,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
             long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c_mid = 0;
             int       fell_back = 0; // diagnostic: sweep queries of this lane that went to the ring search
             int       far = 0;       // queries of this lane whose neighbour is beyond the halo lists' certified radius
-            if (fa.stamps) c0 = __builtin_amdgcn_s_memtime();
+            if (SLAM_STAMPS(fa)) c0 = __builtin_amdgcn_s_memtime();
 
             int pass = 0;
             for (int p0 = 0; p0 < n; ++pass) {
@@ -957,7 +458,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                         p0 -= kBlock; // the tail is addressed as p0 + kBlock + i
                     }
                     __syncthreads();
-                    if (fa.stamps) c_mid = __builtin_amdgcn_s_memtime();
+                    if (SLAM_STAMPS(fa)) c_mid = __builtin_amdgcn_s_memtime();
                     drain_queue<StartT, SWEEP == 2>(ix, lp, mv, fa, T, off, n, nga, p0, acc, tail, wave_cnt, queue);
                     p0 += kBlock + tail;
                     if (p0 < n) __syncthreads(); // the queue is reused by the next pass
@@ -992,7 +493,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                 for (int o = 32; o > 0; o >>= 1) far += __shfl_xor(far, o);
                 if (lane == 0) wave_cnt[wave] = (unsigned)far;
             }
-            if (fa.stamps) c1 = __builtin_amdgcn_s_memtime();
+            if (SLAM_STAMPS(fa)) c1 = __builtin_amdgcn_s_memtime();
             // wavefront reduction on the DPP path, then LDS across the 16 wavefronts
             double *my = partial + ((iter & 1) * kWaves + wave) * kNumAcc;
             {
@@ -1000,9 +501,9 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                 if ((lane & 7) == 0) my[lane >> 3] = v8;
                 if (lane == 0) my[8] = v9;
             }
-            if (fa.stamps) c2 = __builtin_amdgcn_s_memtime();
+            if (SLAM_STAMPS(fa)) c2 = __builtin_amdgcn_s_memtime();
             __syncthreads();
-            if (fa.stamps) c3 = __builtin_amdgcn_s_memtime();
+            if (SLAM_STAMPS(fa)) c3 = __builtin_amdgcn_s_memtime();
 
             // wavefront 0 alone adds the 16 partials (fixed order: bitwise reproducible)
             // and solves; the others wait at the barrier below and read the new pose.
@@ -1049,6 +550,16 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                     bc[6] = d_out;
                     bc[7] = (double)nc_out;
                 }
+                if (at_switch) {
+                    // The hand-over decision is taken HERE, between the two barriers of the iteration: every
+                    // wavefront wrote its count before the first, none writes the next iteration's before the
+                    // second.  The total goes out through slot 0 of this iteration's partial sums, which
+                    // wavefront 0 has finished reading and nobody writes again before the barriers of iteration
+                    // + 1 (so every wavefront reads ONE value and the workgroup decides uniformly).
+                    unsigned far_all = 0;
+                    for (int w = 0; w < kWaves; ++w) far_all += wave_cnt[w];
+                    if (lane == 0) partial[(iter & 1) * kWaves * kNumAcc] = (double)far_all;
+                }
             }
             __syncthreads();
             r00 = uniform(bc[0]); // the same in every lane: keep the pose in scalar registers
@@ -1060,7 +571,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
             delta = uniform(bc[6]);
             n_corr = (int)uniform(bc[7]);
             ++iters;
-            if (fa.stamps) {
+            if (SLAM_STAMPS(fa)) {
                 for (int o = 32; o > 0; o >>= 1) fell_back += __shfl_xor(fell_back, o);
                 if ((tid & 63) == 0) {
                     const long long c4 = __builtin_amdgcn_s_memtime();
@@ -1091,8 +602,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
             if (at_switch) {
                 // hand over unless too many queries are still far from the map (outliers, a scan that has not
                 // settled): each of them would cost the list form a ring search from HBM per iteration
-                unsigned far_all = 0;
-                for (int w = 0; w < kWaves; ++w) far_all += wave_cnt[w];
+                const unsigned far_all = (unsigned)uniform(partial[(iter & 1) * kWaves * kNumAcc]);
                 if (far_all * (unsigned)fa.far_div <= (unsigned)n) {
                     hand_over = true; // the list sweeps continue from here
                     break;
@@ -1494,350 +1004,9 @@ __global__ __launch_bounds__(256) void icp_nearest_kernel(ModelView mv, int cls,
 
 // ---------------------------------------------------------------- host side
 
-struct DevBuf {
-    void  *p = nullptr;
-    size_t cap = 0;
-    int reserve(size_t bytes)
-    {
-        if (bytes <= cap) return SLAM_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        SLAM_HIP(hipMalloc(&p, bytes));
-        cap = bytes;
-        return SLAM_OK;
-    }
-    ~DevBuf()
-    {
-        if (p) (void)hipFree(p);
-    }
-};
-
 } // namespace
 
-struct slam_icp {
-    slam_icp_params prm;
-    int             sub_step = 10; // icp.cpp:27
-    ModelView       mv;
-    bool            in_lds = false;
-    bool            start32 = false;
-    int             G = 8;
-    int             sweep = 0;     // 0 ring search, 2 halo-list sweeps (list_search) for every iteration
-    void           *d_lblob = nullptr;
-    size_t          list_lds_bytes = 0;
-    bool            have_lists = false;
-    size_t          lds_bytes = 0;
-    void           *d_blob = nullptr;
-    double         *d_normals = nullptr;
-    DevBuf          w_pts, w_off, w_nga, w_R, w_t, w_res, w_stamps, w_pose, w_ew, w_state, w_single;
-    int             hint_n = -1, hint_nga = 0; // set by slam_icp_fit around its single-scan call
-    bool            two_phase = false;   // ring search, then list sweeps (the point-to-point default)
-    bool            split_launch = false; // SLAM_ICP_SPLIT=1: the two forms as two launches (measurements)
-    bool            phase_events = false; // diagnostic: time the two launches separately (slam_icp_debug_phase_ms)
-    hipEvent_t      ev[3] = {nullptr, nullptr, nullptr};
-    double          phase_ms[2] = {0, 0};
-    int             phase_calls = 0;
-    bool            ev_pending = false;
-    int             far_div = 32;        // see FitArgs
-    int             switch_iter = 10;    // ring-search iterations before a scan may change to list sweeps (tools/switch_sweep.sh)
-    int             n_stamps = 0;
-    bool            want_step_pose = false; // set around slam_icp_fit()
-    int             last_n = 0, last_nga = 0; // template of the last slam_icp_fit()
-    double          last_indist = 0;
-    bool            have_last = false;
-};
-
 namespace {
-
-template <typename StartT>
-void fill_index(std::vector<unsigned char> &blob, const ModelView &mv, const std::vector<float> cls_xy[2],
-                const std::vector<int> cell_of[2])
-{
-    const int ncells = mv.lat.nx * mv.lat.ny;
-    float2   *pts = reinterpret_cast<float2 *>(blob.data() + mv.off_pts);
-    StartT   *oidx = reinterpret_cast<StartT *>(blob.data() + mv.off_oidx);
-    for (int c = 0; c < 2; ++c) {
-        StartT *start = reinterpret_cast<StartT *>(blob.data() + mv.off_start[c]);
-        const int n = mv.n_cls[c];
-        std::vector<int> count(ncells + 1, 0);
-        for (int i = 0; i < n; ++i) count[cell_of[c][i] + 1]++;
-        for (int k = 0; k < ncells; ++k) count[k + 1] += count[k];
-        for (int k = 0; k <= ncells; ++k) start[k] = (StartT)count[k];
-        std::vector<int> fill(count.begin(), count.end() - 1);
-        for (int i = 0; i < n; ++i) { // stable: equal cells keep original order
-            const int pos = fill[cell_of[c][i]]++;
-            pts[mv.base[c] + pos] = make_float2(cls_xy[c][2 * i], cls_xy[c][2 * i + 1]);
-            oidx[mv.base[c] + pos] = (StartT)i;
-        }
-    }
-}
-
-inline unsigned align16(unsigned v) { return (v + 15u) & ~15u; }
-
-int build_lists(slam_icp *h, const std::vector<float> xy[2], const int cnt[2], const float lo[2], const float hi[2],
-                float maxabs, unsigned lds_total);
-
-int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, int n_nga)
-{
-    std::vector<float> xy[2];
-    const double *src[2] = {m_ga, m_nga};
-    const int     cnt[2] = {n_ga, n_nga};
-    float  lo[2] = {FLT_MAX, FLT_MAX}, hi[2] = {-FLT_MAX, -FLT_MAX};
-    double sum[2] = {0, 0};
-    size_t nfin = 0;
-    for (int c = 0; c < 2; ++c) {
-        xy[c].resize(2 * (size_t)cnt[c]);
-        for (int i = 0; i < 2 * cnt[c]; ++i) xy[c][i] = (float)src[c][i]; // icp.cpp:54,60
-        for (int i = 0; i < cnt[c]; ++i) {
-            const float x = xy[c][2 * i], y = xy[c][2 * i + 1];
-            if (!std::isfinite(x) || !std::isfinite(y)) continue;
-            lo[0] = std::min(lo[0], x);
-            hi[0] = std::max(hi[0], x);
-            lo[1] = std::min(lo[1], y);
-            hi[1] = std::max(hi[1], y);
-            sum[0] += x;
-            sum[1] += y;
-            ++nfin;
-        }
-    }
-    if (nfin == 0) {
-        lo[0] = lo[1] = 0.f;
-        hi[0] = hi[1] = 1.f;
-        nfin = 1;
-    }
-    const int n_all = n_ga + n_nga;
-    const int max_cls = std::max(n_ga, n_nga);
-
-    int lds_cap = 0;
-    int dev = 0;
-    SLAM_HIP(hipGetDevice(&dev));
-    SLAM_HIP(hipDeviceGetAttribute(&lds_cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
-    const unsigned lds_total = std::min<unsigned>((unsigned)lds_cap, kLdsTotal);
-    const unsigned scratch = kScratchBytes;
-
-    // LDS budget for the two start arrays (u16 entries) after points + original indices
-    const long fixed16 = (long)scratch + align16(8u * n_all) + align16(2u * n_all) + 64;
-    long       cells_lds = ((long)lds_total - fixed16) / (2 * 2) - 1;
-    bool       lds = !h->prm.force_global && max_cls <= 65535 && cells_lds >= 256;
-
-    const float w = std::max(hi[0] - lo[0], 1e-3f), ht = std::max(hi[1] - lo[1], 1e-3f);
-    const float maxabs = std::max(std::max(std::fabs(lo[0]), std::fabs(hi[0])),
-                                  std::max(std::fabs(lo[1]), std::fabs(hi[1])));
-    long budget = lds ? cells_lds : std::min<long>(std::max<long>(4L * n_all, 1024), 1L << 22);
-    // target about two cells per point on wall-like maps; never more than the budget
-    long want = std::min<long>(budget, std::max<long>(64, 2L * n_all));
-    double hcell = h->prm.cell_size > 0 ? h->prm.cell_size : std::sqrt((double)w * ht / (double)want);
-    hcell = std::max(hcell, (double)maxabs * 1.52587890625e-05 /* 2^-16 */);
-    hcell = std::max(hcell, 1e-4);
-    int nx, ny;
-    for (;;) {
-        nx = (int)std::floor(w / hcell) + 1;
-        ny = (int)std::floor(ht / hcell) + 1;
-        if ((long)nx * ny <= budget) break;
-        hcell *= 1.05;
-    }
-
-    ModelView &mv = h->mv;
-    memset(&mv, 0, sizeof mv);
-    mv.lat.nx = nx;
-    mv.lat.ny = ny;
-    mv.lat.x0 = lo[0];
-    mv.lat.y0 = lo[1];
-    mv.lat.h = (float)hcell;
-    mv.lat.inv_h = 1.0f / mv.lat.h;
-    // the cell map floor(fl(fl(x-x0)*inv_h)) is monotone and off by at most ~3*2^-24*nx cells per evaluation,
-    // i.e. ~6*2^-24*maxabs metres for a model point and a query together; 2^-19*maxabs covers that 5x
-    // (and stays below h/8 by the choice of h above)
-    mv.lat.margin = std::max(mv.lat.h * 0.0009765625f, maxabs * 1.9073486328125e-06f);
-    mv.n_cls[0] = n_ga;
-    mv.n_cls[1] = n_nga;
-    mv.base[0] = 0;
-    mv.base[1] = n_ga;
-    mv.cx = sum[0] / (double)nfin;
-    mv.cy = sum[1] / (double)nfin;
-
-    h->start32 = !lds; // the HBM-resident index always uses 32-bit positions
-    const unsigned esz = h->start32 ? 4u : 2u;
-    const int      ncells = nx * ny;
-    unsigned       o = 0;
-    mv.off_pts = o;
-    o = align16(o + 8u * (unsigned)n_all);
-    mv.off_start[0] = o;
-    o = align16(o + esz * (unsigned)(ncells + 1));
-    mv.off_start[1] = o;
-    o = align16(o + esz * (unsigned)(ncells + 1));
-    mv.off_oidx = o;
-    o = align16(o + esz * (unsigned)n_all);
-    mv.blob_bytes = o;
-    if (lds && scratch + o > lds_total) lds = false, h->start32 = false; // keeps u16 entries, read from HBM
-    h->in_lds = lds;
-    h->lds_bytes = lds ? scratch + o : scratch;
-
-    // cell of every model point, with the SAME float expression the kernels use
-    std::vector<int> cell_of[2];
-    for (int c = 0; c < 2; ++c) {
-        cell_of[c].resize(cnt[c]);
-        for (int i = 0; i < cnt[c]; ++i) {
-            const float x = xy[c][2 * i], y = xy[c][2 * i + 1];
-            int cxi = (int)std::floor((x - mv.lat.x0) * mv.lat.inv_h);
-            int cyi = (int)std::floor((y - mv.lat.y0) * mv.lat.inv_h);
-            if (!std::isfinite(x)) cxi = 0;
-            if (!std::isfinite(y)) cyi = 0;
-            cxi = std::min(std::max(cxi, 0), nx - 1);
-            cyi = std::min(std::max(cyi, 0), ny - 1);
-            cell_of[c][i] = cyi * nx + cxi;
-        }
-    }
-    std::vector<unsigned char> blob(mv.blob_bytes, 0);
-    if (h->start32)
-        fill_index<uint32_t>(blob, mv, xy, cell_of);
-    else
-        fill_index<uint16_t>(blob, mv, xy, cell_of);
-
-    SLAM_HIP(hipMalloc(&h->d_blob, mv.blob_bytes));
-    SLAM_HIP(hipMemcpy(h->d_blob, blob.data(), mv.blob_bytes, hipMemcpyHostToDevice));
-    mv.blob = static_cast<const unsigned char *>(h->d_blob);
-    if (h->sweep == 2 || h->two_phase) SLAM_TRY(build_lists(h, xy, cnt, lo, hi, maxabs, lds_total));
-    return SLAM_OK;
-}
-
-// Halo lists for the list-sweep mode (ModelView::lblob): picks the smallest list-lattice pitch for which
-// points (with their halo copies), start arrays and axis bits fit LDS beside the scratch.  Leaves
-// have_lists false when nothing fits (the caller then keeps the ring search).
-int build_lists(slam_icp *h, const std::vector<float> xy[2], const int cnt[2], const float lo[2], const float hi[2],
-                float maxabs, unsigned lds_total)
-{
-    ModelView &mv = h->mv;
-    h->have_lists = false;
-    const double budget = (double)lds_total - (double)kScratchBytes - 64.0;
-    const float  margin_abs = maxabs * 1.9073486328125e-06f; // 2^-19 * maxabs, as for the cell lattice
-    struct Ent { int cell; float key; int pt; };
-    for (double frac : {0.25, 0.125}) {
-        for (double hs = 0.25; hs <= 64.0; hs *= 1.12) {
-            const double pad_m = hs * frac; // halo in metres
-            if (pad_m < 8.0 * margin_abs) continue;
-            const double x0 = (double)lo[0] - pad_m, y0 = (double)lo[1] - pad_m;
-            const long   nx = (long)std::floor(((double)hi[0] + pad_m - x0) / hs) + 1, ny = (long)std::floor(((double)hi[1] + pad_m - y0) / hs) + 1;
-            if (nx * ny > 60000) continue;
-            const int ncells = (int)(nx * ny);
-            // entries per class
-            size_t n_ent[2] = {0, 0};
-            bool   ok = true;
-            for (int c = 0; c < 2 && ok; ++c) {
-                for (int i = 0; i < cnt[c]; ++i) {
-                    const double px = xy[c][2 * i], py = xy[c][2 * i + 1];
-                    if (!std::isfinite(px) || !std::isfinite(py)) continue;
-                    const long ax = std::max(0L, (long)std::floor((px - pad_m - x0) / hs)), bx = std::min(nx - 1, (long)std::floor((px + pad_m - x0) / hs));
-                    const long ay = std::max(0L, (long)std::floor((py - pad_m - y0) / hs)), by = std::min(ny - 1, (long)std::floor((py + pad_m - y0) / hs));
-                    n_ent[c] += (size_t)((bx - ax + 1) * (by - ay + 1));
-                }
-                if (n_ent[c] > 65535) ok = false;
-            }
-            if (!ok) continue;
-            const size_t bytes = align16(8u * (unsigned)(n_ent[0] + n_ent[1])) + 2 * (size_t)align16(2u * (unsigned)(ncells + 1)) +
-                                 2 * (size_t)align16(4u * (unsigned)(ncells / 16 + 1));
-            if ((double)bytes > budget) continue;
-            // ---- build
-            unsigned o = 0;
-            mv.loff_pts = o;
-            o = align16(o + 8u * (unsigned)(n_ent[0] + n_ent[1]));
-            for (int c = 0; c < 2; ++c) {
-                mv.loff_start[c] = o;
-                o = align16(o + 2u * (unsigned)(ncells + 1));
-            }
-            for (int c = 0; c < 2; ++c) {
-                mv.loff_axis[c] = o;
-                o = align16(o + 4u * (unsigned)(ncells / 16 + 1));
-            }
-            mv.lblob_bytes = o;
-            mv.lbase[0] = 0;
-            mv.lbase[1] = (int)n_ent[0];
-            mv.llat.nx = (int)nx;
-            mv.llat.ny = (int)ny;
-            mv.llat.x0 = (float)x0;
-            mv.llat.y0 = (float)y0;
-            mv.llat.h = (float)hs;
-            mv.llat.inv_h = 1.0f / mv.llat.h;
-            mv.llat.margin = std::max(mv.llat.h * 0.0009765625f, margin_abs);
-            mv.lpad = (float)frac;
-            mv.lkeps = 8.0f * 2.0f * maxabs * 1.1920929e-07f; // 8 ulp of |x| + |y| <= 2 maxabs (query within the lattice)
-            // a point within `cert` of a query lies within cert + (cell-map rounding) of the query's nominal cell
-            const double cert = pad_m - 4.0 * (double)mv.llat.margin - 2.0 * std::fabs((double)mv.llat.x0 - x0) - 2.0 * std::fabs((double)mv.llat.y0 - y0);
-            if (cert <= 0) continue;
-            mv.cert2 = (float)(cert * cert * 0.999);
-            std::vector<unsigned char> blob(o, 0);
-            float2 *lpts = reinterpret_cast<float2 *>(blob.data() + mv.loff_pts);
-            for (int c = 0; c < 2; ++c) {
-                std::vector<Ent> ent;
-                ent.reserve(n_ent[c]);
-                for (int i = 0; i < cnt[c]; ++i) {
-                    const double px = xy[c][2 * i], py = xy[c][2 * i + 1];
-                    if (!std::isfinite(px) || !std::isfinite(py)) continue;
-                    const long ax = std::max(0L, (long)std::floor((px - pad_m - x0) / hs)), bx = std::min(nx - 1, (long)std::floor((px + pad_m - x0) / hs));
-                    const long ay = std::max(0L, (long)std::floor((py - pad_m - y0) / hs)), by = std::min(ny - 1, (long)std::floor((py + pad_m - y0) / hs));
-                    for (long yy = ay; yy <= by; ++yy)
-                        for (long xx = ax; xx <= bx; ++xx) ent.push_back({(int)(yy * nx + xx), 0.f, i});
-                }
-                std::stable_sort(ent.begin(), ent.end(), [](const Ent &a, const Ent &b) { return a.cell < b.cell; });
-                unsigned short *start = reinterpret_cast<unsigned short *>(blob.data() + mv.loff_start[c]);
-                unsigned       *axis = reinterpret_cast<unsigned *>(blob.data() + mv.loff_axis[c]);
-                size_t          a = 0;
-                for (int k = 0; k < ncells; ++k) {
-                    start[k] = (unsigned short)a;
-                    size_t e = a;
-                    float  mn[2] = {FLT_MAX, FLT_MAX}, mx[2] = {-FLT_MAX, -FLT_MAX};
-                    while (e < ent.size() && ent[e].cell == k) {
-                        for (int d = 0; d < 2; ++d) {
-                            const float v = xy[c][2 * ent[e].pt + d];
-                            mn[d] = std::min(mn[d], v);
-                            mx[d] = std::max(mx[d], v);
-                        }
-                        ++e;
-                    }
-                    // ordering key: the direction (x, y, x+y, x-y) whose densest key window is the sparsest --
-                    // a window of the converged search radius must hold few entries, or the walk is long
-                    int best_dir = (mx[1] - mn[1]) > (mx[0] - mn[0]) ? 1 : 0;
-                    if (e - a >= 8) {
-                        size_t             best_metric = SIZE_MAX;
-                        std::vector<float> keys(e - a);
-                        for (int dir : {best_dir, 1 - best_dir, 2, 3}) {
-                            for (size_t j = a; j < e; ++j) keys[j - a] = list_key(dir, xy[c][2 * ent[j].pt], xy[c][2 * ent[j].pt + 1]);
-                            std::sort(keys.begin(), keys.end());
-                            const float win = (dir < 2 ? 1.0f : 1.41421356f) * 0.06f; // +-3 cm around the query
-                            size_t      metric = 0, lo_j = 0;
-                            for (size_t j = 0; j < keys.size(); ++j) {
-                                while (keys[j] - keys[lo_j] > win) ++lo_j;
-                                metric = std::max(metric, j - lo_j + 1);
-                            }
-                            if (dir >= 2) metric += metric / 4 + 1; // an axis key is cheaper and exact: prefer it when close
-                            if (metric < best_metric) {
-                                best_metric = metric;
-                                best_dir = dir;
-                            }
-                        }
-                    }
-                    axis[k >> 4] |= (unsigned)best_dir << (2 * (k & 15));
-                    for (size_t j = a; j < e; ++j) ent[j].key = list_key(best_dir, xy[c][2 * ent[j].pt], xy[c][2 * ent[j].pt + 1]);
-                    std::stable_sort(ent.begin() + a, ent.begin() + e, [](const Ent &p, const Ent &q) { return p.key < q.key; });
-                    a = e;
-                }
-                start[ncells] = (unsigned short)a;
-                for (size_t j = 0; j < ent.size(); ++j)
-                    lpts[mv.lbase[c] + j] = make_float2(xy[c][2 * ent[j].pt], xy[c][2 * ent[j].pt + 1]);
-            }
-            SLAM_HIP(hipMalloc(&h->d_lblob, mv.lblob_bytes));
-            SLAM_HIP(hipMemcpy(h->d_lblob, blob.data(), mv.lblob_bytes, hipMemcpyHostToDevice));
-            mv.lblob = static_cast<const unsigned char *>(h->d_lblob);
-            h->list_lds_bytes = kScratchBytes + mv.lblob_bytes;
-            h->have_lists = true;
-            if (getenv("SLAM_ICP_DEBUG"))
-                fprintf(stderr, "halo lists: pitch %.3f m, halo %.3f m, certified radius %.4f m, %d x %d cells, %zu + %zu entries, %u bytes\n", hs,
-                        pad_m, std::sqrt((double)mv.cert2), (int)nx, (int)ny, n_ent[0], n_ent[1], mv.lblob_bytes);
-            return SLAM_OK;
-        }
-    }
-    return SLAM_OK;
-}
 
 int compute_normals(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, int n_nga)
 {
@@ -2047,10 +1216,19 @@ void slam_icp_default_params(slam_icp_params *p)
     p->lanes_per_point = 0;
     p->cell_size = 0.0;
     p->force_global = 0;
+    p->build_on_host = 0;
+    p->first_iterations = 0;
+    p->far_div = 0;
+    p->split_launch = 0;
 }
 
-int slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga,
-                    const slam_icp_params *params, slam_icp_t **out)
+} // extern "C"
+
+namespace {
+
+// Icp::Icp, icp.cpp:26-70; the model arrays are host memory unless on_device
+int icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga, const slam_icp_params *params, bool on_device,
+               slam_icp_t **out)
 {
     SLAM_REQUIRE(out, SLAM_E_INVALID, "slam_icp_create: null out pointer");
     *out = nullptr;
@@ -2071,15 +1249,25 @@ int slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga
     h->sweep = h->prm.lanes_per_point == -2 ? 2 : 0;
     h->G = h->prm.lanes_per_point > 0 ? h->prm.lanes_per_point : (h->prm.lanes_per_point == -1 ? 0 : 2);
     h->two_phase = h->prm.lanes_per_point == 0 && h->prm.mode == SLAM_ICP_P2P;
+    if (h->prm.first_iterations > 0) h->switch_iter = h->prm.first_iterations;
+    if (h->prm.far_div > 0) h->far_div = h->prm.far_div;
+    h->split_launch = h->prm.split_launch != 0;
+#ifdef SLAM_MEASURE
     if (const char *e = getenv("SLAM_ICP_SPLIT")) h->split_launch = atoi(e) != 0;
     if (const char *e = getenv("SLAM_ICP_CELL")) h->prm.cell_size = atof(e); // measurements: overrides the pitch
     if (const char *e = getenv("SLAM_ICP_SWITCH_ITER")) h->switch_iter = atoi(e);
     if (const char *e = getenv("SLAM_ICP_FAR_DIV")) h->far_div = std::max(atoi(e), 1);
-    int rc = build_index(h, m_ga, n_ga, m_nga, n_nga);
-    if (rc == SLAM_OK && (h->G & (h->G - 1) || h->G > 64)) {
+#endif
+    int rc = SLAM_OK;
+    if (h->G & (h->G - 1) || h->G > 64) {
         set_error("lanes_per_point must be one of 1,2,4,8,16,32,64 (got %d)", h->G);
         rc = SLAM_E_INVALID;
     }
+    if (rc == SLAM_OK && on_device && h->prm.mode == SLAM_ICP_P2L) {
+        set_error("slam_icp_create_dev: the point-to-line mode takes its model from host arrays");
+        rc = SLAM_E_UNSUPPORTED;
+    }
+    if (rc == SLAM_OK) rc = build_index(h, m_ga, n_ga, m_nga, n_nga, on_device);
     if (rc == SLAM_OK && h->prm.mode == SLAM_ICP_P2L) rc = compute_normals(h, m_ga, n_ga, m_nga, n_nga);
     if (rc != SLAM_OK) {
         slam_icp_destroy(h);
@@ -2089,15 +1277,56 @@ int slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga
     return SLAM_OK;
 }
 
+} // namespace
+
+extern "C" {
+
+int slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga,
+                    const slam_icp_params *params, slam_icp_t **out)
+{
+    return icp_create(m_ga, n_ga, m_nga, n_nga, params, false, out);
+}
+
+int slam_icp_create_dev(const double *d_m_ga, int n_ga, const double *d_m_nga, int n_nga,
+                        const slam_icp_params *params, slam_icp_t **out)
+{
+    return icp_create(d_m_ga, n_ga, d_m_nga, n_nga, params, true, out);
+}
+
 void slam_icp_destroy(slam_icp_t *icp)
 {
     if (!icp) return;
-    if (icp->d_blob) (void)hipFree(icp->d_blob);
-    if (icp->d_lblob) (void)hipFree(icp->d_lblob);
+    // the buffers go back to the library's pool, not to hipFree (which would wait for the device itself)
+    (void)hipDeviceSynchronize();
+    release_index(icp);
     for (auto &e : icp->ev)
         if (e) (void)hipEventDestroy(e);
     if (icp->d_normals) (void)hipFree(icp->d_normals);
+    for (DevBuf *b : {&icp->w_pts, &icp->w_off, &icp->w_nga, &icp->w_R, &icp->w_t, &icp->w_res, &icp->w_stamps, &icp->w_pose,
+                      &icp->w_ew, &icp->w_state, &icp->w_single})
+        b->release();
     delete icp;
+}
+
+int slam_icp_build_info(slam_icp_t *icp, int *on_device, double ms[4])
+{
+    SLAM_REQUIRE(icp, SLAM_E_INVALID, "null handle");
+    if (on_device) *on_device = icp->built_on_device ? 1 : 0;
+    if (ms)
+        for (int k = 0; k < 4; ++k) ms[k] = icp->build_ms[k];
+    return SLAM_OK;
+}
+
+int slam_icp_index_blob(slam_icp_t *icp, int which, void *buf, size_t cap, size_t *bytes)
+{
+    SLAM_REQUIRE(icp && (which == 0 || which == 1), SLAM_E_INVALID, "slam_icp_index_blob: bad arguments");
+    const void  *src = which == 0 ? icp->d_blob : (icp->have_lists ? icp->d_lblob : nullptr);
+    const size_t n = which == 0 ? icp->mv.blob_bytes : (icp->have_lists ? icp->mv.lblob_bytes : 0);
+    if (bytes) *bytes = n;
+    if (!buf || n == 0) return SLAM_OK;
+    SLAM_REQUIRE(cap >= n, SLAM_E_INVALID, "slam_icp_index_blob: buffer of %zu bytes, blob has %zu", cap, n);
+    SLAM_HIP(hipMemcpy(buf, src, n, hipMemcpyDeviceToHost));
+    return SLAM_OK;
 }
 
 int slam_icp_set_max_iterations(slam_icp_t *icp, int val)
@@ -2142,12 +1371,14 @@ int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *
     fa.indist = indist;
     fa.step_pose = icp->want_step_pose ? static_cast<double *>(icp->w_pose.p) : nullptr;
     fa.stamps = nullptr;
+#ifdef SLAM_MEASURE
     if (getenv("SLAM_ICP_STAMPS")) {
         SLAM_TRY(icp->w_stamps.reserve((size_t)n_scans * kWaves * kStampSlots * sizeof(long long)));
         SLAM_HIP(hipMemsetAsync(icp->w_stamps.p, 0, (size_t)n_scans * kWaves * kStampSlots * sizeof(long long), as_stream(stream)));
         fa.stamps = static_cast<long long *>(icp->w_stamps.p);
         icp->n_stamps = n_scans * kWaves;
     }
+#endif
     // one scan against a model too large for LDS: many small workgroups per iteration instead of one
     if (n_scans == 1 && !icp->in_lds && icp->prm.mode == SLAM_ICP_P2P && icp->prm.lanes_per_point == 0 && !fa.stamps)
         return fit_single(icp, fa, as_stream(stream));
@@ -2262,6 +1493,7 @@ int slam_icp_get_edge_weight(slam_icp_t *icp, double eW[9])
     return SLAM_OK;
 }
 
+#ifdef SLAM_MEASURE // declared in include/slam_mi355x_measure.h
 // diagnostic (not in the public header): per wavefront, mean cycles in the four phases, sweep
 // fall-backs, and the search cycles of iterations 0-3 of the last batch launched with SLAM_ICP_STAMPS=1 in the environment
 // diagnostic (not in the public header): with `on`, the default schedule runs as two launches (ring search,
@@ -2320,6 +1552,8 @@ int slam_icp_debug_stamps(slam_icp_t *icp, double out[9])
     for (int k = 0; k < kStampSlots; ++k) out[k] /= icp->n_stamps;
     return SLAM_OK;
 }
+
+#endif // SLAM_MEASURE
 
 int slam_icp_index_info(slam_icp_t *icp, int *nx, int *ny, double *cell, int *in_lds, size_t *lds_bytes,
                         int *lanes_per_point)

@@ -1,0 +1,448 @@
+// icp_search.hpp -- device side of the exact 1-NN search on the cell index and of one point-to-point step
+// (kdtree.cpp:378-391,515-683; icpPointToPoint.cpp:59-172), shared by the ICP translation units.
+#pragma once
+#include "icp_model.hpp"
+
+namespace slam {
+namespace icp {
+
+__device__ inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+struct Best {
+    float    d;    // squared float distance (kdtree.h:33)
+    unsigned oidx; // original index within the class (kdtree.h:34); filled by nn_search on return
+    int      pos;  // position in the sorted pts array, -1 = none
+};
+
+// kdtree.cpp:610-612: dis += squared(data[i][k]-qv[k]), k = 0 then 1, no FMA
+__device__ inline float dist2(const float2 m, float qx, float qy)
+{
+    const float dx = m.x - qx;
+    const float dy = m.y - qy;
+    return __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+}
+
+// Candidate i at squared distance d.  Ties go to the lowest ORIGINAL index (the
+// reference leaves ties to the kd-tree's visit order; this is the brute-force
+// arbiter's rule, kdtree.cpp:360-375): the index is only read when d == best.
+template <typename StartT>
+__device__ inline void consider(Best &b, float d, int i, const StartT *oidx)
+{
+    if (d < b.d) {
+        b.d = d;
+        b.pos = i;
+    } else if (d == b.d && b.pos >= 0) {
+        if ((unsigned)oidx[i] < (unsigned)oidx[b.pos]) b.pos = i;
+    }
+}
+
+// All points of cells [c0, c1] of one lattice row: they are contiguous in the
+// sorted array.  The G lanes of the group take consecutive points; four loads
+// are kept in flight per lane and their distances are independent chains.
+// EXACT = false is the fast form: branch-free minimum by (distance, position)
+// plus a flag that says whether an exact tie d == best was ever seen; the
+// caller then repeats the search with EXACT = true (ties by original index).
+template <int G, typename StartT, bool EXACT>
+__device__ inline void scan_span(Best &b, bool &tie, const StartT *start, const float2 *pts, const StartT *oidx,
+                                 int row_base, int c0, int c1, int sub, float qx, float qy)
+{
+    if (c0 > c1) return;
+    const int a = (int)start[row_base + c0];
+    const int e = (int)start[row_base + c1 + 1];
+    int       i = a + sub;
+    for (; i + 3 * G < e; i += 4 * G) {
+        const float2 m0 = pts[i], m1 = pts[i + G], m2 = pts[i + 2 * G], m3 = pts[i + 3 * G];
+        const float  d0 = dist2(m0, qx, qy), d1 = dist2(m1, qx, qy), d2 = dist2(m2, qx, qy), d3 = dist2(m3, qx, qy);
+        if (EXACT) {
+            if (fminf(fminf(d0, d1), fminf(d2, d3)) <= b.d) {
+                consider<StartT>(b, d0, i, oidx);
+                consider<StartT>(b, d1, i + G, oidx);
+                consider<StartT>(b, d2, i + 2 * G, oidx);
+                consider<StartT>(b, d3, i + 3 * G, oidx);
+            }
+        } else {
+            // min of the four (first position wins), then one compare against the running best
+            const bool  s01 = d1 < d0, s23 = d3 < d2;
+            const float m01 = s01 ? d1 : d0, m23 = s23 ? d3 : d2;
+            const int   p01 = s01 ? i + G : i, p23 = s23 ? i + 3 * G : i + 2 * G;
+            const bool  s = m23 < m01;
+            const float m = s ? m23 : m01;
+            const int   pm = s ? p23 : p01;
+            tie |= (d0 == d1) | (d2 == d3) | (m01 == m23) | (m == b.d);
+            const bool up = m < b.d;
+            b.d = up ? m : b.d;
+            b.pos = up ? pm : b.pos;
+        }
+    }
+    for (; i < e; i += G) {
+        const float d = dist2(pts[i], qx, qy);
+        if (EXACT) {
+            consider<StartT>(b, d, i, oidx);
+        } else {
+            tie |= (d == b.d);
+            const bool up = d < b.d;
+            b.d = up ? d : b.d;
+            b.pos = up ? i : b.pos;
+        }
+    }
+}
+
+// Fast-path minimum over the G lanes of a group: (distance, position) only, on the DPP cross-lane path for
+// the steps inside a row of 16 (no LDS round trip); equal distances at different positions raise `tie`,
+// which sends the group to the exact pass.  `tie` itself is OR-ed over the group.
+template <int CTRL>
+__device__ inline void lean_step_dpp(Best &b, bool &tie)
+{
+    const float od = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(b.d), CTRL, 0xf, 0xf, false));
+    const int   op = __builtin_amdgcn_update_dpp(0, b.pos, CTRL, 0xf, 0xf, false);
+    const int   ot = __builtin_amdgcn_update_dpp(0, (int)tie, CTRL, 0xf, 0xf, false);
+    tie |= (bool)ot | ((od == b.d) & (op != b.pos) & (op >= 0) & (b.pos >= 0));
+    const bool take = (od < b.d) | ((od == b.d) & (op >= 0) & ((b.pos < 0) | (op < b.pos)));
+    b.d = take ? od : b.d;
+    b.pos = take ? op : b.pos;
+}
+
+__device__ inline void lean_step_shfl(Best &b, bool &tie, int mask)
+{
+    const float od = __shfl_xor(b.d, mask);
+    const int   op = __shfl_xor(b.pos, mask);
+    const int   ot = __shfl_xor((int)tie, mask);
+    tie |= (bool)ot | ((od == b.d) & (op != b.pos) & (op >= 0) & (b.pos >= 0));
+    const bool take = (od < b.d) | ((od == b.d) & (op >= 0) & ((b.pos < 0) | (op < b.pos)));
+    b.d = take ? od : b.d;
+    b.pos = take ? op : b.pos;
+}
+
+template <int G>
+__device__ inline void group_min_lean(Best &b, bool &tie)
+{
+    if (G >= 2) lean_step_dpp<0xB1>(b, tie);  // quad_perm [1,0,3,2]
+    if (G >= 4) lean_step_dpp<0x4E>(b, tie);  // quad_perm [2,3,0,1]
+    if (G >= 8) lean_step_dpp<0x141>(b, tie); // row_half_mirror
+    if (G >= 16) lean_step_dpp<0x140>(b, tie); // row_mirror
+    if (G >= 32) lean_step_shfl(b, tie, 16);
+    if (G >= 64) lean_step_shfl(b, tie, 32);
+}
+
+template <int G, typename StartT>
+__device__ inline void group_min(Best &b, const StartT *oidx)
+{
+    b.oidx = b.pos >= 0 ? (unsigned)oidx[b.pos] : 0xffffffffu;
+#pragma unroll
+    for (int off = 1; off < G; off <<= 1) {
+        const float    od = __shfl_xor(b.d, off);
+        const unsigned oo = (unsigned)__shfl_xor((int)b.oidx, off);
+        const int      op = __shfl_xor(b.pos, off);
+        if (od < b.d || (od == b.d && oo < b.oidx)) {
+            b.d = od;
+            b.oidx = oo;
+            b.pos = op;
+        }
+    }
+}
+
+template <int G, typename StartT, bool EXACT>
+__device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, float qx, float qy,
+                                      int sub, double gate, bool &tie);
+
+// The search proper: fast pass, and the exact pass only for a group that met an
+// exact distance tie (measure zero on noisy data, common on gridded maps).
+template <int G, typename StartT>
+__device__ inline Best nn_search(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls,
+                                 float qx, float qy, int sub, double gate)
+{
+    bool tie = false;
+    Best b = nn_search_impl<G, StartT, false>(ix, mv, cls, qx, qy, sub, gate, tie); // `tie` is group-wide
+    if (tie) {
+        bool unused = false;
+        b = nn_search_impl<G, StartT, true>(ix, mv, cls, qx, qy, sub, gate, unused);
+    }
+    return b;
+}
+
+// Exact 1-NN of (qx,qy) among the points of class `cls`, searched by the G
+// lanes of a group (`sub` = lane within the group).  `gate` (double, squared
+// metres) lets the search stop once no unseen point can pass the inlier test
+// of icpPointToPoint.cpp:76; pass +inf for an ungated search.  On return all
+// G lanes hold the same result; pos < 0 when the class is empty.
+//
+// Order of visits: the query's own cell, then square rings of radius 1, 2, 4,
+// ... cells.  Inside a ring only the cells that intersect the disk of the
+// current best distance are read (a skipped cell lies entirely farther than
+// the best found so far, which only shrinks), and cells of the previous,
+// smaller square are not read again.  The search ends when the best distance
+// is below the distance to the ring's outer edge (minus a margin that absorbs
+// the f32 rounding of the cell assignment), when that edge is beyond the
+// inlier gate, or when the ring covers the whole lattice.
+template <int G, typename StartT, bool EXACT>
+__device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls,
+                                      float qx, float qy, int sub, double gate, bool &tie)
+{
+    const Lattice &L = mv.lat;
+    const StartT *start = ix.start[cls];
+    const float2 *pts = ix.pts + mv.base[cls];
+    const StartT *oidx = ix.oidx + mv.base[cls];
+
+    Best b;
+    b.d = FLT_MAX;
+    b.oidx = 0xffffffffu;
+    b.pos = -1;
+    if (mv.n_cls[cls] <= 0) return b;
+
+    const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
+    const int   cx = clampi((int)floorf(fx), 0, L.nx - 1);
+    const int   cy = clampi((int)floorf(fy), 0, L.ny - 1);
+
+    scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, cy * L.nx, cx, cx, sub, qx, qy);
+    if (G > 1) {
+        if (EXACT)
+            group_min<G, StartT>(b, oidx);
+        else
+            group_min_lean<G>(b, tie);
+    }
+
+    int rp = 0; // radius of the square already visited
+    for (int r = 1;; r *= 2) {
+        // the ring's own extent, then the disk of the current best distance
+        int y_lo = max(cy - r, 0), y_hi = min(cy + r, L.ny - 1);
+        int x_lo = max(cx - r, 0), x_hi = min(cx + r, L.nx - 1);
+        const bool covers = (x_lo == 0) & (y_lo == 0) & (x_hi == L.nx - 1) & (y_hi == L.ny - 1);
+        if (b.d < FLT_MAX) {
+            // points of a column (row) above cell(q + R) have x (y) > q + R: the cell map is monotone
+            const float R = (__fsqrt_rn(b.d) + L.margin) * L.inv_h;
+            x_lo = max(x_lo, (int)floorf(fx - R));
+            x_hi = min(x_hi, (int)floorf(fx + R));
+            y_lo = max(y_lo, (int)floorf(fy - R));
+            y_hi = min(y_hi, (int)floorf(fy + R));
+        }
+        for (int y = y_lo; y <= y_hi; ++y) {
+            const int row = y * L.nx;
+            if (y >= cy - rp && y <= cy + rp) {
+                scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, row, x_lo, min(x_hi, cx - rp - 1), sub, qx, qy);
+                scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, row, max(x_lo, cx + rp + 1), x_hi, sub, qx, qy);
+            } else {
+                scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, row, x_lo, x_hi, sub, qx, qy);
+            }
+        }
+        if (G > 1) {
+            if (EXACT)
+                group_min<G, StartT>(b, oidx);
+            else
+                group_min_lean<G>(b, tie);
+        }
+        const float bound = (float)r * L.h - L.margin;
+        const float b2 = bound * bound;
+        // every point outside the ring's square is farther than `bound` in x or in y
+        if (covers || b.d < b2 || (double)b2 >= gate) break;
+        rp = r;
+    }
+    if (G == 1 || !EXACT) b.oidx = b.pos >= 0 ? (unsigned)oidx[b.pos] : 0xffffffffu;
+    return b;
+}
+
+// Wavefront sum of a double on the VALU's DPP cross-lane path (no LDS
+// crossbar): a 16-lane prefix by row_shr 1,2,4,8, then row_bcast 15 and 31 fold
+// the four rows; lane 63 holds the total, which is returned to all lanes.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_shift_f64(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double uniform(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+__device__ inline double wave_sum(double v)
+{
+    v += dpp_shift_f64<0x111, 0xf>(v); // row_shr:1
+    v += dpp_shift_f64<0x112, 0xf>(v); // row_shr:2
+    v += dpp_shift_f64<0x114, 0xf>(v); // row_shr:4
+    v += dpp_shift_f64<0x118, 0xf>(v); // row_shr:8
+    v += dpp_shift_f64<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v += dpp_shift_f64<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ inline double shfl_xor_f64(double v, int mask)
+{
+    return __hiloint2double(__shfl_xor(__double2hiint(v), mask), __shfl_xor(__double2loint(v), mask));
+}
+
+// Wavefront sums of EIGHT doubles at once: each exchange step halves the number of values a lane
+// carries (lanes 0-31 keep values 0-3 and take the partner's, lanes 32-63 keep 4-7, and so on), so
+// 10 additions per lane replace 48.  On return every lane holds the total of value (lane >> 3).
+// Fixed order: bitwise reproducible.
+__device__ inline double wave_sum8(const double a[8])
+{
+    const int  lane = (int)threadIdx.x & 63;
+    const bool h32 = lane & 32, h16 = lane & 16, h8 = lane & 8;
+    double v4[4], v2[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v4[k] = (h32 ? a[k + 4] : a[k]) + shfl_xor_f64(h32 ? a[k] : a[k + 4], 32);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) v2[k] = (h16 ? v4[k + 2] : v4[k]) + shfl_xor_f64(h16 ? v4[k] : v4[k + 2], 16);
+    double v = (h8 ? v2[1] : v2[0]) + dpp_shift_f64<0x128, 0xf>(h8 ? v2[0] : v2[1]); // row_ror:8 = lane ^ 8
+    v += dpp_shift_f64<0x141, 0xf>(v); // row_half_mirror: lane ^ 7
+    v += dpp_shift_f64<0xB1, 0xf>(v);  // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_shift_f64<0x4E, 0xf>(v);  // quad_perm [2,3,0,1]: lane ^ 2
+    return v;
+}
+
+// icpPointToPoint.cpp:159-162, closed form of svd -> V*U^T (oracle: o_p2p_rotation)
+__device__ inline void p2p_rotation(const double H[4], double R_[4])
+{
+    const double det = H[0] * H[3] - H[1] * H[2];
+    double a, b;
+    if (det >= 0.0) {
+        a = H[0] + H[3];
+        b = H[1] - H[2];
+    } else {
+        a = H[0] - H[3];
+        b = H[1] + H[2];
+    }
+    const double n = sqrt(a * a + b * b);
+    double c = 1.0, s = 0.0;
+    if (n > 0.0) {
+        const double inv_n = 1.0 / n;
+        c = a * inv_n;
+        s = b * inv_n;
+    }
+    if (det >= 0.0) {
+        R_[0] = c;
+        R_[1] = -s;
+        R_[2] = s;
+        R_[3] = c;
+    } else {
+        R_[0] = c;
+        R_[1] = s;
+        R_[2] = s;
+        R_[3] = -c;
+    }
+}
+
+// matrix.cpp:420-508 Gauss-Jordan with full pivoting, 3x3, one rhs (oracle: o_solve3)
+__device__ inline bool solve3(double A[9], double b[3])
+{
+    int indxc[3], indxr[3], ipiv[3] = {0, 0, 0};
+    int irow = 0, icol = 0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double big = 0.0;
+        for (int j = 0; j < 3; j++)
+            if (ipiv[j] != 1)
+                for (int k = 0; k < 3; k++)
+                    if (ipiv[k] == 0 && fabs(A[3 * j + k]) >= big) {
+                        big = fabs(A[3 * j + k]);
+                        irow = j;
+                        icol = k;
+                    }
+        ++ipiv[icol];
+        if (irow != icol) {
+            for (int l = 0; l < 3; l++) {
+                const double tmp = A[3 * irow + l];
+                A[3 * irow + l] = A[3 * icol + l];
+                A[3 * icol + l] = tmp;
+            }
+            const double tmp = b[irow];
+            b[irow] = b[icol];
+            b[icol] = tmp;
+        }
+        indxr[i] = irow;
+        indxc[i] = icol;
+        if (fabs(A[3 * icol + icol]) < 1e-20) return false;
+        const double pivinv = 1.0 / A[3 * icol + icol];
+        A[3 * icol + icol] = 1.0;
+        for (int l = 0; l < 3; l++) A[3 * icol + l] *= pivinv;
+        b[icol] *= pivinv;
+        for (int ll = 0; ll < 3; ll++)
+            if (ll != icol) {
+                const double dum = A[3 * ll + icol];
+                A[3 * ll + icol] = 0.0;
+                for (int l = 0; l < 3; l++) A[3 * ll + l] -= A[3 * icol + l] * dum;
+                b[ll] -= b[icol] * dum;
+            }
+    }
+    (void)indxr;
+    (void)indxc; // column unscrambling only affects the inverse, not the solution vector
+    return true;
+}
+
+// One point-to-point step from the nine sums S = {n, sum(p_m - c), sum(p_t - c), sum (p_t - c)(p_m - c)^T}
+// (c = mv.cx, mv.cy): icpPointToPoint.cpp:128-171.  pose = r00 r01 r10 r11 t0 t1, updated in place when there
+// is a correspondence; returns the step's delta (-1 without correspondences, :128-131).
+__device__ inline double p2p_step(const double S[kNumAcc], const ModelView &mv, double pose[6], int &n_corr)
+{
+    n_corr = (int)S[0];
+    if (n_corr == 0) return -1.0;
+    const double inv = 1.0 / S[0];
+    const double ma0 = S[1] * inv, ma1 = S[2] * inv; // mean of (p_m - c)
+    const double mb0 = S[3] * inv, mb1 = S[4] * inv; // mean of (p_t - c)
+    double       H[4], R_[4], t_[2];
+    H[0] = S[5] - S[3] * ma0;
+    H[1] = S[6] - S[3] * ma1;
+    H[2] = S[7] - S[4] * ma0;
+    H[3] = S[8] - S[4] * ma1;
+    p2p_rotation(H, R_);
+    const double mm0 = mv.cx + ma0, mm1 = mv.cy + ma1;
+    const double mt0 = mv.cx + mb0, mt1 = mv.cy + mb1;
+    t_[0] = mm0 - (R_[0] * mt0 + R_[1] * mt1); // :163
+    t_[1] = mm1 - (R_[2] * mt0 + R_[3] * mt1);
+    const double r00 = pose[0], r01 = pose[1], r10 = pose[2], r11 = pose[3], t0 = pose[4], t1 = pose[5];
+    pose[0] = R_[0] * r00 + R_[1] * r10; // :166-167 R = R_*R ; t = R_*t + t_
+    pose[1] = R_[0] * r01 + R_[1] * r11;
+    pose[2] = R_[2] * r00 + R_[3] * r10;
+    pose[3] = R_[2] * r01 + R_[3] * r11;
+    pose[4] = (R_[0] * t0 + R_[1] * t1) + t_[0];
+    pose[5] = (R_[2] * t0 + R_[3] * t1) + t_[1];
+    const double a0 = R_[0] - 1.0, a3 = R_[3] - 1.0;
+    const double nr2 = a0 * a0 + R_[1] * R_[1] + R_[2] * R_[2] + a3 * a3;
+    const double nt2 = t_[0] * t_[0] + t_[1] * t_[1];
+    return sqrt(nr2 > nt2 ? nr2 : nt2); // :170 max of the two norms (sqrt is monotone: same value)
+}
+
+struct Pose {
+    double r00, r01, r10, r11, t0, t1;
+};
+
+// icpPointToPoint.cpp:69-70: (r00*x + r01*y) + t0 in double, stored to float
+__device__ inline void transform_query(const Pose &T, const double2 P, float &qx, float &qy)
+{
+    qx = (float)__dadd_rn(__dadd_rn(__dmul_rn(T.r00, P.x), __dmul_rn(T.r01, P.y)), T.t0);
+    qy = (float)__dadd_rn(__dadd_rn(__dmul_rn(T.r10, P.x), __dmul_rn(T.r11, P.y)), T.t1);
+}
+
+__device__ inline void add_p2p_xy(const ModelView &mv, const float2 m, float qx, float qy, double acc[kNumAcc]);
+
+// icpPointToPoint.cpp:76,96-99,116-126,159: one inlier correspondence into the running sums
+template <typename StartT>
+__device__ inline void add_p2p(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, const Best &b, float qx,
+                               float qy, double acc[kNumAcc])
+{
+    add_p2p_xy(mv, ix.pts[mv.base[cls] + b.pos], qx, qy, acc);
+}
+
+__device__ inline void add_p2p_xy(const ModelView &mv, const float2 m, float qx, float qy, double acc[kNumAcc])
+{
+    const double ax = (double)m.x - mv.cx, ay = (double)m.y - mv.cy;
+    const double bx = (double)qx - mv.cx, by = (double)qy - mv.cy;
+    acc[0] += 1.0;
+    acc[1] += ax;
+    acc[2] += ay;
+    acc[3] += bx;
+    acc[4] += by;
+    acc[5] += bx * ax; // H[a][b] = sum q_t[a]*q_m[b]  (:159)
+    acc[6] += bx * ay;
+    acc[7] += by * ax;
+    acc[8] += by * ay;
+}
+
+} // namespace icp
+} // namespace slam

@@ -1,5 +1,8 @@
 // runtime.hip -- device plumbing behind the C-ABI (memory, streams, events).
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
 
 #include "common.hpp"
 
@@ -33,6 +36,104 @@ int require_device()
         return SLAM_E_NO_DEVICE;
     }
     return SLAM_OK;
+}
+
+namespace {
+struct PoolBlock {
+    void  *p;
+    size_t cap;
+    int    dev;
+};
+std::mutex                         g_pool_mu;
+std::vector<PoolBlock>            *g_pool_free = nullptr;   // never destroyed: the HIP runtime may be gone at exit
+std::unordered_map<void *, PoolBlock> *g_pool_live = nullptr;
+size_t                             g_pool_cached = 0;
+constexpr size_t kPoolMaxCached = 512u << 20, kPoolMaxBlocks = 64;
+
+size_t pool_round(size_t bytes)
+{
+    size_t c = 256;
+    while (c < bytes) c += c >= 4096 ? c / 4 : c; // doubling up to 4 KB, then steps of a quarter
+    return (c + 255) & ~(size_t)255;
+}
+} // namespace
+
+void *pool_alloc(size_t bytes)
+{
+    const size_t want = pool_round(bytes ? bytes : 1);
+    int          dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("pool_alloc: no current HIP device");
+        return nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pool_free) {
+            g_pool_free = new std::vector<PoolBlock>();
+            g_pool_live = new std::unordered_map<void *, PoolBlock>();
+        }
+        int best = -1;
+        for (int i = 0; i < (int)g_pool_free->size(); ++i) {
+            const PoolBlock &b = (*g_pool_free)[i];
+            if (b.dev == dev && b.cap >= want && b.cap <= 2 * want && (best < 0 || b.cap < (*g_pool_free)[best].cap)) best = i;
+        }
+        if (best >= 0) {
+            const PoolBlock b = (*g_pool_free)[best];
+            g_pool_free->erase(g_pool_free->begin() + best);
+            g_pool_cached -= b.cap;
+            (*g_pool_live)[b.p] = b;
+            return b.p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { // give the cached blocks back and try once more
+        (void)hipGetLastError();
+        pool_trim();
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        set_error("pool_alloc: hipMalloc of %zu bytes failed (%s)", want, hipGetErrorString(e));
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    (*g_pool_live)[p] = PoolBlock{p, want, dev};
+    return p;
+}
+
+void pool_free(void *p)
+{
+    if (!p) return;
+    PoolBlock b{p, 0, 0};
+    bool      keep = false;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pool_live) return;
+        auto it = g_pool_live->find(p);
+        if (it == g_pool_live->end()) return; // not ours
+        b = it->second;
+        g_pool_live->erase(it);
+        keep = g_pool_free->size() < kPoolMaxBlocks && g_pool_cached + b.cap <= kPoolMaxCached;
+        if (keep) {
+            g_pool_free->push_back(b);
+            g_pool_cached += b.cap;
+        }
+    }
+    if (!keep) (void)hipFree(b.p);
+}
+
+void pool_trim()
+{
+    std::vector<PoolBlock> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        if (!g_pool_free) return;
+        drop.swap(*g_pool_free);
+        g_pool_cached = 0;
+    }
+    for (const PoolBlock &b : drop) (void)hipFree(b.p);
 }
 
 } // namespace slam
