@@ -109,6 +109,9 @@ typedef struct {
     int    far_div;         /* default schedule: hand over once at most n / far_div queries are beyond the lists'
                                certified radius (0 = library default, 32) */
     int    split_launch;    /* 1 = the two search forms as two launches instead of one (same results) */
+    int    spread_scans;    /* batches of at most this many scans (one, in the reference's usage) run in the
+                               spread form: every scan over many workgroups of one persistent launch, 64 lanes
+                               per query (icp_single.hip); 0 = library default (CUs / 16), -1 = never */
 } slam_icp_params;
 
 typedef struct {

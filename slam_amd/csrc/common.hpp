@@ -24,6 +24,9 @@ inline hipStream_t as_stream(slam_stream_t s) { return reinterpret_cast<hipStrea
 void *pool_alloc(size_t bytes);
 void  pool_free(void *p);
 void  pool_trim(); // hipFree of everything cached
+// One pinned host buffer per host thread (grown on demand, never freed), for a call's staging and read-back;
+// valid until the same thread asks again.
+void *pinned_scratch(size_t bytes);
 
 } // namespace slam
 

@@ -50,29 +50,6 @@ using namespace slam::icp;
 
 namespace {
 
-struct FitArgs {
-    const double2 *pts;
-    const int     *scan_off;
-    const int     *scan_nga;
-    double        *R;
-    double        *t;
-    slam_icp_result *result;
-    double        *trace;
-    int            max_iter;
-    double         min_delta;
-    double         indist;
-    double        *step_pose; // nullable; per scan 6 doubles: R,t as the last executed step found them
-    long long     *stamps; // diagnostic only (SLAM_ICP_STAMPS=1): per scan, cycles in [search, reduce, barrier, solve]
-    // Two search forms per scan: the ring search runs at least the first switch_iter iterations (by then a scan
-    // is normally within the certified radius of the halo lists), the list sweeps the rest.  One launch does
-    // both (icp_fit_fused_kernel); as two launches of icp_fit_kernel (SLAM_ICP_SPLIT=1, measurements) the
-    // hand-over goes through state[scan] = iterations done, or -1 when the scan finished in the ring search.
-    int           *state;
-    int            phase;  // icp_fit_kernel: 0 = the only launch, 1 = ring search of two launches, 2 = list sweeps of two
-    int            switch_iter;
-    int            far_div;       // hand over once at most n / far_div queries are beyond the lists' certified radius
-};
-
 // List-sweep mode: the query's own cell of the list lattice, one sweep over its halo list, certified when
 // the best distance is below the halo radius.  Returns false (undecided) otherwise.
 struct ListPtrs {
@@ -383,14 +360,6 @@ __device__ inline void point_pass_reg(const IndexPtrs<StartT> &ix, const ModelVi
 // more than half a workgroup of points is left, then the widest group that
 // still covers the rest in one pass (a 1081-point scan is 1024 points at G = 1
 // plus 57 points at G = 16), so no pass runs nearly empty.
-// The state of one scan's fit that outlives a run of iterations: the pose (the same in every lane) and the
-// counters that go into slam_icp_result.
-struct FitState {
-    double r00, r01, r10, r11, t0, t1, delta;
-    int    iters, n_corr;
-    bool   hand_over;
-};
-
 // Iterations fs.iters .. max_iter-1 of the workgroup's scan in one search form (SWEEP 0: ring search with G lanes
 // per point on the cell index `ix`; SWEEP 2: list sweeps on the halo lists `lp`, the undecided few on `ix`).
 // phase 1 stops from fa.switch_iter on with fs.hand_over set as soon as the list form can take over (see the guard).
@@ -656,13 +625,6 @@ __device__ inline FitState load_fit(const FitArgs &fa, int s, int iter_begin)
     return fs;
 }
 
-__device__ inline void fill_lds(unsigned char *dst, const unsigned char *blob, unsigned bytes)
-{
-    const uint4 *src = reinterpret_cast<const uint4 *>(blob);
-    uint4       *d4 = reinterpret_cast<uint4 *>(dst);
-    for (unsigned i = threadIdx.x; i < bytes / 16u; i += kBlock) d4[i] = src[i];
-}
-
 template <int G, bool LDS, typename StartT, int MODE, int SWEEP>
 __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs fa)
 {
@@ -726,109 +688,6 @@ __global__ __launch_bounds__(kBlock) void icp_fit_fused_kernel(ModelView mv, Fit
         fit_iterations<1, StartT, MODE, 2>(mv, fa, ix, lp, smem, s, off, n, nga, 2, fs);
     }
     if (threadIdx.x == 0) store_fit(fa, s, fs, 0);
-}
-
-// ------------------------------------------------------------ one scan, low latency
-// A batch of ONE scan (the reference's own usage: scan_registration matches scan by scan) would keep a single
-// workgroup -- one CU of 256 -- busy for all iterations, with the index read from HBM/L2 when the model is
-// large.  Instead every iteration is two small launches: icp_step_kernel spreads the scan's points over as
-// many workgroups as it takes (kStepLanes lanes per point, ring search on the index in HBM/L2) and leaves one
-// row of nine partial sums per workgroup; icp_solve_kernel adds the rows in fixed order (bitwise reproducible),
-// solves and updates the pose in place.  A `done` flag turns the remaining launches into no-ops once
-// min_delta is reached.  ctrl: [0] iterations done, [1] done flag, [2] correspondences of the last step.
-constexpr int kStepLanes = 8, kStepBlock = 256, kStepPoints = kStepBlock / kStepLanes;
-
-template <typename StartT>
-__global__ __launch_bounds__(kStepBlock) void icp_step_kernel(ModelView mv, const double2 *pts, int n, int nga,
-                                                              const double *pose, double indist, double *partial,
-                                                              const int *ctrl)
-{
-    if (ctrl[1]) return;
-    __shared__ double wsum[kStepBlock / 64][kNumAcc];
-    const IndexPtrs<StartT> ix = make_ptrs<StartT>(mv.blob, mv);
-    const Pose T = {pose[0], pose[1], pose[2], pose[3], pose[4], pose[5]};
-    const int  tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int  p = blockIdx.x * kStepPoints + tid / kStepLanes, sub = tid % kStepLanes;
-    double     acc[kNumAcc];
-#pragma unroll
-    for (int k = 0; k < kNumAcc; ++k) acc[k] = 0.0;
-    if (p < n) {
-        const int cls = p < nga ? 0 : 1;
-        if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
-            float qx, qy;
-            transform_query(T, pts[p], qx, qy);
-            const Best b = nn_search<kStepLanes, StartT>(ix, mv, cls, qx, qy, sub, indist);
-            if (sub == 0 && b.pos >= 0 && (double)b.d < indist) add_p2p<StartT>(ix, mv, cls, b, qx, qy, acc); // :76
-        }
-    }
-    const double v8 = wave_sum8(acc), v9 = wave_sum(acc[8]);
-    if ((lane & 7) == 0) wsum[wave][lane >> 3] = v8;
-    if (lane == 0) wsum[wave][8] = v9;
-    __syncthreads();
-    if (tid < kNumAcc) {
-        double v = 0.0;
-        for (int w = 0; w < kStepBlock / 64; ++w) v += wsum[w][tid];
-        partial[(size_t)blockIdx.x * kNumAcc + tid] = v;
-    }
-}
-
-__global__ __launch_bounds__(64) void icp_solve_kernel(ModelView mv, const double *partial, int n_blocks, double *pose,
-                                                       int *ctrl, double *delta_out, int max_iter, double min_delta,
-                                                       double *trace, double *step_pose)
-{
-    if (ctrl[1]) return;
-    const int lane = threadIdx.x;
-    double    mine = 0.0;
-    if (lane < kNumAcc)
-        for (int b = 0; b < n_blocks; ++b) mine += partial[(size_t)b * kNumAcc + lane];
-    double S[kNumAcc];
-#pragma unroll
-    for (int k = 0; k < kNumAcc; ++k)
-        S[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), k),
-                                __builtin_amdgcn_readlane(__double2loint(mine), k));
-    double o[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) o[k] = pose[k];
-    if (lane == 0 && step_pose)
-        for (int k = 0; k < 6; ++k) step_pose[k] = o[k]; // R,t as this step found them (edge weights)
-    int          nc = 0;
-    const double d = p2p_step(S, mv, o, nc);
-    if (lane == 0) {
-        const int it = ctrl[0];
-        for (int k = 0; k < 6; ++k) pose[k] = o[k];
-        *delta_out = d;
-        ctrl[0] = it + 1;
-        ctrl[2] = nc;
-        if (d < min_delta || it + 1 >= max_iter) ctrl[1] = 1; // icp.cpp:119-121
-        if (trace) {
-            double *tr = trace + (size_t)it * 8;
-            for (int k = 0; k < 6; ++k) tr[k] = o[k];
-            tr[6] = d;
-            tr[7] = (double)nc;
-        }
-    }
-}
-
-// copies the pose between the caller's R[4], t[2] and the contiguous six doubles the step kernels use, and
-// writes the result record at the end
-__global__ void icp_single_io_kernel(double *R, double *t, double *pose, const int *ctrl, const double *delta,
-                                     slam_icp_result *result, int to_pose)
-{
-    if (threadIdx.x != 0) return;
-    if (to_pose) {
-        for (int k = 0; k < 4; ++k) pose[k] = R[k];
-        pose[4] = t[0];
-        pose[5] = t[1];
-    } else {
-        for (int k = 0; k < 4; ++k) R[k] = pose[k];
-        t[0] = pose[4];
-        t[1] = pose[5];
-        if (result) {
-            result->iters = ctrl[0];
-            result->n_corr = ctrl[2];
-            result->delta = *delta;
-        }
-    }
 }
 
 // Normals for the point-to-line mode, icpPointToPlane.cpp:279-305,340-349: for
@@ -1098,48 +957,6 @@ int launch_fit_m(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
     return SLAM_E_INVALID;
 }
 
-// One scan: per iteration a step launch over ceil(n / 32) workgroups and a solve launch (see icp_step_kernel).
-// The scan's size has to be known on the host to size the grid: one 8-byte read of the offsets.
-int fit_single(slam_icp *h, const FitArgs &fa, hipStream_t st)
-{
-    int off[2] = {0, h->hint_n}, nga = h->hint_nga;
-    if (h->hint_n < 0) { // not called through slam_icp_fit: read the scan's size back (one synchronisation)
-        SLAM_HIP(hipMemcpyAsync(off, fa.scan_off, sizeof off, hipMemcpyDeviceToHost, st));
-        SLAM_HIP(hipMemcpyAsync(&nga, fa.scan_nga, sizeof nga, hipMemcpyDeviceToHost, st));
-        SLAM_HIP(hipStreamSynchronize(st));
-    }
-    const int n = off[1] - off[0];
-    const int n_blocks = (n + kStepPoints - 1) / kStepPoints;
-    SLAM_TRY(h->w_single.reserve(sizeof(double) * (8 + (size_t)std::max(n_blocks, 1) * kNumAcc) + 64));
-    double *pose = static_cast<double *>(h->w_single.p), *delta = pose + 6, *partial = pose + 8;
-    int    *ctrl = reinterpret_cast<int *>(partial + (size_t)std::max(n_blocks, 1) * kNumAcc);
-    SLAM_HIP(hipMemsetAsync(pose + 6, 0, 16, st));
-    SLAM_HIP(hipMemsetAsync(ctrl, 0, 16, st));
-    hipLaunchKernelGGL(icp_single_io_kernel, dim3(1), dim3(64), 0, st, fa.R, fa.t, pose, ctrl, delta, fa.result, 1);
-    if (n >= 5 && fa.max_iter > 0) { // icp.cpp:100-103
-        const double2 *pts = fa.pts + off[0];
-        for (int it = 0; it < fa.max_iter; ++it) {
-            if (h->start32)
-                hipLaunchKernelGGL((icp_step_kernel<uint32_t>), dim3(n_blocks), dim3(kStepBlock), 0, st, h->mv, pts, n, nga,
-                                   pose, fa.indist, partial, ctrl);
-            else
-                hipLaunchKernelGGL((icp_step_kernel<uint16_t>), dim3(n_blocks), dim3(kStepBlock), 0, st, h->mv, pts, n, nga,
-                                   pose, fa.indist, partial, ctrl);
-            hipLaunchKernelGGL(icp_solve_kernel, dim3(1), dim3(64), 0, st, h->mv, partial, n_blocks, pose, ctrl, delta,
-                               fa.max_iter, fa.min_delta, fa.trace, fa.step_pose);
-            if ((it & 31) == 31 && it + 1 < fa.max_iter) { // long limits: stop issuing once the scan has converged
-                int done[2] = {0, 0};
-                SLAM_HIP(hipMemcpyAsync(done, ctrl, sizeof done, hipMemcpyDeviceToHost, st));
-                SLAM_HIP(hipStreamSynchronize(st));
-                if (done[1]) break;
-            }
-        }
-    }
-    hipLaunchKernelGGL(icp_single_io_kernel, dim3(1), dim3(64), 0, st, fa.R, fa.t, pose, ctrl, delta, fa.result, 0);
-    SLAM_HIP(hipGetLastError());
-    return SLAM_OK;
-}
-
 int launch_fit(slam_icp *h, const FitArgs &fa_in, int n_scans, hipStream_t st)
 {
     if (n_scans <= 0) return SLAM_OK;
@@ -1220,6 +1037,7 @@ void slam_icp_default_params(slam_icp_params *p)
     p->first_iterations = 0;
     p->far_div = 0;
     p->split_launch = 0;
+    p->spread_scans = 0;
 }
 
 } // extern "C"
@@ -1252,6 +1070,11 @@ int icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga, con
     if (h->prm.first_iterations > 0) h->switch_iter = h->prm.first_iterations;
     if (h->prm.far_div > 0) h->far_div = h->prm.far_div;
     h->split_launch = h->prm.split_launch != 0;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+            h->n_cu = cus;
+    }
 #ifdef SLAM_MEASURE
     if (const char *e = getenv("SLAM_ICP_SPLIT")) h->split_launch = atoi(e) != 0;
     if (const char *e = getenv("SLAM_ICP_CELL")) h->prm.cell_size = atof(e); // measurements: overrides the pitch
@@ -1302,8 +1125,7 @@ void slam_icp_destroy(slam_icp_t *icp)
     for (auto &e : icp->ev)
         if (e) (void)hipEventDestroy(e);
     if (icp->d_normals) (void)hipFree(icp->d_normals);
-    for (DevBuf *b : {&icp->w_pts, &icp->w_off, &icp->w_nga, &icp->w_R, &icp->w_t, &icp->w_res, &icp->w_stamps, &icp->w_pose,
-                      &icp->w_ew, &icp->w_state, &icp->w_single})
+    for (DevBuf *b : {&icp->w_pts, &icp->w_stamps, &icp->w_ew, &icp->w_state, &icp->w_single})
         b->release();
     delete icp;
 }
@@ -1369,7 +1191,7 @@ int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *
     fa.max_iter = icp->prm.max_iter;
     fa.min_delta = icp->prm.min_delta;
     fa.indist = indist;
-    fa.step_pose = icp->want_step_pose ? static_cast<double *>(icp->w_pose.p) : nullptr;
+    fa.step_pose = icp->want_step_pose ? reinterpret_cast<double *>(static_cast<unsigned char *>(icp->w_pts.p) + icp->step_pose_off) : nullptr;
     fa.stamps = nullptr;
 #ifdef SLAM_MEASURE
     if (getenv("SLAM_ICP_STAMPS")) {
@@ -1379,9 +1201,11 @@ int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *
         icp->n_stamps = n_scans * kWaves;
     }
 #endif
-    // one scan against a model too large for LDS: many small workgroups per iteration instead of one
-    if (n_scans == 1 && !icp->in_lds && icp->prm.mode == SLAM_ICP_P2P && icp->prm.lanes_per_point == 0 && !fa.stamps)
-        return fit_single(icp, fa, as_stream(stream));
+    // few scans (one, in the reference's own usage): each scan spread over many workgroups of one persistent launch
+    const int spread_max = icp->prm.spread_scans > 0 ? std::min(icp->prm.spread_scans, icp->n_cu)
+                                                     : (icp->prm.spread_scans < 0 ? 0 : icp->n_cu / kSpreadMinParts);
+    if (n_scans >= 1 && n_scans <= spread_max && icp->prm.mode == SLAM_ICP_P2P && icp->prm.lanes_per_point == 0 && !fa.stamps)
+        return launch_fit_spread(icp, fa, n_scans, as_stream(stream));
     return launch_fit(icp, fa, n_scans, as_stream(stream));
 }
 
@@ -1402,43 +1226,47 @@ int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t
                  n_tga + n_tnga);
     SLAM_TRY(require_device());
     const int n = n_tga + n_tnga;
-    SLAM_TRY(icp->w_pts.reserve(16 * (size_t)n));
-    SLAM_TRY(icp->w_off.reserve(8));
-    SLAM_TRY(icp->w_nga.reserve(4));
-    SLAM_TRY(icp->w_R.reserve(32));
-    SLAM_TRY(icp->w_t.reserve(16));
-    SLAM_TRY(icp->w_res.reserve(sizeof(slam_icp_result)));
-    SLAM_TRY(icp->w_pose.reserve(6 * sizeof(double)));
+    // One block in HBM and one pinned block on the host, the same layout: the template's points, then a header
+    //   [scan_off 0, n | nGA | pad] [R t] [result] [pose of the last executed step]
+    // so that a fit is one copy in, one launch, one copy out (the reference's fit() is synchronous too).
+    const size_t pts_bytes = 16 * (size_t)n, hdr = pts_bytes, o_pose_in = hdr + 16, o_res = o_pose_in + 48, o_step = o_res + 16,
+                 total = o_step + 48;
+    SLAM_TRY(icp->w_pts.reserve(total));
+    unsigned char *hp = static_cast<unsigned char *>(pinned_scratch(total));
+    SLAM_REQUIRE(hp, SLAM_E_NOMEM, "slam_icp_fit: no pinned staging memory");
+    unsigned char *dp = static_cast<unsigned char *>(icp->w_pts.p);
+    if (n_tga) memcpy(hp, t_ga, 16 * (size_t)n_tga);
+    if (n_tnga) memcpy(hp + 16 * (size_t)n_tga, t_nga, 16 * (size_t)n_tnga);
+    int32_t *hh = reinterpret_cast<int32_t *>(hp + hdr);
+    hh[0] = 0, hh[1] = n, hh[2] = n_tga, hh[3] = 0;
+    memcpy(hp + o_pose_in, R, 32);
+    memcpy(hp + o_pose_in + 32, t, 16);
+    memset(hp + o_res, 0, 16);
     hipStream_t st = nullptr;
-    double *dp = static_cast<double *>(icp->w_pts.p);
-    if (n_tga) SLAM_HIP(hipMemcpyAsync(dp, t_ga, 16 * (size_t)n_tga, hipMemcpyHostToDevice, st));
-    if (n_tnga)
-        SLAM_HIP(hipMemcpyAsync(dp + 2 * (size_t)n_tga, t_nga, 16 * (size_t)n_tnga, hipMemcpyHostToDevice, st));
-    const int32_t off[2] = {0, n};
-    const int32_t nga = n_tga;
-    SLAM_HIP(hipMemcpyAsync(icp->w_off.p, off, 8, hipMemcpyHostToDevice, st));
-    SLAM_HIP(hipMemcpyAsync(icp->w_nga.p, &nga, 4, hipMemcpyHostToDevice, st));
-    SLAM_HIP(hipMemcpyAsync(icp->w_R.p, R, 32, hipMemcpyHostToDevice, st));
-    SLAM_HIP(hipMemcpyAsync(icp->w_t.p, t, 16, hipMemcpyHostToDevice, st));
+    SLAM_HIP(hipMemcpyAsync(dp, hp, o_step, hipMemcpyHostToDevice, st));
     icp->want_step_pose = true;
-    icp->hint_n = n;
-    icp->hint_nga = n_tga;
-    const int rc_fit = slam_icp_fit_batch_dev(icp, dp, static_cast<int32_t *>(icp->w_off.p),
-                                              static_cast<int32_t *>(icp->w_nga.p), 1,
-                                              static_cast<double *>(icp->w_R.p), static_cast<double *>(icp->w_t.p),
-                                              indist, static_cast<slam_icp_result *>(icp->w_res.p), nullptr, st);
+    icp->step_pose_off = o_step;
+    icp->spread_points_hint = n;
+    const int rc_fit = slam_icp_fit_batch_dev(icp, reinterpret_cast<double *>(dp), reinterpret_cast<int32_t *>(dp + hdr),
+                                              reinterpret_cast<int32_t *>(dp + hdr + 8), 1,
+                                              reinterpret_cast<double *>(dp + o_pose_in), reinterpret_cast<double *>(dp + o_pose_in + 32),
+                                              indist, reinterpret_cast<slam_icp_result *>(dp + o_res), nullptr, st);
     icp->want_step_pose = false;
-    icp->hint_n = -1;
     SLAM_TRY(rc_fit);
     icp->last_n = n;
     icp->last_nga = n_tga;
     icp->last_indist = indist;
     icp->have_last = true;
-    slam_icp_result res;
-    SLAM_HIP(hipMemcpyAsync(R, icp->w_R.p, 32, hipMemcpyDeviceToHost, st));
-    SLAM_HIP(hipMemcpyAsync(t, icp->w_t.p, 16, hipMemcpyDeviceToHost, st));
-    SLAM_HIP(hipMemcpyAsync(&res, icp->w_res.p, sizeof res, hipMemcpyDeviceToHost, st));
+    SLAM_HIP(hipMemcpyAsync(hp + o_pose_in, dp + o_pose_in, 64, hipMemcpyDeviceToHost, st)); // R, t, result
     SLAM_HIP(hipStreamSynchronize(st));
+    slam_icp_result res;
+    memcpy(&res, hp + o_res, sizeof res);
+    if (res.iters < 0) { // the spread form's exchange gave up (icp_single.hip): nothing was written back
+        set_error("slam_icp_fit: the scan's workgroups lost each other (the GPU is oversubscribed by other persistent kernels?)");
+        return SLAM_E_HIP;
+    }
+    memcpy(R, hp + o_pose_in, 32);
+    memcpy(t, hp + o_pose_in + 32, 16);
     if (result) *result = res;
     return SLAM_OK;
 }
@@ -1480,7 +1308,7 @@ int slam_icp_get_edge_weight(slam_icp_t *icp, double eW[9])
     SLAM_TRY(require_device());
     SLAM_TRY(icp->w_ew.reserve(9 * sizeof(double)));
     const double2 *pts = static_cast<const double2 *>(icp->w_pts.p);
-    const double  *pose = static_cast<const double *>(icp->w_pose.p);
+    const double  *pose = reinterpret_cast<const double *>(static_cast<const unsigned char *>(icp->w_pts.p) + icp->step_pose_off);
     double        *d_ew = static_cast<double *>(icp->w_ew.p);
     if (icp->start32)
         hipLaunchKernelGGL((icp_edge_weight_kernel<uint32_t>), dim3(1), dim3(kBlock), 0, nullptr, icp->mv, pts,

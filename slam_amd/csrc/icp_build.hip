@@ -488,44 +488,93 @@ __global__ __launch_bounds__(256) void idx_count_kernel(BuildArgs a)
     atomicAdd(&a.start[(size_t)c * (a.ncells + 1) + cell], 1u);
 }
 
-// Exclusive prefix of v[0 .. n) in place, v[n] = total, one workgroup of 1024 threads (contiguous chunk per
-// thread); also stored as `esz`-byte entries at `out` (the blob's start array).
-__device__ inline void block_exclusive_scan(unsigned *v, int n, unsigned char *out, int esz, unsigned *s_wave)
+// Exclusive prefix of the per-cell counts of both classes, in place (v[n] = total), also stored as `esz`-byte
+// entries in the blob's start arrays.  Two launches over tiles of 8192 values: the tiles' totals, then every
+// tile adds the totals before it (a few dozen values) and scans itself -- a single workgroup walking 80 k cells
+// took 100 us, one CU's share of the bandwidth.
+constexpr int kScanPer = 8, kScanTile = 1024 * kScanPer;
+
+struct ScanArgs {
+    unsigned      *v[2];    // counts of class 0 / 1, n + 1 values each
+    unsigned char *out[2];  // the blob's start arrays
+    unsigned      *tiles;   // [2][n_tiles] tile totals
+    int            n, n_tiles, esz;
+};
+
+__device__ inline unsigned block_sum_1024(unsigned x, unsigned *s_wave)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (n + 1023) / 1024, a = min(tid * per, n), e = min(a + per, n);
-    unsigned  sum = 0;
-    for (int k = a; k < e; ++k) sum += v[k];
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = x;
+    __syncthreads();
+    unsigned t = 0;
+    for (int w = 0; w < 16; ++w) t += s_wave[w];
+    __syncthreads();
+    return t;
+}
+
+// grid (n_tiles, 2)
+__global__ __launch_bounds__(1024) void scan_tiles_kernel(ScanArgs a)
+{
+    __shared__ unsigned s_wave[16];
+    const int           c = blockIdx.y, k0 = blockIdx.x * kScanTile + (int)threadIdx.x * kScanPer;
+    unsigned            sum = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) sum += k0 + j < a.n ? a.v[c][k0 + j] : 0u;
+    const unsigned t = block_sum_1024(sum, s_wave);
+    if (threadIdx.x == 0) a.tiles[c * a.n_tiles + blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(1024) void scan_apply_kernel(ScanArgs a)
+{
+    __shared__ unsigned s_wave[16];
+    const int           c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned            before = 0;
+    for (int t = tid; t < tile; t += 1024) before += a.tiles[c * a.n_tiles + t];
+    before = block_sum_1024(before, s_wave);
+    const int k0 = tile * kScanTile + tid * kScanPer;
+    unsigned  x[kScanPer], sum = 0;
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {
+        x[j] = k0 + j < a.n ? a.v[c][k0 + j] : 0u;
+        sum += x[j];
+    }
     unsigned incl = sum;
     for (int o = 1; o < 64; o <<= 1) {
         const unsigned t = __shfl_up(incl, o);
         if (lane >= o) incl += t;
     }
-    __syncthreads(); // s_wave may still be read by the previous call
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
-    unsigned before = incl - sum;
-    for (int w = 0; w < wave; ++w) before += s_wave[w];
-    unsigned run = before;
-    for (int k = a; k < e; ++k) {
-        const unsigned c = v[k];
-        v[k] = run;
-        store_entry(out, esz, (size_t)k, run);
-        run += c;
-    }
-    if (tid == 1023) {
-        v[n] = run;
-        store_entry(out, esz, (size_t)n, run);
+    unsigned run = before + incl - sum;
+    for (int w = 0; w < wave; ++w) run += s_wave[w];
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {
+        if (k0 + j <= a.n) { // position n receives the total
+            a.v[c][k0 + j] = run;
+            store_entry(a.out[c], a.esz, (size_t)(k0 + j), run);
+        }
+        run += x[j];
     }
 }
 
-__global__ __launch_bounds__(1024) void idx_scan_kernel(unsigned *start, int ncells, unsigned char *blob, unsigned off0,
-                                                        unsigned off1, int esz)
+int launch_scan(unsigned *v0, unsigned *v1, int n, unsigned char *out0, unsigned char *out1, int esz, unsigned *tiles,
+                hipStream_t st)
 {
-    __shared__ unsigned s_wave[16];
-    block_exclusive_scan(start, ncells, blob + off0, esz, s_wave);
-    block_exclusive_scan(start + (ncells + 1), ncells, blob + off1, esz, s_wave);
+    ScanArgs a;
+    a.v[0] = v0;
+    a.v[1] = v1;
+    a.out[0] = out0;
+    a.out[1] = out1;
+    a.tiles = tiles;
+    a.n = n;
+    a.n_tiles = n / kScanTile + 1; // covers position n itself
+    a.esz = esz;
+    hipLaunchKernelGGL(scan_tiles_kernel, dim3(a.n_tiles, 2), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3(a.n_tiles, 2), dim3(1024), 0, st, a);
+    return SLAM_OK;
 }
+
+inline size_t scan_tile_words(int n) { return 2 * (size_t)(n / kScanTile + 1); }
 
 __global__ __launch_bounds__(256) void idx_fill_kernel(BuildArgs a)
 {
@@ -622,94 +671,109 @@ __global__ __launch_bounds__(256) void list_scatter_kernel(ListArgs a)
         }
 }
 
-__global__ __launch_bounds__(1024) void list_scan_kernel(ListArgs a)
-{
-    __shared__ unsigned s_wave[16];
-    block_exclusive_scan(a.start, a.ncells, a.lblob + a.loff_start[0], 2, s_wave);
-    block_exclusive_scan(a.start + (a.ncells + 1), a.ncells, a.lblob + a.loff_start[1], 2, s_wave);
-}
-
 // One wavefront per (cell, class): the list's ordering key by the densest-window metric, then the entries in
 // (key, point) order -- what the host's two stable sorts leave.  Metric of a key: the largest number of entries
 // whose key lies in [k_j - win, k_j] over the entries j (the host's sliding window over the sorted keys counts
 // exactly that: float subtraction is monotone).
-constexpr int kListStage = 1024; // entries of a cell staged in LDS (more: read through the cache)
+constexpr int kListStage = 256; // entries of a cell staged in LDS per wavefront (more: read through the cache)
+constexpr int kSortWaves = 4;   // wavefronts per workgroup, each taking (cell, class) pairs in turn
 
-__global__ __launch_bounds__(64) void list_sort_kernel(ListArgs a)
+__global__ __launch_bounds__(64 * kSortWaves) void list_sort_kernel(ListArgs a)
 {
-    __shared__ float s_x[kListStage], s_y[kListStage];
-    __shared__ int   s_j[kListStage];
-    const int        cell = blockIdx.x, c = blockIdx.y, lane = threadIdx.x;
-    const unsigned  *st = a.start + (size_t)c * (a.ncells + 1);
-    const int        lo = (int)st[cell], n = (int)st[cell + 1] - lo;
-    if (n <= 0) return;
-    const int    *ent = a.ent + a.lbase[c] + lo;
-    const float2 *xy = a.xyf + a.base[c];
-    const bool    staged = n <= kListStage;
-    if (staged) {
-        for (int k = lane; k < n; k += 64) {
-            const int    j = ent[k];
-            const float2 p = xy[j];
-            s_x[k] = p.x;
-            s_y[k] = p.y;
-            s_j[k] = j;
+    __shared__ float s_xs[kSortWaves][kListStage], s_ys[kSortWaves][kListStage], s_ks[kSortWaves][kListStage];
+    __shared__ int   s_js[kSortWaves][kListStage];
+    const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float           *s_x = s_xs[wave], *s_y = s_ys[wave], *s_k = s_ks[wave];
+    int             *s_j = s_js[wave];
+    const int        n_pairs = 2 * a.ncells, stride = (int)gridDim.x * kSortWaves;
+    for (int pair = (int)blockIdx.x * kSortWaves + wave; pair < n_pairs; pair += stride) {
+        const int       c = pair >= a.ncells ? 1 : 0, cell = pair - c * a.ncells;
+        const unsigned *st = a.start + (size_t)c * (a.ncells + 1);
+        const int       lo = (int)st[cell], n = (int)st[cell + 1] - lo;
+        if (n <= 0) continue;
+        const int    *ent = a.ent + a.lbase[c] + lo;
+        const float2 *xy = a.xyf + a.base[c];
+        const bool    staged = n <= kListStage;
+        // (a wavefront writes and reads only its own stage: program order and a wave barrier are enough)
+        if (staged) {
+            for (int k = lane; k < n; k += 64) {
+                const int    j = ent[k];
+                const float2 p = xy[j];
+                s_x[k] = p.x;
+                s_y[k] = p.y;
+                s_j[k] = j;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __syncthreads();
-    }
-    const auto X = [&](int k) { return staged ? s_x[k] : xy[ent[k]].x; };
-    const auto Y = [&](int k) { return staged ? s_y[k] : xy[ent[k]].y; };
-    const auto J = [&](int k) { return staged ? s_j[k] : ent[k]; };
+        const auto X = [&](int k) { return staged ? s_x[k] : xy[ent[k]].x; };
+        const auto Y = [&](int k) { return staged ? s_y[k] : xy[ent[k]].y; };
+        const auto J = [&](int k) { return staged ? s_j[k] : ent[k]; };
+        // keys of direction `dir`, staged too when the cell is
+        const auto stage_keys = [&](int dir) {
+            if (staged) {
+                __builtin_amdgcn_wave_barrier();
+                for (int k = lane; k < n; k += 64) s_k[k] = list_key(dir, s_x[k], s_y[k]);
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        const auto K = [&](int dir, int k) { return staged ? s_k[k] : list_key(dir, X(k), Y(k)); };
 
-    float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
-    for (int k = lane; k < n; k += 64) {
-        mnx = fminf(mnx, X(k));
-        mxx = fmaxf(mxx, X(k));
-        mny = fminf(mny, Y(k));
-        mxy = fmaxf(mxy, Y(k));
-    }
-    for (int o = 32; o > 0; o >>= 1) {
-        mnx = fminf(mnx, __shfl_xor(mnx, o));
-        mxx = fmaxf(mxx, __shfl_xor(mxx, o));
-        mny = fminf(mny, __shfl_xor(mny, o));
-        mxy = fmaxf(mxy, __shfl_xor(mxy, o));
-    }
-    int best_dir = (mxy - mny) > (mxx - mnx) ? 1 : 0;
-    if (n >= 8) {
-        unsigned  best_metric = 0xffffffffu;
-        const int first = best_dir;
-        for (int t = 0; t < 4; ++t) {
-            const int   dir = t == 0 ? first : (t == 1 ? 1 - first : t);
-            const float win = key_window(dir);
-            unsigned    metric = 0;
-            for (int j = lane; j < n; j += 64) {
-                const float kj = list_key(dir, X(j), Y(j));
-                unsigned    cnt = 0;
-                for (int i = 0; i < n; ++i) {
-                    const float ki = list_key(dir, X(i), Y(i));
-                    cnt += (ki <= kj && !(kj - ki > win)) ? 1u : 0u;
+        float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+        for (int k = lane; k < n; k += 64) {
+            mnx = fminf(mnx, X(k));
+            mxx = fmaxf(mxx, X(k));
+            mny = fminf(mny, Y(k));
+            mxy = fmaxf(mxy, Y(k));
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            mnx = fminf(mnx, __shfl_xor(mnx, o));
+            mxx = fmaxf(mxx, __shfl_xor(mxx, o));
+            mny = fminf(mny, __shfl_xor(mny, o));
+            mxy = fmaxf(mxy, __shfl_xor(mxy, o));
+        }
+        int best_dir = (mxy - mny) > (mxx - mnx) ? 1 : 0;
+        if (n >= 8) {
+            unsigned  best_metric = 0xffffffffu;
+            const int first = best_dir;
+            for (int t = 0; t < 4; ++t) {
+                const int   dir = t == 0 ? first : (t == 1 ? 1 - first : t);
+                const float win = key_window(dir);
+                unsigned    metric = 0;
+                stage_keys(dir);
+                for (int j = lane; j < n; j += 64) {
+                    const float kj = K(dir, j);
+                    unsigned    cnt = 0;
+#pragma unroll 8
+                    for (int i = 0; i < n; ++i) {
+                        const float ki = K(dir, i);
+                        cnt += (ki <= kj && !(kj - ki > win)) ? 1u : 0u;
+                    }
+                    metric = max(metric, cnt);
                 }
-                metric = max(metric, cnt);
-            }
-            for (int o = 32; o > 0; o >>= 1) metric = max(metric, (unsigned)__shfl_xor((int)metric, o));
-            if (dir >= 2) metric += metric / 4 + 1; // an axis key is cheaper and exact: prefer it when close
-            if (metric < best_metric) {
-                best_metric = metric;
-                best_dir = dir;
+                for (int o = 32; o > 0; o >>= 1) metric = max(metric, (unsigned)__shfl_xor((int)metric, o));
+                if (dir >= 2) metric += metric / 4 + 1; // an axis key is cheaper and exact: prefer it when close
+                if (metric < best_metric) {
+                    best_metric = metric;
+                    best_dir = dir;
+                }
             }
         }
-    }
-    if (lane == 0 && best_dir)
-        atomicOr(reinterpret_cast<unsigned *>(a.lblob + a.loff_axis[c]) + (cell >> 4), (unsigned)best_dir << (2 * (cell & 15)));
-    float2 *out = reinterpret_cast<float2 *>(a.lblob + a.loff_pts) + a.lbase[c] + lo;
-    for (int j = lane; j < n; j += 64) {
-        const float x = X(j), y = Y(j), kj = list_key(best_dir, x, y);
-        const int   pj = J(j);
-        int         rank = 0;
-        for (int i = 0; i < n; ++i) {
-            const float ki = list_key(best_dir, X(i), Y(i));
-            rank += (ki < kj || (ki == kj && J(i) < pj)) ? 1 : 0;
+        if (lane == 0 && best_dir)
+            atomicOr(reinterpret_cast<unsigned *>(a.lblob + a.loff_axis[c]) + (cell >> 4), (unsigned)best_dir << (2 * (cell & 15)));
+        float2 *out = reinterpret_cast<float2 *>(a.lblob + a.loff_pts) + a.lbase[c] + lo;
+        stage_keys(best_dir);
+        for (int j = lane; j < n; j += 64) {
+            const float kj = K(best_dir, j);
+            const int   pj = J(j);
+            int         rank = 0;
+#pragma unroll 8
+            for (int i = 0; i < n; ++i) {
+                const float ki = K(best_dir, i);
+                rank += (ki < kj || (ki == kj && J(i) < pj)) ? 1 : 0;
+            }
+            out[rank] = make_float2(X(j), Y(j));
         }
-        out[rank] = make_float2(x, y);
+        __builtin_amdgcn_wave_barrier(); // the stage is rewritten by the next pair
     }
 }
 
@@ -731,27 +795,6 @@ struct Workspace { // pool blocks of one build, returned when it ends
         for (void *p : blocks) pool_free(p);
     }
 };
-
-// a small pinned host buffer per host thread for the build's read-back (allocated once, never freed: the
-// runtime may be gone when thread-local destructors run)
-void *pinned_scratch(size_t bytes)
-{
-    static thread_local void  *p = nullptr;
-    static thread_local size_t cap = 0;
-    if (bytes > cap) {
-        if (p) (void)hipHostFree(p);
-        p = nullptr;
-        cap = 0;
-        const size_t want = std::max<size_t>(bytes, 8192);
-        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
-            (void)hipGetLastError();
-            p = nullptr;
-            return nullptr;
-        }
-        cap = want;
-    }
-    return p;
-}
 
 constexpr int kCandFirst = 24; // candidate pitches counted with the cell index; the rest only if none of them fits
 
@@ -823,10 +866,10 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
     // ---- one workspace block, counters first (one memset): cell counts + cursors, candidate entry counts,
     // list counts + cursors (sized for the largest candidate lattice)
     const auto   t_index = std::chrono::steady_clock::now();
-    const size_t cnt_words = 2 * (size_t)(ncells + 1) + 2 * (size_t)ncells;
+    const size_t cnt_words = 2 * (size_t)(ncells + 1) + 2 * (size_t)ncells + 8;
     size_t       lcells_max = 0;
     for (const ListCand &c : cands) lcells_max = std::max(lcells_max, (size_t)(c.nx * c.ny));
-    const size_t lcnt_words = nc ? 2 * (lcells_max + 1) + 2 * lcells_max : 0;
+    const size_t lcnt_words = nc ? 2 * (lcells_max + 1) + 2 * lcells_max + 8 : 0;
     const size_t zero_bytes = ((4 * cnt_words + 15) & ~(size_t)15) + 16 * (size_t)std::max(nc, 1) + 4 * lcnt_words;
     unsigned char *zero = static_cast<unsigned char *>(ws.get(zero_bytes));
     h->d_blob = pool_alloc(mv.blob_bytes);
@@ -846,6 +889,8 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
     a.cell_of = static_cast<int *>(ws.get(4 * (size_t)n_all));
     a.tmp = static_cast<int *>(ws.get(4 * (size_t)n_all));
     if (!a.xyf || !a.cell_of || !a.tmp) return SLAM_E_NOMEM;
+    unsigned *d_tiles = static_cast<unsigned *>(ws.get(4 * std::max(scan_tile_words(ncells), scan_tile_words((int)lcells_max))));
+    if (!d_tiles) return SLAM_E_NOMEM;
     a.start = reinterpret_cast<unsigned *>(zero);
     a.cursor = a.start + 2 * (size_t)(ncells + 1);
     unsigned long long *d_ent = reinterpret_cast<unsigned long long *>(zero + ((4 * cnt_words + 15) & ~(size_t)15));
@@ -874,7 +919,7 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
         SLAM_HIP(hipEventCreateWithFlags(&ev_ent, hipEventDisableTiming));
         SLAM_HIP(hipEventRecord(ev_ent, st));
     }
-    hipLaunchKernelGGL(idx_scan_kernel, dim3(1), dim3(1024), 0, st, a.start, ncells, a.blob, a.off_start[0], a.off_start[1], a.esz);
+    SLAM_TRY(launch_scan(a.start, a.start + (ncells + 1), ncells, a.blob + a.off_start[0], a.blob + a.off_start[1], a.esz, d_tiles, st));
     hipLaunchKernelGGL(idx_fill_kernel, dim3(pblocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(idx_rank_kernel, dim3(pblocks), dim3(256), 0, st, a);
     SLAM_HIP(hipGetLastError());
@@ -932,9 +977,9 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
             }
             SLAM_HIP(hipMemsetAsync(h->d_lblob, 0, mv.lblob_bytes, st));
             hipLaunchKernelGGL((list_scatter_kernel<0>), dim3(pblocks), dim3(256), 0, st, l);
-            hipLaunchKernelGGL(list_scan_kernel, dim3(1), dim3(1024), 0, st, l);
+            SLAM_TRY(launch_scan(l.start, l.start + (l.ncells + 1), l.ncells, l.lblob + l.loff_start[0], l.lblob + l.loff_start[1], 2, d_tiles, st));
             hipLaunchKernelGGL((list_scatter_kernel<1>), dim3(pblocks), dim3(256), 0, st, l);
-            hipLaunchKernelGGL(list_sort_kernel, dim3(l.ncells, 2), dim3(64), 0, st, l);
+            hipLaunchKernelGGL(list_sort_kernel, dim3(std::min((2 * l.ncells + kSortWaves - 1) / kSortWaves, 1024)), dim3(64 * kSortWaves), 0, st, l);
             SLAM_HIP(hipGetLastError());
             list_done(h);
             h->build_ms[3] = ms_since(t_lists);

@@ -140,8 +140,9 @@ struct slam_icp {
     size_t          lds_bytes = 0;
     void           *d_blob = nullptr;
     double         *d_normals = nullptr;
-    slam::icp::DevBuf          w_pts, w_off, w_nga, w_R, w_t, w_res, w_stamps, w_pose, w_ew, w_state, w_single;
-    int             hint_n = -1, hint_nga = 0; // set by slam_icp_fit around its single-scan call
+    slam::icp::DevBuf          w_pts, w_stamps, w_ew, w_state, w_single; // w_pts: slam_icp_fit's block (points + header)
+    int             spread_points_hint = 0; // points of the batch when the caller knows them (slam_icp_fit), else 0
+    size_t          step_pose_off = 0;   // where in w_pts the pose of the last executed step lies
     bool            two_phase = false;   // ring search, then list sweeps (the point-to-point default)
     bool            split_launch = false; // SLAM_ICP_SPLIT=1: the two forms as two launches (measurements)
     bool            phase_events = false; // diagnostic: time the two launches separately (slam_icp_debug_phase_ms)
@@ -156,6 +157,7 @@ struct slam_icp {
     int             last_n = 0, last_nga = 0; // template of the last slam_icp_fit()
     double          last_indist = 0;
     bool            have_last = false;
+    int             n_cu = 256;          // CUs of the device the handle was made on
     bool            built_on_device = false;
     double          build_ms[4] = {0, 0, 0, 0}; // host pass + upload, cell index kernels, list plan (sync), list kernels
 };

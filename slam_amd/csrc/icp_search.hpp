@@ -43,13 +43,10 @@ __device__ inline void consider(Best &b, float d, int i, const StartT *oidx)
 // plus a flag that says whether an exact tie d == best was ever seen; the
 // caller then repeats the search with EXACT = true (ties by original index).
 template <int G, typename StartT, bool EXACT>
-__device__ inline void scan_span(Best &b, bool &tie, const StartT *start, const float2 *pts, const StartT *oidx,
-                                 int row_base, int c0, int c1, int sub, float qx, float qy)
+__device__ inline void scan_range(Best &b, bool &tie, const float2 *pts, const StartT *oidx, int a, int e, int sub, float qx,
+                                  float qy)
 {
-    if (c0 > c1) return;
-    const int a = (int)start[row_base + c0];
-    const int e = (int)start[row_base + c1 + 1];
-    int       i = a + sub;
+    int i = a + sub;
     for (; i + 3 * G < e; i += 4 * G) {
         const float2 m0 = pts[i], m1 = pts[i + G], m2 = pts[i + 2 * G], m3 = pts[i + 3 * G];
         const float  d0 = dist2(m0, qx, qy), d1 = dist2(m1, qx, qy), d2 = dist2(m2, qx, qy), d3 = dist2(m3, qx, qy);
@@ -85,6 +82,14 @@ __device__ inline void scan_span(Best &b, bool &tie, const StartT *start, const 
             b.pos = up ? i : b.pos;
         }
     }
+}
+
+template <int G, typename StartT, bool EXACT>
+__device__ inline void scan_span(Best &b, bool &tie, const StartT *start, const float2 *pts, const StartT *oidx,
+                                 int row_base, int c0, int c1, int sub, float qx, float qy)
+{
+    if (c0 > c1) return;
+    scan_range<G, StartT, EXACT>(b, tie, pts, oidx, (int)start[row_base + c0], (int)start[row_base + c1 + 1], sub, qx, qy);
 }
 
 // Fast-path minimum over the G lanes of a group: (distance, position) only, on the DPP cross-lane path for
@@ -237,6 +242,220 @@ __device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelVi
         rp = r;
     }
     if (G == 1 || !EXACT) b.oidx = b.pos >= 0 ? (unsigned)oidx[b.pos] : 0xffffffffu;
+    return b;
+}
+
+// scan_range with the number of lanes that share the span known only at run time.  Seed-aware: the running
+// best may be a point of this very span (a search seeded with last iteration's neighbour meets it again), which
+// is not a tie.
+template <typename StartT, bool EXACT>
+__device__ inline void scan_range_rt(Best &b, bool &tie, const float2 *pts, const StartT *oidx, int a, int e, int sub, int G,
+                                     float qx, float qy)
+{
+    int i = a + sub;
+    for (; i + 3 * G < e; i += 4 * G) {
+        const float2 m0 = pts[i], m1 = pts[i + G], m2 = pts[i + 2 * G], m3 = pts[i + 3 * G];
+        const float  d0 = dist2(m0, qx, qy), d1 = dist2(m1, qx, qy), d2 = dist2(m2, qx, qy), d3 = dist2(m3, qx, qy);
+        if (EXACT) {
+            if (fminf(fminf(d0, d1), fminf(d2, d3)) <= b.d) {
+                consider<StartT>(b, d0, i, oidx);
+                consider<StartT>(b, d1, i + G, oidx);
+                consider<StartT>(b, d2, i + 2 * G, oidx);
+                consider<StartT>(b, d3, i + 3 * G, oidx);
+            }
+        } else {
+            const bool  s01 = d1 < d0, s23 = d3 < d2;
+            const float m01 = s01 ? d1 : d0, m23 = s23 ? d3 : d2;
+            const int   p01 = s01 ? i + G : i, p23 = s23 ? i + 3 * G : i + 2 * G;
+            const bool  s = m23 < m01;
+            const float m = s ? m23 : m01;
+            const int   pm = s ? p23 : p01;
+            tie |= (d0 == d1) | (d2 == d3) | (m01 == m23) | ((m == b.d) & (pm != b.pos));
+            const bool up = m < b.d;
+            b.d = up ? m : b.d;
+            b.pos = up ? pm : b.pos;
+        }
+    }
+    for (; i < e; i += G) {
+        const float d = dist2(pts[i], qx, qy);
+        if (EXACT) {
+            consider<StartT>(b, d, i, oidx);
+        } else {
+            tie |= (d == b.d) & (i != b.pos);
+            const bool up = d < b.d;
+            b.d = up ? d : b.d;
+            b.pos = up ? i : b.pos;
+        }
+    }
+}
+
+// A long span by all G lanes of the group, eight loads in flight per lane (a span of thousands of points is a
+// few round trips), then the rest four at a time.  Seed-aware like scan_range_rt.
+constexpr int kDeep = 8;
+template <int G, typename StartT, bool EXACT>
+__device__ inline void scan_range_deep(Best &b, bool &tie, const float2 *pts, const StartT *oidx, int a, int e, int lig, float qx,
+                                       float qy)
+{
+    int i = a + lig;
+    for (; i + (kDeep - 1) * G < e; i += kDeep * G) {
+        float2 m[kDeep];
+#pragma unroll
+        for (int k = 0; k < kDeep; ++k) m[k] = pts[i + k * G];
+#pragma unroll
+        for (int k = 0; k < kDeep; ++k) {
+            const float d = dist2(m[k], qx, qy);
+            if (EXACT) {
+                consider<StartT>(b, d, i + k * G, oidx);
+            } else {
+                tie |= (d == b.d) & (i + k * G != b.pos);
+                const bool up = d < b.d;
+                b.d = up ? d : b.d;
+                b.pos = up ? i + k * G : b.pos;
+            }
+        }
+    }
+    scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, i - lig, e, lig, G, qx, qy);
+}
+
+// What a finished search proves about the query and what the next iteration's search of the same scene
+// point starts from (icp_single.hip): the neighbour's position in the sorted array, and a radius within which
+// the class has no point (the neighbour's distance, or the edge of the last ring when the inlier gate ended
+// the search first).
+struct Seed {
+    int   pos;   // -1: none
+    float empty; // metres; 0: nothing known
+};
+
+// The same search by a WIDE group of G = 16 or 64 lanes (icp_single.hip: few queries, or an index read from
+// HBM/L2, where a query is a chain of dependent loads and the chip has lanes to spare).  A ring level's rows are
+// dealt over the lanes -- as many lanes per row as the level's row count leaves (16 for the 3 x 3 block, one for
+// levels of 33 rows and more) -- so that the extents of ALL rows of the level arrive in one round trip and their
+// points in the next, whatever the radius: a query that is metres from the model (or beyond the inlier gate
+// altogether) costs one or two round trips per level instead of two per row.  A row with more points than its
+// lanes take in two steps (a lidar cloud holds hundreds of points per cell near the sensor) is left to the
+// whole group, one such row after the other.  The query's own cell is part of the first level.  Visits the same
+// cells as nn_search_impl, so the result is the same (ties: flagged by the fast form, resolved by the exact one).
+template <int G, typename StartT, bool EXACT>
+__device__ inline Best nn_search_rows_impl(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, float qx, float qy,
+                                           int lig, double gate, bool &tie, const Seed seed, float move, float &empty_out)
+{
+    static_assert(G == 16 || G == 64, "16 or 64 lanes per query");
+    const Lattice &L = mv.lat;
+    const StartT  *start = ix.start[cls];
+    const float2  *pts = ix.pts + mv.base[cls];
+    const StartT  *oidx = ix.oidx + mv.base[cls];
+
+    Best b;
+    b.d = FLT_MAX;
+    b.oidx = 0xffffffffu;
+    b.pos = -1;
+    empty_out = 0.0f;
+    if (mv.n_cls[cls] <= 0) return b;
+
+    const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
+    const int   cx = clampi((int)floorf(fx), 0, L.nx - 1);
+    const int   cy = clampi((int)floorf(fy), 0, L.ny - 1);
+    const int   group_base = ((int)threadIdx.x & 63) & ~(G - 1); // first lane of this query's group in the wavefront
+
+    int rp = -1, r = 1; // radius of the square already known (visited or proven empty), radius of the next level
+    // Seeds.  (1) Last iteration the class had no point within seed.empty of the query; the query has moved by at
+    // most `move` since, so there is none within D = seed.empty - move of it now: the square of cells that lies
+    // inside that disk needs no visit (only for a query inside the lattice: its own cell is then really its cell).
+    // (2) Last iteration's neighbour is a candidate from the start: the disk of its distance prunes the first level.
+    if (seed.empty > 0.0f && fx >= 0.0f && fx < (float)L.nx && fy >= 0.0f && fy < (float)L.ny) {
+        const float D = seed.empty - move - 2.0f * L.margin;
+        if (D > 0.0f) {
+            const float cells = fminf(D * L.inv_h * 0.70710677f, (float)(L.nx + L.ny)); // (rp + 1) h sqrt(2) <= D
+            rp = (int)floorf(cells) - 1;
+            if (rp >= 0) r = rp + 1;
+        }
+    }
+    if (seed.pos >= 0) {
+        b.d = dist2(pts[seed.pos], qx, qy);
+        b.pos = seed.pos;
+    }
+    float bound;
+    bool  all;
+    for (;; r *= 2) {
+        int y_lo = max(cy - r, 0), y_hi = min(cy + r, L.ny - 1);
+        int x_lo = max(cx - r, 0), x_hi = min(cx + r, L.nx - 1);
+        const bool covers = (x_lo == 0) & (y_lo == 0) & (x_hi == L.nx - 1) & (y_hi == L.ny - 1);
+        if (b.d < FLT_MAX) {
+            const float R = (__fsqrt_rn(b.d) + L.margin) * L.inv_h;
+            x_lo = max(x_lo, (int)floorf(fx - R));
+            x_hi = min(x_hi, (int)floorf(fx + R));
+            y_lo = max(y_lo, (int)floorf(fy - R));
+            y_hi = min(y_hi, (int)floorf(fy + R));
+        }
+        const int nrows = y_hi - y_lo + 1;
+        // lanes per row: the largest power of two that still gives every row of the level a slot (at least one)
+        int lpr_log = 0;
+        while (lpr_log < 4 && (nrows << (lpr_log + 1)) <= G) ++lpr_log;
+        const int lpr = 1 << lpr_log, slot = lig >> lpr_log, sub = lig & (lpr - 1), slots = G >> lpr_log;
+        for (int y0 = y_lo; y0 <= y_hi; y0 += slots) {
+            const int y = y0 + slot, row = y * L.nx;
+            int       a1 = 0, e1 = 0, a2 = 0, e2 = 0; // the row's one or two spans of the sorted array
+            if (y <= y_hi) {
+                if (rp >= 0 && y >= cy - rp && y <= cy + rp) {
+                    const int l1 = min(x_hi, cx - rp - 1), f2 = max(x_lo, cx + rp + 1);
+                    if (x_lo <= l1) a1 = (int)start[row + x_lo], e1 = (int)start[row + l1 + 1];
+                    if (f2 <= x_hi) a2 = (int)start[row + f2], e2 = (int)start[row + x_hi + 1];
+                } else if (x_lo <= x_hi) {
+                    a1 = (int)start[row + x_lo], e1 = (int)start[row + x_hi + 1];
+                }
+            }
+            const bool heavy = (e1 - a1) + (e2 - a2) > 8 * lpr;
+            if (!heavy) {
+                scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, a1, e1, sub, lpr, qx, qy);
+                scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, a2, e2, sub, lpr, qx, qy);
+            }
+            unsigned long long m = __ballot(heavy && sub == 0);
+            if (G < 64) m = (m >> group_base) & ((1ull << G) - 1ull);
+            while (m) {
+                const int src = __builtin_ctzll(m);
+                m &= m - 1;
+                int A1, E1, A2, E2;
+                if (G == 64) {
+                    A1 = __builtin_amdgcn_readlane(a1, src), E1 = __builtin_amdgcn_readlane(e1, src);
+                    A2 = __builtin_amdgcn_readlane(a2, src), E2 = __builtin_amdgcn_readlane(e2, src);
+                } else {
+                    A1 = __shfl(a1, src, G), E1 = __shfl(e1, src, G);
+                    A2 = __shfl(a2, src, G), E2 = __shfl(e2, src, G);
+                }
+                scan_range_deep<G, StartT, EXACT>(b, tie, pts, oidx, A1, E1, lig, qx, qy);
+                scan_range_deep<G, StartT, EXACT>(b, tie, pts, oidx, A2, E2, lig, qx, qy);
+            }
+        }
+        if (EXACT)
+            group_min<G, StartT>(b, oidx);
+        else
+            group_min_lean<G>(b, tie);
+        bound = (float)r * L.h - L.margin;
+        const float b2 = bound * bound;
+        all = covers;
+        if (covers || b.d < b2 || (double)b2 >= gate) break;
+        rp = r;
+    }
+    // every point of the class is at least this far from the query: the neighbour itself when the search ran to
+    // its end (its distance inside the last ring, or the whole lattice seen), else the last ring's edge
+    {
+        const float dn = b.d < FLT_MAX ? __fsqrt_rn(b.d) * 0.999999f : 1.0e30f;
+        empty_out = (all || b.d < bound * bound) ? dn : fminf(dn, bound);
+    }
+    if (!EXACT) b.oidx = b.pos >= 0 ? (unsigned)oidx[b.pos] : 0xffffffffu;
+    return b;
+}
+
+template <int G, typename StartT>
+__device__ inline Best nn_search_rows(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, float qx, float qy, int lig,
+                                      double gate, const Seed seed, float move, float &empty_out)
+{
+    bool tie = false;
+    Best b = nn_search_rows_impl<G, StartT, false>(ix, mv, cls, qx, qy, lig, gate, tie, seed, move, empty_out);
+    if (tie) {
+        bool unused = false;
+        b = nn_search_rows_impl<G, StartT, true>(ix, mv, cls, qx, qy, lig, gate, unused, seed, move, empty_out);
+    }
     return b;
 }
 
@@ -443,6 +662,52 @@ __device__ inline void add_p2p_xy(const ModelView &mv, const float2 m, float qx,
     acc[7] += by * ax;
     acc[8] += by * ay;
 }
+
+struct FitArgs {
+    const double2 *pts;
+    const int     *scan_off;
+    const int     *scan_nga;
+    double        *R;
+    double        *t;
+    slam_icp_result *result;
+    double        *trace;
+    int            max_iter;
+    double         min_delta;
+    double         indist;
+    double        *step_pose; // nullable; per scan 6 doubles: R,t as the last executed step found them
+    long long     *stamps; // diagnostic only (SLAM_ICP_STAMPS=1): per scan, cycles in [search, reduce, barrier, solve]
+    // Two search forms per scan: the ring search runs at least the first switch_iter iterations (by then a scan
+    // is normally within the certified radius of the halo lists), the list sweeps the rest.  One launch does
+    // both (icp_fit_fused_kernel); as two launches of icp_fit_kernel (SLAM_ICP_SPLIT=1, measurements) the
+    // hand-over goes through state[scan] = iterations done, or -1 when the scan finished in the ring search.
+    int           *state;
+    int            phase;  // icp_fit_kernel: 0 = the only launch, 1 = ring search of two launches, 2 = list sweeps of two
+    int            switch_iter;
+    int            far_div;       // hand over once at most n / far_div queries are beyond the lists' certified radius
+};
+
+
+__device__ inline void fill_lds(unsigned char *dst, const unsigned char *blob, unsigned bytes)
+{
+    const uint4 *src = reinterpret_cast<const uint4 *>(blob);
+    uint4       *d4 = reinterpret_cast<uint4 *>(dst);
+    for (unsigned i = threadIdx.x; i < bytes / 16u; i += kBlock) d4[i] = src[i];
+}
+
+
+// The state of one scan's fit that outlives a run of iterations: the pose (the same in every lane) and the
+// counters that go into slam_icp_result.
+struct FitState {
+    double r00, r01, r10, r11, t0, t1, delta;
+    int    iters, n_corr;
+    bool   hand_over;
+};
+
+constexpr int kSpreadMinParts = 16; // the spread form takes batches that leave every scan at least this many workgroups
+
+// icp_single.hip: few scans (one, in the reference's own usage), each spread over many workgroups of one
+// persistent launch
+int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st);
 
 } // namespace icp
 } // namespace slam

@@ -1,4 +1,5 @@
 // runtime.hip -- device plumbing behind the C-ABI (memory, streams, events).
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <unordered_map>
@@ -134,6 +135,27 @@ void pool_trim()
         g_pool_cached = 0;
     }
     for (const PoolBlock &b : drop) (void)hipFree(b.p);
+}
+
+// a small pinned host buffer per host thread for the build's read-back (allocated once, never freed: the
+// runtime may be gone when thread-local destructors run)
+void *pinned_scratch(size_t bytes)
+{
+    static thread_local void  *p = nullptr;
+    static thread_local size_t cap = 0;
+    if (bytes > cap) {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = std::max<size_t>(bytes, 8192);
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            return nullptr;
+        }
+        cap = want;
+    }
+    return p;
 }
 
 } // namespace slam

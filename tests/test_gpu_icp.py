@@ -162,8 +162,16 @@ def test_edge_cases_follow_reference(world):
     R3, t3, res3, _ = icp.fit_batch(b3)
     assert res3["iters"][1] == 0 and np.array_equal(R3[1], R0.reshape(4)) and np.array_equal(t3[1], t0)
     Rg, tg, resg, _ = icp.fit_batch(good)
-    assert np.array_equal(R3[[0, 2]], Rg) and np.array_equal(t3[[0, 2]], tg)
+    # (few scans run in the spread form: a scan's sums are added over as many workgroups as the batch leaves it, so
+    # the same scan in another batch agrees to rounding; with one workgroup per scan it agrees bit for bit)
+    assert np.abs(R3[[0, 2]] - Rg).max() < 1e-12 and np.abs(t3[[0, 2]] - tg).max() < 1e-12
+    assert np.array_equal(res3["n_corr"][[0, 2]], resg["n_corr"]) and np.array_equal(res3["iters"][[0, 2]], resg["iters"])
     icp.close()
+    one = api.Icp(m_ga, m_nga, spread_scans=-1)
+    R3, t3, _, _ = one.fit_batch(b3)
+    Rg, tg, _, _ = one.fit_batch(good)
+    assert np.array_equal(R3[[0, 2]], Rg) and np.array_equal(t3[[0, 2]], tg)
+    one.close()
 
 
 def test_class_constraint_and_small_class_skip():
@@ -320,10 +328,12 @@ def test_edge_weight_matches_oracle(world):
     icp.close()
 
 
-@pytest.mark.parametrize("lanes", [0, 2, -2])
-def test_ragged_scan_sizes(world, lanes):
+@pytest.mark.parametrize("lanes,spread", [(0, 0), (0, -1), (2, 0), (-2, 0)])
+def test_ragged_scan_sizes(world, lanes, spread):
     """Scans from 5 to ~2600 points in one batch: the pass structure (full passes, short tails, the
-    cooperative queue of the sweep mode, scans smaller than one cooperative round) against the oracle."""
+    cooperative queue of the sweep mode, scans smaller than one cooperative round) against the oracle.
+    (0, 0): twelve scans are few enough for the spread form (21 workgroups per scan, 64 lanes per query);
+    (0, -1): the same batch with one workgroup per scan, ring search then list sweeps."""
     m_ga, m_nga, model = world
     pts, off, nga, Rs, ts = [], [0], [], [], []
     for k, beams in enumerate([6, 41, 64, 66, 700, 1026, 1027, 1081, 1090, 1100, 2200, 2600]):
@@ -338,7 +348,7 @@ def test_ragged_scan_sizes(world, lanes):
                             np.array(Rs), np.array(ts), np.zeros((len(nga), 3)))
     sizes = np.diff(batch.scan_off)
     assert sizes.min() >= 5 and sizes.max() > 2 * 1024 + 64
-    icp = api.Icp(m_ga, m_nga, max_iter=12, min_delta=-1.0, lanes_per_point=lanes)
+    icp = api.Icp(m_ga, m_nga, max_iter=12, min_delta=-1.0, lanes_per_point=lanes, spread_scans=spread)
     R, t, res, _ = icp.fit_batch(batch, indist=5.0)
     Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R, batch.t,
                                                   O.icp_params(12, -1.0, 5.0))
@@ -365,11 +375,11 @@ def test_outlier_scans_two_form_schedule(world, frac):
     noisy = synth.ScanBatch(pts, batch.scan_off, batch.scan_nga, batch.R, batch.t, batch.true_poses)
     Ro, to, iters, ncorr, delta = model.fit_batch(noisy.pts, noisy.scan_off, noisy.scan_nga, noisy.R, noisy.t,
                                                   O.icp_params(25, 1e-7, 5.0))
-    for lanes in (0, 2, -2):
-        icp = api.Icp(m_ga, m_nga, max_iter=25, min_delta=1e-7, lanes_per_point=lanes)
+    for lanes, spread in ((0, -1), (0, 0), (2, 0), (-2, 0)):   # (0, -1): the two-form schedule; (0, 0): the spread form
+        icp = api.Icp(m_ga, m_nga, max_iter=25, min_delta=1e-7, lanes_per_point=lanes, spread_scans=spread)
         R, t, res, _ = icp.fit_batch(noisy, indist=5.0)
-        assert np.array_equal(res["iters"], iters) and np.array_equal(res["n_corr"], ncorr), lanes
-        assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL, lanes
+        assert np.array_equal(res["iters"], iters) and np.array_equal(res["n_corr"], ncorr), (lanes, spread)
+        assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL, (lanes, spread)
         icp.close()
 
 
@@ -397,15 +407,14 @@ def test_cell_pitch_is_only_a_cost_parameter(world, cell):
     icp.close()
 
 
-def test_one_launch_and_two_launch_schedules_agree_bitwise(world, monkeypatch):
-    """The default runs both search forms in one launch (the workgroup swaps its LDS contents); SLAM_ICP_SPLIT=1
+def test_one_launch_and_two_launch_schedules_agree_bitwise(world):
+    """The default runs both search forms in one launch (the workgroup swaps its LDS contents); split_launch = 1
     runs them as two launches with the hand-over state in HBM.  Same arithmetic, same order: identical bits."""
     m_ga, m_nga, model = world
     batch = synth.make_batch(24, n_loop=256)
     out = []
-    for split in ("0", "1"):
-        monkeypatch.setenv("SLAM_ICP_SPLIT", split)
-        icp = api.Icp(m_ga, m_nga, max_iter=30, min_delta=1e-6)
+    for split in (0, 1):
+        icp = api.Icp(m_ga, m_nga, max_iter=30, min_delta=1e-6, split_launch=split)
         R, t, res, _ = icp.fit_batch(batch, indist=5.0)
         out.append((R.copy(), t.copy(), res.copy()))
         icp.close()
@@ -420,7 +429,7 @@ def test_two_form_schedule_edge_iteration_counts(world):
     for max_iter, min_delta in ((1, -1.0), (9, -1.0), (10, -1.0), (11, -1.0), (40, 1e-2), (40, 1e-4), (40, 1e-9)):
         Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R, batch.t,
                                                       O.icp_params(max_iter, min_delta, 5.0))
-        icp = api.Icp(m_ga, m_nga, max_iter=max_iter, min_delta=min_delta)
+        icp = api.Icp(m_ga, m_nga, max_iter=max_iter, min_delta=min_delta, spread_scans=-1)   # one workgroup per scan
         assert icp.index_info()["two_forms"] and icp.index_info()["first_iterations"] == 10
         R, t, res, _ = icp.fit_batch(batch, indist=5.0)
         assert np.array_equal(res["iters"], iters), (max_iter, min_delta)

@@ -1,0 +1,141 @@
+"""The spread form of the ICP (slam_amd/csrc/icp_single.hip): few scans -- one, in the reference's own usage
+(scan_registration.cpp:139-159 -> IcpPointToPoint::fit, icp.cpp:80-122) -- each dealt over many workgroups of one
+persistent launch that exchange their nine sums once per iteration.  Against the oracle and against the
+one-workgroup-per-scan kernels; same tolerances as tests/test_gpu_icp.py."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from slam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL, ANG_TOL = 1e-4, 1e-5
+
+
+def yaw(R):
+    R = np.asarray(R).reshape(-1, 4)
+    return np.arctan2(R[:, 2], R[:, 0])
+
+
+def ang_diff(a, b):
+    d = a - b
+    return np.abs((d + np.pi) % (2 * np.pi) - np.pi)
+
+
+def check_against_oracle(m_ga, m_nga, batch, max_iter, min_delta, nn=O.NN_KDTREE, **kw):
+    model = O.IcpModel(m_ga, m_nga)
+    Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R, batch.t,
+                                                  O.icp_params(max_iter, min_delta, 5.0, nn))
+    icp = api.Icp(m_ga, m_nga, max_iter=max_iter, min_delta=min_delta, **kw)
+    R, t, res, tr = icp.fit_batch(batch, indist=5.0, trace=True)
+    assert np.array_equal(res["iters"], iters), (res["iters"], iters)
+    assert np.array_equal(res["n_corr"], ncorr)
+    assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL
+    assert np.abs(res["delta"] - delta).max() < 1e-9
+    R2, t2, res2, _ = icp.fit_batch(batch, indist=5.0)
+    assert np.array_equal(R, R2) and np.array_equal(t, t2)          # bitwise reproducible
+    return icp, R, t, res, tr
+
+
+@pytest.mark.parametrize("n_scans", [1, 3, 16])
+@pytest.mark.parametrize("force_global", [0, 1])
+def test_spread_matches_oracle_and_batch_kernels(n_scans, force_global):
+    """Model in LDS (every workgroup copies it) and in HBM/L2; 1, 3 and 16 scans (256, 85, 16 workgroups each)."""
+    m_ga, m_nga = synth.make_map()
+    batch = synth.make_batch(n_scans, n_loop=256)
+    icp, R, t, res, tr = check_against_oracle(m_ga, m_nga, batch, 30, 1e-6, force_global=force_global)
+    icp.close()
+    # the same scans with one workgroup per scan: the same correspondences, the sums in another order
+    ref = api.Icp(m_ga, m_nga, max_iter=30, min_delta=1e-6, force_global=force_global, spread_scans=-1)
+    Rb, tb, resb, _ = ref.fit_batch(batch, indist=5.0)
+    assert np.array_equal(resb["iters"], res["iters"]) and np.array_equal(resb["n_corr"], res["n_corr"])
+    assert np.abs(tb - t).max() < 1e-9 and np.abs(Rb - R).max() < 1e-9
+    ref.close()
+
+
+def test_spread_trace_follows_the_oracle_step_by_step():
+    m_ga, m_nga = synth.make_map()
+    batch = synth.make_batch(1, n_loop=256)
+    model = O.IcpModel(m_ga, m_nga)
+    t_ga, t_nga = batch.scan(0)
+    Ro, to, otr, steps = model.fit(t_ga, t_nga, batch.R[0].reshape(2, 2), batch.t[0], O.icp_params(20, 1e-6, 5.0))
+    icp = api.Icp(m_ga, m_nga)
+    R, t, res, tr = icp.fit_batch(batch, trace=True)
+    assert res["iters"][0] == steps
+    for k in range(steps):
+        assert np.abs(tr[0, k, :6] - otr[k, :6]).max() < 1e-9, k
+        assert tr[0, k, 7] == otr[k, 7]
+    icp.close()
+
+
+def test_spread_large_model_and_large_scans():
+    """2 x 19 999 model points (index in HBM, 32-bit starts); scans of 1081, 4096, 4097 (16 lanes per query from there
+    on) and 19 999 + 3 000 points (the CCICP cap per class, icpTools.h:21), class-constrained."""
+    m_ga, m_nga = synth.make_map(39998)
+    rs = np.random.RandomState(5)
+    pts, off, nga, Rs, ts = [], [0], [], [], []
+    for k, (n_g, n_n) in enumerate([(150, 931), (1000, 3096), (1000, 3097), (3000, 19999)]):
+        th = 0.03 * (k + 1)
+        Rt, tt = synth.pose_to_Rt(0.25 - 0.1 * k, -0.2 + 0.1 * k, th)
+        Rt = Rt.reshape(2, 2)
+        # scene = model points seen from the pose (x = R^T (m - t)) plus noise
+        ga = (m_ga[rs.choice(len(m_ga), n_g, replace=n_g > len(m_ga))] - tt) @ Rt + rs.randn(n_g, 2) * 0.01
+        ng = (m_nga[rs.choice(len(m_nga), n_n, replace=n_n > len(m_nga))] - tt) @ Rt + rs.randn(n_n, 2) * 0.01
+        pts += [ga, ng]
+        off.append(off[-1] + n_g + n_n)
+        nga.append(n_g)
+        R0, t0 = synth.pose_to_Rt(0.25 - 0.1 * k + 0.2, -0.2 + 0.1 * k - 0.15, th + 0.03)
+        Rs.append(R0.reshape(4))
+        ts.append(t0)
+    batch = synth.ScanBatch(np.ascontiguousarray(np.concatenate(pts)), np.array(off, np.int32), np.array(nga, np.int32),
+                            np.array(Rs), np.array(ts), np.zeros((4, 3)))
+    icp, R, t, res, _ = check_against_oracle(m_ga, m_nga, batch, 25, 1e-6)
+    assert not icp.index_info()["in_lds"]
+    icp.close()
+
+
+def test_spread_edge_cases():
+    """Ragged batch: a scan below 5 points is left untouched (icp.cpp:100-103), a scan with no correspondence stops at
+    delta -1 with its pose unchanged (icpPointToPoint.cpp:128-131), a class with <= 3 model points is skipped (:59,93);
+    exact distance ties (gridded model with duplicates) take the exact pass."""
+    rs = np.random.RandomState(11)
+    gx, gy = np.meshgrid(np.arange(60) * 0.5, np.arange(40) * 0.5)
+    grid = np.stack([gx.ravel(), gy.ravel()], 1)
+    m_nga = np.concatenate([grid, grid[:200]])
+    m_ga = grid[:3] + 0.1                                  # three points: the class is skipped
+    R0, t0 = synth.pose_to_Rt(0.1, -0.05, 0.01)
+    scans = [grid[rs.choice(len(grid), 500)] + 0.25,         # every query is equidistant from four model points
+             np.zeros((3, 2)),                              # too short
+             np.full((10, 2), 900.0),                       # nothing within the gate
+             grid[rs.choice(len(grid), 64)] + rs.randn(64, 2) * 0.02]
+    nga = [0, 1, 0, 10]                                     # the last scan's first 10 points are class GA: ignored
+    off = np.cumsum([0] + [len(x) for x in scans]).astype(np.int32)
+    Rs, ts = np.tile(R0.reshape(4), (4, 1)), np.tile(t0, (4, 1))
+    Rs[0], ts[0] = [1, 0, 0, 1], [0, 0]                     # identity: the ties of scan 0 are exact in float
+    batch = synth.ScanBatch(np.ascontiguousarray(np.concatenate(scans)), off, np.array(nga, np.int32),
+                            Rs, ts, np.zeros((4, 3)))
+    # exact ties: the reference leaves them to the kd-tree's visit order (kdtree.cpp:612-618); the brute-force
+    # arbiter (:360-375) and the GPU take the lowest original index
+    icp, R, t, res, _ = check_against_oracle(m_ga, m_nga, batch, 15, 1e-6, nn=O.NN_BRUTE)
+    assert res["iters"][1] == 0 and np.array_equal(R[1], R0.reshape(4)) and np.array_equal(t[1], t0)
+    assert (res["iters"][2], res["n_corr"][2], res["delta"][2]) == (1, 0, -1.0)
+    assert np.array_equal(R[2], R0.reshape(4)) and np.array_equal(t[2], t0)
+    assert res["n_corr"][3] == 54
+    icp.close()
+
+
+def test_host_fit_goes_through_the_spread_form_and_keeps_edge_weights():
+    """slam_icp_fit (Icp::fit, host arrays) + getEdgeWeight of its last step, model too large for LDS."""
+    m_ga, m_nga = synth.make_map(39998)
+    batch = synth.make_batch(1, n_loop=256)
+    t_ga, t_nga = batch.scan(0)
+    model = O.IcpModel(m_ga, m_nga)
+    Ro, to, otr, steps = model.fit(t_ga, t_nga, batch.R[0].reshape(2, 2), batch.t[0], O.icp_params(20, 1e-6, 5.0))
+    icp = api.Icp(m_ga, m_nga)
+    R, t, res = icp.fit(t_ga, t_nga, batch.R[0], batch.t[0], 5.0)
+    assert res.iters == steps
+    assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro))[0] < ANG_TOL
+    eW = icp.edge_weight()
+    assert np.isfinite(eW).all() and eW[0, 0] > 0
+    icp.close()

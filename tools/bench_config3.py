@@ -69,6 +69,8 @@ def run():
         s_ga, s_nga, _ = front_end(clouds[k], True, None)                # setSceneCloud
         b = time.perf_counter()
         R0, t0_ = synth.pose_to_Rt(rel[0] + 0.1, rel[1] - 0.1, rel[2] + 0.02)
+        if k == 1 and os.environ.get("SLAM_DUMP_CASE"):                  # the arrays of one match, for offline analysis
+            np.savez(os.environ["SLAM_DUMP_CASE"], m_ga=m_ga, m_nga=m_nga, s_ga=s_ga, s_nga=s_nga, R0=R0, t0=t0_)
         R, t, res = icp.fit(s_ga, s_nga, R0, t0_)                        # doICPMatch: IcpPointToPoint::fit
         c = time.perf_counter()
         yaw = np.arctan2(R[1, 0], R[0, 0])
