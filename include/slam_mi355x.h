@@ -277,6 +277,17 @@ int slam_grid_raycast_stats(slam_grid_t *g, int *n_tiles, int *n_items, int *n_s
 /* the two int32 planes ([hits | misses], 2*size_x*size_y ints, toroidal
  * storage order) for a collective merge; see slam_mi355x_rccl.h */
 int slam_grid_counts_dev(slam_grid_t *g, int32_t **d_planes, size_t *n_ints);
+/* Rows of the planes (storage order) that received counts since the planes were last reset or folded, tracked
+ * on the device by the update kernels: a merge moves only these.  row_hi < row_lo = none.  The host form
+ * synchronises; d_range = two ints {lowest row, -(highest row)} (0x7f7f7f7f each when none). */
+int slam_grid_dirty_rows(slam_grid_t *g, int *row_lo, int *row_hi);
+int slam_grid_dirty_rows_dev(slam_grid_t *g, int32_t **d_range);
+/* Periodic merges of a running map (BASELINE config 5): with an accumulator, the count planes hold what THIS
+ * GPU added since the last merge; after the all-reduce of those rows slam_grid_fold adds them to the
+ * accumulator (the merged totals) and zeroes them, so that nothing is summed twice at the next merge.
+ * Finalize and the read-backs see accumulator + planes. */
+int slam_grid_enable_accumulator(slam_grid_t *g);
+int slam_grid_fold(slam_grid_t *g, int row_lo, int row_hi, slam_stream_t stream);
 
 /* ------------------------------------------------------ ground segmentation
  * Stands for class groundSegmentation (ground_segmentation/include/ground_segmentation/
@@ -375,6 +386,60 @@ int slam_ccicp_split_dev(slam_ccicp_t *h, const float *d_xyzg, int n, int stride
  * (optional) gets the four nearest indices. */
 int slam_ccicp_height_dev(slam_ccicp_t *h, const float *d_ground, int n, int stride, const double pose[7], double *z_out,
                           int *n_corr, int nn_idx[4], slam_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Streaming mapper (BASELINE config 5).  Stands where scan_registration (scan_registration.cpp:109-199: one
+ * doICPMatch per scan against the target it keeps) feeds local_mapper (local_mapper.cpp:65-130: addToMap at
+ * 50 Hz): chunks of scans go from pinned host memory through registration into the occupancy grid on three
+ * HIP streams (copy of chunk k+1 | ICP of chunk k | grid update of chunk k-1), the ICP target is a sliding
+ * window of the scans registered so far, and every merge_every chunks the grid is merged over the GPUs
+ * (slam_mapper_use_comm, slam_mi355x_rccl.h) and finalized.
+ * ---------------------------------------------------------------------- */
+typedef struct slam_mapper slam_mapper_t;
+
+typedef struct {
+    int    grid_size_x, grid_size_y;
+    double resolution;
+    slam_grid_params grid;     /* rolling = 1: the window follows slam_mapper_push's window_x/y (mls.cpp:408-479) */
+    slam_icp_params  icp;
+    double indist;             /* icpTools.cpp:188 (5.0) */
+    int    max_scans, max_points; /* reservation per chunk */
+    int    window_chunks;      /* sliding local map: the target is the registered points of the last W chunks
+                                  (decimated); 0 = the model given at create stays the target */
+    int    rebuild_every;      /* chunks between rebuilds of the sliding target (>= 1) */
+    int    target_points;      /* points the sliding target holds at most, both classes (2 x 19999: icpTools.h:21) */
+    int    keep_prior;         /* 1 = the model given at create stays part of every rebuilt target */
+    int    merge_every;        /* chunks between merges over the GPUs + finalize; 0 = only at slam_mapper_finish */
+    int    pipelined;          /* 1 = three streams; 0 = one stage after the other on one stream (same results) */
+    int    strict_window;      /* 1 = a rebuild waits for the newest registered chunk (reproducible targets; the
+                                  pipeline stalls for one registration); 0 = it takes what has finished */
+} slam_mapper_params;
+
+void slam_mapper_default_params(slam_mapper_params *p);
+/* m_ga / m_nga: the prior map (host, f64 xy), the first ICP target (at least 5 points, icp.cpp:38-43) */
+int  slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int n_ga, const double *m_nga, int n_nga,
+                        slam_mapper_t **out);
+void slam_mapper_destroy(slam_mapper_t *m);
+/* The producer fills the PINNED buffers of slot slam_mapper_next_slot() -- points (xy f64), scan_off
+ * (n_scans + 1, from 0), scan_nga, initial poses R0 (4 per scan) and t0 (2 per scan) -- and pushes. */
+int  slam_mapper_next_slot(slam_mapper_t *m, int *slot);
+int  slam_mapper_chunk_buffers(slam_mapper_t *m, int slot, double **pts, int32_t **scan_off, int32_t **scan_nga,
+                               double **R0, double **t0);
+/* enqueues the chunk in the next slot and returns at once; window_x/y: where a rolling grid is centred for it */
+int  slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_x, double window_y, int *slot);
+/* blocks until the chunk last pushed into `slot` is registered and mapped; its poses to host memory (optional) */
+int  slam_mapper_wait(slam_mapper_t *m, int slot, double *R_out, double *t_out);
+/* last merge (if a communicator is installed), finalize, and waits for everything */
+int  slam_mapper_finish(slam_mapper_t *m);
+int  slam_mapper_grid(slam_mapper_t *m, slam_grid_t **grid);      /* owned by the mapper */
+int  slam_mapper_target(slam_mapper_t *m, slam_icp_t **icp);      /* the current ICP target (owned by the mapper) */
+int  slam_mapper_stats(slam_mapper_t *m, long *chunks, long *merges, long *rebuilds, double *rebuild_ms,
+                       int last_merge_rows[2]);
+/* How a merge is carried out: begin is enqueued behind a chunk's grid update, finish when the next chunk's
+ * registration has been enqueued (so the GPU is busy while the host waits for the rows to merge).  Installed
+ * by slam_mapper_use_comm; with none, the periodic step is finalize alone. */
+typedef int (*slam_mapper_merge_fn)(void *ctx, slam_grid_t *grid, slam_stream_t stream, int *row_lo, int *row_hi);
+int  slam_mapper_set_merge(slam_mapper_t *m, slam_mapper_merge_fn begin, slam_mapper_merge_fn finish, void *ctx);
 
 #ifdef __cplusplus
 }

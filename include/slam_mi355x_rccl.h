@@ -34,6 +34,18 @@ int  slam_comm_info(slam_comm_t *comm, int *rank, int *n_ranks);
 
 /* ncclAllReduce(planes, planes, 2*size_x*size_y, ncclInt32, ncclSum) on `stream` */
 int  slam_grid_allreduce(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream);
+/* the same for rows [row_lo, row_hi] of both planes only (one grouped pair of all-reduces) */
+int  slam_grid_allreduce_rows(slam_grid_t *grid, slam_comm_t *comm, int row_lo, int row_hi, slam_stream_t stream);
+/* Merge of the rows ANY rank touched, without the host knowing them in advance:
+ *   begin : on `stream`, the ranks' device-tracked dirty ranges (slam_grid_dirty_rows_dev) are united with
+ *           one 8-byte all-reduce and start travelling to the host; returns at once -- enqueue other work
+ *           (the next batch's registration) before calling finish;
+ *   finish: waits for that range on the host, then enqueues the all-reduce of those rows on `stream`;
+ *           *row_lo / *row_hi (optional) receive the range (row_hi < row_lo: nothing to merge). */
+int  slam_grid_merge_begin(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream);
+int  slam_grid_merge_finish(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream, int *row_lo, int *row_hi);
+/* the streaming mapper's periodic merge (slam_mapper_params::merge_every) over this communicator */
+int  slam_mapper_use_comm(slam_mapper_t *mapper, slam_comm_t *comm);
 
 #ifdef __cplusplus
 }

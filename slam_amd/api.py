@@ -46,6 +46,13 @@ class GridParams(C.Structure):
                 ("raycast_wg_per_cu", C.c_int)]
 
 
+class MapperParams(C.Structure):
+    _fields_ = [("grid_size_x", C.c_int), ("grid_size_y", C.c_int), ("resolution", C.c_double), ("grid", GridParams),
+                ("icp", IcpParams), ("indist", C.c_double), ("max_scans", C.c_int), ("max_points", C.c_int),
+                ("window_chunks", C.c_int), ("rebuild_every", C.c_int), ("target_points", C.c_int),
+                ("keep_prior", C.c_int), ("merge_every", C.c_int), ("pipelined", C.c_int), ("strict_window", C.c_int)]
+
+
 class GsegParams(C.Structure):
     _fields_ = [("rmax", C.c_double), ("num_seedpoints", C.c_int), ("gp_lengthparameter", C.c_double),
                 ("gp_covariancescale", C.c_double), ("gp_modelnoise", C.c_double),
@@ -83,12 +90,16 @@ EXPORTS = [
     "slam_grid_raycast", "slam_grid_raycast_dev", "slam_grid_raycast_scans_dev",
     "slam_grid_finalize", "slam_grid_add_scan_inorder", "slam_grid_read_counts",
     "slam_grid_read_occupancy", "slam_grid_read_num_pts", "slam_grid_total_updates",
-    "slam_grid_info", "slam_grid_counts_dev", "slam_grid_raycast_stats",
+    "slam_grid_info", "slam_grid_counts_dev", "slam_grid_raycast_stats", "slam_grid_dirty_rows", "slam_grid_dirty_rows_dev",
+    "slam_grid_enable_accumulator", "slam_grid_fold",
     "slam_gseg_default_params", "slam_gseg_create", "slam_gseg_destroy", "slam_gseg_reserve",
     "slam_gseg_segment", "slam_gseg_segment_dev", "slam_gseg_split_dev", "slam_gseg_read_model",
     "slam_gseg_classify_ga_dev",
     "slam_ccicp_create", "slam_ccicp_destroy", "slam_ccicp_voxel_downsample_dev", "slam_ccicp_split_dev",
     "slam_ccicp_height_dev", "slam_ccicp_bin_order_dev", "slam_ccicp_select_dev",
+    "slam_mapper_default_params", "slam_mapper_create", "slam_mapper_destroy", "slam_mapper_next_slot",
+    "slam_mapper_chunk_buffers", "slam_mapper_push", "slam_mapper_wait", "slam_mapper_finish", "slam_mapper_grid",
+    "slam_mapper_target", "slam_mapper_stats", "slam_mapper_set_merge",
 ]
 
 
@@ -185,6 +196,10 @@ def lib():
     L.slam_grid_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.slam_grid_counts_dev.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]
+    L.slam_grid_dirty_rows.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.slam_grid_dirty_rows_dev.argtypes = [_vp, C.POINTER(_vp)]
+    L.slam_grid_enable_accumulator.argtypes = [_vp]
+    L.slam_grid_fold.argtypes = [_vp, C.c_int, C.c_int, _vp]
     L.slam_gseg_default_params.restype = None
     L.slam_gseg_default_params.argtypes = [C.POINTER(GsegParams)]
     L.slam_gseg_create.argtypes = [C.POINTER(GsegParams), C.POINTER(_vp)]
@@ -197,6 +212,21 @@ def lib():
     L.slam_gseg_read_model.argtypes = [_vp, _vp, _vp, _vp]
     L.slam_gseg_classify_ga_dev.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp, _vp]
     L.slam_grid_raycast_stats.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.slam_mapper_default_params.restype = None
+    L.slam_mapper_default_params.argtypes = [C.POINTER(MapperParams)]
+    L.slam_mapper_create.argtypes = [C.POINTER(MapperParams), _vp, C.c_int, _vp, C.c_int, C.POINTER(_vp)]
+    L.slam_mapper_destroy.restype = None
+    L.slam_mapper_destroy.argtypes = [_vp]
+    L.slam_mapper_next_slot.argtypes = [_vp, C.POINTER(C.c_int)]
+    L.slam_mapper_chunk_buffers.argtypes = [_vp, C.c_int] + [C.POINTER(_vp)] * 5
+    L.slam_mapper_push.argtypes = [_vp, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)]
+    L.slam_mapper_wait.argtypes = [_vp, C.c_int, _vp, _vp]
+    L.slam_mapper_finish.argtypes = [_vp]
+    L.slam_mapper_grid.argtypes = [_vp, C.POINTER(_vp)]
+    L.slam_mapper_target.argtypes = [_vp, C.POINTER(_vp)]
+    L.slam_mapper_stats.argtypes = [_vp, C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_double),
+                                    C.POINTER(C.c_int)]
+    L.slam_mapper_set_merge.argtypes = [_vp, _vp, _vp, _vp]
     _lib = L
     return L
 
@@ -638,6 +668,17 @@ class Grid:
         check(lib().slam_grid_raycast_stats(self.h, C.byref(t), C.byref(i), C.byref(s)))
         return dict(tiles=t.value, items=i.value, segments=s.value)
 
+    def dirty_rows(self):
+        lo, hi = C.c_int(), C.c_int()
+        check(lib().slam_grid_dirty_rows(self.h, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def enable_accumulator(self):
+        check(lib().slam_grid_enable_accumulator(self.h))
+
+    def fold(self, row_lo, row_hi, stream=None):
+        check(lib().slam_grid_fold(self.h, int(row_lo), int(row_hi), _sp(stream)))
+
     def counts_dev(self):
         p, n = _vp(), C.c_size_t()
         check(lib().slam_grid_counts_dev(self.h, C.byref(p), C.byref(n)))
@@ -646,6 +687,104 @@ class Grid:
     def close(self):
         if getattr(self, "h", None):
             lib().slam_grid_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Mapper:
+    """slam_mapper_t: the streaming form of the path (BASELINE config 5).  push() copies a chunk of a ScanBatch into
+    the next slot's pinned buffers and enqueues it; wait() returns its registered poses."""
+
+    def __init__(self, m_ga, m_nga, grid=None, icp=None, **kw):
+        p = MapperParams()
+        lib().slam_mapper_default_params(C.byref(p))
+        for k, v in (grid or {}).items():
+            setattr(p.grid, k, v)
+        for k, v in (icp or {}).items():
+            setattr(p.icp, k, v)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        self.params = p
+        m_ga = np.ascontiguousarray(m_ga, dtype=np.float64).reshape(-1, 2)
+        m_nga = np.ascontiguousarray(m_nga, dtype=np.float64).reshape(-1, 2)
+        h = _vp()
+        check(lib().slam_mapper_create(C.byref(p), _ptr(m_ga), len(m_ga), _ptr(m_nga), len(m_nga), C.byref(h)))
+        self.h = h.value
+        self._views = {}
+        g = _vp()
+        check(lib().slam_mapper_grid(self.h, C.byref(g)))
+        self.grid = object.__new__(Grid)
+        self.grid.h, self.grid.size_x, self.grid.size_y = g.value, p.grid_size_x, p.grid_size_y
+        self.grid.resolution, self.grid.cells, self.grid.params = p.resolution, p.grid_size_x * p.grid_size_y, p.grid
+        self.grid.close = lambda: None      # owned by the mapper
+
+    def _slot_views(self, slot):
+        if slot not in self._views:
+            ptrs = [_vp() for _ in range(5)]
+            check(lib().slam_mapper_chunk_buffers(self.h, slot, *[C.byref(x) for x in ptrs]))
+            ns, npts = self.params.max_scans, self.params.max_points
+
+            def view(ptr, count, dtype):
+                buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr.value)
+                return np.frombuffer(buf, dtype=dtype, count=count)
+            self._views[slot] = (view(ptrs[0], 2 * npts, np.float64), view(ptrs[1], ns + 1, np.int32),
+                                 view(ptrs[2], ns, np.int32), view(ptrs[3], 4 * ns, np.float64),
+                                 view(ptrs[4], 2 * ns, np.float64))
+        return self._views[slot]
+
+    def push(self, batch, window_xy=(0.0, 0.0)):
+        """batch: a synth.ScanBatch (scan_off from 0).  Returns the slot."""
+        slot = C.c_int()
+        check(lib().slam_mapper_next_slot(self.h, C.byref(slot)))
+        pts, off, nga, R, t = self._slot_views(slot.value)
+        S, P = batch.n_scans, batch.n_points
+        pts[:2 * P] = batch.pts.reshape(-1)
+        off[:S + 1] = batch.scan_off
+        nga[:S] = batch.scan_nga
+        R[:4 * S] = batch.R.reshape(-1)
+        t[:2 * S] = batch.t.reshape(-1)
+        out = C.c_int()
+        check(lib().slam_mapper_push(self.h, S, P, float(window_xy[0]), float(window_xy[1]), C.byref(out)))
+        self._n = getattr(self, "_n", {})
+        self._n[out.value] = S
+        return out.value
+
+    def wait(self, slot):
+        S = self._n.get(slot, 0)
+        R, t = np.zeros((S, 4)), np.zeros((S, 2))
+        check(lib().slam_mapper_wait(self.h, int(slot), _ptr(R), _ptr(t)))
+        return R, t
+
+    def finish(self):
+        check(lib().slam_mapper_finish(self.h))
+
+    def stats(self):
+        c, m, r = C.c_long(), C.c_long(), C.c_long()
+        ms, rows = C.c_double(), (C.c_int * 2)()
+        check(lib().slam_mapper_stats(self.h, C.byref(c), C.byref(m), C.byref(r), C.byref(ms), rows))
+        return dict(chunks=c.value, merges=m.value, rebuilds=r.value, rebuild_ms=ms.value, last_merge_rows=(rows[0], rows[1]))
+
+    def target_index_info(self):
+        h = _vp()
+        check(lib().slam_mapper_target(self.h, C.byref(h)))
+        icp = object.__new__(Icp)
+        icp.h = h.value
+        info = icp.index_info()
+        icp.h = None
+        return info
+
+    def use_comm(self, comm):
+        check(rccl_lib().slam_mapper_use_comm(self.h, comm.h))
+        self._comm = comm
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().slam_mapper_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -792,7 +931,8 @@ class Ccicp:
 # ------------------------------------------------------------------ RCCL merge
 _rccl = None
 RCCL_EXPORTS = ["slam_comm_unique_id", "slam_comm_create", "slam_comm_adopt", "slam_comm_destroy",
-                "slam_comm_info", "slam_grid_allreduce"]
+                "slam_comm_info", "slam_grid_allreduce", "slam_grid_allreduce_rows", "slam_grid_merge_begin",
+                "slam_grid_merge_finish", "slam_mapper_use_comm"]
 
 
 def rccl_lib():
@@ -811,6 +951,10 @@ def rccl_lib():
     R.slam_comm_destroy.restype = None
     R.slam_comm_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     R.slam_grid_allreduce.argtypes = [_vp, _vp, _vp]
+    R.slam_grid_allreduce_rows.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp]
+    R.slam_grid_merge_begin.argtypes = [_vp, _vp, _vp]
+    R.slam_grid_merge_finish.argtypes = [_vp, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    R.slam_mapper_use_comm.argtypes = [_vp, _vp]
     _rccl = R
     return R
 
@@ -839,6 +983,19 @@ class Comm:
 
     def allreduce_grid(self, grid, stream=None):
         check(rccl_lib().slam_grid_allreduce(grid.h, self.h, _sp(stream)))
+
+    def allreduce_rows(self, grid, row_lo, row_hi, stream=None):
+        check(rccl_lib().slam_grid_allreduce_rows(grid.h, self.h, int(row_lo), int(row_hi), _sp(stream)))
+
+    def merge_begin(self, grid, stream=None):
+        """Unites the ranks' device-tracked dirty rows (8-byte all-reduce) and sends them to the host; returns at once."""
+        check(rccl_lib().slam_grid_merge_begin(grid.h, self.h, _sp(stream)))
+
+    def merge_finish(self, grid, stream=None):
+        """Waits for the united range, enqueues the all-reduce of those rows; returns (row_lo, row_hi)."""
+        lo, hi = C.c_int(), C.c_int()
+        check(rccl_lib().slam_grid_merge_finish(grid.h, self.h, _sp(stream), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
 
     def close(self):
         if getattr(self, "h", None):

@@ -45,6 +45,8 @@ struct GridView {
     int32_t *hits;         // [sx*sy] storage order
     int32_t *misses;       // [sx*sy] storage order
     unsigned long long *updates;
+    int     *dirty;        // [2] storage rows touched since the counts were last reset: {lowest, -highest}
+    const int32_t *acc_hits, *acc_misses; // nullable: counts folded away by slam_grid_fold (merged totals)
 };
 
 __device__ inline int storage_index(const GridView &g, int x, int y)
@@ -89,6 +91,21 @@ __device__ inline bool point_cell(const GridView &g, float px, float py, int *cx
 
 constexpr int kUpdateSlots = 1024;
 
+// Rows of the planes (storage order) that hold counts: a merge over the GPUs moves only these
+// (slam_mi355x_rccl.h).  Wave minimum, then one pair of atomics per wavefront.
+__device__ inline void mark_dirty_rows(int *dirty, int row_lo, int row_hi /* -1: none */)
+{
+    int lo = row_hi >= 0 ? row_lo : 0x7fffffff, nhi = row_hi >= 0 ? -row_hi : 0x7fffffff;
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off));
+        nhi = min(nhi, __shfl_xor(nhi, off));
+    }
+    if ((threadIdx.x & 63) == 0 && lo != 0x7fffffff) {
+        atomicMin(&dirty[0], lo);
+        atomicMin(&dirty[1], nhi);
+    }
+}
+
 // Counter of cell updates: wave reduction, then one atomic per wavefront into
 // one of kUpdateSlots slots (same-address device atomics retire at ~11 ns each,
 // so thousands of wavefronts must not share one word); the reader sums the slots.
@@ -107,6 +124,7 @@ __global__ __launch_bounds__(256) void endpoints_kernel(GridView g, const float 
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     unsigned  did = 0;
+    int       row = -1;
     if (i < n_obs + n_gnd) {
         const bool   is_obs = i < n_obs;
         const float *p = is_obs ? obs + (size_t)i * stride : gnd + (size_t)(i - n_obs) * stride;
@@ -115,8 +133,10 @@ __global__ __launch_bounds__(256) void endpoints_kernel(GridView g, const float 
             const int s = storage_index(g, cx, cy);
             atomicAdd(is_obs ? &g.hits[s] : &g.misses[s], 1); // mls.cpp:99 / :135 as counts
             did = 1;
+            row = s / g.sx;
         }
     }
+    mark_dirty_rows(g.dirty, row, row);
     block_add_updates(g.updates, did);
 }
 
@@ -236,6 +256,7 @@ __global__ __launch_bounds__(256) void raycast_global_kernel(GridView g, const B
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     unsigned  did = 0;
+    int       rlo = 0, rhi = -1;
     if (i < n) {
         const Beam b = beams[i];
         if (b.x0 >= 0) {
@@ -268,8 +289,13 @@ __global__ __launch_bounds__(256) void raycast_global_kernel(GridView g, const B
                 did = dy + 1;
             }
             atomicAdd(&g.hits[storage_index(g, b.x1, b.y1)], 1);
+            const int ra = storage_index(g, 0, b.y0) / g.sx, rb = storage_index(g, 0, b.y1) / g.sx;
+            const bool wraps = (ra <= rb) != (b.y0 <= b.y1); // the beam crosses the toroidal seam: every row may be touched
+            rlo = wraps ? 0 : min(ra, rb);
+            rhi = wraps ? g.sy - 1 : max(ra, rb);
         }
     }
+    mark_dirty_rows(g.dirty, rlo, rhi);
     block_add_updates(g.updates, did);
 }
 
@@ -515,6 +541,7 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
     }
     const int n_segs = own_prefix ? s_segoff[n_tiles] : queue[1];
     unsigned  did = 0;
+    int       d_lo = 0x7fffffff, d_hi = -1; // storage rows this lane wrote back
 
     for (;;) {
         __syncthreads(); // the previous segment's write-back has read the tile
@@ -653,8 +680,13 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
             const int s = storage_index(g, tx0 + lx, ty0 + ly);
             if (v & 0xffffu) atomicAdd(&g.misses[s], (int)(v & 0xffffu));
             if (v >> 16) atomicAdd(&g.hits[s], (int)(v >> 16));
+            int row = ty0 + ly + g.oy; // the storage row of s (storage_index without its division)
+            row -= row >= g.sy ? g.sy : 0;
+            d_lo = min(d_lo, row);
+            d_hi = max(d_hi, row);
         }
     }
+    mark_dirty_rows(g.dirty, d_lo, d_hi);
     block_add_updates(g.updates, did);
 }
 
@@ -666,7 +698,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(GridView g, double inc, d
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= g.sx) return;
     const int s = storage_index(g, x, y);
-    const int h = g.hits[s], m = g.misses[s];
+    const int h = g.hits[s] + (g.acc_hits ? g.acc_hits[s] : 0), m = g.misses[s] + (g.acc_misses ? g.acc_misses[s] : 0);
     double    v = inc * (double)h;
     int8_t    o = -1;
     if (h > 0 && v > minp) o = 100; // mls.cpp:101-105
@@ -681,8 +713,24 @@ __global__ __launch_bounds__(256) void gather_counts_kernel(GridView g, int32_t 
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= g.sx) return;
     const int s = storage_index(g, x, y);
-    hits_w[x + (size_t)g.sx * y] = g.hits[s];
-    misses_w[x + (size_t)g.sx * y] = g.misses[s];
+    hits_w[x + (size_t)g.sx * y] = g.hits[s] + (g.acc_hits ? g.acc_hits[s] : 0);
+    misses_w[x + (size_t)g.sx * y] = g.misses[s] + (g.acc_misses ? g.acc_misses[s] : 0);
+}
+
+// slam_grid_fold: rows [row_lo, row_hi] of the count planes are added to the accumulator planes and zeroed
+__global__ __launch_bounds__(256) void fold_rows_kernel(int32_t *planes, int32_t *acc, size_t cells, int sx, int row_lo, int n_rows)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)n_rows * sx;
+    if (i >= n) return;
+    const size_t k = (size_t)row_lo * sx + i;
+    for (int p = 0; p < 2; ++p) {
+        const size_t j = p * cells + k;
+        const int    v = planes[j];
+        if (v) {
+            acc[j] += v;
+            planes[j] = 0;
+        }
+    }
 }
 
 // MLS::setPose roll, mls.cpp:461-468: cells that rolled into the window are cleared
@@ -695,6 +743,10 @@ __global__ __launch_bounds__(256) void roll_clear_kernel(GridView g, int dx, int
         const int s = storage_index(g, x, y);
         g.hits[s] = 0;
         g.misses[s] = 0;
+        if (g.acc_hits) {
+            const_cast<int32_t *>(g.acc_hits)[s] = 0;
+            const_cast<int32_t *>(g.acc_misses)[s] = 0;
+        }
         num_pts[s] = 0.0;
         occ_state[s] = -1;
     }
@@ -717,6 +769,8 @@ __global__ __launch_bounds__(256) void inorder_count_kernel(GridView g, const fl
     const int s = storage_index(g, cx, cy);
     const unsigned long long old = atomicAdd(&delta[s], is_obs ? (1ull << 32) : 1ull);
     atomicAdd(is_obs ? &g.hits[s] : &g.misses[s], 1);
+    atomicMin(&g.dirty[0], s / g.sx);
+    atomicMin(&g.dirty[1], -(s / g.sx));
     if (old == 0ull) {
         const int k = atomicAdd(n_touched, 1);
         touched[k] = s;
@@ -782,6 +836,8 @@ struct slam_grid {
     int             *d_touched = nullptr; // [2*cap_points] + counter
     size_t           cap_touched = 0;
     unsigned long long *d_updates = nullptr;
+    int             *d_dirty = nullptr;    // [2] see GridView::dirty
+    int32_t         *d_acc = nullptr;      // [hits | misses] accumulator planes (slam_grid_enable_accumulator)
     Beam            *d_beams = nullptr;
     size_t           cap_beams = 0;
     int4            *d_chunk_box = nullptr;
@@ -943,6 +999,7 @@ int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_
     alloc((void **)&g->d_num_s, g->cells * sizeof(double));
     alloc((void **)&g->d_occ_s, g->cells);
     alloc((void **)&g->d_updates, kUpdateSlots * sizeof(unsigned long long));
+    alloc((void **)&g->d_dirty, 4 * sizeof(int));
     if (rc != SLAM_OK) {
         slam_grid_destroy(g);
         return rc;
@@ -958,6 +1015,8 @@ int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_
     v.hits = g->d_planes;
     v.misses = g->d_planes + g->cells;
     v.updates = g->d_updates;
+    v.dirty = g->d_dirty;
+    v.acc_hits = v.acc_misses = nullptr;
     rc = slam_grid_clear(g, nullptr);
     if (rc == SLAM_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = SLAM_E_HIP;
     if (rc != SLAM_OK) {
@@ -973,7 +1032,7 @@ void slam_grid_destroy(slam_grid_t *g)
     if (!g) return;
     void *ptrs[] = {g->d_planes, g->d_num_w, g->d_occ_w, g->d_num_s,     g->d_occ_s, g->d_delta,
                     g->d_touched, g->d_updates, g->d_beams, g->d_chunk_box, g->d_stage,
-                    g->d_tile_cnt, g->d_tile_fill, g->d_queue, g->d_items};
+                    g->d_tile_cnt, g->d_tile_fill, g->d_queue, g->d_items, g->d_dirty, g->d_acc};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -989,6 +1048,8 @@ int slam_grid_clear(slam_grid_t *g, slam_stream_t stream)
     SLAM_HIP(hipMemsetAsync(g->d_occ_w, 0xff, g->cells, st)); // -1 = unknown (mls.cpp:26)
     SLAM_HIP(hipMemsetAsync(g->d_occ_s, 0xff, g->cells, st));
     SLAM_HIP(hipMemsetAsync(g->d_updates, 0, kUpdateSlots * sizeof(unsigned long long), st));
+    SLAM_HIP(hipMemsetAsync(g->d_dirty, 0x7f, 2 * sizeof(int), st)); // {lowest, -highest} = "no row"
+    if (g->d_acc) SLAM_HIP(hipMemsetAsync(g->d_acc, 0, 2 * g->cells * sizeof(int32_t), st));
     g->state_from_inorder = false;
     return SLAM_OK;
 }
@@ -997,6 +1058,50 @@ int slam_grid_reset_counts(slam_grid_t *g, slam_stream_t stream)
 {
     SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
     SLAM_HIP(hipMemsetAsync(g->d_planes, 0, 2 * g->cells * sizeof(int32_t), as_stream(stream)));
+    SLAM_HIP(hipMemsetAsync(g->d_dirty, 0x7f, 2 * sizeof(int), as_stream(stream)));
+    return SLAM_OK;
+}
+
+int slam_grid_enable_accumulator(slam_grid_t *g)
+{
+    SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
+    if (g->d_acc) return SLAM_OK;
+    SLAM_HIP(hipMalloc((void **)&g->d_acc, 2 * g->cells * sizeof(int32_t)));
+    SLAM_HIP(hipMemset(g->d_acc, 0, 2 * g->cells * sizeof(int32_t)));
+    g->gv.acc_hits = g->d_acc;
+    g->gv.acc_misses = g->d_acc + g->cells;
+    return SLAM_OK;
+}
+
+int slam_grid_fold(slam_grid_t *g, int row_lo, int row_hi, slam_stream_t stream)
+{
+    SLAM_REQUIRE(g && g->d_acc, SLAM_E_INVALID, "slam_grid_fold: needs slam_grid_enable_accumulator");
+    hipStream_t st = as_stream(stream);
+    if (row_hi >= row_lo) {
+        SLAM_REQUIRE(row_lo >= 0 && row_hi < g->gv.sy, SLAM_E_INVALID, "slam_grid_fold: rows %d..%d outside the grid", row_lo, row_hi);
+        const size_t n = (size_t)(row_hi - row_lo + 1) * g->gv.sx;
+        hipLaunchKernelGGL(fold_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g->d_planes, g->d_acc, g->cells,
+                           g->gv.sx, row_lo, row_hi - row_lo + 1);
+        SLAM_HIP(hipGetLastError());
+    }
+    SLAM_HIP(hipMemsetAsync(g->d_dirty, 0x7f, 2 * sizeof(int), st));
+    return SLAM_OK;
+}
+
+int slam_grid_dirty_rows_dev(slam_grid_t *g, int32_t **d_range)
+{
+    SLAM_REQUIRE(g && d_range, SLAM_E_INVALID, "slam_grid_dirty_rows_dev: bad arguments");
+    *d_range = g->d_dirty;
+    return SLAM_OK;
+}
+
+int slam_grid_dirty_rows(slam_grid_t *g, int *row_lo, int *row_hi)
+{
+    SLAM_REQUIRE(g && row_lo && row_hi, SLAM_E_INVALID, "slam_grid_dirty_rows: bad arguments");
+    int r[2];
+    SLAM_HIP(hipMemcpy(r, g->d_dirty, sizeof r, hipMemcpyDeviceToHost));
+    *row_lo = r[0] > g->gv.sy ? 0 : r[0];
+    *row_hi = r[0] > g->gv.sy ? -1 : -r[1];
     return SLAM_OK;
 }
 

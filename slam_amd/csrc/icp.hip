@@ -1021,6 +1021,22 @@ int launch_fit(slam_icp *h, const FitArgs &fa_in, int n_scans, hipStream_t st)
 
 } // namespace
 
+namespace slam {
+namespace icp {
+// the caller knows that no enqueued work uses the handle any more (the mapper waits on an event instead of the device)
+void destroy_unsynchronised(slam_icp *icp)
+{
+    if (!icp) return;
+    release_index(icp);
+    for (auto &e : icp->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (icp->d_normals) (void)hipFree(icp->d_normals);
+    for (DevBuf *b : {&icp->w_pts, &icp->w_stamps, &icp->w_ew, &icp->w_state, &icp->w_single}) b->release();
+    delete icp;
+}
+} // namespace icp
+} // namespace slam
+
 extern "C" {
 
 void slam_icp_default_params(slam_icp_params *p)
@@ -1121,13 +1137,7 @@ void slam_icp_destroy(slam_icp_t *icp)
     if (!icp) return;
     // the buffers go back to the library's pool, not to hipFree (which would wait for the device itself)
     (void)hipDeviceSynchronize();
-    release_index(icp);
-    for (auto &e : icp->ev)
-        if (e) (void)hipEventDestroy(e);
-    if (icp->d_normals) (void)hipFree(icp->d_normals);
-    for (DevBuf *b : {&icp->w_pts, &icp->w_stamps, &icp->w_ew, &icp->w_state, &icp->w_single})
-        b->release();
-    delete icp;
+    slam::icp::destroy_unsynchronised(icp);
 }
 
 int slam_icp_build_info(slam_icp_t *icp, int *on_device, double ms[4])

@@ -168,5 +168,6 @@ namespace icp {
 // arrays unless on_device; fills h->mv, h->d_blob, h->d_lblob, ...
 int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, int n_nga, bool on_device);
 void release_index(slam_icp *h);
+void destroy_unsynchronised(slam_icp *h); // slam_icp_destroy without its device synchronisation
 } // namespace icp
 } // namespace slam

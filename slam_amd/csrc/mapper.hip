@@ -1,0 +1,456 @@
+// mapper.hip -- the streaming form of the path (BASELINE config 5): chunks of scans go from pinned host
+// memory through registration into the occupancy grid on three HIP streams, the ICP target is a sliding window
+// of the scans registered so far, and every few chunks the grid is merged over the GPUs and finalized.
+//
+// Stands where scan_registration and local_mapper run one callback per scan (scan_registration.cpp:109-199:
+// setSceneCloud -> doICPMatch against the target it keeps, :139-159; local_mapper.cpp:65-130: addToMap at
+// 50 Hz).  Per chunk k, with two device slots:
+//   copy stream : pinned chunk k -> HBM                                            -> event copied
+//   icp  stream : wait copied -> slam_icp_fit_batch_dev against the current target -> decimate the registered
+//                 points into the window ring                                       -> event registered
+//   grid stream : wait registered -> slam_grid_set_pose (rolling window, mls.cpp:408-479) + Bresenham update
+//                 -> every merge_every chunks: dirty-row merge over the ranks (hook installed by
+//                 slam_mapper_use_comm, slam_mi355x_rccl.h), fold into the accumulator, finalize -> event mapped
+// so that the copy of chunk k+1, the registration of chunk k and the map update of chunk k-1 overlap.
+// Every rebuild_every chunks the target is rebuilt on the device (slam_icp_create_dev, icp_build.hip) from the
+// prior map (optional) plus the decimated points of the last window_chunks chunks whose registration has
+// finished: the newest chunk is not waited for, so the target lags by one chunk instead of stalling the pipeline
+// (the north-star's "sliding-window local map ... accepting staleness").
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "icp_model.hpp"
+
+using namespace slam;
+
+namespace {
+
+// registered points of a chunk, every stride-th of each class, into the window ring (map frame, f64 xy)
+__global__ __launch_bounds__(256) void window_points_kernel(const double2 *pts, const int *scan_off, const int *scan_nga,
+                                                            const int *ga_before, int n_scans, int n_points, const double *R,
+                                                            const double *t, int stride_ga, int stride_nga, double2 *out_ga,
+                                                            double2 *out_nga)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_points) return;
+    int lo = 0, hi = n_scans - 1; // scan of point i: the last s with scan_off[s] <= i
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (scan_off[mid] <= i)
+            lo = mid;
+        else
+            hi = mid - 1;
+    }
+    const int  s = lo, j = i - scan_off[s], g = scan_nga[s];
+    const bool is_ga = j < g;
+    const int  rank = is_ga ? ga_before[s] + j : (scan_off[s] - ga_before[s]) + (j - g);
+    const int  stride = is_ga ? stride_ga : stride_nga;
+    if (rank % stride) return;
+    const double2 P = pts[i];
+    const double *Rs = R + 4 * (size_t)s, *ts = t + 2 * (size_t)s;
+    double2       q;
+    q.x = __dadd_rn(__dadd_rn(__dmul_rn(Rs[0], P.x), __dmul_rn(Rs[1], P.y)), ts[0]); // icpPointToPoint.cpp:69-70 (kept f64)
+    q.y = __dadd_rn(__dadd_rn(__dmul_rn(Rs[2], P.x), __dmul_rn(Rs[3], P.y)), ts[1]);
+    (is_ga ? out_ga : out_nga)[rank / stride] = q;
+}
+
+struct Slot {
+    double  *d_pts = nullptr, *d_R = nullptr, *d_t = nullptr;
+    int32_t *d_off = nullptr, *d_nga = nullptr, *d_gab = nullptr;
+    // pinned staging the producer fills
+    double  *h_pts = nullptr, *h_R = nullptr, *h_t = nullptr;
+    int32_t *h_off = nullptr, *h_nga = nullptr, *h_gab = nullptr;
+    hipEvent_t copied = nullptr, registered = nullptr, mapped = nullptr;
+    bool     busy = false;
+    int      n_scans = 0;
+};
+
+struct WindowEntry {
+    double2 *ga = nullptr, *nga = nullptr; // device, room for max_points each
+    int      n_ga = 0, n_nga = 0;
+    long     chunk = -1;                   // which chunk lies here
+    hipEvent_t ready = nullptr;            // recorded behind the kernel that filled it
+};
+
+} // namespace
+
+struct slam_mapper {
+    slam_mapper_params prm;
+    slam_grid_t       *grid = nullptr;
+    slam_icp_t        *target = nullptr, *retired = nullptr;
+    hipEvent_t         target_used = nullptr, retired_used = nullptr; // behind the last launch that read the handle
+    hipStream_t        copy = nullptr, icp_s = nullptr, grid_s = nullptr;
+    Slot               slot[2];
+    int                next = 0;
+    long               chunks = 0, merges = 0, rebuilds = 0, last_rebuild = -1;
+    std::vector<WindowEntry> window;
+    std::vector<double> prior_ga, prior_nga; // host copies of the model given at create
+    double            *d_model_ga = nullptr, *d_model_nga = nullptr;
+    size_t             cap_model = 0;
+    slam_mapper_merge_fn merge_begin = nullptr, merge_finish = nullptr;
+    void              *merge_ctx = nullptr;
+    bool               merge_pending = false;
+    int                last_rows[2] = {0, -1};
+    double             rebuild_ms = 0;
+};
+
+namespace {
+
+#define MAP_HIP(expr) SLAM_HIP(expr)
+
+void retire_now(slam_mapper *m)
+{
+    if (!m->retired) return;
+    if (m->retired_used) (void)hipEventSynchronize(m->retired_used);
+    slam::icp::destroy_unsynchronised(m->retired);
+    m->retired = nullptr;
+}
+
+// decimation that keeps about target_points / (2 * window) points of a class per chunk
+int stride_for(const slam_mapper *m, int n)
+{
+    const int per_chunk = std::max(64, m->prm.target_points / std::max(2 * m->prm.window_chunks, 1));
+    return std::max(1, (n + per_chunk - 1) / per_chunk);
+}
+
+int rebuild_target(slam_mapper *m)
+{
+    // everything in the window whose registration has finished (the newest may still be running: skipped)
+    std::vector<const WindowEntry *> use;
+    for (const WindowEntry &w : m->window) {
+        if (w.chunk < 0) continue;
+        if (m->prm.strict_window) MAP_HIP(hipEventSynchronize(w.ready)); // reproducible: wait for the newest too
+        if (hipEventQuery(w.ready) == hipSuccess) use.push_back(&w);
+    }
+    (void)hipGetLastError();
+    std::sort(use.begin(), use.end(), [](const WindowEntry *a, const WindowEntry *b) { return a->chunk < b->chunk; });
+    if ((int)use.size() > m->prm.window_chunks) use.erase(use.begin(), use.end() - m->prm.window_chunks); // the newest W
+    size_t n_ga = m->prm.keep_prior ? m->prior_ga.size() / 2 : 0, n_nga = m->prm.keep_prior ? m->prior_nga.size() / 2 : 0;
+    const size_t p_ga = n_ga, p_nga = n_nga;
+    for (const WindowEntry *w : use) n_ga += (size_t)w->n_ga, n_nga += (size_t)w->n_nga;
+    if (use.empty() || n_ga + n_nga < 5) return SLAM_OK; // nothing registered yet: keep the current target
+    const auto t0 = std::chrono::steady_clock::now();
+    if (n_ga + n_nga > m->cap_model) {
+        if (m->d_model_ga) pool_free(m->d_model_ga);
+        m->cap_model = (n_ga + n_nga) * 2;
+        m->d_model_ga = static_cast<double *>(pool_alloc(16 * m->cap_model));
+        if (!m->d_model_ga) return SLAM_E_NOMEM;
+    }
+    m->d_model_nga = m->d_model_ga + 2 * n_ga;
+    hipStream_t st = nullptr; // the build runs on the default stream: everything it reads is complete by now
+    if (p_ga) MAP_HIP(hipMemcpyAsync(m->d_model_ga, m->prior_ga.data(), 16 * p_ga, hipMemcpyHostToDevice, st));
+    if (p_nga) MAP_HIP(hipMemcpyAsync(m->d_model_nga, m->prior_nga.data(), 16 * p_nga, hipMemcpyHostToDevice, st));
+    size_t o_ga = p_ga, o_nga = p_nga;
+    for (const WindowEntry *w : use) {
+        if (w->n_ga) MAP_HIP(hipMemcpyAsync(m->d_model_ga + 2 * o_ga, w->ga, 16 * (size_t)w->n_ga, hipMemcpyDeviceToDevice, st));
+        if (w->n_nga) MAP_HIP(hipMemcpyAsync(m->d_model_nga + 2 * o_nga, w->nga, 16 * (size_t)w->n_nga, hipMemcpyDeviceToDevice, st));
+        o_ga += (size_t)w->n_ga;
+        o_nga += (size_t)w->n_nga;
+    }
+    slam_icp_t *fresh = nullptr;
+    SLAM_TRY(slam_icp_create_dev(m->d_model_ga, (int)n_ga, m->d_model_nga, (int)n_nga, &m->prm.icp, &fresh));
+    retire_now(m); // the handle before last: its launches ended chunks ago
+    m->retired = m->target;
+    std::swap(m->retired_used, m->target_used);
+    m->target = fresh;
+    ++m->rebuilds;
+    m->last_rebuild = m->chunks;
+    m->rebuild_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return SLAM_OK;
+}
+
+int finish_merge(slam_mapper *m)
+{
+    if (!m->merge_pending) return SLAM_OK;
+    m->merge_pending = false;
+    int lo = 0, hi = -1;
+    SLAM_TRY(m->merge_finish(m->merge_ctx, m->grid, (slam_stream_t)m->grid_s, &lo, &hi));
+    m->last_rows[0] = lo;
+    m->last_rows[1] = hi;
+    SLAM_TRY(slam_grid_fold(m->grid, lo, hi, (slam_stream_t)m->grid_s));
+    SLAM_TRY(slam_grid_finalize(m->grid, (slam_stream_t)m->grid_s));
+    ++m->merges;
+    return SLAM_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+void slam_mapper_default_params(slam_mapper_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof *p);
+    p->grid_size_x = p->grid_size_y = 2000;
+    p->resolution = 0.05;
+    slam_grid_default_params(&p->grid);
+    p->grid.min_cluster_points = 20; // local_mapper.cpp:86
+    slam_icp_default_params(&p->icp);
+    p->indist = 5.0;                 // icpTools.cpp:188
+    p->max_scans = 256;
+    p->max_points = 256 * 1081;
+    p->window_chunks = 0;
+    p->rebuild_every = 1;
+    p->target_points = 2 * 19999;    // ICP_MAX_PTS per class, icpTools.h:21
+    p->keep_prior = 0;
+    p->merge_every = 0;
+    p->pipelined = 1;
+    p->strict_window = 0;
+}
+
+int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int n_ga, const double *m_nga, int n_nga,
+                       slam_mapper_t **out)
+{
+    SLAM_REQUIRE(params && out, SLAM_E_INVALID, "slam_mapper_create: bad arguments");
+    *out = nullptr;
+    SLAM_REQUIRE(params->max_scans > 0 && params->max_points > 0 && params->window_chunks >= 0 && params->rebuild_every >= 1 &&
+                     params->merge_every >= 0,
+                 SLAM_E_INVALID, "slam_mapper_create: bad parameters");
+    SLAM_TRY(require_device());
+    slam_mapper *m = new (std::nothrow) slam_mapper();
+    SLAM_REQUIRE(m, SLAM_E_NOMEM, "slam_mapper_create: out of host memory");
+    m->prm = *params;
+    int rc = slam_grid_create(params->grid_size_x, params->grid_size_y, params->resolution, &params->grid, &m->grid);
+    if (rc == SLAM_OK) rc = slam_icp_create(m_ga, n_ga, m_nga, n_nga, &params->icp, &m->target); // the prior map: the first target
+    auto hip = [&](hipError_t e) {
+        if (rc == SLAM_OK && e != hipSuccess) rc = hip_fail(e, "slam_mapper_create", __FILE__, __LINE__);
+    };
+    if (rc == SLAM_OK) {
+        m->prior_ga.assign(m_ga, m_ga + 2 * (size_t)n_ga);
+        m->prior_nga.assign(m_nga, m_nga + 2 * (size_t)n_nga);
+        if (params->pipelined) {
+            hip(hipStreamCreateWithFlags(&m->copy, hipStreamNonBlocking));
+            hip(hipStreamCreateWithFlags(&m->icp_s, hipStreamNonBlocking));
+            hip(hipStreamCreateWithFlags(&m->grid_s, hipStreamNonBlocking));
+        } else {
+            hip(hipStreamCreateWithFlags(&m->copy, hipStreamNonBlocking));
+            m->icp_s = m->grid_s = m->copy;
+        }
+        hip(hipEventCreateWithFlags(&m->target_used, hipEventDisableTiming));
+        hip(hipEventCreateWithFlags(&m->retired_used, hipEventDisableTiming));
+        const size_t np = (size_t)params->max_points, ns = (size_t)params->max_scans;
+        for (Slot &b : m->slot) {
+            hip(hipMalloc((void **)&b.d_pts, 16 * np));
+            hip(hipMalloc((void **)&b.d_off, 4 * (ns + 1)));
+            hip(hipMalloc((void **)&b.d_nga, 4 * ns));
+            hip(hipMalloc((void **)&b.d_gab, 4 * (ns + 1)));
+            hip(hipMalloc((void **)&b.d_R, 32 * ns));
+            hip(hipMalloc((void **)&b.d_t, 16 * ns));
+            hip(hipHostMalloc((void **)&b.h_pts, 16 * np, hipHostMallocDefault));
+            hip(hipHostMalloc((void **)&b.h_off, 4 * (ns + 1), hipHostMallocDefault));
+            hip(hipHostMalloc((void **)&b.h_nga, 4 * ns, hipHostMallocDefault));
+            hip(hipHostMalloc((void **)&b.h_gab, 4 * (ns + 1), hipHostMallocDefault));
+            hip(hipHostMalloc((void **)&b.h_R, 32 * ns, hipHostMallocDefault));
+            hip(hipHostMalloc((void **)&b.h_t, 16 * ns, hipHostMallocDefault));
+            hip(hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
+            hip(hipEventCreateWithFlags(&b.registered, hipEventDisableTiming));
+            hip(hipEventCreateWithFlags(&b.mapped, hipEventDisableTiming));
+        }
+        // the window keeps one entry more than it uses: the newest is still being written when a rebuild looks
+        m->window.resize(params->window_chunks ? (size_t)params->window_chunks + 1 : 0);
+        const size_t per = (size_t)std::max(64, params->target_points / std::max(2 * params->window_chunks, 1)) + 8;
+        for (WindowEntry &w : m->window) {
+            hip(hipMalloc((void **)&w.ga, 16 * per));
+            hip(hipMalloc((void **)&w.nga, 16 * per));
+            hip(hipEventCreateWithFlags(&w.ready, hipEventDisableTiming));
+        }
+    }
+    if (rc != SLAM_OK) {
+        slam_mapper_destroy(m);
+        return rc;
+    }
+    *out = m;
+    return SLAM_OK;
+}
+
+void slam_mapper_destroy(slam_mapper_t *m)
+{
+    if (!m) return;
+    (void)hipDeviceSynchronize();
+    for (Slot &b : m->slot) {
+        for (void *p : {(void *)b.d_pts, (void *)b.d_off, (void *)b.d_nga, (void *)b.d_gab, (void *)b.d_R, (void *)b.d_t})
+            if (p) (void)hipFree(p);
+        for (void *p : {(void *)b.h_pts, (void *)b.h_off, (void *)b.h_nga, (void *)b.h_gab, (void *)b.h_R, (void *)b.h_t})
+            if (p) (void)hipHostFree(p);
+        for (hipEvent_t e : {b.copied, b.registered, b.mapped})
+            if (e) (void)hipEventDestroy(e);
+    }
+    for (WindowEntry &w : m->window) {
+        if (w.ga) (void)hipFree(w.ga);
+        if (w.nga) (void)hipFree(w.nga);
+        if (w.ready) (void)hipEventDestroy(w.ready);
+    }
+    if (m->d_model_ga) pool_free(m->d_model_ga);
+    if (m->target) slam_icp_destroy(m->target);
+    if (m->retired) slam_icp_destroy(m->retired);
+    if (m->grid) slam_grid_destroy(m->grid);
+    if (m->target_used) (void)hipEventDestroy(m->target_used);
+    if (m->retired_used) (void)hipEventDestroy(m->retired_used);
+    const bool one = m->icp_s == m->copy;
+    if (m->copy) (void)hipStreamDestroy(m->copy);
+    if (!one && m->icp_s) (void)hipStreamDestroy(m->icp_s);
+    if (!one && m->grid_s) (void)hipStreamDestroy(m->grid_s);
+    delete m;
+}
+
+int slam_mapper_chunk_buffers(slam_mapper_t *m, int slot, double **pts, int32_t **scan_off, int32_t **scan_nga, double **R0,
+                              double **t0)
+{
+    SLAM_REQUIRE(m && (slot == 0 || slot == 1), SLAM_E_INVALID, "slam_mapper_chunk_buffers: bad arguments");
+    Slot &b = m->slot[slot];
+    if (pts) *pts = b.h_pts;
+    if (scan_off) *scan_off = b.h_off;
+    if (scan_nga) *scan_nga = b.h_nga;
+    if (R0) *R0 = b.h_R;
+    if (t0) *t0 = b.h_t;
+    return SLAM_OK;
+}
+
+int slam_mapper_next_slot(slam_mapper_t *m, int *slot)
+{
+    SLAM_REQUIRE(m && slot, SLAM_E_INVALID, "slam_mapper_next_slot: bad arguments");
+    *slot = m->next;
+    return SLAM_OK;
+}
+
+int slam_mapper_set_merge(slam_mapper_t *m, slam_mapper_merge_fn begin, slam_mapper_merge_fn finish, void *ctx)
+{
+    SLAM_REQUIRE(m && ((begin && finish) || (!begin && !finish)), SLAM_E_INVALID, "slam_mapper_set_merge: bad arguments");
+    m->merge_begin = begin;
+    m->merge_finish = finish;
+    m->merge_ctx = ctx;
+    if (begin) SLAM_TRY(slam_grid_enable_accumulator(m->grid));
+    return SLAM_OK;
+}
+
+int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_x, double window_y, int *slot_out)
+{
+    SLAM_REQUIRE(m && n_scans > 0 && n_points > 0, SLAM_E_INVALID, "slam_mapper_push: bad arguments");
+    SLAM_REQUIRE(n_scans <= m->prm.max_scans && n_points <= m->prm.max_points, SLAM_E_INVALID,
+                 "slam_mapper_push: chunk of %d scans / %d points exceeds the reservation (%d / %d)", n_scans, n_points,
+                 m->prm.max_scans, m->prm.max_points);
+    const int s = m->next;
+    m->next ^= 1;
+    Slot &b = m->slot[s];
+    SLAM_REQUIRE(!b.busy, SLAM_E_INVALID, "slam_mapper_push: slot %d still holds a chunk that was not waited for", s);
+    SLAM_REQUIRE(b.h_off[0] == 0 && b.h_off[n_scans] == n_points, SLAM_E_INVALID, "slam_mapper_push: scan_off does not span the chunk");
+    // points of class GA before each scan (the window's decimation ranks points per class)
+    b.h_gab[0] = 0;
+    for (int k = 0; k < n_scans; ++k) b.h_gab[k + 1] = b.h_gab[k] + b.h_nga[k];
+    const int n_ga = b.h_gab[n_scans], n_nga = n_points - n_ga;
+
+    // ---- sliding target: rebuilt before this chunk's registration is enqueued
+    if (m->prm.window_chunks && m->chunks > 0 && m->chunks - std::max<long>(m->last_rebuild, 0) >= m->prm.rebuild_every)
+        SLAM_TRY(rebuild_target(m));
+
+    // ---- copy
+    MAP_HIP(hipMemcpyAsync(b.d_pts, b.h_pts, 16 * (size_t)n_points, hipMemcpyHostToDevice, m->copy));
+    MAP_HIP(hipMemcpyAsync(b.d_off, b.h_off, 4 * (size_t)(n_scans + 1), hipMemcpyHostToDevice, m->copy));
+    MAP_HIP(hipMemcpyAsync(b.d_nga, b.h_nga, 4 * (size_t)n_scans, hipMemcpyHostToDevice, m->copy));
+    MAP_HIP(hipMemcpyAsync(b.d_gab, b.h_gab, 4 * (size_t)(n_scans + 1), hipMemcpyHostToDevice, m->copy));
+    MAP_HIP(hipMemcpyAsync(b.d_R, b.h_R, 32 * (size_t)n_scans, hipMemcpyHostToDevice, m->copy));
+    MAP_HIP(hipMemcpyAsync(b.d_t, b.h_t, 16 * (size_t)n_scans, hipMemcpyHostToDevice, m->copy));
+    MAP_HIP(hipEventRecord(b.copied, m->copy));
+    // ---- register
+    MAP_HIP(hipStreamWaitEvent(m->icp_s, b.copied, 0));
+    SLAM_TRY(slam_icp_fit_batch_dev(m->target, b.d_pts, b.d_off, b.d_nga, n_scans, b.d_R, b.d_t, m->prm.indist, nullptr, nullptr,
+                                    (slam_stream_t)m->icp_s));
+    MAP_HIP(hipEventRecord(m->target_used, m->icp_s));
+    if (m->prm.window_chunks) {
+        WindowEntry &w = m->window[(size_t)(m->chunks % (long)m->window.size())];
+        const int    sg = stride_for(m, n_ga), sn = stride_for(m, n_nga);
+        hipLaunchKernelGGL(window_points_kernel, dim3((n_points + 255) / 256), dim3(256), 0, m->icp_s,
+                           reinterpret_cast<const double2 *>(b.d_pts), b.d_off, b.d_nga, b.d_gab, n_scans, n_points, b.d_R, b.d_t, sg, sn,
+                           w.ga, w.nga);
+        MAP_HIP(hipGetLastError());
+        w.n_ga = (n_ga + sg - 1) / sg;
+        w.n_nga = (n_nga + sn - 1) / sn;
+        w.chunk = m->chunks;
+        MAP_HIP(hipEventRecord(w.ready, m->icp_s));
+    }
+    MAP_HIP(hipEventRecord(b.registered, m->icp_s));
+    // ---- the previous chunk's merge, now that this chunk's registration is in the queue ahead of the wait
+    SLAM_TRY(finish_merge(m));
+    // ---- map
+    MAP_HIP(hipStreamWaitEvent(m->grid_s, b.registered, 0));
+    SLAM_TRY(slam_grid_set_pose(m->grid, window_x, window_y, (slam_stream_t)m->grid_s)); // MLS::setPose, mls.cpp:408-479
+    SLAM_TRY(slam_grid_raycast_scans_dev(m->grid, b.d_pts, b.d_off, n_scans, n_points, b.d_R, b.d_t, (slam_stream_t)m->grid_s));
+    ++m->chunks;
+    if (m->prm.merge_every && m->chunks % m->prm.merge_every == 0) {
+        if (m->merge_begin) {
+            int lo = 0, hi = -1;
+            SLAM_TRY(m->merge_begin(m->merge_ctx, m->grid, (slam_stream_t)m->grid_s, &lo, &hi));
+            m->merge_pending = true;
+        } else {
+            SLAM_TRY(slam_grid_finalize(m->grid, (slam_stream_t)m->grid_s)); // one GPU: the periodic part is the occupancy output
+            ++m->merges;
+        }
+    }
+    MAP_HIP(hipEventRecord(b.mapped, m->grid_s));
+    b.busy = true;
+    b.n_scans = n_scans;
+    if (slot_out) *slot_out = s;
+    return SLAM_OK;
+}
+
+int slam_mapper_wait(slam_mapper_t *m, int slot, double *R_out, double *t_out)
+{
+    SLAM_REQUIRE(m && (slot == 0 || slot == 1), SLAM_E_INVALID, "slam_mapper_wait: bad arguments");
+    Slot &b = m->slot[slot];
+    if (!b.busy) return SLAM_OK;
+    MAP_HIP(hipEventSynchronize(b.registered));
+    if (R_out) MAP_HIP(hipMemcpyAsync(R_out, b.d_R, 32 * (size_t)b.n_scans, hipMemcpyDeviceToHost, m->copy));
+    if (t_out) MAP_HIP(hipMemcpyAsync(t_out, b.d_t, 16 * (size_t)b.n_scans, hipMemcpyDeviceToHost, m->copy));
+    MAP_HIP(hipEventSynchronize(b.mapped)); // the slot's device buffers are free again
+    if (R_out || t_out) MAP_HIP(hipStreamSynchronize(m->copy));
+    b.busy = false;
+    return SLAM_OK;
+}
+
+int slam_mapper_finish(slam_mapper_t *m)
+{
+    SLAM_REQUIRE(m, SLAM_E_INVALID, "null handle");
+    SLAM_TRY(finish_merge(m));
+    if (m->merge_begin) { // whatever was added since the last merge
+        int lo = 0, hi = -1;
+        SLAM_TRY(m->merge_begin(m->merge_ctx, m->grid, (slam_stream_t)m->grid_s, &lo, &hi));
+        m->merge_pending = true;
+        SLAM_TRY(finish_merge(m));
+    } else {
+        SLAM_TRY(slam_grid_finalize(m->grid, (slam_stream_t)m->grid_s));
+    }
+    MAP_HIP(hipStreamSynchronize(m->copy));
+    MAP_HIP(hipStreamSynchronize(m->icp_s));
+    MAP_HIP(hipStreamSynchronize(m->grid_s));
+    return SLAM_OK;
+}
+
+int slam_mapper_grid(slam_mapper_t *m, slam_grid_t **grid)
+{
+    SLAM_REQUIRE(m && grid, SLAM_E_INVALID, "slam_mapper_grid: bad arguments");
+    *grid = m->grid;
+    return SLAM_OK;
+}
+
+int slam_mapper_target(slam_mapper_t *m, slam_icp_t **icp)
+{
+    SLAM_REQUIRE(m && icp, SLAM_E_INVALID, "slam_mapper_target: bad arguments");
+    *icp = m->target;
+    return SLAM_OK;
+}
+
+int slam_mapper_stats(slam_mapper_t *m, long *chunks, long *merges, long *rebuilds, double *rebuild_ms, int last_merge_rows[2])
+{
+    SLAM_REQUIRE(m, SLAM_E_INVALID, "null handle");
+    if (chunks) *chunks = m->chunks;
+    if (merges) *merges = m->merges;
+    if (rebuilds) *rebuilds = m->rebuilds;
+    if (rebuild_ms) *rebuild_ms = m->rebuild_ms;
+    if (last_merge_rows) last_merge_rows[0] = m->last_rows[0], last_merge_rows[1] = m->last_rows[1];
+    return SLAM_OK;
+}
+
+} // extern "C"

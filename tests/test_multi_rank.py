@@ -80,6 +80,57 @@ def test_two_rank_merge_equals_single_process(tmp_path):
     assert np.array_equal(o1, o2) and np.array_equal(n1, n2)
 
 
+def _merge_worker(rank, world, port, out):
+    """The streaming mapper's periodic merge as two processes: per chunk a rank adds its scans' counts to its local
+    planes and tracks the rows it touched; every K chunks the ranks unite their dirty ranges with one MIN all-reduce of
+    {lowest, -highest}, sum those rows of the planes, fold them into the accumulator and zero them (what
+    slam_grid_merge_begin / _finish / slam_grid_fold do on the device)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = synth.make_batch(16, n_loop=64)
+    mine = full.shard(rank, world)
+    K, chunk = 2, 2
+    planes = torch.zeros(2, GRID, GRID, dtype=torch.int32)
+    acc = torch.zeros_like(planes)
+    BIG = 0x7f7f7f7f
+    dirty = [BIG, BIG]
+    n_chunks = mine.n_scans // chunk
+    for c in range(n_chunks):
+        sub = mine.shard(c, n_chunks)
+        h, m = _planes_for(sub, sub.true_poses)
+        planes += torch.from_numpy(np.stack([h, m]).reshape(2, GRID, GRID))
+        rows = np.flatnonzero((h.reshape(GRID, GRID) != 0).any(1) | (m.reshape(GRID, GRID) != 0).any(1))
+        if len(rows):
+            dirty = [min(dirty[0], int(rows.min())), min(dirty[1], -int(rows.max()))]
+        if (c + 1) % K == 0 or c == n_chunks - 1:
+            rng = torch.tensor(dirty, dtype=torch.int32)
+            dist.all_reduce(rng, op=dist.ReduceOp.MIN)
+            lo, hi = int(rng[0]), -int(rng[1])
+            if rng[0] <= GRID:
+                part = planes[:, lo:hi + 1].contiguous()
+                dist.all_reduce(part)
+                acc[:, lo:hi + 1] += part
+                assert int(planes[:, :lo].abs().sum()) == 0 and int(planes[:, hi + 1:].abs().sum()) == 0
+                planes[:, lo:hi + 1] = 0
+            dirty = [BIG, BIG]
+    if rank == 0:
+        np.save(out, (acc + planes).numpy().reshape(2, -1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_periodic_merge_equals_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "periodic.npy")
+    mp.spawn(_merge_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    merged = np.load(out)
+    full = synth.make_batch(16, n_loop=64)
+    hits, misses = _planes_for(full, full.true_poses)
+    assert np.array_equal(merged[0], hits) and np.array_equal(merged[1], misses)
+
+
 def test_rccl_library_exports_header_symbols():
     import re
     from slam_amd import api, build
