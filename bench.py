@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path of BASELINE.json on MI355X.
 
-One "step" = one pass of the per-scan hot path over one batch resident in HBM
-(BASELINE config 2 per GPU): 256 synthetic 1081-beam scans, each registered
-against the 10k-point map with 30 fixed ICP iterations (min_delta = -1), then
-ray-cast from their registered poses into one 2000 x 2000 @ 0.05 m grid
-(Bresenham free space + hits), then the counts are folded into the evidence /
-occupancy planes (finalize).  With N > 1 every rank does that for its own 256
-scans (weak scaling) and the int32 hit/miss planes are merged with one RCCL
-all-reduce per step before finalize.
+Default (BASELINE config 2 per GPU): one "step" = one pass of the per-scan hot path over one batch resident in
+HBM: 256 synthetic 1081-beam scans, each registered against the 10k-point map with 30 fixed ICP iterations
+(min_delta = -1), then ray-cast from their registered poses into one 2000 x 2000 @ 0.05 m grid (Bresenham free
+space + hits), then the counts are folded into the evidence / occupancy planes (finalize).  With N > 1 every rank
+does that for its own 256 scans (weak scaling) and the rows of the int32 hit/miss planes that any rank touched are
+merged with one RCCL all-reduce per step (slam_grid_merge_begin / _finish of the library) before finalize.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --config 3      # 64-ring clouds through the CCICP chain, one scan at a time (the reference's usage)
+    python bench.py --config 4      # one GPU's share of config 4: 1024 scans, 4000 x 4000 grid
+    python bench.py --config 5      # streaming mapper: sliding-window target, periodic merge, PCIe inclusive
 
-Rank 0 prints ONE JSON line.  `value` is registered scan-points/s over the whole
-job; `grid_cell_updates_per_s` is the second half of BASELINE.json's metric.
+Rank 0 prints ONE JSON line.  `value` is registered scan-points/s over the whole job with inputs resident in HBM;
+`grid_cell_updates_per_s` is the second half of BASELINE.json's metric; `value_pcie_inclusive` is the same workload
+fed from pinned host memory through the streaming mapper (SURVEY 8(d) metric (1): H2D of scans + kernels + D2H of
+poses); `model_build_ms` is what 8(d) asks to report separately (the map upload + index build of a match).
 """
 import argparse
 import json
@@ -95,21 +98,85 @@ def cpu_baseline(m_ga, m_nga, batch, grid_size, res):
     }
 
 
-def pmc_traffic(kernel, field="hbm_bytes_per_launch"):
-    """HBM bytes per launch of `kernel` from the committed PMC summary of this same
-    command (profiles/rNN_traffic.json, written by tools/summarize_profiles.py from
-    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes); None if not profiled.
-    field "valu_busy_frac": share of SIMD cycles that issued a VALU instruction (same file)."""
+def pmc_profile():
+    """The committed PMC summary of this same command (profiles/rNN_traffic.json, written by
+    tools/summarize_profiles.py from separate rocprofv3 --pmc passes): (file name, dict) or (None, {})."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
     if not files:
-        return None
+        return None, {}
     try:
-        t = json.load(open(files[-1]))
-        key = kernel if kernel in t else ("raycast_tiled_kernel" if kernel.startswith("raycast") else None)
-        return t[key].get(field) if key else None
+        return os.path.relpath(files[-1], ROOT), json.load(open(files[-1]))
     except Exception:
-        return None
+        return None, {}
+
+
+def model_build_times(api, synth, m_ga, m_nga):
+    """slam_icp_create (Icp::Icp, icp.cpp:26-70: model copy + index) wall time per call, the buffer pool warm:
+    the 10 k-point map of the bench and a 2 x 19 999-point model (the CCICP cap, icpTools.h:21)."""
+    rs = np.random.RandomState(3)
+    big = (rs.randn(19999, 2) * [30.0, 20.0], rs.rand(19999, 2) * [80.0, 60.0] - [40.0, 30.0])
+    out = {}
+    for name, (ga, nga) in (("map_%d_points" % (len(m_ga) + len(m_nga)), (m_ga, m_nga)), ("model_2x19999_points", big)):
+        api.Icp(ga, nga).close()
+        ts, parts = [], None
+        for _ in range(12):
+            t0 = time.perf_counter()
+            icp = api.Icp(ga, nga)
+            ts.append(time.perf_counter() - t0)
+            parts = icp.build_info()
+            icp.close()
+        out[name] = {"ms": float(np.median(ts) * 1e3), "min_ms": float(min(ts) * 1e3), "on_device": parts[0],
+                     "host_ms_upload_extent|cell_index|list_plan|lists": [round(x, 4) for x in parts[1]]}
+    return out
+
+
+def single_scan_times(api, synth, m_ga, m_nga):
+    """BASELINE config 1 on the GPU -- one 1081-beam scan against the 10 k-point map through the host API
+    (slam_icp_fit: Icp::fit of one doICPMatch, icpTools.cpp:188), 20 iterations."""
+    batch = synth.make_batch(1, n_loop=256)
+    t_ga, t_nga = batch.scan(0)
+    icp = api.Icp(m_ga, m_nga, max_iter=20, min_delta=-1.0)
+    icp.fit(t_ga, t_nga, batch.R[0], batch.t[0], 5.0)
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        icp.fit(t_ga, t_nga, batch.R[0], batch.t[0], 5.0)
+        ts.append(time.perf_counter() - t0)
+    icp.close()
+    n = len(t_ga) + len(t_nga)
+    return {"fit_ms_1081_points_20_iterations_host_api": float(np.median(ts) * 1e3),
+            "registered_points_per_s": n / float(np.median(ts))}
+
+
+def stream_rate(api, synth, m_ga, m_nga, batch, grid_size, n_chunks=6, **kw):
+    """The same batch fed from pinned host memory through the streaming mapper (H2D | ICP | raycast on three streams):
+    seconds per chunk in steady state, PCIe inclusive."""
+    mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=grid_size, grid_size_y=grid_size,
+                    resolution=RES, max_scans=batch.n_scans, max_points=batch.n_points,
+                    icp=dict(max_iter=N_ITERS, min_delta=-1.0), **kw)
+    for s in (mp.push(batch), mp.push(batch)):   # warm-up: both slots, every scratch buffer
+        mp.wait(s)
+    api.synchronize()
+    t0 = time.perf_counter()
+    pending = []
+    for k in range(n_chunks):
+        if len(pending) == 2:
+            mp.wait(pending.pop(0))          # poses of chunk k-2 back on the host, its slot free
+        pending.append(mp.push(batch))
+    for s in pending:
+        R, t = mp.wait(s)
+    mp.finish()
+    dt = (time.perf_counter() - t0) / n_chunks
+    st = mp.stats()
+    mp.close()
+    return dt, R, t, st
+
+
+def run_config3(n_clouds):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_config3
+    return bench_config3.measure(n_clouds)
 
 
 def main():
@@ -118,23 +185,36 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--scans", type=int, default=N_SCANS, help="scans per GPU (default: config 2; config 4: 1024)")
-    ap.add_argument("--grid", type=int, default=GRID, help="grid side in cells (default: config 2; config 4: 4000)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE config: 2 (default, the headline), 3 (64-ring clouds, one match per cloud), 4 (one GPU's "
+                         "share: 1024 scans, 4000^2 grid), 5 (streaming mapper)")
+    ap.add_argument("--scans", type=int, default=None, help="scans per GPU (default: 256; config 4: 1024)")
+    ap.add_argument("--grid", type=int, default=None, help="grid side in cells (default: 2000; config 4: 4000)")
+    ap.add_argument("--clouds", type=int, default=50, help="config 3: clouds of the sequence")
+    ap.add_argument("--stream-scans", type=int, default=10240, help="config 5: scans of the stream per GPU")
+    ap.add_argument("--chunk", type=int, default=256, help="config 5: scans per chunk")
+    ap.add_argument("--window", type=int, default=4, help="config 5: chunks in the sliding local map (0 = fixed target)")
+    ap.add_argument("--thin", type=float, default=0.1, help="config 5: pitch of the window's thinning lattice in metres (0 = stride)")
+    ap.add_argument("--rebuild-every", type=int, default=4, help="config 5: chunks between rebuilds of the target")
+    ap.add_argument("--merge-every", type=int, default=8, help="config 5: chunks between merges over the GPUs + finalize")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per scan point (0 = library default)")
     ap.add_argument("--cell", type=float, default=0.0, help="ICP cell pitch in metres (0 = library default)")
     ap.add_argument("--raycast", choices=["tiled", "global"], default="tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip model build, single scan, streaming and config-3 legs")
     ap.add_argument("--no-graph", action="store_true",
                     help="N=1: launch every step call by call instead of replaying one captured hipGraph")
     ap.add_argument("--no-torch", action="store_true", help="N=1 only: do not import torch at all")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="torch.distributed backend for N>1 (nccl = RCCL; gloo only to rehearse the N>1 path "
-                         "with several ranks on ONE GPU: --one-device)")
+                    help="N>1 data plane: nccl = the library's RCCL merge (slam_grid_merge_begin/_finish); gloo = a "
+                         "torch.distributed all-reduce of the same rows, only to rehearse the N>1 path with several "
+                         "ranks on ONE GPU (--one-device), where RCCL cannot run")
     ap.add_argument("--one-device", action="store_true", help="all ranks use GPU 0 (rehearsal with --backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
-                    help="rehearse the N>1 code path (process group + all-reduce) with one rank")
+                    help="rehearse the N>1 code path (communicator + row merge) with one rank")
     args = ap.parse_args()
-    GRID = args.grid
+    S = args.scans or (1024 if args.config == 4 else N_SCANS)
+    GRID = args.grid or (4000 if args.config == 4 else GRID)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
@@ -144,8 +224,18 @@ def main():
             raise SystemExit("--gpus %d needs a launch through torch.distributed.run" % args.gpus)
         args.gpus = world
 
+    if args.config == 3:
+        assert world == 1, "config 3 is a single-GPU sequence"
+        from slam_amd import api
+        api.set_device(0)
+        out = run_config3(args.clouds)
+        out.update({"n_gpus": 1, "higher_is_better": True, "data": "synthetic", "vs_baseline": None,
+                    "dtype": "f64 pose / f32 distance", "device": api.device_info()[0]})
+        print(json.dumps(out), flush=True)
+        return
+
     torch = dist = None
-    if world > 1 or not args.no_torch:
+    if world > 1 or args.force_dist or not args.no_torch:
         # torch first, so that this process runs ONE HIP runtime (torch's) for
         # both the library's kernels and RCCL
         import torch
@@ -154,20 +244,46 @@ def main():
     from slam_amd import api, synth
     api.set_device(local_rank)
     multi = world > 1 or args.force_dist
+    comm = None
     if multi:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
+        # control plane (rendezvous, barriers, the maximum over the ranks' clocks) over gloo; the data plane -- the
+        # planes' rows -- goes through the library's own RCCL communicator, whose id rank 0 hands out here
+        dist.init_process_group("gloo")
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
+            ids = [api.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            # RCCL prints its version banner on stdout when a communicator is made: keep stdout for the ONE JSON line
+            sys.stdout.flush()
+            keep = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                comm = api.Comm(ids[0], rank, world)
+            finally:
+                sys.stdout.flush()
+                os.dup2(keep, 1)
+                os.close(keep)
+
+    m_ga, m_nga = synth.make_map(MAP_POINTS)
+
+    def barrier():
+        if multi:
+            dist.barrier()
+
+    def sync():
+        api.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
+
+    if args.config == 5:
+        run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist if multi else None, sync, barrier)
+        return
 
     # ---- synthetic inputs of BASELINE config 2 (per rank: its own 256 scans of the loop)
-    S = args.scans
-    m_ga, m_nga = synth.make_map(MAP_POINTS)
     batch = synth.make_batch(S, n_loop=S * world, first=rank * S)
     P = batch.n_points
     icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, lanes_per_point=args.lanes, cell_size=args.cell)
@@ -183,144 +299,161 @@ def main():
     d_res = api.DeviceArray((S,), api.RESULT_DTYPE)
 
     planes = None
-    if multi:
-        # zero-copy view of the library's [hits | misses] planes for the collective
+    if multi and comm is None:
+        # rehearsal (gloo, several ranks on one GPU): a zero-copy torch view of the library's [hits | misses] planes
         ptr, n_ints = grid.counts_dev()
 
         class _Planes:
             __cuda_array_interface__ = {"shape": (n_ints,), "typestr": "<i4", "data": (ptr, False),
                                         "version": 2, "strides": None}
-        planes = torch.as_tensor(_Planes(), device=torch.device("cuda", local_rank))
-        assert planes.data_ptr() == ptr
-
-    def sync():
-        api.synchronize()
-        if torch is not None:
-            torch.cuda.synchronize()
-
-    def barrier():
-        if multi:
-            dist.barrier()
+        planes = torch.as_tensor(_Planes(), device=torch.device("cuda", local_rank)).view(2, GRID, GRID)
 
     ev = [[api.Event() for _ in range(5)] for _ in range(args.steps)]
 
     # N=1: all calls go to one created stream, so that a step can be captured into a hipGraph and replayed
     # with a single launch (about nine launches per step otherwise).
     # N>1: two streams.  A: poses in, ICP, then -- once the previous step's finalize has released the planes --
-    # count reset and raycast.  B: the RCCL sum of the planes and finalize.  The registration of step k+1 (which
-    # does not touch the planes) runs while step k's planes are merged over xGMI and finalized.
-    st = None if multi else api.Stream()
-    if multi:
-        s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
-        a, b = s_a.cuda_stream, s_b.cuda_stream
-        ev_ray, ev_fin = api.Event(), api.Event()      # planes written by the raycast / released by finalize
-        L = api.lib()
-    else:
-        a = b = st
+    # count reset, raycast and the 8-byte exchange of the rows the ranks touched (slam_grid_merge_begin).
+    # B: the RCCL sum of those rows (slam_grid_merge_finish) and finalize.  The host issues step k+1's
+    # registration BEFORE it waits for step k's row range, so the registration of step k+1 (which does not
+    # touch the planes) runs while step k's rows are summed over xGMI and finalized.  No warm-up knowledge.
+    streams = {"a": api.Stream()}
+    streams["b"] = api.Stream() if multi else streams["a"]
+    ev_ray, ev_fin = api.Event(), api.Event()      # planes written by the raycast / released by finalize
+    merge_rows_seen = []
 
-    def step(e=None):
-        # one batch: initial poses in, a fresh local count map, register, ray-cast, merge over the GPUs, finalize
+    def front(e=None):
+        """The registration of a step: initial poses in, ICP (does not touch the planes)."""
+        a = streams["a"]
         d_pose.copy_from(d_pose0, a)
         if e: e[0].record(a)
         icp.fit_batch_dev(d_pts, d_off, d_nga, S, d_R, d_t, 5.0, d_res, None, a)
         if e: e[1].record(a)
+
+    def middle(e=None):
+        """The grid update of a step (and, N>1, the start of the exchange of the touched rows)."""
+        a = streams["a"]
         if multi:
-            api.check(L.slam_stream_wait_event(a, ev_fin.ptr))   # no-op before the first finalize
+            a.wait_event(ev_fin)                   # the previous step's merge + finalize have released the planes
         grid.reset_counts(a)
         grid.raycast_scans_dev(d_pts, d_off, S, P, d_R, d_t, a)
         if e: e[2].record(a)
         if multi:
+            if comm is not None:
+                comm.merge_begin(grid, a)
             ev_ray.record(a)
-            api.check(L.slam_stream_wait_event(b, ev_ray.ptr))
-            with torch.cuda.stream(s_b):
-                for part in merge_parts:  # RCCL sum of the int32 planes over xGMI (the touched rows of both planes)
-                    dist.all_reduce(part)
+
+    def back(e=None):
+        """The merge of the touched rows and finalize."""
+        b = streams["b"]
+        if multi:
+            b.wait_event(ev_ray)
+            if comm is not None:
+                merge_rows_seen.append(comm.merge_finish(grid, b))      # waits for the 8-byte range, then the row all-reduce
+            else:
+                ev_ray.synchronize()
+                lo, hi = grid.dirty_rows()
+                rng = torch.tensor([lo if hi >= lo else 1 << 30, -hi if hi >= lo else 1 << 30], dtype=torch.int64)
+                dist.all_reduce(rng, op=dist.ReduceOp.MIN)
+                lo, hi = int(rng[0]), -int(rng[1])
+                merge_rows_seen.append((lo, hi))
+                if hi >= lo:
+                    for k in range(2):
+                        part = planes[k, lo:hi + 1]
+                        host = part.cpu()
+                        dist.all_reduce(host)
+                        part.copy_(host)
+                    torch.cuda.synchronize()
         if e: e[3].record(b)
         grid.finalize(b)
         if e: e[4].record(b)
         if multi:
             ev_fin.record(b)
 
-    merge_parts = [planes] if multi else []
+    def run_steps(n, events=None):
+        """n steps; N>1 software-pipelined: the registration of step k+1 is issued before the host waits for the
+        rows of step k's merge, and runs on the GPU while those rows are summed and finalized."""
+        if n <= 0:
+            return
+        E = (lambda k: events[k]) if events else (lambda k: None)
+        if not multi:
+            for k in range(n):
+                front(E(k))
+                middle(E(k))
+                back(E(k))
+            return
+        front(E(0))
+        middle(E(0))
+        for k in range(n):
+            if k + 1 < n:
+                front(E(k + 1))
+            back(E(k))
+            if k + 1 < n:
+                middle(E(k + 1))
+
     grid.clear()
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     sync()
-    merge_rows = None
-    if multi and args.warmup:
-        # The planes are row-major: the rows any rank touched are one contiguous slice of each plane.  The
-        # warm-up steps (full-plane merges) show which rows that is; the timed steps merge those rows only
-        # (room of 30 m in a 100 m grid: about a third of the bytes).  Checked after the timed loop: nothing
-        # outside the slice, and the merged total equals the ranks' updates.
-        both = planes.view(2, GRID, GRID)
-        rows = (both != 0).any(dim=2).any(dim=0).nonzero()
-        y0 = int(rows.min().item()) if rows.numel() else 0
-        y1 = int(rows.max().item()) + 1 if rows.numel() else 0
-        yr = torch.tensor([-y0, y1], dtype=torch.int64, device="cuda")
-        dist.all_reduce(yr, op=dist.ReduceOp.MAX)
-        y0, y1 = max(0, -int(yr[0].item()) - 16), min(GRID, int(yr[1].item()) + 16)
-        merge_rows = (y0, y1)
-        merge_parts = [both[0, y0:y1].reshape(-1), both[1, y0:y1].reshape(-1)]
-        assert all(p_.is_contiguous() and p_.data_ptr() == planes.data_ptr() + 4 * (k_ * GRID * GRID + y0 * GRID)
-                   for k_, p_ in enumerate(merge_parts))
     upd_per_step = None
     if args.warmup:
+        # every step starts from reset counts, but the update counter keeps running
         upd_per_step = grid.total_updates() // args.warmup
     grid.clear()
     sync()
     barrier()
     sync()
     graph = None
-    if st is not None and not args.no_graph and args.warmup:
+    if not multi and not args.no_graph and args.warmup:
         try:
-            graph = api.Graph(st)
+            graph = api.Graph(streams["a"])
             with graph:      # the warm-up ran the same calls: every scratch buffer exists
-                step()
+                front()
+                middle()
+                back()
             sync()
             graph.launch()   # one replay outside the timed region: a graph that cannot run must not cost the bench
             sync()
         except Exception as ex:   # fall back to launching call by call on a fresh stream
             print("hipGraph capture/replay failed (%s); launching call by call" % ex, file=sys.stderr)
             graph = None
-            st = api.Stream()
-            step()
+            streams["a"] = streams["b"] = api.Stream()
+            front()
+            middle()
+            back()
             sync()
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        if graph is not None:
+    if graph is not None:
+        for k in range(args.steps):
             graph.launch()
-        else:
-            step(ev[k])
+    else:
+        run_steps(args.steps, ev)
     sync()
     barrier()
     sync()
     elapsed = time.perf_counter() - t0
     if graph is not None:    # per-kernel times from a few event-bracketed steps outside the timed region
         ev = ev[:min(len(ev), 10)]
-        for e in ev:
-            step(e)
+        run_steps(len(ev), ev)
         sync()
 
     if upd_per_step is None:
         upd_per_step = grid.total_updates() // max(args.steps, 1)
     if multi:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        cnt = torch.tensor([P, upd_per_step], dtype=torch.int64, device="cuda")
+        cnt = torch.tensor([P, upd_per_step], dtype=torch.int64)
         dist.all_reduce(cnt)
         total_pts, total_upd = int(cnt[0].item()), int(cnt[1].item())
         # the merged planes of the last step hold every rank's updates of that step, once
-        merged = int(planes.to(torch.int64).sum().item())
+        hits, misses = grid.read_counts()
+        merged = int(hits.astype(np.int64).sum() + misses.astype(np.int64).sum())
         assert merged == total_upd, "merged planes hold %d updates, the ranks made %d" % (merged, total_upd)
-        if merge_rows is not None:
-            inside = int(sum(p_.to(torch.int64).sum().item() for p_ in merge_parts))
-            assert inside == merged, "updates outside the merged rows %s" % (merge_rows,)
     else:
         total_pts, total_upd = P, upd_per_step
 
     # per-kernel device time from the HIP events recorded on the launch stream
-    seg = np.array([[e[i].elapsed_ms(e[i + 1]) for i in range(4)] for e in ev]) if args.steps else np.zeros((1, 4))
+    seg = np.array([[e[i].elapsed_ms(e[i + 1]) for i in range(4)] for e in ev]) if len(ev) else np.zeros((1, 4))
     ms_icp, ms_ray, ms_merge, ms_fin = seg.mean(axis=0)
 
     # sanity on the result of the last step (not timed): all scans registered
@@ -333,33 +466,40 @@ def main():
     if rank == 0:
         info = icp.index_info()
         M = len(m_ga) + len(m_nga)
-        # algorithmic bytes: per scan 16*T + 8*M + 96, all iterations fused
+        # ALGORITHMIC bytes: ICP per scan 16*T + 8*M + 96, all iterations fused; the halo lists the
+        # library builds for itself are NOT algorithmic bytes (reported beside, as index_bytes_read_per_launch)
         icp_bytes = 16 * P + S * (8 * M + 96)
         ray_bytes = 8 * upd_per_step + 16 * P           # 8 B RMW per cell update + 16 B per beam
         fin_bytes = GRID * GRID * 17                     # 2x4 B counts in, 8 B evidence + 1 B occupancy out
-        kernels = {}
         fused = bool(info.get("two_forms")) and args.lanes == 0
-        if fused:
-            # one launch reads the scans, the cell index (8 B/point + starts), the halo lists and the poses
-            kernels["icp_fit_fused_kernel (ring search, then list sweeps)"] = {
-                "ms": float(ms_icp), "alg_bytes": icp_bytes + S * int(info.get("list_bytes", 0))}
-        else:
-            kernels["icp_fit_kernel"] = {"ms": float(ms_icp), "alg_bytes": icp_bytes}
-        kernels.update({
+        icp_name = "icp_fit_fused_kernel" if fused else "icp_fit_kernel"
+        kernels = {
+            icp_name: {"ms": float(ms_icp), "alg_bytes": icp_bytes,
+                       "index_bytes_read_per_launch": S * (int(info.get("lds_bytes", 0)) + (int(info.get("list_bytes", 0)) if fused else 0))},
             "raycast_tiled_kernel (+ beams, work list)": {"ms": float(ms_ray), "alg_bytes": ray_bytes},
             "finalize_kernel": {"ms": float(ms_fin), "alg_bytes": fin_bytes},
-        })
+        }
         for k in kernels.values():
             k["GBps"] = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
         dom = max(kernels, key=lambda n: kernels[n]["ms"])
+        prof_file, prof = pmc_profile()
+        pk = prof.get(dom.split(" ")[0], {})
+        busy, lanes = pk.get("valu_busy_frac"), pk.get("valu_active_lane_share")
         roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,
-                "traffic": pmc_traffic(dom.split(" ")[0]),
+                "traffic": pk.get("hbm_bytes_per_launch"),
+                "traffic_source": ("%s (rocprofv3 --pmc passes of this command, committed; not measured in this run)" % prof_file)
+                if prof_file else None,
                 "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "avg_launch_ms": kernels[dom]["ms"],
-                "valu_busy_frac": pmc_traffic(dom.split(" ")[0], "valu_busy_frac"),
-                "note": "the ICP kernel is VALU-issue bound (exact 1-NN search in LDS, one workgroup per scan, "
-                        "launch time = slowest scan), not HBM-bound: valu_busy_frac (PMC) is the share of SIMD "
-                        "cycles that issued a VALU instruction; see DESIGN.md 4.1"}
+                "alg_bytes_formula": "16*P + S*(8*M + 96) (SURVEY 8(d)); P=%d points, S=%d scans, M=%d model points" % (P, S, M),
+                "valu": {"busy_frac": busy, "active_lane_share": lanes,
+                         "lane_slot_frac": (busy * lanes) if (busy is not None and lanes is not None) else None,
+                         "source": prof_file,
+                         "meaning": "busy_frac = SIMD cycles that issued a VALU instruction; active_lane_share = "
+                                    "SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); their product is the share of "
+                                    "VALU lane-slots that did work -- the bound this kernel runs against"},
+                "note": "the ICP kernel is VALU-issue bound (exact 1-NN search in LDS, one workgroup per scan, launch "
+                        "time = slowest scan), not HBM-bound: see DESIGN.md 4.1"}
         out = {
             "metric": "registered_scan_points_per_s", "value": total_pts * args.steps / elapsed,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -370,11 +510,12 @@ def main():
                                    "iterations vs %d-point map, Bresenham raycast into %dx%d @%.2f m, "
                                    "finalize%s" % ("2" if (S, GRID) == (256, 2000) else ("4" if (S, GRID) == (1024, 4000) else "2 (resized)"),
                                                    S, P, N_ITERS, M, GRID, GRID, RES,
-                                                   ", %s all-reduce of the touched rows of the int32 planes" % ("RCCL" if args.backend == "nccl" else "gloo (rehearsal)") if multi else ""),
+                                                   ", all-reduce of the touched rows of the int32 planes (%s)" %
+                                                   ("slam_grid_merge_begin/_finish over RCCL" if comm is not None else "gloo rehearsal") if multi else ""),
                        "scans_per_gpu": S, "icp_iters": N_ITERS, "grid": [GRID, GRID], "resolution": RES,
                        "map_points": M, "icp_index": info, "raycast": args.raycast,
                        "raycast_worklist": grid.raycast_stats(),
-                       "merge_rows": list(merge_rows) if multi and merge_rows else None},
+                       "merge_rows": list(merge_rows_seen[-1]) if multi and merge_rows_seen else None},
             "grid_cell_updates_per_s": total_upd * args.steps / elapsed,
             "cell_updates_per_step": total_upd,
             "point_iterations_per_s": total_pts * N_ITERS * args.steps / elapsed,
@@ -385,11 +526,96 @@ def main():
             "max_pose_error_m": pose_err,
             "device": api.device_info()[0],
         }
+        if world == 1 and not args.no_extras:
+            # the model build reported separately; metric (1) with the transfers in; the reference's own
+            # usage (one scan per match); config 3's match
+            out["model_build_ms"] = model_build_times(api, synth, m_ga, m_nga)
+            dt, Rs, ts, st = stream_rate(api, synth, m_ga, m_nga, batch, GRID)
+            assert np.abs(ts - batch.true_poses[:, :2]).max() < 0.05
+            out["value_pcie_inclusive"] = P / dt
+            out["pcie_inclusive"] = {"ms_per_chunk": dt * 1e3, "chunk_scans": S,
+                                     "path": "slam_mapper_push/_wait: pinned host chunk -> H2D | ICP | raycast on three "
+                                             "streams -> poses D2H; steady state over 6 chunks"}
+            out["single_scan"] = single_scan_times(api, synth, m_ga, m_nga)
+            try:
+                c3 = run_config3(8)
+                out["config3"] = {k: c3[k] for k in ("workload", "ms_per_cloud", "clouds_per_s", "model_points",
+                                                     "mean_icp_iterations", "target_model_ms")}
+            except Exception as ex:   # the headline line must not depend on the extra leg
+                out["config3"] = {"error": str(ex)}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(m_ga, m_nga, batch, GRID, RES)
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()
+        if comm is not None:
+            comm.close()
+        dist.destroy_process_group()
+
+
+def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, barrier):
+    """BASELINE config 5: a stream of scans per GPU through slam_mapper_* -- pinned chunks -> H2D | ICP | raycast on
+    three streams, sliding-window target (last 4 chunks, rebuilt every 4), merge over the GPUs + finalize every 8
+    chunks.  PCIe inclusive by construction."""
+    chunk, n_total = args.chunk, args.stream_scans
+    n_chunks = max(1, n_total // chunk)
+    # every rank streams its own stretch of ONE loop of n_chunks * chunk * world scans: every chunk is new ground
+    # (a repeated chunk would fill the sliding window with exact duplicates: distance ties, the slow exact pass)
+    log("rank %d: generating %d chunks of %d scans" % (rank, n_chunks, chunk))
+    chunks = [synth.make_batch(chunk, n_loop=n_chunks * chunk * world, first=(rank * n_chunks + k) * chunk) for k in range(n_chunks)]
+    base = chunks[0]
+    # the local map stays small enough for the index to live in LDS (about 10 k points): a 5 k-point prior map plus
+    # at most 5 k points of the last four chunks
+    m_ga, m_nga = synth.make_map(5000)
+    mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=GRID, grid_size_y=GRID,
+                    resolution=RES, max_scans=chunk, max_points=max(c.n_points for c in chunks), icp=dict(max_iter=N_ITERS, min_delta=-1.0),
+                    window_chunks=args.window, rebuild_every=args.rebuild_every, keep_prior=1, target_points=5000,
+                    thin_res=args.thin, merge_every=args.merge_every)
+    if comm is not None:
+        mp.use_comm(comm)
+    for s in (mp.push(base), mp.push(base)):
+        mp.wait(s)
+    sync()
+    barrier()
+    t0 = time.perf_counter()
+    pending, worst = [], 0.0
+    for k in range(n_chunks):
+        if len(pending) == 2:
+            slot, j = pending.pop(0)
+            R, t = mp.wait(slot)
+            worst = max(worst, float(np.abs(t - chunks[j].true_poses[:, :2]).max()))
+        pending.append((mp.push(chunks[k]), k))
+    for slot, j in pending:
+        R, t = mp.wait(slot)
+        worst = max(worst, float(np.abs(t - chunks[j].true_poses[:, :2]).max()))
+    mp.finish()
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    upd = mp.grid.total_updates()
+    st = mp.stats()
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        pts = sum(c.n_points for c in chunks) * world
+        print(json.dumps({
+            "metric": "registered_scan_points_per_s", "value": pts / elapsed, "unit": "points/s", "n_gpus": world,
+            "steps": n_chunks, "warmup": 2, "ms_per_step": elapsed / n_chunks * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 pose / f32 distance / int32 counts", "data": "synthetic",
+            "config": {"workload": "BASELINE config 5 per GPU: %d scans streamed in chunks of %d from pinned host memory, %d ICP "
+                                   "iterations against a sliding-window target (5 k-point prior map + 5 k points of the last 4 chunks, rebuilt on "
+                                   "the device every 4), Bresenham raycast into %dx%d @%.2f m, merge over the GPUs + finalize every 8 chunks"
+                                   % (n_chunks * chunk, chunk, N_ITERS, GRID, GRID, RES),
+                       "pcie_inclusive": True, "mapper": st, "target_index": mp.target_index_info()},
+            "grid_cell_updates_per_s": upd * world / elapsed, "max_pose_error_m": worst, "device": api.device_info()[0]}), flush=True)
+    mp.close()
+    if dist is not None:
+        dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

@@ -404,8 +404,8 @@ typedef struct {
     slam_icp_params  icp;
     double indist;             /* icpTools.cpp:188 (5.0) */
     int    max_scans, max_points; /* reservation per chunk */
-    int    window_chunks;      /* sliding local map: the target is the registered points of the last W chunks
-                                  (decimated); 0 = the model given at create stays the target */
+    int    window_chunks;      /* sliding local map: the target is the registered points of the last W <= 8 chunks
+                                  (thinned or decimated); 0 = the model given at create stays the target */
     int    rebuild_every;      /* chunks between rebuilds of the sliding target (>= 1) */
     int    target_points;      /* points the sliding target holds at most, both classes (2 x 19999: icpTools.h:21) */
     int    keep_prior;         /* 1 = the model given at create stays part of every rebuilt target */
@@ -413,6 +413,9 @@ typedef struct {
     int    pipelined;          /* 1 = three streams; 0 = one stage after the other on one stream (same results) */
     int    strict_window;      /* 1 = a rebuild waits for the newest registered chunk (reproducible targets; the
                                   pipeline stalls for one registration); 0 = it takes what has finished */
+    double thin_res;           /* > 0: the window is thinned to one point per cell of this pitch (metres) and class over
+                                  the grid's extent, the oldest measurement of a cell kept (where pcl::VoxelGrid keeps a
+                                  centroid, icpTools.cpp:620-633); 0: every stride-th point of a chunk instead */
 } slam_mapper_params;
 
 void slam_mapper_default_params(slam_mapper_params *p);

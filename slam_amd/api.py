@@ -50,7 +50,8 @@ class MapperParams(C.Structure):
     _fields_ = [("grid_size_x", C.c_int), ("grid_size_y", C.c_int), ("resolution", C.c_double), ("grid", GridParams),
                 ("icp", IcpParams), ("indist", C.c_double), ("max_scans", C.c_int), ("max_points", C.c_int),
                 ("window_chunks", C.c_int), ("rebuild_every", C.c_int), ("target_points", C.c_int),
-                ("keep_prior", C.c_int), ("merge_every", C.c_int), ("pipelined", C.c_int), ("strict_window", C.c_int)]
+                ("keep_prior", C.c_int), ("merge_every", C.c_int), ("pipelined", C.c_int), ("strict_window", C.c_int),
+                ("thin_res", C.c_double)]
 
 
 class GsegParams(C.Structure):
@@ -775,6 +776,7 @@ class Mapper:
         icp = object.__new__(Icp)
         icp.h = h.value
         info = icp.index_info()
+        info["built_on_device"], info["build_host_ms"] = icp.build_info()
         icp.h = None
         return info
 

@@ -677,6 +677,8 @@ __global__ __launch_bounds__(256) void list_scatter_kernel(ListArgs a)
 // exactly that: float subtraction is monotone).
 constexpr int kListStage = 256; // entries of a cell staged in LDS per wavefront (more: read through the cache)
 constexpr int kSortWaves = 4;   // wavefronts per workgroup, each taking (cell, class) pairs in turn
+constexpr int kSmallCell = 128; // lists up to this long: one wavefront, quadratic counting; longer: a workgroup that sorts
+constexpr int kBigCell = 4096;  // entries a workgroup sorts in LDS (longer lists: quadratic through the cache, correct and slow)
 
 __global__ __launch_bounds__(64 * kSortWaves) void list_sort_kernel(ListArgs a)
 {
@@ -690,7 +692,7 @@ __global__ __launch_bounds__(64 * kSortWaves) void list_sort_kernel(ListArgs a)
         const int       c = pair >= a.ncells ? 1 : 0, cell = pair - c * a.ncells;
         const unsigned *st = a.start + (size_t)c * (a.ncells + 1);
         const int       lo = (int)st[cell], n = (int)st[cell + 1] - lo;
-        if (n <= 0) continue;
+        if (n <= 0 || n > kSmallCell) continue; // longer lists: list_sort_big_kernel
         const int    *ent = a.ent + a.lbase[c] + lo;
         const float2 *xy = a.xyf + a.base[c];
         const bool    staged = n <= kListStage;
@@ -774,6 +776,143 @@ __global__ __launch_bounds__(64 * kSortWaves) void list_sort_kernel(ListArgs a)
             out[rank] = make_float2(X(j), Y(j));
         }
         __builtin_amdgcn_wave_barrier(); // the stage is rewritten by the next pair
+    }
+}
+
+// Long lists (a wall a metre from the sensor, seen by a thousand scans): one workgroup per (cell, class), bitonic
+// sorts in LDS.  The metric of a key is read off its sorted keys -- for entry j the first i with
+// fl(k_j - k_i) <= win by bisection (the host's sliding window) --, the final order is the sort by (key, point).
+__device__ inline void bitonic_sort_lds(float *key, int *val, int N /* power of two */)
+{
+    for (int k = 2; k <= N; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < N / 2; t += blockDim.x) {
+                const int i = ((t / j) * 2 * j) + (t % j), ixj = i + j; // partner pairs of this step
+                const bool  up = (i & k) == 0;
+                const float ka = key[i], kb = key[ixj];
+                const int   va = val[i], vb = val[ixj];
+                const bool  gt = ka > kb || (ka == kb && va > vb);
+                if (gt == up) {
+                    key[i] = kb, key[ixj] = ka;
+                    val[i] = vb, val[ixj] = va;
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ __launch_bounds__(256) void list_sort_big_kernel(ListArgs a)
+{
+    __shared__ float s_key[kBigCell];
+    __shared__ int   s_val[kBigCell];
+    __shared__ unsigned s_red[4];
+    const int       c = blockIdx.y, cell = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned *st = a.start + (size_t)c * (a.ncells + 1);
+    const int       lo = (int)st[cell], n = (int)st[cell + 1] - lo;
+    if (n <= kSmallCell) return;
+    const int    *ent = a.ent + a.lbase[c] + lo;
+    const float2 *xy = a.xyf + a.base[c];
+    float2       *out = reinterpret_cast<float2 *>(a.lblob + a.loff_pts) + a.lbase[c] + lo;
+    // extent
+    float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+    for (int k = tid; k < n; k += 256) {
+        const float2 p = xy[ent[k]];
+        mnx = fminf(mnx, p.x), mxx = fmaxf(mxx, p.x);
+        mny = fminf(mny, p.y), mxy = fmaxf(mxy, p.y);
+    }
+    __shared__ float s_ext[4][4];
+    for (int o = 32; o > 0; o >>= 1) {
+        mnx = fminf(mnx, __shfl_xor(mnx, o)), mxx = fmaxf(mxx, __shfl_xor(mxx, o));
+        mny = fminf(mny, __shfl_xor(mny, o)), mxy = fmaxf(mxy, __shfl_xor(mxy, o));
+    }
+    if (lane == 0) s_ext[wave][0] = mnx, s_ext[wave][1] = mxx, s_ext[wave][2] = mny, s_ext[wave][3] = mxy;
+    __syncthreads();
+    mnx = fminf(fminf(s_ext[0][0], s_ext[1][0]), fminf(s_ext[2][0], s_ext[3][0]));
+    mxx = fmaxf(fmaxf(s_ext[0][1], s_ext[1][1]), fmaxf(s_ext[2][1], s_ext[3][1]));
+    mny = fminf(fminf(s_ext[0][2], s_ext[1][2]), fminf(s_ext[2][2], s_ext[3][2]));
+    mxy = fmaxf(fmaxf(s_ext[0][3], s_ext[1][3]), fmaxf(s_ext[2][3], s_ext[3][3]));
+    int        best_dir = (mxy - mny) > (mxx - mnx) ? 1 : 0;
+    const bool lds = n <= kBigCell;
+    int        N = 1;
+    while (N < n) N <<= 1;
+    unsigned  best_metric = 0xffffffffu;
+    const int first = best_dir;
+    for (int t = 0; t < 4; ++t) { // n >= 8 here
+        const int   dir = t == 0 ? first : (t == 1 ? 1 - first : t);
+        const float win = key_window(dir);
+        unsigned    metric = 0;
+        if (lds) {
+            __syncthreads();
+            for (int k = tid; k < N; k += 256) {
+                const float2 p = k < n ? xy[ent[k]] : make_float2(0.f, 0.f);
+                s_key[k] = k < n ? list_key(dir, p.x, p.y) : FLT_MAX;
+                s_val[k] = k;
+            }
+            __syncthreads();
+            bitonic_sort_lds(s_key, s_val, N);
+            for (int j = tid; j < n; j += 256) {
+                const float kj = s_key[j];
+                int         a0 = 0, b0 = j; // first i in [0, j] with !(kj - key[i] > win)
+                while (a0 < b0) {
+                    const int mid = (a0 + b0) >> 1;
+                    if (kj - s_key[mid] > win)
+                        a0 = mid + 1;
+                    else
+                        b0 = mid;
+                }
+                metric = max(metric, (unsigned)(j - a0 + 1));
+            }
+        } else {
+            for (int j = tid; j < n; j += 256) {
+                const float2 pj = xy[ent[j]];
+                const float  kj = list_key(dir, pj.x, pj.y);
+                unsigned     cnt = 0;
+                for (int i = 0; i < n; ++i) {
+                    const float2 pi = xy[ent[i]];
+                    const float  ki = list_key(dir, pi.x, pi.y);
+                    cnt += (ki <= kj && !(kj - ki > win)) ? 1u : 0u;
+                }
+                metric = max(metric, cnt);
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) metric = max(metric, (unsigned)__shfl_xor((int)metric, o));
+        __syncthreads();
+        if (lane == 0) s_red[wave] = metric;
+        __syncthreads();
+        metric = max(max(s_red[0], s_red[1]), max(s_red[2], s_red[3]));
+        if (dir >= 2) metric += metric / 4 + 1; // an axis key is cheaper and exact: prefer it when close
+        if (metric < best_metric) {
+            best_metric = metric;
+            best_dir = dir;
+        }
+    }
+    if (tid == 0 && best_dir)
+        atomicOr(reinterpret_cast<unsigned *>(a.lblob + a.loff_axis[c]) + (cell >> 4), (unsigned)best_dir << (2 * (cell & 15)));
+    if (lds) {
+        __syncthreads();
+        for (int k = tid; k < N; k += 256) {
+            const int    j = k < n ? ent[k] : 0x7fffffff;
+            const float2 p = k < n ? xy[j] : make_float2(0.f, 0.f);
+            s_key[k] = k < n ? list_key(best_dir, p.x, p.y) : FLT_MAX;
+            s_val[k] = j; // ties by point: the order of the host's stable sort
+        }
+        __syncthreads();
+        bitonic_sort_lds(s_key, s_val, N);
+        for (int k = tid; k < n; k += 256) out[k] = xy[s_val[k]];
+    } else {
+        for (int j = tid; j < n; j += 256) {
+            const int    pj = ent[j];
+            const float2 P = xy[pj];
+            const float  kj = list_key(best_dir, P.x, P.y);
+            int          rank = 0;
+            for (int i = 0; i < n; ++i) {
+                const int    pi = ent[i];
+                const float2 Q = xy[pi];
+                const float  ki = list_key(best_dir, Q.x, Q.y);
+                rank += (ki < kj || (ki == kj && pi < pj)) ? 1 : 0;
+            }
+            out[rank] = P;
+        }
     }
 }
 
@@ -980,6 +1119,7 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
             SLAM_TRY(launch_scan(l.start, l.start + (l.ncells + 1), l.ncells, l.lblob + l.loff_start[0], l.lblob + l.loff_start[1], 2, d_tiles, st));
             hipLaunchKernelGGL((list_scatter_kernel<1>), dim3(pblocks), dim3(256), 0, st, l);
             hipLaunchKernelGGL(list_sort_kernel, dim3(std::min((2 * l.ncells + kSortWaves - 1) / kSortWaves, 1024)), dim3(64 * kSortWaves), 0, st, l);
+            hipLaunchKernelGGL(list_sort_big_kernel, dim3(l.ncells, 2), dim3(256), 0, st, l);
             SLAM_HIP(hipGetLastError());
             list_done(h);
             h->build_ms[3] = ms_since(t_lists);

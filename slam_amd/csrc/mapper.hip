@@ -57,6 +57,98 @@ __global__ __launch_bounds__(256) void window_points_kernel(const double2 *pts, 
     (is_ga ? out_ga : out_nga)[rank / stride] = q;
 }
 
+// ---- thinning of the window: at most one point per cell of a lattice of pitch thin_res over the grid's extent and
+// class -- the point with the lowest rank in window order (oldest chunk first, scan order inside): deterministic,
+// and a wall seen by a thousand scans stays one point per cell instead of a thousand (pcl::VoxelGrid keeps the
+// centroid, icpTools.cpp:620-633; a measured point is kept here so that the map holds only measurements).
+struct Segs { // the window's points of one class, in window order
+    const double2 *p[8];
+    int            n[8];
+    int            count, total;
+};
+struct ThinGeom {
+    double x0, y0, inv;
+    int    nx, ny;
+};
+
+__device__ inline bool seg_point(const Segs &s, int i, double2 *out)
+{
+    int k = 0;
+    while (k < s.count - 1 && i >= s.n[k]) i -= s.n[k], ++k;
+    *out = s.p[k][i];
+    return true;
+}
+
+__device__ inline int thin_cell(const ThinGeom &g, const double2 q)
+{
+    const double fx = floor((q.x - g.x0) * g.inv), fy = floor((q.y - g.y0) * g.inv);
+    if (!(fx >= 0.0 && fx < (double)g.nx && fy >= 0.0 && fy < (double)g.ny)) return -1; // outside the grid (or NaN)
+    return (int)fy * g.nx + (int)fx;
+}
+
+__global__ __launch_bounds__(256) void thin_min_kernel(Segs s, ThinGeom g, unsigned *lat)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= s.total) return;
+    double2 q;
+    seg_point(s, i, &q);
+    const int c = thin_cell(g, q);
+    if (c >= 0) atomicMin(&lat[c], (unsigned)i);
+}
+
+// PASS 0: winners per block; PASS 1: the winners, every stride-th, written in rank order
+template <int PASS>
+__global__ __launch_bounds__(256) void thin_pick_kernel(Segs s, ThinGeom g, const unsigned *lat, unsigned *block_count,
+                                                        const unsigned *block_off, int stride, double2 *out)
+{
+    __shared__ unsigned s_w[4];
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double2   q = make_double2(0.0, 0.0);
+    bool      win = false;
+    if (i < s.total) {
+        seg_point(s, i, &q);
+        const int c = thin_cell(g, q);
+        win = c >= 0 && lat[c] == (unsigned)i;
+    }
+    const unsigned long long m = __ballot(win);
+    if (lane == 0) s_w[wave] = (unsigned)__popcll(m);
+    __syncthreads();
+    if (PASS == 0) {
+        if (threadIdx.x == 0) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        return;
+    }
+    unsigned k = block_off[blockIdx.x] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) k += s_w[w];
+    if (win && k % (unsigned)stride == 0) out[k / (unsigned)stride] = q;
+}
+
+// exclusive prefix of the block counts (a few thousand), total behind the last; one workgroup
+__global__ __launch_bounds__(1024) void thin_scan_kernel(const unsigned *cnt, int n, unsigned *off, unsigned *total)
+{
+    __shared__ unsigned s_wave[16], s_carry;
+    const int           tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int      i = base + tid;
+        const unsigned v = i < n ? cnt[i] : 0u;
+        unsigned       x = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (lane == 63) s_wave[wave] = x;
+        __syncthreads();
+        unsigned before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_wave[w];
+        if (i < n) off[i] = before + x - v;
+        __syncthreads();
+        if (tid == 1023) s_carry = before + x;
+        __syncthreads();
+    }
+    if (tid == 0) *total = s_carry;
+}
+
 struct Slot {
     double  *d_pts = nullptr, *d_R = nullptr, *d_t = nullptr;
     int32_t *d_off = nullptr, *d_nga = nullptr, *d_gab = nullptr;
@@ -90,6 +182,11 @@ struct slam_mapper {
     std::vector<double> prior_ga, prior_nga; // host copies of the model given at create
     double            *d_model_ga = nullptr, *d_model_nga = nullptr;
     size_t             cap_model = 0;
+    unsigned          *d_thin = nullptr;      // [2][nx*ny] lowest window rank per lattice cell and class
+    unsigned          *d_thin_blk = nullptr;  // [2][blocks + blocks + 1] winners per block, their prefix, the total
+    size_t             cap_thin_blk = 0;
+    double2           *d_thin_out[2] = {nullptr, nullptr};
+    size_t             cap_thin_out = 0;
     slam_mapper_merge_fn merge_begin = nullptr, merge_finish = nullptr;
     void              *merge_ctx = nullptr;
     bool               merge_pending = false;
@@ -112,8 +209,58 @@ void retire_now(slam_mapper *m)
 // decimation that keeps about target_points / (2 * window) points of a class per chunk
 int stride_for(const slam_mapper *m, int n)
 {
+    if (m->prm.thin_res > 0) return 1; // thinned over the whole window at rebuild time
     const int per_chunk = std::max(64, m->prm.target_points / std::max(2 * m->prm.window_chunks, 1));
     return std::max(1, (n + per_chunk - 1) / per_chunk);
+}
+
+// one class of the window thinned into out[]; *n_out = points written
+int thin_class(slam_mapper *m, const std::vector<const WindowEntry *> &use, int cls, int cap, double2 *out, int *n_out, hipStream_t st)
+{
+    Segs s;
+    memset(&s, 0, sizeof s);
+    for (const WindowEntry *w : use) {
+        const int n = cls ? w->n_nga : w->n_ga;
+        if (!n) continue;
+        s.p[s.count] = cls ? w->nga : w->ga;
+        s.n[s.count] = n;
+        s.total += n;
+        ++s.count;
+    }
+    *n_out = 0;
+    if (!s.total) return SLAM_OK;
+    ThinGeom g;
+    int      gx = 0, gy = 0;
+    double   res = 0;
+    SLAM_TRY(slam_grid_info(m->grid, &gx, &gy, &res, nullptr, nullptr));
+    g.inv = 1.0 / m->prm.thin_res;
+    g.nx = (int)std::ceil(gx * res * g.inv);
+    g.ny = (int)std::ceil(gy * res * g.inv);
+    g.x0 = -0.5 * gx * res; // the grid's extent in the map frame (mls.h:167-175: origin -res*size/2)
+    g.y0 = -0.5 * gy * res;
+    const size_t cells = (size_t)g.nx * g.ny;
+    const int    blocks = (s.total + 255) / 256;
+    if (!m->d_thin) MAP_HIP(hipMalloc((void **)&m->d_thin, 4 * cells));
+    if ((size_t)(2 * blocks + 1) > m->cap_thin_blk) {
+        if (m->d_thin_blk) (void)hipFree(m->d_thin_blk);
+        m->cap_thin_blk = (size_t)(2 * blocks + 1) * 2;
+        MAP_HIP(hipMalloc((void **)&m->d_thin_blk, 4 * m->cap_thin_blk));
+    }
+    unsigned *cnt = m->d_thin_blk, *off = cnt + blocks, *total = off + blocks;
+    MAP_HIP(hipMemsetAsync(m->d_thin, 0xff, 4 * cells, st));
+    hipLaunchKernelGGL(thin_min_kernel, dim3(blocks), dim3(256), 0, st, s, g, m->d_thin);
+    hipLaunchKernelGGL((thin_pick_kernel<0>), dim3(blocks), dim3(256), 0, st, s, g, m->d_thin, cnt, off, 1, out);
+    hipLaunchKernelGGL(thin_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, blocks, off, total);
+    unsigned *h_total = static_cast<unsigned *>(pinned_scratch(64));
+    SLAM_REQUIRE(h_total, SLAM_E_NOMEM, "no pinned memory");
+    MAP_HIP(hipMemcpyAsync(h_total, total, 4, hipMemcpyDeviceToHost, st));
+    MAP_HIP(hipStreamSynchronize(st));
+    const int kept = (int)*h_total;
+    const int stride = std::max(1, (kept + cap - 1) / std::max(cap, 1)); // more cells than the target may hold: every stride-th
+    hipLaunchKernelGGL((thin_pick_kernel<1>), dim3(blocks), dim3(256), 0, st, s, g, m->d_thin, cnt, off, stride, out);
+    MAP_HIP(hipGetLastError());
+    *n_out = (kept + stride - 1) / stride;
+    return SLAM_OK;
 }
 
 int rebuild_target(slam_mapper *m)
@@ -128,11 +275,29 @@ int rebuild_target(slam_mapper *m)
     (void)hipGetLastError();
     std::sort(use.begin(), use.end(), [](const WindowEntry *a, const WindowEntry *b) { return a->chunk < b->chunk; });
     if ((int)use.size() > m->prm.window_chunks) use.erase(use.begin(), use.end() - m->prm.window_chunks); // the newest W
-    size_t n_ga = m->prm.keep_prior ? m->prior_ga.size() / 2 : 0, n_nga = m->prm.keep_prior ? m->prior_nga.size() / 2 : 0;
-    const size_t p_ga = n_ga, p_nga = n_nga;
-    for (const WindowEntry *w : use) n_ga += (size_t)w->n_ga, n_nga += (size_t)w->n_nga;
-    if (use.empty() || n_ga + n_nga < 5) return SLAM_OK; // nothing registered yet: keep the current target
-    const auto t0 = std::chrono::steady_clock::now();
+    if (use.empty()) return SLAM_OK; // nothing registered yet: keep the current target
+    const auto   t0 = std::chrono::steady_clock::now();
+    const size_t p_ga = m->prm.keep_prior ? m->prior_ga.size() / 2 : 0, p_nga = m->prm.keep_prior ? m->prior_nga.size() / 2 : 0;
+    hipStream_t  st = nullptr; // the build runs on the default stream: everything it reads is complete by now
+    const bool   thin = m->prm.thin_res > 0;
+    size_t       w_ga = 0, w_nga = 0;
+    for (const WindowEntry *w : use) w_ga += (size_t)w->n_ga, w_nga += (size_t)w->n_nga;
+    if (thin) { // one point per lattice cell and class over the whole window
+        const int cap = std::max(64, m->prm.target_points / 2);
+        if ((size_t)cap > m->cap_thin_out) {
+            for (double2 *&p : m->d_thin_out)
+                if (p) (void)hipFree(p), p = nullptr;
+            m->cap_thin_out = (size_t)cap;
+            for (double2 *&p : m->d_thin_out) MAP_HIP(hipMalloc((void **)&p, 16 * m->cap_thin_out));
+        }
+        int n0 = 0, n1 = 0;
+        SLAM_TRY(thin_class(m, use, 0, cap, m->d_thin_out[0], &n0, st));
+        SLAM_TRY(thin_class(m, use, 1, cap, m->d_thin_out[1], &n1, st));
+        w_ga = (size_t)n0;
+        w_nga = (size_t)n1;
+    }
+    const size_t n_ga = p_ga + w_ga, n_nga = p_nga + w_nga;
+    if (n_ga + n_nga < 5) return SLAM_OK;
     if (n_ga + n_nga > m->cap_model) {
         if (m->d_model_ga) pool_free(m->d_model_ga);
         m->cap_model = (n_ga + n_nga) * 2;
@@ -140,15 +305,19 @@ int rebuild_target(slam_mapper *m)
         if (!m->d_model_ga) return SLAM_E_NOMEM;
     }
     m->d_model_nga = m->d_model_ga + 2 * n_ga;
-    hipStream_t st = nullptr; // the build runs on the default stream: everything it reads is complete by now
     if (p_ga) MAP_HIP(hipMemcpyAsync(m->d_model_ga, m->prior_ga.data(), 16 * p_ga, hipMemcpyHostToDevice, st));
     if (p_nga) MAP_HIP(hipMemcpyAsync(m->d_model_nga, m->prior_nga.data(), 16 * p_nga, hipMemcpyHostToDevice, st));
-    size_t o_ga = p_ga, o_nga = p_nga;
-    for (const WindowEntry *w : use) {
-        if (w->n_ga) MAP_HIP(hipMemcpyAsync(m->d_model_ga + 2 * o_ga, w->ga, 16 * (size_t)w->n_ga, hipMemcpyDeviceToDevice, st));
-        if (w->n_nga) MAP_HIP(hipMemcpyAsync(m->d_model_nga + 2 * o_nga, w->nga, 16 * (size_t)w->n_nga, hipMemcpyDeviceToDevice, st));
-        o_ga += (size_t)w->n_ga;
-        o_nga += (size_t)w->n_nga;
+    if (thin) {
+        if (w_ga) MAP_HIP(hipMemcpyAsync(m->d_model_ga + 2 * p_ga, m->d_thin_out[0], 16 * w_ga, hipMemcpyDeviceToDevice, st));
+        if (w_nga) MAP_HIP(hipMemcpyAsync(m->d_model_nga + 2 * p_nga, m->d_thin_out[1], 16 * w_nga, hipMemcpyDeviceToDevice, st));
+    } else {
+        size_t o_ga = p_ga, o_nga = p_nga;
+        for (const WindowEntry *w : use) {
+            if (w->n_ga) MAP_HIP(hipMemcpyAsync(m->d_model_ga + 2 * o_ga, w->ga, 16 * (size_t)w->n_ga, hipMemcpyDeviceToDevice, st));
+            if (w->n_nga) MAP_HIP(hipMemcpyAsync(m->d_model_nga + 2 * o_nga, w->nga, 16 * (size_t)w->n_nga, hipMemcpyDeviceToDevice, st));
+            o_ga += (size_t)w->n_ga;
+            o_nga += (size_t)w->n_nga;
+        }
     }
     slam_icp_t *fresh = nullptr;
     SLAM_TRY(slam_icp_create_dev(m->d_model_ga, (int)n_ga, m->d_model_nga, (int)n_nga, &m->prm.icp, &fresh));
@@ -199,6 +368,7 @@ void slam_mapper_default_params(slam_mapper_params *p)
     p->merge_every = 0;
     p->pipelined = 1;
     p->strict_window = 0;
+    p->thin_res = 0.0;
 }
 
 int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int n_ga, const double *m_nga, int n_nga,
@@ -206,8 +376,8 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
 {
     SLAM_REQUIRE(params && out, SLAM_E_INVALID, "slam_mapper_create: bad arguments");
     *out = nullptr;
-    SLAM_REQUIRE(params->max_scans > 0 && params->max_points > 0 && params->window_chunks >= 0 && params->rebuild_every >= 1 &&
-                     params->merge_every >= 0,
+    SLAM_REQUIRE(params->max_scans > 0 && params->max_points > 0 && params->window_chunks >= 0 && params->window_chunks <= 8 &&
+                     params->rebuild_every >= 1 && params->merge_every >= 0 && params->thin_res >= 0,
                  SLAM_E_INVALID, "slam_mapper_create: bad parameters");
     SLAM_TRY(require_device());
     slam_mapper *m = new (std::nothrow) slam_mapper();
@@ -251,7 +421,8 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
         }
         // the window keeps one entry more than it uses: the newest is still being written when a rebuild looks
         m->window.resize(params->window_chunks ? (size_t)params->window_chunks + 1 : 0);
-        const size_t per = (size_t)std::max(64, params->target_points / std::max(2 * params->window_chunks, 1)) + 8;
+        const size_t per = params->thin_res > 0 ? (size_t)params->max_points
+                                                : (size_t)std::max(64, params->target_points / std::max(2 * params->window_chunks, 1)) + 8;
         for (WindowEntry &w : m->window) {
             hip(hipMalloc((void **)&w.ga, 16 * per));
             hip(hipMalloc((void **)&w.nga, 16 * per));
@@ -284,6 +455,8 @@ void slam_mapper_destroy(slam_mapper_t *m)
         if (w.ready) (void)hipEventDestroy(w.ready);
     }
     if (m->d_model_ga) pool_free(m->d_model_ga);
+    for (void *p : {(void *)m->d_thin, (void *)m->d_thin_blk, (void *)m->d_thin_out[0], (void *)m->d_thin_out[1]})
+        if (p) (void)hipFree(p);
     if (m->target) slam_icp_destroy(m->target);
     if (m->retired) slam_icp_destroy(m->retired);
     if (m->grid) slam_grid_destroy(m->grid);

@@ -56,6 +56,10 @@ def models():
     dense = rs.randn(6000, 2) * 0.4     # hundreds of points per cell near the centre, lists still fit
     yield "dense cluster", dense[:1000], dense[1000:], {}
     yield "coarse forced pitch", m_ga, m_nga, {"cell_size": 1.3}
+    blob = rs.randn(6000, 2) * 0.004 + [2.0, 1.0]   # one list cell holds thousands of entries: past the LDS sort
+    yield "thousands of points in a centimetre", blob[:500], np.concatenate([blob[500:], rs.rand(50, 2) * 10]), {}
+    wall = np.stack([rs.rand(3000) * 0.5, 3.0 + rs.randn(3000) * 0.002], 1)   # a wall seen by a thousand scans
+    yield "dense wall segment (long lists, sorted in LDS)", wall[:100], np.concatenate([wall[100:], m_nga[:3000]]), {}
 
 
 @pytest.mark.parametrize("case", list(models()), ids=lambda c: c[0])

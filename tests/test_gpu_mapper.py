@@ -87,7 +87,24 @@ def decimate(n, per_chunk):
     return np.arange(0, n, stride)
 
 
-def test_sliding_window_target_and_periodic_merge_match_oracle():
+def thin_points(pts, pitch, extent, cap):
+    """slam_mapper_params::thin_res: the first point (window order) of every lattice cell over the grid's extent,
+    every stride-th of them if they are more than the target holds."""
+    if len(pts) == 0:
+        return pts
+    inv = 1.0 / pitch
+    n = int(np.ceil(extent * inv))
+    fx, fy = np.floor((pts[:, 0] + 0.5 * extent) * inv), np.floor((pts[:, 1] + 0.5 * extent) * inv)
+    ok = (fx >= 0) & (fx < n) & (fy >= 0) & (fy < n)
+    cell = np.where(ok, fy * n + fx, -1).astype(np.int64)
+    _, first = np.unique(cell, return_index=True)
+    first = np.sort(first[cell[first] >= 0])
+    stride = max(1, -(-len(first) // cap))
+    return pts[first[::stride]]
+
+
+@pytest.mark.parametrize("thin", [0.0, 0.1])
+def test_sliding_window_target_and_periodic_merge_match_oracle(thin):
     """window_chunks = 2, a rebuild before every chunk (strict: reproducible), a merge every 2 chunks over a one-rank
     RCCL communicator folded into the accumulator.  The oracle runs the same schedule: the target of chunk k is the
     prior map plus the decimated registered points of chunks k-2, k-1 (its own poses); the first chunk is matched
@@ -99,6 +116,7 @@ def test_sliding_window_target_and_periodic_merge_match_oracle():
     comm = api.Comm(api.Comm.unique_id(), 0, 1)
     got = run_mapper(m_ga, m_nga, batch, chunk, rolling=0, comm=comm, grid_size_x=size, grid_size_y=size, resolution=res,
                      window_chunks=W, rebuild_every=1, target_points=target_points, merge_every=2, strict_window=1, keep_prior=1,
+                     thin_res=thin,
                      icp=dict(max_iter=20, min_delta=1e-6))
     n_chunks = n_scans // chunk
     assert got["stats"]["chunks"] == n_chunks and got["stats"]["rebuilds"] == n_chunks - 1
@@ -107,7 +125,10 @@ def test_sliding_window_target_and_periodic_merge_match_oracle():
     Ro, to = np.zeros((n_scans, 4)), np.zeros((n_scans, 2))
     window = []
     for s0, s1, c in chunks_of(batch, chunk):
-        if window:                       # keep_prior: the prior map stays in front of the window's points
+        if window and thin:              # one point per 0.1 m cell and class over the window: the lowest rank wins
+            ga = np.concatenate([m_ga, thin_points(np.concatenate([w[0] for w in window[-W:]]), thin, size * res, target_points // 2)])
+            nga = np.concatenate([m_nga, thin_points(np.concatenate([w[1] for w in window[-W:]]), thin, size * res, target_points // 2)])
+        elif window:                     # keep_prior: the prior map stays in front of the window's points
             ga = np.concatenate([m_ga] + [w[0] for w in window[-W:]])
             nga = np.concatenate([m_nga] + [w[1] for w in window[-W:]])
         else:
@@ -122,7 +143,10 @@ def test_sliding_window_target_and_periodic_merge_match_oracle():
             reg_ga.append(q[:c.scan_nga[s]])
             reg_nga.append(q[c.scan_nga[s]:])
         reg_ga, reg_nga = np.concatenate(reg_ga), np.concatenate(reg_nga)
-        window.append((reg_ga[decimate(len(reg_ga), per_chunk)], reg_nga[decimate(len(reg_nga), per_chunk)]))
+        if thin:
+            window.append((reg_ga, reg_nga))
+        else:
+            window.append((reg_ga[decimate(len(reg_ga), per_chunk)], reg_nga[decimate(len(reg_nga), per_chunk)]))
     R, t = got["R"], got["t"]
     assert np.abs(t - to).max() < 1e-4 and np.abs(R - Ro).max() < 1e-5
     assert np.abs(t - batch.true_poses[:, :2]).max() < 0.1
