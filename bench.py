@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--merge-every", type=int, default=8, help="config 5: chunks between merges over the GPUs + finalize")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per scan point (0 = library default)")
     ap.add_argument("--cell", type=float, default=0.0, help="ICP cell pitch in metres (0 = library default)")
-    ap.add_argument("--raycast", choices=["tiled", "global"], default="tiled")
+    ap.add_argument("--raycast", choices=["tiled", "merge", "global"], default="tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip model build, single scan, streaming and config-3 legs")
     ap.add_argument("--no-graph", action="store_true",
@@ -288,7 +288,7 @@ def main():
     P = batch.n_points
     icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, lanes_per_point=args.lanes, cell_size=args.cell)
     grid = api.Grid(GRID, GRID, RES, rolling=0, min_cluster_points=20,
-                    raycast_impl=api.RAYCAST_TILED if args.raycast == "tiled" else api.RAYCAST_GLOBAL)
+                    raycast_impl={"tiled": api.RAYCAST_TILED, "merge": api.RAYCAST_TILED_MERGE, "global": api.RAYCAST_GLOBAL}[args.raycast])
     d_pts = api.DeviceArray.from_host(batch.pts, np.float64)
     d_off = api.DeviceArray.from_host(batch.scan_off, np.int32)
     d_nga = api.DeviceArray.from_host(batch.scan_nga, np.int32)

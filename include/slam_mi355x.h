@@ -195,6 +195,7 @@ typedef struct slam_grid slam_grid_t;
 
 #define SLAM_RAYCAST_TILED  0 /* LDS-binned tiles, coalesced write-back */
 #define SLAM_RAYCAST_GLOBAL 1 /* one global atomic per traversed cell */
+#define SLAM_RAYCAST_TILED_MERGE 2 /* tiled, and the lanes of a wavefront that stand on one cell add once */
 
 typedef struct {
     double max_range;           /* mls.h:161 (75) */

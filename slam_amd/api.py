@@ -19,7 +19,7 @@ SLAM_OK = 0
 E_INVALID, E_NO_DEVICE, E_HIP, E_TOO_FEW_MODEL, E_TOO_FEW_SCENE, E_NOMEM, E_UNSUPPORTED = \
     -1, -2, -3, -4, -5, -6, -7
 ICP_P2P, ICP_P2L = 0, 1
-RAYCAST_TILED, RAYCAST_GLOBAL = 0, 1
+RAYCAST_TILED, RAYCAST_GLOBAL, RAYCAST_TILED_MERGE = 0, 1, 2
 
 
 class SlamError(RuntimeError):

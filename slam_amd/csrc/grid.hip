@@ -487,6 +487,7 @@ __host__ __device__ inline int adaptive_seg(long total_items, int n_workgroups)
     return (int)(per < 20 ? 20 : (per > 128 ? 128 : per));
 }
 
+template <bool MERGE>
 __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView g, const Beam *beams, int n,
                                                                         const int *items, const int *item_off,
                                                                         const int *seg_off, int n_tiles,
@@ -655,11 +656,33 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
                 a4 += su4 + (carry ? sv4 : 0);
                 eu = e2 + (carry ? bias : 0u);
             };
+            // MERGE: 64 consecutive beams of a scan leave the sensor through the same cells for their first ~230
+            // steps (adjacent beams are 0.25 degrees apart), and LDS atomics of one instruction to one address are
+            // served one after the other.  Lanes are ordered by angle, so lanes on the same cell are neighbours: the
+            // first lane of a run adds the run's length, the others add nothing.  A step on which every lane has a
+            // cell of its own (the far field) costs the compare only.
+            const auto add_miss = [&]() {
+                if (!MERGE) {
+                    atomicAdd(reinterpret_cast<unsigned *>(tb + a4), 1u);
+                    return;
+                }
+                const int  prev = __builtin_amdgcn_update_dpp(-1, a4, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                const bool leader = a4 != prev; // also after a lane that is not stepping (its value does not arrive)
+                const unsigned long long on = __ballot(true), lead = __ballot(leader);
+                if (lead == on) {
+                    atomicAdd(reinterpret_cast<unsigned *>(tb + a4), 1u);
+                } else {
+                    const unsigned long long ends = lead | ~on; // a run ends before the next leader or idle lane
+                    const unsigned long long rest = lane == 63 ? 0ull : ends >> (lane + 1);
+                    const unsigned run = rest ? (unsigned)__builtin_ctzll(rest) + 1u : (unsigned)(64 - lane);
+                    if (leader) atomicAdd(reinterpret_cast<unsigned *>(tb + a4), run);
+                }
+            };
             while (__any(miss >= kWalkUnroll)) {
                 if (miss >= kWalkUnroll) {
 #pragma unroll
                     for (int k = 0; k < kWalkUnroll; ++k) {
-                        atomicAdd(reinterpret_cast<unsigned *>(tb + a4), 1u);
+                        add_miss();
                         advance();
                     }
                     miss -= kWalkUnroll;
@@ -667,7 +690,7 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
             }
 #pragma unroll
             for (int k = 0; k < kWalkUnroll - 1; ++k) {
-                if (miss > k) atomicAdd(reinterpret_cast<unsigned *>(tb + a4), 1u);
+                if (miss > k) add_miss();
                 advance(); // a finished lane's cell is not used again
             }
             p = p_next;
@@ -857,6 +880,7 @@ struct slam_grid {
     int              last_chunks = 0;
     int              ablate = 0;     // debug: SLAM_RAYCAST_ABLATE bit mask (timing experiments only)
     int              wg_per_cu = 2;
+    bool             merge = false;  // tiled raycast: lanes on one cell add once (SLAM_RAYCAST_TILED_MERGE)
     void            *d_stage = nullptr;   // host-API staging
     size_t           cap_stage = 0;
     bool             state_from_inorder = false;
@@ -889,7 +913,7 @@ int reserve_beams(slam_grid *g, size_t n)
     SLAM_TRY(reserve(&p, &cc, chunks * sizeof(int4)));
     g->d_chunk_box = static_cast<int4 *>(p);
     g->cap_chunks = cc / sizeof(int4);
-    if (g->prm.raycast_impl == SLAM_RAYCAST_TILED) {
+    if (g->prm.raycast_impl != SLAM_RAYCAST_GLOBAL) {
         const size_t n_tiles = (size_t)((g->gv.sx + kTile - 1) / kTile) * ((g->gv.sy + kTile - 1) / kTile);
         if (!g->d_tile_cnt) {
             SLAM_HIP(hipMalloc((void **)&g->d_tile_cnt, n_tiles * sizeof(int)));
@@ -908,7 +932,7 @@ int reserve_beams(slam_grid *g, size_t n)
 int walk_beams(slam_grid *g, int n, hipStream_t st)
 {
     const int n_chunks = (n + kBlock - 1) / kBlock; // culling blocks
-    if (g->prm.raycast_impl == SLAM_RAYCAST_TILED) {
+    if (g->prm.raycast_impl != SLAM_RAYCAST_GLOBAL) {
         const int tiles_x = (g->gv.sx + kTile - 1) / kTile, tiles_y = (g->gv.sy + kTile - 1) / kTile;
         const int n_tiles = tiles_x * tiles_y;
         int      *item_off = g->d_tile_fill, *seg_off = g->d_tile_fill + (n_tiles + 1);
@@ -918,9 +942,9 @@ int walk_beams(slam_grid *g, int n, hipStream_t st)
             // one pass over the block boxes; the raycast workgroups derive the segment offsets themselves
             hipLaunchKernelGGL(tile_items_wg_kernel, dim3(n_tiles), dim3(1024), 0, st, g->d_chunk_box, n_chunks, tiles_x,
                                g->gv.sx, g->gv.sy, g->d_tile_cnt, g->d_items, g->d_queue);
-            hipLaunchKernelGGL(raycast_tiled_kernel, dim3(g->wg_per_cu * g->n_cu), dim3(kTileThreads), 0, st, g->gv, g->d_beams,
-                               n, g->d_items, item_off, seg_off, n_tiles, g->d_queue, tiles_x, g->seg_items, g->ablate,
-                               g->d_tile_cnt, n_chunks);
+            hipLaunchKernelGGL(g->merge ? raycast_tiled_kernel<true> : raycast_tiled_kernel<false>, dim3(g->wg_per_cu * g->n_cu),
+                               dim3(kTileThreads), 0, st, g->gv, g->d_beams, n, g->d_items, item_off, seg_off, n_tiles, g->d_queue,
+                               tiles_x, g->seg_items, g->ablate, g->d_tile_cnt, n_chunks);
         } else {
             hipLaunchKernelGGL((tile_items_kernel<0>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
                                n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items, g->d_queue);
@@ -930,9 +954,9 @@ int walk_beams(slam_grid *g, int n, hipStream_t st)
             hipLaunchKernelGGL((tile_items_kernel<1>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
                                n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items, g->d_queue);
             // persistent workgroups, two per CU (66 KB of LDS each); each drains the queue and exits
-            hipLaunchKernelGGL(raycast_tiled_kernel, dim3(g->wg_per_cu * g->n_cu), dim3(kTileThreads), 0, st, g->gv, g->d_beams,
-                               n, g->d_items, item_off, seg_off, n_tiles, g->d_queue, tiles_x, seg_items, g->ablate,
-                               (const int *)nullptr, 0);
+            hipLaunchKernelGGL(g->merge ? raycast_tiled_kernel<true> : raycast_tiled_kernel<false>, dim3(g->wg_per_cu * g->n_cu),
+                               dim3(kTileThreads), 0, st, g->gv, g->d_beams, n, g->d_items, item_off, seg_off, n_tiles, g->d_queue,
+                               tiles_x, seg_items, g->ablate, (const int *)nullptr, 0);
         }
     } else {
         hipLaunchKernelGGL(raycast_global_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g->gv, g->d_beams, n);
@@ -985,7 +1009,9 @@ int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_
     // most that cannot carry into the hit half
     g->seg_items = std::min(std::max(g->prm.raycast_seg_items, 0), 1023);
     if (g->prm.raycast_wg_per_cu > 0) g->wg_per_cu = std::min(g->prm.raycast_wg_per_cu, 8);
+    g->merge = g->prm.raycast_impl == SLAM_RAYCAST_TILED_MERGE;
 #ifdef SLAM_MEASURE
+    if (const char *e = getenv("SLAM_RAYCAST_MERGE")) g->merge = atoi(e) != 0;
     if (const char *e = getenv("SLAM_RAYCAST_SEG")) g->seg_items = std::min(std::max(0, atoi(e)), 1023);
     if (const char *e = getenv("SLAM_RAYCAST_ABLATE")) g->ablate = atoi(e);
     if (const char *e = getenv("SLAM_RAYCAST_WGPCU")) g->wg_per_cu = std::max(1, atoi(e));

@@ -1,0 +1,67 @@
+"""BASELINE configs 2 and 4 at FULL size against the oracle, no sampling: every scan of the batch through
+oicp_fit_batch (OpenMP over scans), every beam of the batch through the sequential-per-beam Bresenham oracle
+(ogrid_raycast_mt: OpenMP over beams, atomic increments -- integer sums, order-free).  Tolerances as everywhere:
+correspondence counts equal, poses within 1e-4 m / 1e-5 rad, grid counts bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from slam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+THREADS = max(1, min(os.cpu_count() or 1, 32))
+
+
+def yaw(R):
+    R = np.asarray(R).reshape(-1, 4)
+    return np.arctan2(R[:, 2], R[:, 0])
+
+
+def ang_diff(a, b):
+    d = a - b
+    return np.abs((d + np.pi) % (2 * np.pi) - np.pi)
+
+
+@pytest.mark.parametrize("n_scans,size,min_delta", [(256, 2000, -1.0), (256, 2000, 1e-6), (1024, 4000, -1.0)],
+                         ids=["config2-fixed-30", "config2-early-exit", "config4-share"])
+def test_full_batch_matches_oracle(n_scans, size, min_delta):
+    m_ga, m_nga = synth.make_map()
+    batch = synth.make_batch(n_scans)
+    icp = api.Icp(m_ga, m_nga, max_iter=30, min_delta=min_delta)
+    R, t, res, _ = icp.fit_batch(batch, indist=5.0)
+    icp.close()
+    model = O.IcpModel(m_ga, m_nga)
+    Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R, batch.t,
+                                                  O.icp_params(30, min_delta, 5.0), n_threads=THREADS)
+    assert np.array_equal(res["iters"], iters)
+    assert np.array_equal(res["n_corr"], ncorr)
+    assert np.abs(t - to).max() < 1e-4 and ang_diff(yaw(R), yaw(Ro)).max() < 1e-5
+    # the last step's size: the sums run in another order, and over a thousand scans one query rounds to the other
+    # side of a float somewhere, which moves that scan's last step by parts in a million (the poses stay within tolerance)
+    assert np.abs(res["delta"] - delta).max() < 1e-5
+
+    # the whole batch ray-cast from the GPU's own poses, every implementation, against the oracle
+    gp = O.grid_params(size, size, 0.05, min_cluster_points=20)
+    ends, origins = [], []
+    for s in range(n_scans):
+        o, e = batch.scan_off[s], batch.scan_off[s + 1]
+        ends.append(O.transform_points(batch.pts[o:e], R[s], t[s]))
+        origins.append(np.tile(t[s].astype(np.float32), (e - o, 1)))
+    H, M, upd = O.grid_raycast(gp, np.concatenate(origins), np.concatenate(ends), n_threads=THREADS)
+    d = [api.DeviceArray.from_host(a, dt) for a, dt in
+         ((batch.pts, np.float64), (batch.scan_off, np.int32), (R, np.float64), (t, np.float64))]
+    for impl in (api.RAYCAST_TILED, api.RAYCAST_TILED_MERGE):
+        g = api.Grid(size, size, 0.05, rolling=0, min_cluster_points=20, raycast_impl=impl)
+        g.raycast_scans_dev(d[0], d[1], n_scans, batch.n_points, d[2], d[3])
+        g.finalize()
+        api.synchronize()
+        hits, misses = g.read_counts()
+        assert np.array_equal(hits, H) and np.array_equal(misses, M), impl
+        assert g.total_updates() == upd == int(H.sum()) + int(M.sum())
+        num, occ = np.zeros(size * size), np.full(size * size, -1, np.int8)
+        O.grid_finalize(gp, H, M, num, occ)
+        assert np.array_equal(g.read_occupancy(), occ)
+        assert np.array_equal(g.read_num_pts(), num)
+        g.close()

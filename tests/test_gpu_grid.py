@@ -74,7 +74,7 @@ def test_y_bound_quirk_non_square():
         g.close()
 
 
-@pytest.mark.parametrize("impl", [api.RAYCAST_TILED, api.RAYCAST_GLOBAL])
+@pytest.mark.parametrize("impl", [api.RAYCAST_TILED, api.RAYCAST_TILED_MERGE, api.RAYCAST_GLOBAL])
 def test_raycast_config1_golden_and_oracle(impl, golden_dir):
     """BASELINE config 1 grid: 500 x 500 @ 0.1 m, one scan from its true pose."""
     G = np.load(os.path.join(golden_dir, "grid_golden.npz"))
@@ -93,7 +93,7 @@ def test_raycast_config1_golden_and_oracle(impl, golden_dir):
     g.close()
 
 
-@pytest.mark.parametrize("impl", [api.RAYCAST_TILED, api.RAYCAST_GLOBAL])
+@pytest.mark.parametrize("impl", [api.RAYCAST_TILED, api.RAYCAST_TILED_MERGE, api.RAYCAST_GLOBAL])
 @pytest.mark.parametrize("size,res", [((300, 300), 0.25), ((257, 131), 0.3), ((64, 64), 1.0)])
 def test_raycast_random_beams_bit_exact(impl, size, res):
     """All octants, beams leaving the window, degenerate beams, tile borders."""
@@ -263,7 +263,7 @@ def test_config2_grid_full_size_properties(size, res):
     d_R = api.DeviceArray.from_host(R, np.float64)
     d_t = api.DeviceArray.from_host(t, np.float64)
     out = []
-    for impl in (api.RAYCAST_TILED, api.RAYCAST_GLOBAL):
+    for impl in (api.RAYCAST_TILED, api.RAYCAST_GLOBAL, api.RAYCAST_TILED_MERGE):
         g = api.Grid(size, size, res, rolling=0, min_cluster_points=20, raycast_impl=impl)
         g.raycast_scans_dev(d_pts, d_off, batch.n_scans, batch.n_points, d_R, d_t)
         api.synchronize()
@@ -275,5 +275,6 @@ def test_config2_grid_full_size_properties(size, res):
             assert np.array_equal(h2, 2 * out[0][0]) and np.array_equal(m2, 2 * out[0][1])
         g.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
-    assert out[0][2] == out[1][2] == out[0][0].sum() + out[0][1].sum()
+    assert np.array_equal(out[0][0], out[2][0]) and np.array_equal(out[0][1], out[2][1])
+    assert out[0][2] == out[1][2] == out[2][2] == out[0][0].sum() + out[0][1].sum()
     assert out[0][0].sum() == batch.n_points          # every beam ends inside this grid
