@@ -27,10 +27,13 @@ namespace slam_amd {
 
 enum RegistrationType { SCAN_TO_SCAN = 0, SCAN_TO_MAP = 1 }; // icpTools.h
 
+#ifndef SLAM_AMD_POSE_DEFINED
+#define SLAM_AMD_POSE_DEFINED
 struct Pose { // geometry_msgs::Pose
     double x = 0, y = 0, z = 0;
     double qx = 0, qy = 0, qz = 0, qw = 1;
 };
+#endif
 
 namespace detail {
 // tf::Matrix3x3(q).getEulerYPR(yaw, pitch, roll, 1)
@@ -185,6 +188,15 @@ public:
     }
 
     double getResidual() const { return -1; } // :637-641 ("TODO: calculate this somehow")
+    // :644-650: copies of seg_target, seg_scene, ground_target, ground_scene as x, y, z per point
+    void getSegmentedClouds(std::vector<float> &target, std::vector<float> &scene, std::vector<float> &g_target,
+                            std::vector<float> &g_scene) const
+    {
+        copy_out(seg_target_, seg_target_n_, target);
+        copy_out(seg_scene_, seg_scene_n_, scene);
+        copy_out(ground_target_, ground_target_n_, g_target);
+        copy_out(ground_scene_, ground_scene_n_, g_scene);
+    }
     int    getNumberCorrespondences() const { return num_corr_; }
     // sizes of what getSegmentedClouds would copy out (:644-650)
     int targetSize() const { return seg_target_n_; }
@@ -260,6 +272,14 @@ private:
         else
             ok(slam_ccicp_bin_order_dev(cc_, (const float *)obs_.p, (const uint8_t *)flags_.p, obs_n_, 4, (float *)dst.p,
                                         &n_dst, nullptr));
+    }
+    static void copy_out(const Cloud &c, int n, std::vector<float> &xyz)
+    {
+        std::vector<float> rec(4 * (size_t)n + 4);
+        if (n > 0) ok(slam_memcpy_d2h(rec.data(), c.p, 16 * (size_t)n, nullptr));
+        xyz.resize(3 * (size_t)n);
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < 3; ++k) xyz[3 * (size_t)i + k] = rec[4 * (size_t)i + k];
     }
     static void download(std::vector<double> &v, const double *d, int n)
     {

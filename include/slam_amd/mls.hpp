@@ -3,19 +3,36 @@
 // uses (local_mapper.cpp:29,86,107), over the C-ABI (slam_mi355x.h).
 //
 // The reference takes PCL clouds and geometry_msgs poses and runs the ground
-// segmentation inside addToOccupancy (mls.cpp:66-67); this adapter starts just
-// below that: the caller hands over the already segmented obstacle ("drv") and
-// ground points as float arrays (PointXYZGD is a 32-byte record = 8 floats, x, y, z first).
-// getDrivability() fills a struct laid out like nav_msgs/OccupancyGrid
-// (mls.h:167-175): data[x + size_x*y] in {-1, 0, 100}, origin -res*size/2.
+// segmentation inside addToOccupancy (mls.cpp:59-67).  Both levels are here:
+//   addToOccupancy(cloud_xyz, n, stride)            the one-cloud form: segmentGround on the device
+//                                                   (slam_gseg_*), split into drv / ground clouds, the two
+//                                                   point loops of mls.cpp:73-142 in their order, and the
+//                                                   drv cloud appended to global_cloud (:144-149);
+//   addToOccupancy(obstacle, n, ground, n, stride)  below the segmentation, for callers that have the
+//                                                   segmented clouds already (PointXYZGD = 8 floats).
+// Clouds are float arrays (x, y, z first, `stride` floats per point), poses the Pose struct below
+// (the pose part of geometry_msgs::PoseStamped).  getDrivability() fills a struct laid out like
+// nav_msgs/OccupancyGrid (mls.h:167-175): data[x + size_x*y] in {-1, 0, 100}, origin -res*size/2.
+// global_cloud lives on the host, as the reference's PCL cloud does.
 #pragma once
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <vector>
 
 #include "slam_mi355x.h"
 
 namespace slam_amd {
+
+#ifndef SLAM_AMD_POSE_DEFINED
+#define SLAM_AMD_POSE_DEFINED
+struct Pose { // geometry_msgs::Pose
+    double x = 0, y = 0, z = 0;
+    double qx = 0, qy = 0, qz = 0, qw = 1;
+};
+#endif
 
 struct OccupancyGrid { // the fields of nav_msgs::OccupancyGrid that MLS fills
     struct {
@@ -34,6 +51,7 @@ public:
         slam_grid_params p;
         slam_grid_default_params(&p);
         p.rolling = roll ? 1 : 0;
+        rolling_ = roll;
         if (slam_grid_create(size_x_, size_y_, res, &p, &h_) != SLAM_OK) {
             std::fprintf(stderr, "%s\n", slam_last_error());
             h_ = nullptr;
@@ -45,12 +63,149 @@ public:
         grid_.info.origin_y = -(res * size_y_ / 2);
         grid_.data.assign((size_t)size_x_ * size_y_, (int8_t)-1);
     }
-    ~MLS() { slam_grid_destroy(h_); }
+    ~MLS()
+    {
+        slam_device_synchronize();
+        for (void *p : {d_cloud_, d_labels_, d_gnd_, d_obs_, d_counts_}) slam_free(p);
+        slam_gseg_destroy(gseg_);
+        slam_grid_destroy(h_);
+    }
     MLS(const MLS &) = delete;
     MLS &operator=(const MLS &) = delete;
 
-    void clearMap() { if (h_) slam_grid_clear(h_, nullptr); }                                 // mls.cpp:18-31
-    void setPose(double x, double y) { if (h_) slam_grid_set_pose(h_, x, y, nullptr); }      // mls.cpp:408-479
+    void clearMap()                                                                           // mls.cpp:18-31
+    {
+        if (h_) slam_grid_clear(h_, nullptr);
+        global_cloud_.clear();
+    }
+    void setPose(double x, double y)                                                          // mls.cpp:408-479
+    {
+        if (!h_) return;
+        double x0 = 0, y0 = 0;
+        slam_grid_get_pose(h_, &x0, &y0);
+        slam_grid_set_pose(h_, x, y, nullptr);
+        double x1 = 0, y1 = 0;
+        slam_grid_get_pose(h_, &x1, &y1);
+        if (rolling_ && !disable_pointcloud_ && (x1 != x0 || y1 != y0)) {
+            // global_cloud follows the window (:433-454): shift by -dx*res, -dy*res, then PassThrough x, y within
+            // +-min(size)*res/2 (float limits, closed interval)
+            const float sx = (float)-(x1 - x0), sy = (float)-(y1 - y0);
+            const float crop = (float)(std::min(grid_.info.width, grid_.info.height) * grid_.info.resolution / 2);
+            size_t      k = 0;
+            for (size_t i = 0; i + 2 < global_cloud_.size(); i += 3) {
+                const float px = global_cloud_[i] + sx, py = global_cloud_[i + 1] + sy, pz = global_cloud_[i + 2];
+                if (px >= -crop && px <= crop && py >= -crop && py <= crop) {
+                    global_cloud_[k] = px, global_cloud_[k + 1] = py, global_cloud_[k + 2] = pz;
+                    k += 3;
+                }
+            }
+            global_cloud_.resize(k);
+        }
+    }
+    void setPose(const Pose &p) { setPose(p.x, p.y); }
+    // mls.cpp:59-150, the one-cloud form: segmentGround (groundSegmentation.cpp:91-468) on the device, the drv
+    // (obstacle below robot height) and ground clouds, then the two point loops in the reference's order
+    void addToOccupancy(const float *cloud_xyz, int n, int stride = 3)
+    {
+        if (!h_ || n <= 0) return;
+        if (!gseg_ && slam_gseg_create(nullptr, &gseg_) != SLAM_OK) return warn();
+        if (n > cap_) {
+            slam_device_synchronize();
+            for (void *p : {d_cloud_, d_labels_, d_gnd_, d_obs_}) slam_free(p);
+            d_cloud_ = d_labels_ = d_gnd_ = d_obs_ = nullptr;
+            cap_ = n + n / 4;
+            if (slam_malloc(&d_cloud_, sizeof(float) * (size_t)cap_ * 8) != SLAM_OK || slam_malloc(&d_labels_, (size_t)cap_) != SLAM_OK ||
+                slam_malloc(&d_gnd_, 16 * (size_t)cap_) != SLAM_OK || slam_malloc(&d_obs_, 16 * (size_t)cap_) != SLAM_OK) {
+                cap_ = 0;
+                return warn();
+            }
+        }
+        if (!d_counts_ && slam_malloc(&d_counts_, 16) != SLAM_OK) return warn();
+        if (stride > 8) return (void)std::fprintf(stderr, "MLS::addToOccupancy: stride %d > 8 floats\n", stride);
+        if (slam_memcpy_h2d(d_cloud_, cloud_xyz, sizeof(float) * (size_t)n * stride, nullptr) != SLAM_OK) return warn();
+        if (slam_gseg_segment_dev(gseg_, (const float *)d_cloud_, n, stride, (uint8_t *)d_labels_, nullptr) != SLAM_OK) return warn();
+        if (slam_gseg_split_dev(gseg_, (const float *)d_cloud_, n, stride, (const uint8_t *)d_labels_, (float *)d_gnd_, (float *)d_obs_,
+                                (int32_t *)d_counts_, nullptr) != SLAM_OK)
+            return warn();
+        int32_t counts[2] = {0, 0}; // ground, obstacle
+        if (slam_memcpy_d2h(counts, d_counts_, sizeof counts, nullptr) != SLAM_OK) return warn();
+        if (slam_grid_add_scan_inorder_dev(h_, (const float *)d_obs_, counts[1], (const float *)d_gnd_, counts[0], 4, nullptr) != SLAM_OK)
+            return warn();
+        if (!disable_pointcloud_ && counts[1] > 0) { // *global_cloud += drv_cloud (:144-149)
+            std::vector<float> drv(4 * (size_t)counts[1]);
+            if (slam_memcpy_d2h(drv.data(), d_obs_, 16 * (size_t)counts[1], nullptr) != SLAM_OK) return warn();
+            for (int i = 0; i < counts[1]; ++i) global_cloud_.insert(global_cloud_.end(), &drv[4 * (size_t)i], &drv[4 * (size_t)i] + 3);
+        }
+        last_counts_[0] = counts[1];
+        last_counts_[1] = counts[0];
+    }
+    // mls.cpp:34-53: setPose, then (rolling) the cloud turned into the global orientation and offset by the
+    // sub-cell residual curPose - pose (tf::poseMsgToEigen + pcl::transformPointCloud: computed in double, stored
+    // as float), then addToOccupancy of that cloud
+    void addToMap(const float *cloud_xyz, int n, int stride, const Pose &pose)
+    {
+        setPose(pose);
+        if (!h_ || n <= 0) return;
+        if (!rolling_) return addToOccupancy(cloud_xyz, n, stride);
+        double cx = 0, cy = 0;
+        slam_grid_get_pose(h_, &cx, &cy);
+        const double tx = cx - pose.x, ty = cy - pose.y, tz = pose.z;
+        const double d = pose.qx * pose.qx + pose.qy * pose.qy + pose.qz * pose.qz + pose.qw * pose.qw, s2 = d > 0 ? 2.0 / d : 0.0;
+        const double xs = pose.qx * s2, ys = pose.qy * s2, zs = pose.qz * s2, wx = pose.qw * xs, wy = pose.qw * ys, wz = pose.qw * zs,
+                     xx = pose.qx * xs, xy = pose.qx * ys, xz = pose.qx * zs, yy = pose.qy * ys, yz = pose.qy * zs, zz = pose.qz * zs;
+        const double r[9] = {1.0 - (yy + zz), xy - wz, xz + wy, xy + wz, 1.0 - (xx + zz), yz - wx, xz - wy, yz + wx, 1.0 - (xx + yy)};
+        trans_.resize(3 * (size_t)n);
+        for (int i = 0; i < n; ++i) {
+            const double px = cloud_xyz[(size_t)i * stride], py = cloud_xyz[(size_t)i * stride + 1], pz = cloud_xyz[(size_t)i * stride + 2];
+            trans_[3 * (size_t)i] = (float)(r[0] * px + r[1] * py + r[2] * pz + tx);
+            trans_[3 * (size_t)i + 1] = (float)(r[3] * px + r[4] * py + r[5] * pz + ty);
+            trans_[3 * (size_t)i + 2] = (float)(r[6] * px + r[7] * py + r[8] * pz + tz);
+        }
+        addToOccupancy(trans_.data(), n, 3);
+    }
+    // mls.cpp:481-505: the z offset from graph_slam; the occupancy mode keeps no heights, global_cloud moves
+    void offsetMap(const Pose &pose)
+    {
+        if (disable_pointcloud_) return;
+        for (size_t i = 2; i < global_cloud_.size(); i += 3) global_cloud_[i] += (float)pose.z;
+    }
+    // mls.cpp:508-518: pcl::VoxelGrid(xy, xy, z) over global_cloud: one centroid per occupied voxel, in increasing
+    // voxel index (x fastest), the voxel lattice anchored at the cloud's minimum as PCL anchors it
+    void filterPointCloud(double xy, double z)
+    {
+        const size_t n = global_cloud_.size() / 3;
+        if (!n) return;
+        float mn[3] = {global_cloud_[0], global_cloud_[1], global_cloud_[2]}, mx[3] = {mn[0], mn[1], mn[2]};
+        for (size_t i = 0; i < n; ++i)
+            for (int k = 0; k < 3; ++k) {
+                mn[k] = std::min(mn[k], global_cloud_[3 * i + k]);
+                mx[k] = std::max(mx[k], global_cloud_[3 * i + k]);
+            }
+        const float inv[3] = {(float)(1.0 / xy), (float)(1.0 / xy), (float)(1.0 / z)};
+        long        lo[3], div[3];
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = (long)std::floor(mn[k] * inv[k]);
+            div[k] = (long)std::floor(mx[k] * inv[k]) - lo[k] + 1;
+        }
+        struct Acc { double s[3] = {0, 0, 0}; long n = 0; };
+        std::map<long, Acc> vox;
+        for (size_t i = 0; i < n; ++i) {
+            long idx = 0, mul = 1;
+            for (int k = 0; k < 3; ++k) {
+                idx += ((long)std::floor(global_cloud_[3 * i + k] * inv[k]) - lo[k]) * mul;
+                mul *= div[k];
+            }
+            Acc &a = vox[idx];
+            for (int k = 0; k < 3; ++k) a.s[k] += global_cloud_[3 * i + k];
+            ++a.n;
+        }
+        global_cloud_.clear();
+        for (const auto &kv : vox)
+            for (int k = 0; k < 3; ++k) global_cloud_.push_back((float)(kv.second.s[k] / (double)kv.second.n));
+    }
+    const std::vector<float> &getGlobalCloud() const { return global_cloud_; }                // mls.h:216 (x, y, z per point)
+    void setDisablePointCloud(bool v) { disable_pointcloud_ = v; }                            // mls.h:223
+    const int *lastSegmentCounts() const { return last_counts_; }                             // drv, ground points of the last cloud
     // mls.cpp:59-150 below the segmentation: obstacle points +1.0, ground points -0.3, in that order
     void addToOccupancy(const float *obstacle, int n_obstacle, const float *ground, int n_ground, int stride = 8)
     {
@@ -75,8 +230,14 @@ public:
     slam_grid_t *handle() { return h_; }
 
 private:
+    void warn() const { std::fprintf(stderr, "MLS: %s\n", slam_last_error()); }
     slam_grid_t  *h_ = nullptr;
+    slam_gseg_t  *gseg_ = nullptr;
     OccupancyGrid grid_;
+    bool          rolling_ = false, disable_pointcloud_ = false;
+    void         *d_cloud_ = nullptr, *d_labels_ = nullptr, *d_gnd_ = nullptr, *d_obs_ = nullptr, *d_counts_ = nullptr;
+    int           cap_ = 0, last_counts_[2] = {0, 0};
+    std::vector<float> global_cloud_, trans_;
 };
 
 } // namespace slam_amd

@@ -261,6 +261,9 @@ int slam_grid_finalize(slam_grid_t *g, slam_stream_t stream);
  * sequential += / -= on the per-cell double, thresholds after every point. */
 int slam_grid_add_scan_inorder(slam_grid_t *g, const float *obs, int n_obs, const float *gnd,
                                int n_gnd, int stride);
+/* the same with the two clouds resident in HBM (what slam_gseg_split_dev leaves); enqueues on `stream` */
+int slam_grid_add_scan_inorder_dev(slam_grid_t *g, const float *d_obs, int n_obs, const float *d_gnd,
+                                   int n_gnd, int stride, slam_stream_t stream);
 
 /* read-back in WINDOW coordinates, row-major data[x + size_x*y] as
  * nav_msgs/OccupancyGrid (mls.h:167-175). Host pointers; synchronous. */

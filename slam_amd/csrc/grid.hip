@@ -1282,17 +1282,18 @@ int slam_grid_finalize(slam_grid_t *g, slam_stream_t stream)
     return SLAM_OK;
 }
 
-int slam_grid_add_scan_inorder(slam_grid_t *g, const float *obs, int n_obs, const float *gnd, int n_gnd,
-                               int stride)
+int slam_grid_add_scan_inorder_dev(slam_grid_t *g, const float *d_obs, int n_obs, const float *d_gnd, int n_gnd, int stride,
+                                   slam_stream_t stream)
 {
-    SLAM_REQUIRE(g && n_obs >= 0 && n_gnd >= 0 && stride >= 2 && (obs || !n_obs) && (gnd || !n_gnd),
-                 SLAM_E_INVALID, "slam_grid_add_scan_inorder: bad arguments");
+    SLAM_REQUIRE(g && n_obs >= 0 && n_gnd >= 0 && stride >= 2 && (d_obs || !n_obs) && (d_gnd || !n_gnd), SLAM_E_INVALID,
+                 "slam_grid_add_scan_inorder_dev: bad arguments");
     SLAM_TRY(require_device());
     const int n = n_obs + n_gnd;
     if (n == 0) return SLAM_OK;
+    hipStream_t st = as_stream(stream);
     if (!g->d_delta) {
         SLAM_HIP(hipMalloc((void **)&g->d_delta, g->cells * sizeof(unsigned long long)));
-        SLAM_HIP(hipMemset(g->d_delta, 0, g->cells * sizeof(unsigned long long)));
+        SLAM_HIP(hipMemsetAsync(g->d_delta, 0, g->cells * sizeof(unsigned long long), st));
     }
     {
         void  *p = g->d_touched;
@@ -1301,19 +1302,29 @@ int slam_grid_add_scan_inorder(slam_grid_t *g, const float *obs, int n_obs, cons
         g->d_touched = static_cast<int *>(p);
         g->cap_touched = cap;
     }
+    int *counter = g->d_touched + n;
+    SLAM_HIP(hipMemsetAsync(counter, 0, sizeof(int), st));
+    hipLaunchKernelGGL(inorder_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g->gv, d_obs, n_obs, d_gnd, n_gnd, stride,
+                       g->d_delta, g->d_touched, counter);
+    hipLaunchKernelGGL(inorder_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g->gv, g->prm.occupancy_increment,
+                       g->prm.occupancy_decrement, (double)g->prm.min_cluster_points, g->d_delta, g->d_touched, counter,
+                       g->d_num_s, g->d_occ_s, g->d_updates);
+    SLAM_HIP(hipGetLastError());
+    g->state_from_inorder = true;
+    return SLAM_OK;
+}
+
+int slam_grid_add_scan_inorder(slam_grid_t *g, const float *obs, int n_obs, const float *gnd, int n_gnd,
+                               int stride)
+{
+    SLAM_REQUIRE(g && n_obs >= 0 && n_gnd >= 0 && stride >= 2 && (obs || !n_obs) && (gnd || !n_gnd),
+                 SLAM_E_INVALID, "slam_grid_add_scan_inorder: bad arguments");
+    SLAM_TRY(require_device());
+    if (n_obs + n_gnd == 0) return SLAM_OK;
     float *d_obs, *d_gnd;
     SLAM_TRY(stage_points(g, obs, n_obs, gnd, n_gnd, stride, &d_obs, &d_gnd));
-    int *counter = g->d_touched + n;
-    SLAM_HIP(hipMemsetAsync(counter, 0, sizeof(int), nullptr));
-    hipLaunchKernelGGL(inorder_count_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, g->gv, d_obs, n_obs,
-                       d_gnd, n_gnd, stride, g->d_delta, g->d_touched, counter);
-    hipLaunchKernelGGL(inorder_apply_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, g->gv,
-                       g->prm.occupancy_increment, g->prm.occupancy_decrement,
-                       (double)g->prm.min_cluster_points, g->d_delta, g->d_touched, counter, g->d_num_s,
-                       g->d_occ_s, g->d_updates);
-    SLAM_HIP(hipGetLastError());
+    SLAM_TRY(slam_grid_add_scan_inorder_dev(g, d_obs, n_obs, d_gnd, n_gnd, stride, nullptr));
     SLAM_HIP(hipStreamSynchronize(nullptr));
-    g->state_from_inorder = true;
     return SLAM_OK;
 }
 

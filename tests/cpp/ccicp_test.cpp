@@ -49,6 +49,16 @@ int main(int argc, char **argv)
     if (!f) return 2;
     std::fwrite(v, 8, 16, f);
     std::fclose(f);
+    // getSegmentedClouds (icpTools.cpp:644-650, scan_registration.cpp:142): four clouds of the sizes reported above
+    std::vector<float> c_target, c_scene, c_gt, c_gs;
+    icp.getSegmentedClouds(c_target, c_scene, c_gt, c_gs);
+    if ((int)c_target.size() != 3 * icp.targetSize() || (int)c_scene.size() != 3 * icp.sceneSize() ||
+        (int)c_gt.size() != 3 * icp.groundTargetSize() || (int)c_gs.size() != 3 * icp.groundSceneSize())
+        return 4;
+    f = std::fopen((out + ".scene").c_str(), "wb");
+    if (!f) return 2;
+    std::fwrite(c_scene.data(), 4, c_scene.size(), f);
+    std::fclose(f);
     // a scene too small to match: the sentinel of icpTools.cpp:179-184
     icp.setSceneCloud(scene.data(), 3, 3);
     const slam_amd::Pose bad = icp.doICPMatch(pose);

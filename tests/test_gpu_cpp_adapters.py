@@ -129,6 +129,8 @@ def test_ccicp_facade_matches_oracle_chain(tmp_path, rtype):
     s_ga, s_nga = O.ccicp_split(seg_scene, None)
     gnd_scene, n_gvox = O.voxel_downsample(np.concatenate([B[lab_b == O.GSEG_GROUND], np.zeros((int((lab_b == O.GSEG_GROUND).sum()), 1), np.float32)], 1), (0.5, 0.5, 5.0))
     assert list(got[8:16]) == [len(seg_target), n_vox, len(gnd_a), n_gvox, len(m_ga), len(m_nga), len(s_ga), len(s_nga)]
+    scene_xyz = np.fromfile(out + ".scene", np.float32).reshape(-1, 3)      # getSegmentedClouds: the voxel-filtered scene
+    assert len(scene_xyz) == n_vox and np.abs(scene_xyz - seg_scene[:, :3]).max() < 1e-4
     assert len(s_ga) + len(s_nga) > 300 and len(m_ga) + len(m_nga) > 5000
 
     yaw0 = rel_th + 0.03
@@ -145,3 +147,75 @@ def test_ccicp_facade_matches_oracle_chain(tmp_path, rtype):
     assert abs(got[2] - z) < 1e-6            # (near the sensor the ring pattern leaves no ground within 3 m: z may stay)
     # and the match is sane: B's pose in A's frame, to the 0.5 m voxel centroids the scene is reduced to
     assert abs(got[0] - rel[0]) < 0.3 and abs(got[1] - rel[1]) < 0.3 and abs(yaw - rel_th) < 0.03
+
+
+@pytest.mark.gpu
+def test_mls_one_cloud_form_matches_oracle(tmp_path):
+    """MLS::addToMap(cloud, pose) as local_mapper calls it (local_mapper.cpp:107; mls.cpp:34-150): setPose, the cloud
+    turned into the global orientation, segmentGround inside, the drv and ground loops in their order, global_cloud;
+    then offsetMap and filterPointCloud -- against the oracle's segmentation and in-order grid update."""
+    exe = compile_cpp(str(tmp_path), "mls_cloud_test")
+    d = str(tmp_path)
+    clouds, poses = [], []
+    for k in range(3):
+        xyz, p = synth.make_cloud3d(k, n_loop=50)
+        clouds.append(xyz)
+        yaw = 0.02 * k
+        poses.append([0.13 * k, -0.21 * k, 0.0] + _quat_rpy(0.0, 0.0, yaw))
+        xyz.tofile(os.path.join(d, "cloud%d.f32" % k))
+    np.array(poses).tofile(os.path.join(d, "poses.f64"))
+    out = os.path.join(d, "out.bin")
+    subprocess.check_call([exe, d, out, "3"])
+    raw = open(out, "rb").read()
+    head = np.frombuffer(raw[:64], np.float64)
+    occ = np.frombuffer(raw[64:64 + 40000], np.int8)
+    cloud_out = np.frombuffer(raw[64 + 40000:], np.float32).reshape(-1, 3)
+
+    res, size = 0.2, 200
+    gp = O.grid_params(size, size, res, min_cluster_points=20, rolling=1)
+    num, drv, eocc = np.zeros(size * size), np.full(size * size, -1, np.int8), np.full(size * size, -1, np.int8)
+    cx = cy = 0.0
+    gc = np.zeros((0, 3), np.float32)
+    n_drv = n_gnd = 0
+    for k in range(3):
+        px, py = poses[k][0], poses[k][1]
+        dx, dy = int(np.round((px - cx) / res)), int(np.round((py - cy) / res))     # mls.cpp:419-424
+        if dx or dy:
+            from test_gpu_stream import roll
+            num = roll(num.reshape(size, size), dx, dy).reshape(-1)
+            drv = roll(drv.reshape(size, size), dx, dy, -1).reshape(-1)
+            eocc = roll(eocc.reshape(size, size), dx, dy, -1).reshape(-1)
+            cx += dx * res
+            cy += dy * res
+            gc = gc + np.array([-(dx * res), -(dy * res), 0], np.float32)             # :433-454
+            crop = np.float32(size * res / 2)
+            gc = gc[(gc[:, 0] >= -crop) & (gc[:, 0] <= crop) & (gc[:, 1] >= -crop) & (gc[:, 1] <= crop)]
+        yaw = 0.02 * k
+        c, s = np.cos(yaw), np.sin(yaw)
+        # tf's matrix from the quaternion the program was given (not from the angle): the same doubles
+        q = poses[k][3:]
+        dd = sum(v * v for v in q); s2 = 2.0 / dd
+        xs, ys, zs = q[0] * s2, q[1] * s2, q[2] * s2
+        wx, wy, wz, xx, xy, xz, yy, yz, zz = q[3] * xs, q[3] * ys, q[3] * zs, q[0] * xs, q[0] * ys, q[0] * zs, q[1] * ys, q[1] * zs, q[2] * zs
+        Rm = np.array([[1 - (yy + zz), xy - wz, xz + wy], [xy + wz, 1 - (xx + zz), yz - wx], [xz - wy, yz + wx, 1 - (xx + yy)]])
+        P = clouds[k].astype(np.float64)
+        T = np.stack([Rm[0, 0] * P[:, 0] + Rm[0, 1] * P[:, 1] + Rm[0, 2] * P[:, 2] + (cx - px),
+                      Rm[1, 0] * P[:, 0] + Rm[1, 1] * P[:, 1] + Rm[1, 2] * P[:, 2] + (cy - py),
+                      Rm[2, 0] * P[:, 0] + Rm[2, 1] * P[:, 1] + Rm[2, 2] * P[:, 2] + 0.0], 1).astype(np.float32)
+        lab, *_ = O.gseg_segment(T)
+        o, g = T[lab == O.GSEG_OBSTACLE], T[lab == O.GSEG_GROUND]
+        O.grid_add_scan_inorder(gp, np.concatenate([o, np.zeros((len(o), 1), np.float32)], 1),
+                                np.concatenate([g, np.zeros((len(g), 1), np.float32)], 1), num, drv, eocc)
+        gc = np.concatenate([gc, o])
+        n_drv, n_gnd = len(o), len(g)
+    assert (head[0], head[1]) == (cx, cy)
+    assert (int(head[2]), int(head[3])) == (n_drv, n_gnd)
+    assert np.array_equal(occ, eocc)
+    assert int(head[4]) == len(gc)                                      # global_cloud before the filter
+    gc = gc + np.array([0, 0, 0.25], np.float32)                        # offsetMap(z = 0.25)
+    # filterPointCloud(0.1, 0.1): one centroid per voxel; the set of occupied voxels and their centroids
+    assert 0 < len(cloud_out) < len(gc)
+    key = lambda a: np.floor(a / np.float32(0.1)).astype(np.int64)
+    want = {tuple(k) for k in key(gc)}
+    assert len(cloud_out) == len(want)
+    assert abs(float(cloud_out[:, 2].mean()) - float(gc[:, 2].mean())) < 0.05
