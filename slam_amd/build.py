@@ -72,7 +72,8 @@ def build(force=False, verbose=False, measure=False):
     built = []
     if _build_lib(LIB, os.path.join(LIBDIR, "obj"), [], force, verbose):
         built.append(LIB)
-    if measure and _build_lib(MEASURE_LIB, os.path.join(LIBDIR, "obj_measure"), ["-DSLAM_MEASURE"], force, verbose):
+    extra = ["-DSLAM_MEASURE"] + os.environ.get("SLAM_MEASURE_DEFINES", "").split()   # e.g. -DSLAM_SEED_RING=1 for an A/B
+    if measure and _build_lib(MEASURE_LIB, os.path.join(LIBDIR, "obj_measure"), extra, force, verbose):
         built.append(MEASURE_LIB)
     rccl_srcs = [os.path.join(CSRC, s) for s in RCCL_SOURCES if os.path.exists(os.path.join(CSRC, s))]
     if rccl_srcs and (force or _stale(RCCL_LIB, rccl_srcs + _headers() + [LIB])):

@@ -42,6 +42,18 @@ using namespace slam::icp;
 // In-kernel stamps, the two-launch schedule with events and the environment knobs of the round-1 sweeps exist
 // only in a measurement build (python -m slam_amd.build --measure: -DSLAM_MEASURE, a library of its own that
 // the tools/ scripts load); the shipped library reads no environment variable and executes no stamp.
+#ifndef SLAM_SEED_RING
+#define SLAM_SEED_RING 1
+#endif
+#ifndef SLAM_SEED_EMPTY
+#define SLAM_SEED_EMPTY 0
+#endif
+constexpr bool kSeedEmpty = SLAM_SEED_EMPTY != 0; // ... and skip the cells inside the disk the last search proved empty
+// The ring-search form of the batch kernels starts a query's search from last iteration's neighbour of the same scene
+// point (exact: nn_search_seeded).  Measured on config 2 (round 2): 0.394 -> 0.385 ms; with the cells
+// inside the radius the last search proved empty skipped as well (SLAM_SEED_EMPTY): 0.398 ms -- the bookkeeping costs
+// more than the skipped cells, so that half stays off here (the spread form, icp_single.hip, uses both).
+constexpr bool kSeedRing = SLAM_SEED_RING != 0;
 #ifdef SLAM_MEASURE
 #define SLAM_STAMPS(fa) ((fa).stamps != nullptr)
 #else
@@ -292,17 +304,26 @@ __device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ListPtrs &
 
 // One scene point, searched by GG lanes (sub = lane within that group); the
 // group's lane 0 adds the correspondence to its running sums.
-template <int GG, typename StartT, int MODE>
+template <int GG, typename StartT, int MODE, bool SEEDED = false>
 __device__ inline void accumulate_point(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
                                         const Pose &T, const double2 P, bool is_ga, int sub, double acc[kNumAcc],
-                                        int &far)
+                                        int &far, int *seed = nullptr, float *empty = nullptr, float move_r = 0.f, float move_t = 0.f)
 {
     float qx, qy;
     transform_query(T, P, qx, qy);
     if (MODE == SLAM_ICP_P2P) {
         const int cls = is_ga ? 0 : 1;
         if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
-            const Best b = nn_search<GG, StartT>(ix, mv, cls, qx, qy, sub, fa.indist);
+            Best b;
+            if (SEEDED) { // last iteration's neighbour of this scene point prunes the search from the start
+                const float move = move_r * (fabsf((float)P.x) + fabsf((float)P.y) + 1.0e-3f) + move_t;
+                float       e_out;
+                b = nn_search_seeded<GG, StartT>(ix, mv, cls, qx, qy, sub, fa.indist, *seed, kSeedEmpty ? *empty : 0.0f, move, e_out);
+                *seed = b.pos;
+                *empty = e_out;
+            } else {
+                b = nn_search<GG, StartT>(ix, mv, cls, qx, qy, sub, fa.indist);
+            }
             if (sub == 0 && b.pos >= 0 && (double)b.d < fa.indist) add_p2p<StartT>(ix, mv, cls, b, qx, qy, acc); // :76
             far += (sub == 0 && !(b.pos >= 0 && b.d < mv.cert2)) ? 1 : 0; // beyond what the halo lists certify
         }
@@ -349,10 +370,15 @@ __device__ inline void point_pass(const IndexPtrs<StartT> &ix, const ModelView &
 template <int GG, typename StartT, int MODE>
 __device__ inline void point_pass_reg(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
                                       const Pose &T, int n, int nga, int p0, const double2 P, double acc[kNumAcc],
-                                      int &far)
+                                      int &far, int *seed = nullptr, float *empty = nullptr, float move_r = 0.f, float move_t = 0.f)
 {
     const int p = p0 + (int)threadIdx.x / GG;
-    if (p < n) accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, P, p < nga, (int)threadIdx.x % GG, acc, far);
+    if (p < n) {
+        if (seed)
+            accumulate_point<GG, StartT, MODE, true>(ix, mv, fa, T, P, p < nga, (int)threadIdx.x % GG, acc, far, seed, empty, move_r, move_t);
+        else
+            accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, P, p < nga, (int)threadIdx.x % GG, acc, far);
+    }
 }
 
 // One workgroup = one scan, all iterations.  MODE: SLAM_ICP_P2P / SLAM_ICP_P2L.
@@ -387,6 +413,8 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
     // named, not an array: stays in registers (the list-sweep kernel has one full pass per 1024 points: one is enough)
     const double2 Pc0 = hoisted(0), Pc1 = SWEEP ? Pc0 : hoisted(1), Pc2 = SWEEP ? Pc0 : hoisted(2);
 
+    int   sd0 = -1, sd1 = -1, sd2 = -1; // ring form: last iteration's neighbour of the lane's point in each hoisted pass
+    float em0 = 0.f, em1 = 0.f, em2 = 0.f, move_r = 0.f, move_t = 0.f; // ... the radius it proved empty; the last step's size
     bool hand_over = false;
     iters = iter_begin;
     if (n >= 5) { // icp.cpp:100-103
@@ -437,7 +465,10 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                         const int p = p0 + tid / (G > 0 ? G : 1);
                         P = fa.pts[off + min(p, n - 1)];
                     }
-                    point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc, far);
+                    const bool seeded = kSeedRing && MODE == SLAM_ICP_P2P && pass < kHoist;
+                    int       *seed = seeded ? (pass == 0 ? &sd0 : (pass == 1 ? &sd1 : &sd2)) : nullptr;
+                    float     *empty = seeded ? (pass == 0 ? &em0 : (pass == 1 ? &em1 : &em2)) : nullptr;
+                    point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc, far, seed, empty, move_r, move_t);
                     p0 += kBlock / (G > 0 ? G : 1);
                 } else if (rem * 2 > kBlock) {
                     point_pass<1, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
@@ -531,6 +562,12 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                 }
             }
             __syncthreads();
+            if (kSeedRing && kSeedEmpty && !SWEEP) { // |q_new - q_old| <= |dR|_F |p| + |dt| (rounded up)
+                const double n00 = uniform(bc[0]), n01 = uniform(bc[1]), n10 = uniform(bc[2]), n11 = uniform(bc[3]);
+                const double n4 = uniform(bc[4]), n5 = uniform(bc[5]);
+                move_r = (float)sqrt((n00 - r00) * (n00 - r00) + (n01 - r01) * (n01 - r01) + (n10 - r10) * (n10 - r10) + (n11 - r11) * (n11 - r11)) * 1.0001f + 1.0e-7f;
+                move_t = (float)sqrt((n4 - t0) * (n4 - t0) + (n5 - t1) * (n5 - t1)) * 1.0001f + 1.0e-7f;
+            }
             r00 = uniform(bc[0]); // the same in every lane: keep the pose in scalar registers
             r01 = uniform(bc[1]);
             r10 = uniform(bc[2]);

@@ -317,6 +317,122 @@ __device__ inline void scan_range_deep(Best &b, bool &tie, const float2 *pts, co
     scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, i - lig, e, lig, G, qx, qy);
 }
 
+// nn_search with last iteration's neighbour of the same scene point as the first candidate (seed = its position
+// in the sorted array, -1 = none): the disk of its distance prunes the search from the first cell on, where an
+// unseeded search reads its first non-empty ring whole.  When that disk touches at most 3 x 3 cells they are
+// read in one pass and the search is over (every cell the disk touches has been seen); otherwise the rings run
+// as usual from the seeded best.  Same result as nn_search.
+template <int G, typename StartT, bool EXACT>
+__device__ inline Best nn_search_seeded_impl(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, float qx, float qy,
+                                             int sub, double gate, bool &tie, int seed, float empty_in, float move, float &empty_out)
+{
+    const Lattice &L = mv.lat;
+    const StartT  *start = ix.start[cls];
+    const float2  *pts = ix.pts + mv.base[cls];
+    const StartT  *oidx = ix.oidx + mv.base[cls];
+
+    Best b;
+    b.d = FLT_MAX;
+    b.oidx = 0xffffffffu;
+    b.pos = -1;
+    empty_out = 0.0f;
+    if (mv.n_cls[cls] <= 0) return b;
+
+    const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
+    const int   cx = clampi((int)floorf(fx), 0, L.nx - 1);
+    const int   cy = clampi((int)floorf(fy), 0, L.ny - 1);
+    if (seed >= 0) {
+        b.d = dist2(pts[seed], qx, qy);
+        b.pos = seed;
+        const float R = (__fsqrt_rn(b.d) + L.margin) * L.inv_h;
+        const int   x_lo = max(0, (int)floorf(fx - R)), x_hi = min(L.nx - 1, (int)floorf(fx + R));
+        const int   y_lo = max(0, (int)floorf(fy - R)), y_hi = min(L.ny - 1, (int)floorf(fy + R));
+        if (x_hi - x_lo <= 2 && y_hi - y_lo <= 2 && x_lo <= x_hi && y_lo <= y_hi) {
+            for (int y = y_lo; y <= y_hi; ++y)
+                scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, (int)start[y * L.nx + x_lo], (int)start[y * L.nx + x_hi + 1], sub, G, qx, qy);
+            if (G > 1) {
+                if (EXACT)
+                    group_min<G, StartT>(b, oidx);
+                else
+                    group_min_lean<G>(b, tie);
+            }
+            if (G == 1 || !EXACT) b.oidx = (unsigned)oidx[b.pos];
+            empty_out = __fsqrt_rn(b.d) * 0.999999f;
+            return b;
+        }
+    }
+    // cells that lie inside the disk last iteration proved empty, shrunk by the query's move since, need no visit
+    int rp = -1, r = 0;
+    if (empty_in > 0.0f && fx >= 0.0f && fx < (float)L.nx && fy >= 0.0f && fy < (float)L.ny) {
+        const float D = empty_in - move - 2.0f * L.margin;
+        if (D > 0.0f) rp = (int)floorf(fminf(D * L.inv_h * 0.70710677f, (float)(L.nx + L.ny))) - 1;
+    }
+    if (rp < 0) { // the usual start: the query's own cell
+        scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, (int)start[cy * L.nx + cx], (int)start[cy * L.nx + cx + 1], sub, G, qx, qy);
+        if (G > 1) {
+            if (EXACT)
+                group_min<G, StartT>(b, oidx);
+            else
+                group_min_lean<G>(b, tie);
+        }
+        rp = 0;
+    }
+    float bound;
+    bool  all;
+    for (r = rp + 1;; r *= 2) {
+        int y_lo = max(cy - r, 0), y_hi = min(cy + r, L.ny - 1);
+        int x_lo = max(cx - r, 0), x_hi = min(cx + r, L.nx - 1);
+        const bool covers = (x_lo == 0) & (y_lo == 0) & (x_hi == L.nx - 1) & (y_hi == L.ny - 1);
+        if (b.d < FLT_MAX) {
+            const float R = (__fsqrt_rn(b.d) + L.margin) * L.inv_h;
+            x_lo = max(x_lo, (int)floorf(fx - R));
+            x_hi = min(x_hi, (int)floorf(fx + R));
+            y_lo = max(y_lo, (int)floorf(fy - R));
+            y_hi = min(y_hi, (int)floorf(fy + R));
+        }
+        for (int y = y_lo; y <= y_hi; ++y) {
+            const int row = y * L.nx;
+            if (y >= cy - rp && y <= cy + rp) {
+                const int l1 = min(x_hi, cx - rp - 1), f2 = max(x_lo, cx + rp + 1);
+                if (x_lo <= l1) scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, (int)start[row + x_lo], (int)start[row + l1 + 1], sub, G, qx, qy);
+                if (f2 <= x_hi) scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, (int)start[row + f2], (int)start[row + x_hi + 1], sub, G, qx, qy);
+            } else if (x_lo <= x_hi) {
+                scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, (int)start[row + x_lo], (int)start[row + x_hi + 1], sub, G, qx, qy);
+            }
+        }
+        if (G > 1) {
+            if (EXACT)
+                group_min<G, StartT>(b, oidx);
+            else
+                group_min_lean<G>(b, tie);
+        }
+        bound = (float)r * L.h - L.margin;
+        const float b2 = bound * bound;
+        all = covers;
+        if (covers || b.d < b2 || (double)b2 >= gate) break;
+        rp = r;
+    }
+    {
+        const float dn = b.d < FLT_MAX ? __fsqrt_rn(b.d) * 0.999999f : 1.0e30f;
+        empty_out = (all || b.d < bound * bound) ? dn : fminf(dn, bound);
+    }
+    if (G == 1 || !EXACT) b.oidx = b.pos >= 0 ? (unsigned)oidx[b.pos] : 0xffffffffu;
+    return b;
+}
+
+template <int G, typename StartT>
+__device__ inline Best nn_search_seeded(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, float qx, float qy, int sub,
+                                        double gate, int seed, float empty_in, float move, float &empty_out)
+{
+    bool tie = false;
+    Best b = nn_search_seeded_impl<G, StartT, false>(ix, mv, cls, qx, qy, sub, gate, tie, seed, empty_in, move, empty_out);
+    if (tie) {
+        bool unused = false;
+        b = nn_search_seeded_impl<G, StartT, true>(ix, mv, cls, qx, qy, sub, gate, unused, seed, empty_in, move, empty_out);
+    }
+    return b;
+}
+
 // What a finished search proves about the query and what the next iteration's search of the same scene
 // point starts from (icp_single.hip): the neighbour's position in the sorted array, and a radius within which
 // the class has no point (the neighbour's distance, or the edge of the last ring when the inlier gate ended
