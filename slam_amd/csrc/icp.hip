@@ -465,10 +465,16 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                         const int p = p0 + tid / (G > 0 ? G : 1);
                         P = fa.pts[off + min(p, n - 1)];
                     }
-                    const bool seeded = kSeedRing && MODE == SLAM_ICP_P2P && pass < kHoist;
-                    int       *seed = seeded ? (pass == 0 ? &sd0 : (pass == 1 ? &sd1 : &sd2)) : nullptr;
-                    float     *empty = seeded ? (pass == 0 ? &em0 : (pass == 1 ? &em1 : &em2)) : nullptr;
-                    point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc, far, seed, empty, move_r, move_t);
+                    if (kSeedRing && MODE == SLAM_ICP_P2P && pass < kHoist) {
+                        // (the per-pass state is selected by value: a pointer into the three would put them on the stack)
+                        int   sd = pass == 0 ? sd0 : (pass == 1 ? sd1 : sd2);
+                        float em = pass == 0 ? em0 : (pass == 1 ? em1 : em2);
+                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc, far, &sd, &em, move_r, move_t);
+                        sd0 = pass == 0 ? sd : sd0, sd1 = pass == 1 ? sd : sd1, sd2 = pass == 2 ? sd : sd2;
+                        if (kSeedEmpty) em0 = pass == 0 ? em : em0, em1 = pass == 1 ? em : em1, em2 = pass == 2 ? em : em2;
+                    } else {
+                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc, far);
+                    }
                     p0 += kBlock / (G > 0 ? G : 1);
                 } else if (rem * 2 > kBlock) {
                     point_pass<1, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);

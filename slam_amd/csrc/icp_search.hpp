@@ -426,9 +426,10 @@ __device__ inline Best nn_search_seeded(const IndexPtrs<StartT> &ix, const Model
 {
     bool tie = false;
     Best b = nn_search_seeded_impl<G, StartT, false>(ix, mv, cls, qx, qy, sub, gate, tie, seed, empty_in, move, empty_out);
-    if (tie) {
+    if (tie) { // rare: the plain exact search (the seed changes the cost of a search, never its result)
         bool unused = false;
-        b = nn_search_seeded_impl<G, StartT, true>(ix, mv, cls, qx, qy, sub, gate, unused, seed, empty_in, move, empty_out);
+        b = nn_search_impl<G, StartT, true>(ix, mv, cls, qx, qy, sub, gate, unused);
+        empty_out = 0.0f;
     }
     return b;
 }

@@ -9,7 +9,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/profile_$TAG
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf "$OUT" && mkdir -p "$OUT"
-BENCH="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.json 2> $OUT/stats.err || echo "stats pass failed"
 i=0
 for PMC in "FETCH_SIZE" "WRITE_SIZE" \
@@ -19,6 +19,15 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc_$i -- $BENCH > $OUT/pmc_$i.json 2> $OUT/pmc_$i.err || echo "pmc pass $i failed"
 done
+# the run-length merged raycast (measured slower: the counters say why) and the single-scan / config-3 path
+for PMC in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS"; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc_merge -- $BENCH --raycast merge > $OUT/pmc_merge.json 2> $OUT/pmc_merge.err || echo "pmc merge pass failed"
+done
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_merge -- $BENCH --raycast merge > $OUT/stats_merge.json 2> $OUT/stats_merge.err || echo "stats merge failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- python3 bench.py --config 3 --clouds 20 > $OUT/config3.json 2> $OUT/config3.err || echo "config 3 stats failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_build -- python3 tools/profile_build.py > $OUT/build.txt 2> $OUT/build.err || echo "build stats failed"
+timeout -k 10 600 python3 bench.py --config 5 > $OUT/config5.json 2> $OUT/config5.err || echo "config 5 failed"
+timeout -k 10 600 python3 bench.py --config 4 --no-extras --no-cpu-baseline > $OUT/config4.json 2> $OUT/config4.err || echo "config 4 failed"
 # the un-profiled bench line, for reference beside the profiled one
 timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || echo "bench failed"
 ls $OUT

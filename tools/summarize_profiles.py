@@ -76,9 +76,39 @@ for k, cs in acc.items():
         if cycles > 0:
             traffic.setdefault(k, {})["valu_busy_frac"] = 4.0 * mean("SQ_ACTIVE_INST_VALU") / (1024.0 * cycles)
             traffic[k]["kernel_cycles"] = cycles
+    if "SQ_THREAD_CYCLES_VALU" in cs and "SQ_ACTIVE_INST_VALU" in cs:
+        # lanes that did work per issued VALU instruction slot (64 = every lane of every instruction)
+        mean = lambda c: sum(cs[c]) / len(cs[c])
+        if mean("SQ_ACTIVE_INST_VALU") > 0:
+            traffic.setdefault(k, {})["valu_active_lane_share"] = mean("SQ_THREAD_CYCLES_VALU") / (64.0 * mean("SQ_ACTIVE_INST_VALU"))
+    if "SQ_LDS_BANK_CONFLICT" in cs and "SQ_LDS_IDX_ACTIVE" in cs:
+        mean = lambda c: sum(cs[c]) / len(cs[c])
+        if mean("SQ_LDS_IDX_ACTIVE") > 0:
+            traffic.setdefault(k, {})["lds_bank_conflict_share"] = mean("SQ_LDS_BANK_CONFLICT") / mean("SQ_LDS_IDX_ACTIVE")
 json.dump(traffic, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1, sort_keys=True)
-for name in ("bench.json",):
+for name in ("bench.json", "config3.json", "config4.json", "config5.json", "build.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, tag + "_" + name))
+# the side runs: kernel stats of the merged raycast, config 3 and the index build; counters of the merged raycast
+for sub, out in (("stats_merge", "raycast_merge_kernel_stats.csv"), ("stats_c3", "config3_kernel_stats.csv"), ("stats_build", "build_kernel_stats.csv")):
+    st = glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv"))
+    if st:
+        rows = list(csv.DictReader(open(st[0])))
+        with open(os.path.join(dst, tag + "_" + out), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
+            for r in rows:
+                w.writerow([kname(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+macc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(src, "pmc_merge", "*", "*counter_collection.csv")):
+    for r in csv.DictReader(open(f)):
+        macc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+if macc:
+    with open(os.path.join(dst, tag + "_pmc_raycast_merge.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch"])
+        for k in sorted(macc):
+            for c, v in sorted(macc[k].items()):
+                w.writerow([k, c, len(v), "%.6g" % (sum(v) / len(v))])
 print("wrote", sorted(os.listdir(dst)))
