@@ -382,6 +382,10 @@ int build_index_host(slam_icp *h, const double *m_ga, int n_ga, const double *m_
             cell_of[c][i] = lattice_coord(xy[c][2 * i + 1], mv.lat.y0, mv.lat.inv_h, mv.lat.ny) * mv.lat.nx +
                             lattice_coord(xy[c][2 * i], mv.lat.x0, mv.lat.inv_h, mv.lat.nx);
     }
+    for (int c = 0; c < 2; ++c) { // points in the fullest cell (picks the one-scan form's lanes per query)
+        std::vector<int> per(mv.lat.nx * mv.lat.ny, 0);
+        for (int v : cell_of[c]) h->max_cell_points = std::max(h->max_cell_points, ++per[v]);
+    }
     std::vector<unsigned char> blob(mv.blob_bytes, 0);
     if (h->start32)
         fill_index_host<uint32_t>(blob, mv, xy, cell_of);
@@ -498,6 +502,7 @@ struct ScanArgs {
     unsigned      *v[2];    // counts of class 0 / 1, n + 1 values each
     unsigned char *out[2];  // the blob's start arrays
     unsigned      *tiles;   // [2][n_tiles] tile totals
+    unsigned      *most;    // nullable: receives the largest count (points in the fullest cell)
     int            n, n_tiles, esz;
 };
 
@@ -517,11 +522,19 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(ScanArgs a)
 {
     __shared__ unsigned s_wave[16];
     const int           c = blockIdx.y, k0 = blockIdx.x * kScanTile + (int)threadIdx.x * kScanPer;
-    unsigned            sum = 0;
+    unsigned            sum = 0, most = 0;
 #pragma unroll
-    for (int j = 0; j < kScanPer; ++j) sum += k0 + j < a.n ? a.v[c][k0 + j] : 0u;
+    for (int j = 0; j < kScanPer; ++j) {
+        const unsigned x = k0 + j < a.n ? a.v[c][k0 + j] : 0u;
+        sum += x;
+        most = max(most, x);
+    }
     const unsigned t = block_sum_1024(sum, s_wave);
     if (threadIdx.x == 0) a.tiles[c * a.n_tiles + blockIdx.x] = t;
+    if (a.most) {
+        for (int o = 32; o > 0; o >>= 1) most = max(most, (unsigned)__shfl_xor((int)most, o));
+        if ((threadIdx.x & 63) == 0 && most > __hip_atomic_load(a.most, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a.most, most);
+    }
 }
 
 __global__ __launch_bounds__(1024) void scan_apply_kernel(ScanArgs a)
@@ -558,9 +571,10 @@ __global__ __launch_bounds__(1024) void scan_apply_kernel(ScanArgs a)
 }
 
 int launch_scan(unsigned *v0, unsigned *v1, int n, unsigned char *out0, unsigned char *out1, int esz, unsigned *tiles,
-                hipStream_t st)
+                hipStream_t st, unsigned *most = nullptr)
 {
     ScanArgs a;
+    a.most = most;
     a.v[0] = v0;
     a.v[1] = v1;
     a.out[0] = out0;
@@ -1009,7 +1023,7 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
     size_t       lcells_max = 0;
     for (const ListCand &c : cands) lcells_max = std::max(lcells_max, (size_t)(c.nx * c.ny));
     const size_t lcnt_words = nc ? 2 * (lcells_max + 1) + 2 * lcells_max + 8 : 0;
-    const size_t zero_bytes = ((4 * cnt_words + 15) & ~(size_t)15) + 16 * (size_t)std::max(nc, 1) + 4 * lcnt_words;
+    const size_t zero_bytes = ((4 * cnt_words + 15) & ~(size_t)15) + 16 * (size_t)std::max(nc, 1) + 4 * lcnt_words + 16;
     unsigned char *zero = static_cast<unsigned char *>(ws.get(zero_bytes));
     h->d_blob = pool_alloc(mv.blob_bytes);
     if (!zero || !h->d_blob) return SLAM_E_NOMEM;
@@ -1034,6 +1048,7 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
     a.cursor = a.start + 2 * (size_t)(ncells + 1);
     unsigned long long *d_ent = reinterpret_cast<unsigned long long *>(zero + ((4 * cnt_words + 15) & ~(size_t)15));
     unsigned           *d_lcnt = reinterpret_cast<unsigned *>(d_ent + 2 * (size_t)std::max(nc, 1));
+    unsigned           *d_most = reinterpret_cast<unsigned *>(zero + zero_bytes - 16); // points in the fullest cell
     a.blob = static_cast<unsigned char *>(h->d_blob);
     a.off_pts = mv.off_pts;
     a.off_start[0] = mv.off_start[0];
@@ -1058,7 +1073,7 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
         SLAM_HIP(hipEventCreateWithFlags(&ev_ent, hipEventDisableTiming));
         SLAM_HIP(hipEventRecord(ev_ent, st));
     }
-    SLAM_TRY(launch_scan(a.start, a.start + (ncells + 1), ncells, a.blob + a.off_start[0], a.blob + a.off_start[1], a.esz, d_tiles, st));
+    SLAM_TRY(launch_scan(a.start, a.start + (ncells + 1), ncells, a.blob + a.off_start[0], a.blob + a.off_start[1], a.esz, d_tiles, st, d_most));
     hipLaunchKernelGGL(idx_fill_kernel, dim3(pblocks), dim3(256), 0, st, a);
     hipLaunchKernelGGL(idx_rank_kernel, dim3(pblocks), dim3(256), 0, st, a);
     SLAM_HIP(hipGetLastError());
@@ -1126,7 +1141,10 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
         }
     }
     // the workspace goes back to the pool when this returns: the device must be done with it
+    unsigned *h_most = reinterpret_cast<unsigned *>(static_cast<unsigned char *>(pinned_scratch(16 * (size_t)std::max(nc, 1) + 64)) + 16 * (size_t)std::max(nc, 1));
+    if (h_most) SLAM_HIP(hipMemcpyAsync(h_most, d_most, 4, hipMemcpyDeviceToHost, st));
     SLAM_HIP(hipStreamSynchronize(st));
+    if (h_most) h->max_cell_points = (int)*h_most;
     h->built_on_device = true;
     return SLAM_OK;
 }

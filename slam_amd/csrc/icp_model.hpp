@@ -158,6 +158,7 @@ struct slam_icp {
     double          last_indist = 0;
     bool            have_last = false;
     int             n_cu = 256;          // CUs of the device the handle was made on
+    int             max_cell_points = 0; // points in the fullest cell of the index (either class)
     bool            built_on_device = false;
     double          build_ms[4] = {0, 0, 0, 0}; // host pass + upload, cell index kernels, list plan (sync), list kernels
 };

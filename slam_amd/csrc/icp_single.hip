@@ -20,6 +20,7 @@
 // (iters = -1) instead of hanging the queue.  All workgroups of a launch must be resident together: the grid is
 // at most one workgroup per CU.
 #include <algorithm>
+#include <cstdlib>
 
 #include "icp_search.hpp"
 
@@ -29,6 +30,7 @@ using namespace slam::icp;
 namespace {
 
 constexpr int      kSB = 512, kSW = kSB / 64;      // threads / wavefronts of a spread workgroup (256 VGPRs per lane: no spills)
+constexpr int      kDenseCell = 64;                // points in the fullest cell from which a query gets 64 lanes instead of 16
 constexpr int      kGranPerWg = 2 * kNumAcc;       // 18 granules: hi and lo half of nine doubles
 constexpr unsigned long long kSpinTicks = 200000000ull; // 2 s of the 100 MHz wall clock
 
@@ -201,7 +203,7 @@ __device__ inline bool spread_iterations(const ModelView &mv, const FitArgs &fa,
 // grid (parts, n_scans); a workgroup whose scan does not need it exits at once
 template <typename StartT, bool LDS>
 __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitArgs fa, unsigned long long *gran, float2 *qstate,
-                                                                int qcap)
+                                                                int qcap, int wide_max)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = blockIdx.y, parts = (int)gridDim.x, part = blockIdx.x;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitAr
     const int n = fa.scan_off[s + 1] - off;
     const int nga = fa.scan_nga[s];
     if (n < 5 || fa.max_iter <= 0) return; // icp.cpp:100-103: R, t untouched
-    const bool wide = n <= 4096;
+    const bool wide = n <= wide_max; // 64 lanes per query up to here, 16 beyond
     if (part >= active_parts(n, wide ? 64 : 16, parts)) return;
     const unsigned char *base = mv.blob;
     if (LDS) {
@@ -275,14 +277,22 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
     SLAM_TRY(h->w_state.reserve(sizeof(float2) * (size_t)qcap));
     float2    *qstate = static_cast<float2 *>(h->w_state.p);
     const dim3 grid(parts, n_scans);
+    // Lanes per query.  A 2-D map holds a handful of points per cell: 16 lanes take a query's cells in one or two
+    // steps, a 1081-point scan is 34 workgroups, and the exchange between them is the larger part of an iteration --
+    // fewer workgroups, cheaper exchange (0.17 against 0.22 ms for 20 iterations).  A lidar cloud holds hundreds of
+    // points per cell near the sensor: there a query wants the whole wavefront (config 3: 0.46 against 1.03 ms).
+    int        wide_max = h->max_cell_points > kDenseCell ? 4096 : 0;
+#ifdef SLAM_MEASURE
+    if (const char *e = getenv("SLAM_SPREAD_WIDE_MAX")) wide_max = atoi(e);
+#endif
     if (h->in_lds) {
         auto kern = icp_fit_spread_kernel<uint16_t, true>;
         SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-        hipLaunchKernelGGL(kern, grid, dim3(kSB), h->lds_bytes, st, h->mv, fa, gran, qstate, qcap);
+        hipLaunchKernelGGL(kern, grid, dim3(kSB), h->lds_bytes, st, h->mv, fa, gran, qstate, qcap, wide_max);
     } else if (h->start32) {
-        hipLaunchKernelGGL((icp_fit_spread_kernel<uint32_t, false>), grid, dim3(kSB), kScratchBytes, st, h->mv, fa, gran, qstate, qcap);
+        hipLaunchKernelGGL((icp_fit_spread_kernel<uint32_t, false>), grid, dim3(kSB), kScratchBytes, st, h->mv, fa, gran, qstate, qcap, wide_max);
     } else {
-        hipLaunchKernelGGL((icp_fit_spread_kernel<uint16_t, false>), grid, dim3(kSB), kScratchBytes, st, h->mv, fa, gran, qstate, qcap);
+        hipLaunchKernelGGL((icp_fit_spread_kernel<uint16_t, false>), grid, dim3(kSB), kScratchBytes, st, h->mv, fa, gran, qstate, qcap, wide_max);
     }
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
