@@ -149,20 +149,20 @@ def single_scan_times(api, synth, m_ga, m_nga):
             "registered_points_per_s": n / float(np.median(ts))}
 
 
-def stream_rate(api, synth, m_ga, m_nga, batch, grid_size, n_chunks=6, **kw):
+def stream_rate(api, synth, m_ga, m_nga, batch, grid_size, n_chunks=12, **kw):
     """The same batch fed from pinned host memory through the streaming mapper (H2D | ICP | raycast on three streams):
     seconds per chunk in steady state, PCIe inclusive."""
     mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=grid_size, grid_size_y=grid_size,
                     resolution=RES, max_scans=batch.n_scans, max_points=batch.n_points,
                     icp=dict(max_iter=N_ITERS, min_delta=-1.0), **kw)
-    for s in (mp.push(batch), mp.push(batch)):   # warm-up: both slots, every scratch buffer
+    for s in [mp.push(batch) for _ in range(mp.n_slots)]:   # warm-up: every slot, every scratch buffer
         mp.wait(s)
     api.synchronize()
     t0 = time.perf_counter()
     pending = []
     for k in range(n_chunks):
-        if len(pending) == 2:
-            mp.wait(pending.pop(0))          # poses of chunk k-2 back on the host, its slot free
+        if len(pending) == mp.n_slots:
+            mp.wait(pending.pop(0))          # poses of the oldest chunk in flight back on the host, its slot free
         pending.append(mp.push(batch))
     for s in pending:
         R, t = mp.wait(s)
@@ -202,8 +202,11 @@ def main():
     ap.add_argument("--raycast", choices=["tiled", "merge", "global"], default="tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip model build, single scan, streaming and config-3 legs")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not overlap the grid update of step k-1 with the registration of step k (one stream: a captured "
+                         "hipGraph per step at N=1, call by call otherwise)")
     ap.add_argument("--no-graph", action="store_true",
-                    help="N=1: launch every step call by call instead of replaying one captured hipGraph")
+                    help="with --no-pipeline at N=1: launch every step call by call instead of replaying one captured hipGraph")
     ap.add_argument("--no-torch", action="store_true", help="N=1 only: do not import torch at all")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N>1 data plane: nccl = the library's RCCL merge (slam_grid_merge_begin/_finish); gloo = a "
@@ -308,58 +311,52 @@ def main():
                                         "version": 2, "strides": None}
         planes = torch.as_tensor(_Planes(), device=torch.device("cuda", local_rank)).view(2, GRID, GRID)
 
-    ev = [[api.Event() for _ in range(5)] for _ in range(args.steps)]
-
-    # N=1: all calls go to one created stream, so that a step can be captured into a hipGraph and replayed
-    # with a single launch (about nine launches per step otherwise).
-    # N>1: two streams.  A: poses in, ICP, then -- once the previous step's finalize has released the planes --
-    # count reset, raycast and the 8-byte exchange of the rows the ranks touched (slam_grid_merge_begin).
-    # B: the RCCL sum of those rows (slam_grid_merge_finish) and finalize.  The host issues step k+1's
-    # registration BEFORE it waits for step k's row range, so the registration of step k+1 (which does not
-    # touch the planes) runs while step k's rows are summed over xGMI and finalized.  No warm-up knowledge.
-    streams = {"a": api.Stream()}
-    streams["b"] = api.Stream() if multi else streams["a"]
-    ev_ray, ev_fin = api.Event(), api.Event()      # planes written by the raycast / released by finalize
+    # ---- how steps are launched
+    # pipeline (default): two streams over CONSECUTIVE steps.  A: initial poses in, ICP of step k (touches no plane).
+    #   B: count reset, raycast, [N>1: exchange of the touched rows, RCCL sum of those rows,] finalize of step k-1.  The
+    #   registration of a batch fills a CU with one workgroup for as long as its scan takes, and the launch ends with
+    #   the slowest scan: the grid update of the batch before takes the CUs that fall idle in that tail (0.53 -> 0.44 ms
+    #   per step on config 2).  Every step still does all of its work; K steps are timed to completion.  With N>1 the
+    #   host's wait for the 8-byte row range of step k-1 comes after step k's registration has been enqueued.
+    # graph: one stream, one captured hipGraph replayed per step (N=1).  calls: one stream, call by call.
+    launch = "pipeline" if not args.no_pipeline else ("calls" if (multi or args.no_graph or not args.warmup) else "graph")
+    sa, sb = api.Stream(), api.Stream()
+    pose = [d_pose, api.DeviceArray(d_pose0.shape, np.float64)]
+    pR = [p_.view(0, batch.R.shape) for p_ in pose]
+    pt = [p_.view(batch.R.size, batch.t.shape) for p_ in pose]
+    icp_done = [api.Event() for _ in range(2)]
+    grid_done = [api.Event() for _ in range(2)]
     merge_rows_seen = []
 
-    def front(e=None):
-        """The registration of a step: initial poses in, ICP (does not touch the planes)."""
-        a = streams["a"]
-        d_pose.copy_from(d_pose0, a)
+    def enqueue_icp(k, a, e=None):
+        s_ = k % 2
+        a.wait_event(grid_done[s_])                    # the grid update two steps ago has read these poses
+        pose[s_].copy_from(d_pose0, a)
         if e: e[0].record(a)
-        icp.fit_batch_dev(d_pts, d_off, d_nga, S, d_R, d_t, 5.0, d_res, None, a)
+        icp.fit_batch_dev(d_pts, d_off, d_nga, S, pR[s_], pt[s_], 5.0, d_res, None, a)
         if e: e[1].record(a)
+        icp_done[s_].record(a)
 
-    def middle(e=None):
-        """The grid update of a step (and, N>1, the start of the exchange of the touched rows)."""
-        a = streams["a"]
-        if multi:
-            a.wait_event(ev_fin)                   # the previous step's merge + finalize have released the planes
-        grid.reset_counts(a)
-        grid.raycast_scans_dev(d_pts, d_off, S, P, d_R, d_t, a)
-        if e: e[2].record(a)
+    def enqueue_grid(k, b, e=None):
+        s_ = k % 2
+        b.wait_event(icp_done[s_])
+        grid.reset_counts(b)
+        grid.raycast_scans_dev(d_pts, d_off, S, P, pR[s_], pt[s_], b)
+        if e: e[2].record(b)
         if multi:
             if comm is not None:
-                comm.merge_begin(grid, a)
-            ev_ray.record(a)
-
-    def back(e=None):
-        """The merge of the touched rows and finalize."""
-        b = streams["b"]
-        if multi:
-            b.wait_event(ev_ray)
-            if comm is not None:
+                comm.merge_begin(grid, b)
                 merge_rows_seen.append(comm.merge_finish(grid, b))      # waits for the 8-byte range, then the row all-reduce
-            else:
-                ev_ray.synchronize()
+            else:                                                       # gloo rehearsal on one GPU
+                b.synchronize()
                 lo, hi = grid.dirty_rows()
                 rng = torch.tensor([lo if hi >= lo else 1 << 30, -hi if hi >= lo else 1 << 30], dtype=torch.int64)
                 dist.all_reduce(rng, op=dist.ReduceOp.MIN)
                 lo, hi = int(rng[0]), -int(rng[1])
                 merge_rows_seen.append((lo, hi))
                 if hi >= lo:
-                    for k in range(2):
-                        part = planes[k, lo:hi + 1]
+                    for j in range(2):
+                        part = planes[j, lo:hi + 1]
                         host = part.cpu()
                         dist.all_reduce(host)
                         part.copy_(host)
@@ -367,32 +364,27 @@ def main():
         if e: e[3].record(b)
         grid.finalize(b)
         if e: e[4].record(b)
-        if multi:
-            ev_fin.record(b)
+        grid_done[s_].record(b)
 
-    def run_steps(n, events=None):
-        """n steps; N>1 software-pipelined: the registration of step k+1 is issued before the host waits for the
-        rows of step k's merge, and runs on the GPU while those rows are summed and finalized."""
+    def run_steps(n, events=None, pipelined=True):
         if n <= 0:
             return
         E = (lambda k: events[k]) if events else (lambda k: None)
-        if not multi:
+        if pipelined:
             for k in range(n):
-                front(E(k))
-                middle(E(k))
-                back(E(k))
-            return
-        front(E(0))
-        middle(E(0))
-        for k in range(n):
-            if k + 1 < n:
-                front(E(k + 1))
-            back(E(k))
-            if k + 1 < n:
-                middle(E(k + 1))
+                enqueue_icp(k, sa, E(k))
+                if k >= 1:
+                    enqueue_grid(k - 1, sb, E(k - 1))
+            enqueue_grid(n - 1, sb, E(n - 1))
+        else:
+            for k in range(n):
+                enqueue_icp(k, sa, E(k))
+                enqueue_grid(k, sa, E(k))
 
+    for e_ in grid_done:
+        e_.record(sb)
     grid.clear()
-    run_steps(args.warmup)
+    run_steps(args.warmup, pipelined=launch == "pipeline")
     sync()
     upd_per_step = None
     if args.warmup:
@@ -403,38 +395,39 @@ def main():
     barrier()
     sync()
     graph = None
-    if not multi and not args.no_graph and args.warmup:
+    if launch == "graph":
         try:
-            graph = api.Graph(streams["a"])
+            graph = api.Graph(sa)
             with graph:      # the warm-up ran the same calls: every scratch buffer exists
-                front()
-                middle()
-                back()
+                pose[0].copy_from(d_pose0, sa)
+                icp.fit_batch_dev(d_pts, d_off, d_nga, S, pR[0], pt[0], 5.0, d_res, None, sa)
+                grid.reset_counts(sa)
+                grid.raycast_scans_dev(d_pts, d_off, S, P, pR[0], pt[0], sa)
+                grid.finalize(sa)
             sync()
             graph.launch()   # one replay outside the timed region: a graph that cannot run must not cost the bench
             sync()
         except Exception as ex:   # fall back to launching call by call on a fresh stream
             print("hipGraph capture/replay failed (%s); launching call by call" % ex, file=sys.stderr)
-            graph = None
-            streams["a"] = streams["b"] = api.Stream()
-            front()
-            middle()
-            back()
+            graph, launch = None, "calls"
+            sa = sb = api.Stream()
+            run_steps(1, pipelined=False)
             sync()
     t0 = time.perf_counter()
     if graph is not None:
         for k in range(args.steps):
             graph.launch()
     else:
-        run_steps(args.steps, ev)
+        run_steps(args.steps, pipelined=launch == "pipeline")
     sync()
     barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    if graph is not None:    # per-kernel times from a few event-bracketed steps outside the timed region
-        ev = ev[:min(len(ev), 10)]
-        run_steps(len(ev), ev)
-        sync()
+    # per-kernel times from a few event-bracketed steps run one after the other, outside the timed region
+    ev = [[api.Event() for _ in range(5)] for _ in range(min(max(args.steps, 1), 10))]
+    run_steps(len(ev), ev, pipelined=False)
+    sync()
+    d_R, d_t = pR[(len(ev) - 1) % 2], pt[(len(ev) - 1) % 2]
 
     if upd_per_step is None:
         upd_per_step = grid.total_updates() // max(args.steps, 1)
@@ -505,7 +498,9 @@ def main():
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 pose / f32 distance / int32 counts",
-            "data": "synthetic", "launch": "hipGraph replay of one captured step" if graph is not None else "call by call",
+            "data": "synthetic",
+            "launch": {"pipeline": "two streams over consecutive steps: ICP of step k beside the grid update of step k-1",
+                       "graph": "hipGraph replay of one captured step", "calls": "one stream, call by call"}[launch],
             "config": {"workload": "BASELINE config %s per GPU: %d x 1081-beam scans (%d points), %d ICP "
                                    "iterations vs %d-point map, Bresenham raycast into %dx%d @%.2f m, "
                                    "finalize%s" % ("2" if (S, GRID) == (256, 2000) else ("4" if (S, GRID) == (1024, 4000) else "2 (resized)"),
@@ -535,7 +530,7 @@ def main():
             out["value_pcie_inclusive"] = P / dt
             out["pcie_inclusive"] = {"ms_per_chunk": dt * 1e3, "chunk_scans": S,
                                      "path": "slam_mapper_push/_wait: pinned host chunk -> H2D | ICP | raycast on three "
-                                             "streams -> poses D2H; steady state over 6 chunks"}
+                                             "streams -> poses D2H; steady state over 12 chunks, three in flight"}
             out["single_scan"] = single_scan_times(api, synth, m_ga, m_nga)
             try:
                 c3 = run_config3(8)
@@ -573,14 +568,14 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, ba
                     thin_res=args.thin, merge_every=args.merge_every)
     if comm is not None:
         mp.use_comm(comm)
-    for s in (mp.push(base), mp.push(base)):
+    for s in [mp.push(base) for _ in range(mp.n_slots)]:
         mp.wait(s)
     sync()
     barrier()
     t0 = time.perf_counter()
     pending, worst = [], 0.0
     for k in range(n_chunks):
-        if len(pending) == 2:
+        if len(pending) == mp.n_slots:
             slot, j = pending.pop(0)
             R, t = mp.wait(slot)
             worst = max(worst, float(np.abs(t - chunks[j].true_poses[:, :2]).max()))
@@ -603,7 +598,7 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, ba
         pts = sum(c.n_points for c in chunks) * world
         print(json.dumps({
             "metric": "registered_scan_points_per_s", "value": pts / elapsed, "unit": "points/s", "n_gpus": world,
-            "steps": n_chunks, "warmup": 2, "ms_per_step": elapsed / n_chunks * 1e3, "higher_is_better": True, "scaling": "weak",
+            "steps": n_chunks, "warmup": mp.n_slots, "ms_per_step": elapsed / n_chunks * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 pose / f32 distance / int32 counts", "data": "synthetic",
             "config": {"workload": "BASELINE config 5 per GPU: %d scans streamed in chunks of %d from pinned host memory, %d ICP "
                                    "iterations against a sliding-window target (5 k-point prior map + 5 k points of the last 4 chunks, rebuilt on "

@@ -67,6 +67,9 @@ int slam_memcpy_h2d_async(void *dst_dev, const void *src_pinned, size_t bytes, s
 int slam_memcpy_d2h_async(void *dst_pinned, const void *src_dev, size_t bytes, slam_stream_t stream);
 int slam_stream_wait_event(slam_stream_t stream, slam_event_t ev);
 int slam_stream_create(slam_stream_t *stream);
+/* priority > 0: the device's highest stream priority, < 0: its lowest, 0: the middle.  When workgroups of several
+ * streams wait for CUs, those of the higher priority are placed first. */
+int slam_stream_create_with_priority(slam_stream_t *stream, int priority);
 int slam_stream_destroy(slam_stream_t stream);
 int slam_stream_synchronize(slam_stream_t stream);
 int slam_device_synchronize(void);
@@ -417,6 +420,9 @@ typedef struct {
     int    pipelined;          /* 1 = three streams; 0 = one stage after the other on one stream (same results) */
     int    strict_window;      /* 1 = a rebuild waits for the newest registered chunk (reproducible targets; the
                                   pipeline stalls for one registration); 0 = it takes what has finished */
+    int    slots;              /* chunks in flight (device + pinned buffers each): 2..4, default 3 -- with three the
+                                  host enqueues chunk k while k-1 registers and k-2 is mapped, so the ICP stream never
+                                  waits for the host (two: 0.53 ms per 256-scan chunk, three: 0.45) */
     double thin_res;           /* > 0: the window is thinned to one point per cell of this pitch (metres) and class over
                                   the grid's extent, the oldest measurement of a cell kept (where pcl::VoxelGrid keeps a
                                   centroid, icpTools.cpp:620-633); 0: every stride-th point of a chunk instead */
@@ -430,6 +436,7 @@ void slam_mapper_destroy(slam_mapper_t *m);
 /* The producer fills the PINNED buffers of slot slam_mapper_next_slot() -- points (xy f64), scan_off
  * (n_scans + 1, from 0), scan_nga, initial poses R0 (4 per scan) and t0 (2 per scan) -- and pushes. */
 int  slam_mapper_next_slot(slam_mapper_t *m, int *slot);
+int  slam_mapper_slots(slam_mapper_t *m, int *n_slots);
 int  slam_mapper_chunk_buffers(slam_mapper_t *m, int slot, double **pts, int32_t **scan_off, int32_t **scan_nga,
                                double **R0, double **t0);
 /* enqueues the chunk in the next slot and returns at once; window_x/y: where a rolling grid is centred for it */

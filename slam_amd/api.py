@@ -51,7 +51,7 @@ class MapperParams(C.Structure):
                 ("icp", IcpParams), ("indist", C.c_double), ("max_scans", C.c_int), ("max_points", C.c_int),
                 ("window_chunks", C.c_int), ("rebuild_every", C.c_int), ("target_points", C.c_int),
                 ("keep_prior", C.c_int), ("merge_every", C.c_int), ("pipelined", C.c_int), ("strict_window", C.c_int),
-                ("thin_res", C.c_double)]
+                ("slots", C.c_int), ("thin_res", C.c_double)]
 
 
 class GsegParams(C.Structure):
@@ -76,7 +76,7 @@ EXPORTS = [
     "slam_memcpy_d2d", "slam_host_alloc", "slam_host_free", "slam_memcpy_h2d_async",
     "slam_memcpy_d2h_async", "slam_stream_wait_event", "slam_graph_begin_capture", "slam_graph_end_capture",
     "slam_graph_launch", "slam_graph_destroy",
-    "slam_stream_create", "slam_stream_destroy", "slam_stream_synchronize",
+    "slam_stream_create", "slam_stream_create_with_priority", "slam_stream_destroy", "slam_stream_synchronize",
     "slam_device_synchronize", "slam_event_create", "slam_event_destroy", "slam_event_record",
     "slam_event_synchronize", "slam_event_elapsed_ms",
     "slam_icp_default_params", "slam_icp_create", "slam_icp_create_dev", "slam_icp_destroy",
@@ -98,7 +98,7 @@ EXPORTS = [
     "slam_gseg_classify_ga_dev",
     "slam_ccicp_create", "slam_ccicp_destroy", "slam_ccicp_voxel_downsample_dev", "slam_ccicp_split_dev",
     "slam_ccicp_height_dev", "slam_ccicp_bin_order_dev", "slam_ccicp_select_dev",
-    "slam_mapper_default_params", "slam_mapper_create", "slam_mapper_destroy", "slam_mapper_next_slot",
+    "slam_mapper_default_params", "slam_mapper_create", "slam_mapper_destroy", "slam_mapper_next_slot", "slam_mapper_slots",
     "slam_mapper_chunk_buffers", "slam_mapper_push", "slam_mapper_wait", "slam_mapper_finish", "slam_mapper_grid",
     "slam_mapper_target", "slam_mapper_stats", "slam_mapper_set_merge",
 ]
@@ -147,6 +147,7 @@ def lib():
     L.slam_graph_launch.argtypes = [_vp, _vp]
     L.slam_graph_destroy.argtypes = [_vp]
     L.slam_stream_create.argtypes = [C.POINTER(_vp)]
+    L.slam_stream_create_with_priority.argtypes = [C.POINTER(_vp), C.c_int]
     L.slam_stream_destroy.argtypes = [_vp]
     L.slam_stream_synchronize.argtypes = [_vp]
     L.slam_event_create.argtypes = [C.POINTER(_vp)]
@@ -220,6 +221,7 @@ def lib():
     L.slam_mapper_destroy.restype = None
     L.slam_mapper_destroy.argtypes = [_vp]
     L.slam_mapper_next_slot.argtypes = [_vp, C.POINTER(C.c_int)]
+    L.slam_mapper_slots.argtypes = [_vp, C.POINTER(C.c_int)]
     L.slam_mapper_chunk_buffers.argtypes = [_vp, C.c_int] + [C.POINTER(_vp)] * 5
     L.slam_mapper_push.argtypes = [_vp, C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int)]
     L.slam_mapper_wait.argtypes = [_vp, C.c_int, _vp, _vp]
@@ -356,9 +358,12 @@ class PinnedArray:
 
 
 class Stream:
-    def __init__(self):
+    def __init__(self, priority=None):
         p = _vp()
-        check(lib().slam_stream_create(C.byref(p)))
+        if priority is None:
+            check(lib().slam_stream_create(C.byref(p)))
+        else:
+            check(lib().slam_stream_create_with_priority(C.byref(p), int(priority)))
         self.ptr = p.value
 
     def synchronize(self):
@@ -718,6 +723,9 @@ class Mapper:
         check(lib().slam_mapper_create(C.byref(p), _ptr(m_ga), len(m_ga), _ptr(m_nga), len(m_nga), C.byref(h)))
         self.h = h.value
         self._views = {}
+        ns = C.c_int()
+        check(lib().slam_mapper_slots(self.h, C.byref(ns)))
+        self.n_slots = ns.value
         g = _vp()
         check(lib().slam_mapper_grid(self.h, C.byref(g)))
         self.grid = object.__new__(Grid)

@@ -160,6 +160,8 @@ struct Slot {
     int      n_scans = 0;
 };
 
+constexpr int kMaxSlots = 4;
+
 struct WindowEntry {
     double2 *ga = nullptr, *nga = nullptr; // device, room for max_points each
     int      n_ga = 0, n_nga = 0;
@@ -175,7 +177,8 @@ struct slam_mapper {
     slam_icp_t        *target = nullptr, *retired = nullptr;
     hipEvent_t         target_used = nullptr, retired_used = nullptr; // behind the last launch that read the handle
     hipStream_t        copy = nullptr, icp_s = nullptr, grid_s = nullptr;
-    Slot               slot[2];
+    Slot               slot[kMaxSlots];
+    int                n_slots = 3;
     int                next = 0;
     long               chunks = 0, merges = 0, rebuilds = 0, last_rebuild = -1;
     std::vector<WindowEntry> window;
@@ -369,6 +372,7 @@ void slam_mapper_default_params(slam_mapper_params *p)
     p->pipelined = 1;
     p->strict_window = 0;
     p->thin_res = 0.0;
+    p->slots = 3;
 }
 
 int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int n_ga, const double *m_nga, int n_nga,
@@ -402,7 +406,9 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
         hip(hipEventCreateWithFlags(&m->target_used, hipEventDisableTiming));
         hip(hipEventCreateWithFlags(&m->retired_used, hipEventDisableTiming));
         const size_t np = (size_t)params->max_points, ns = (size_t)params->max_scans;
-        for (Slot &b : m->slot) {
+        m->n_slots = params->slots >= 2 && params->slots <= kMaxSlots ? params->slots : 3;
+        for (int k = 0; k < m->n_slots; ++k) {
+            Slot &b = m->slot[k];
             hip(hipMalloc((void **)&b.d_pts, 16 * np));
             hip(hipMalloc((void **)&b.d_off, 4 * (ns + 1)));
             hip(hipMalloc((void **)&b.d_nga, 4 * ns));
@@ -472,7 +478,7 @@ void slam_mapper_destroy(slam_mapper_t *m)
 int slam_mapper_chunk_buffers(slam_mapper_t *m, int slot, double **pts, int32_t **scan_off, int32_t **scan_nga, double **R0,
                               double **t0)
 {
-    SLAM_REQUIRE(m && (slot == 0 || slot == 1), SLAM_E_INVALID, "slam_mapper_chunk_buffers: bad arguments");
+    SLAM_REQUIRE(m && slot >= 0 && slot < m->n_slots, SLAM_E_INVALID, "slam_mapper_chunk_buffers: bad arguments");
     Slot &b = m->slot[slot];
     if (pts) *pts = b.h_pts;
     if (scan_off) *scan_off = b.h_off;
@@ -486,6 +492,13 @@ int slam_mapper_next_slot(slam_mapper_t *m, int *slot)
 {
     SLAM_REQUIRE(m && slot, SLAM_E_INVALID, "slam_mapper_next_slot: bad arguments");
     *slot = m->next;
+    return SLAM_OK;
+}
+
+int slam_mapper_slots(slam_mapper_t *m, int *n_slots)
+{
+    SLAM_REQUIRE(m && n_slots, SLAM_E_INVALID, "slam_mapper_slots: bad arguments");
+    *n_slots = m->n_slots;
     return SLAM_OK;
 }
 
@@ -506,7 +519,7 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
                  "slam_mapper_push: chunk of %d scans / %d points exceeds the reservation (%d / %d)", n_scans, n_points,
                  m->prm.max_scans, m->prm.max_points);
     const int s = m->next;
-    m->next ^= 1;
+    m->next = (m->next + 1) % m->n_slots;
     Slot &b = m->slot[s];
     SLAM_REQUIRE(!b.busy, SLAM_E_INVALID, "slam_mapper_push: slot %d still holds a chunk that was not waited for", s);
     SLAM_REQUIRE(b.h_off[0] == 0 && b.h_off[n_scans] == n_points, SLAM_E_INVALID, "slam_mapper_push: scan_off does not span the chunk");
@@ -571,7 +584,7 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
 
 int slam_mapper_wait(slam_mapper_t *m, int slot, double *R_out, double *t_out)
 {
-    SLAM_REQUIRE(m && (slot == 0 || slot == 1), SLAM_E_INVALID, "slam_mapper_wait: bad arguments");
+    SLAM_REQUIRE(m && slot >= 0 && slot < m->n_slots, SLAM_E_INVALID, "slam_mapper_wait: bad arguments");
     Slot &b = m->slot[slot];
     if (!b.busy) return SLAM_OK;
     MAP_HIP(hipEventSynchronize(b.registered));

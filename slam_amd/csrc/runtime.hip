@@ -299,6 +299,19 @@ int slam_stream_create(slam_stream_t *stream)
     return SLAM_OK;
 }
 
+int slam_stream_create_with_priority(slam_stream_t *stream, int priority)
+{
+    SLAM_REQUIRE(stream, SLAM_E_INVALID, "slam_stream_create_with_priority: null out pointer");
+    SLAM_TRY(require_device());
+    int lo = 0, hi = 0; // numerically lower = higher priority
+    SLAM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const int   p = priority > 0 ? hi : (priority < 0 ? lo : (lo + hi) / 2);
+    hipStream_t s;
+    SLAM_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p));
+    *stream = (slam_stream_t)s;
+    return SLAM_OK;
+}
+
 int slam_stream_destroy(slam_stream_t stream)
 {
     if (!stream) return SLAM_OK;

@@ -28,15 +28,13 @@ def run_mapper(m_ga, m_nga, batch, chunk, rolling, comm=None, **kw):
     if comm is not None:
         mp.use_comm(comm)
     R, t = np.zeros((batch.n_scans, 4)), np.zeros((batch.n_scans, 2))
-    pending = {}
+    pending = []                                  # chunks in flight, oldest first: at most one per slot
     for s0, s1, c in chunks_of(batch, chunk):
-        slot = mp.push(c, window_xy=(batch.t[s0, 0], batch.t[s0, 1]))
-        other = slot ^ 1
-        if other in pending:                      # the chunk before this one: its poses, and its slot is free again
-            a, b = pending.pop(other)
-            R[a:b], t[a:b] = mp.wait(other)
-        pending[slot] = (s0, s1)
-    for slot, (a, b) in pending.items():
+        if len(pending) == mp.n_slots:            # the slot the next push takes: its chunk's poses, and it is free again
+            slot, a, b = pending.pop(0)
+            R[a:b], t[a:b] = mp.wait(slot)
+        pending.append((mp.push(c, window_xy=(batch.t[s0, 0], batch.t[s0, 1])), s0, s1))
+    for slot, a, b in pending:
         R[a:b], t[a:b] = mp.wait(slot)
     mp.finish()
     out = dict(R=R, t=t, counts=mp.grid.read_counts(), occ=mp.grid.read_occupancy(), pose=mp.grid.get_pose(), stats=mp.stats())
@@ -44,11 +42,11 @@ def run_mapper(m_ga, m_nga, batch, chunk, rolling, comm=None, **kw):
     return out
 
 
-@pytest.mark.parametrize("n_scans,chunk,size,res", [(48, 8, 600, 0.1), (21, 5, 400, 0.15)])
-def test_fixed_target_rolling_window_matches_oracle(n_scans, chunk, size, res):
+@pytest.mark.parametrize("n_scans,chunk,size,res,slots", [(48, 8, 600, 0.1, 3), (21, 5, 400, 0.15, 2), (40, 4, 400, 0.15, 4)])
+def test_fixed_target_rolling_window_matches_oracle(n_scans, chunk, size, res, slots):
     m_ga, m_nga = synth.make_map(10000)
     batch = synth.make_batch(n_scans, n_loop=64)
-    kw = dict(grid_size_x=size, grid_size_y=size, resolution=res, max_range=0.45 * size * res)
+    kw = dict(grid_size_x=size, grid_size_y=size, resolution=res, max_range=0.45 * size * res, slots=slots)
     a = run_mapper(m_ga, m_nga, batch, chunk, rolling=1, pipelined=1, **kw)
     b = run_mapper(m_ga, m_nga, batch, chunk, rolling=1, pipelined=0, **kw)
     assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"])             # pipelined == stage after stage
