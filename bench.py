@@ -149,7 +149,7 @@ def single_scan_times(api, synth, m_ga, m_nga):
             "registered_points_per_s": n / float(np.median(ts))}
 
 
-def stream_rate(api, synth, m_ga, m_nga, batch, grid_size, n_chunks=12, **kw):
+def stream_rate(api, synth, m_ga, m_nga, batch, grid_size, n_chunks=48, **kw):
     """The same batch fed from pinned host memory through the streaming mapper (H2D | ICP | raycast on three streams):
     seconds per chunk in steady state, PCIe inclusive."""
     mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=grid_size, grid_size_y=grid_size,
@@ -320,7 +320,7 @@ def main():
     #   host's wait for the 8-byte row range of step k-1 comes after step k's registration has been enqueued.
     # graph: one stream, one captured hipGraph replayed per step (N=1).  calls: one stream, call by call.
     launch = "pipeline" if not args.no_pipeline else ("calls" if (multi or args.no_graph or not args.warmup) else "graph")
-    sa, sb = api.Stream(), api.Stream()
+    sa, sb = api.Stream(), api.Stream(priority=1)   # two priority levels: never the same hardware queue (see mapper.hip)
     pose = [d_pose, api.DeviceArray(d_pose0.shape, np.float64)]
     pR = [p_.view(0, batch.R.shape) for p_ in pose]
     pt = [p_.view(batch.R.size, batch.t.shape) for p_ in pose]
@@ -530,7 +530,7 @@ def main():
             out["value_pcie_inclusive"] = P / dt
             out["pcie_inclusive"] = {"ms_per_chunk": dt * 1e3, "chunk_scans": S,
                                      "path": "slam_mapper_push/_wait: pinned host chunk -> H2D | ICP | raycast on three "
-                                             "streams -> poses D2H; steady state over 12 chunks, three in flight"}
+                                             "streams -> poses D2H; 48 chunks, three in flight, filling and draining included"}
             out["single_scan"] = single_scan_times(api, synth, m_ga, m_nga)
             try:
                 c3 = run_config3(8)

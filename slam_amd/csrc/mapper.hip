@@ -396,9 +396,16 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
         m->prior_ga.assign(m_ga, m_ga + 2 * (size_t)n_ga);
         m->prior_nga.assign(m_nga, m_nga + 2 * (size_t)n_nga);
         if (params->pipelined) {
-            hip(hipStreamCreateWithFlags(&m->copy, hipStreamNonBlocking));
-            hip(hipStreamCreateWithFlags(&m->icp_s, hipStreamNonBlocking));
-            hip(hipStreamCreateWithFlags(&m->grid_s, hipStreamNonBlocking));
+            // One priority level each.  HIP deals the streams of a process over a few hardware queues per priority level
+            // (four unless GPU_MAX_HW_QUEUES says otherwise), in an order that depends on what the application created
+            // before: two of these three on one queue run one after the other (measured: 0.42 ms per chunk alone, 0.54 and
+            // 0.65 ms with one and two idle application streams made first).  Queues of different levels are never
+            // shared, and the levels themselves make no measurable difference to the kernels (tools/pipeline_experiment.py).
+            int lo = 0, hi = 0; // numerically lower = higher priority
+            hip(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            hip(hipStreamCreateWithPriority(&m->copy, hipStreamNonBlocking, lo));
+            hip(hipStreamCreateWithPriority(&m->icp_s, hipStreamNonBlocking, (lo + hi) / 2));
+            hip(hipStreamCreateWithPriority(&m->grid_s, hipStreamNonBlocking, hi));
         } else {
             hip(hipStreamCreateWithFlags(&m->copy, hipStreamNonBlocking));
             m->icp_s = m->grid_s = m->copy;

@@ -182,3 +182,28 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["merge_rows"] is not None
     assert d["config"]["scans_per_gpu"] == 64
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()       # counts devices without initialising the runtime
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: RCCL does not put two ranks on one device")
+def test_bench_two_ranks_rccl_merge():
+    """Two ranks, one GPU each, the library's own RCCL communicator (slam_comm_create, slam_grid_merge_begin/_finish):
+    bench.py itself asserts that the merged planes of the last step hold both ranks' updates exactly once."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--scans", "64", "--no-cpu-baseline"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    lo, hi = d["config"]["merge_rows"]
+    assert 0 <= lo <= hi < 2000
+    assert "RCCL" in d["config"]["workload"]
