@@ -423,6 +423,14 @@ def main():
     barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    # the same K steps one after the other on one stream (outside the timed region, N=1): what the pipelining buys
+    seq_ms = None
+    if launch == "pipeline" and not multi:
+        sync()
+        t1 = time.perf_counter()
+        run_steps(args.steps, pipelined=False)
+        sync()
+        seq_ms = (time.perf_counter() - t1) / max(args.steps, 1) * 1e3
     # per-kernel times from a few event-bracketed steps run one after the other, outside the timed region
     ev = [[api.Event() for _ in range(5)] for _ in range(min(max(args.steps, 1), 10))]
     run_steps(len(ev), ev, pipelined=False)
@@ -514,6 +522,9 @@ def main():
             "grid_cell_updates_per_s": total_upd * args.steps / elapsed,
             "cell_updates_per_step": total_upd,
             "point_iterations_per_s": total_pts * N_ITERS * args.steps / elapsed,
+            "one_stream": None if seq_ms is None else
+            {"ms_per_step": seq_ms, "value": total_pts / (seq_ms * 1e-3),
+             "what": "the same steps call by call on ONE stream, nothing overlapped (measured after the timed region)"},
             "kernel_ms": {"icp": float(ms_icp), "raycast": float(ms_ray), "merge": float(ms_merge),
                           "finalize": float(ms_fin)},
             "kernels": kernels,

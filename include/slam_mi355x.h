@@ -426,6 +426,9 @@ typedef struct {
     double thin_res;           /* > 0: the window is thinned to one point per cell of this pitch (metres) and class over
                                   the grid's extent, the oldest measurement of a cell kept (where pcl::VoxelGrid keeps a
                                   centroid, icpTools.cpp:620-633); 0: every stride-th point of a chunk instead */
+    int    background_rebuild; /* 1 (default) = the sliding target is rebuilt on a thread of the mapper's own and adopted
+                                  by the first push after it is complete (a push waits for it only when the next rebuild
+                                  is due or after min(rebuild_every, 4) pushes); 0 or strict_window = inside the push */
 } slam_mapper_params;
 
 void slam_mapper_default_params(slam_mapper_params *p);

@@ -27,6 +27,12 @@ void  pool_trim(); // hipFree of everything cached
 // One pinned host buffer per host thread (grown on demand, never freed), for a call's staging and read-back;
 // valid until the same thread asks again.
 void *pinned_scratch(size_t bytes);
+// The stream the index build and the mapper's target rebuild run on: one per device, created on first use at the
+// highest priority level and never destroyed.  A level of its own, because HIP deals the streams of one level over a
+// few hardware queues shared in creation order: on the default stream the build's dozen short kernels and three host
+// waits queued behind whatever registration shared that queue (0.4 ms each).  Null on failure (callers fall back to
+// the default stream).
+hipStream_t build_stream();
 
 } // namespace slam
 

@@ -956,9 +956,17 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
     const auto   t_begin = std::chrono::steady_clock::now();
     const int    n_all = n_ga + n_nga;
     const int    cnt[2] = {n_ga, n_nga};
-    hipStream_t  st = nullptr;
+    hipStream_t  st = build_stream();
     Workspace    ws;
     const int    pblocks = (n_all + 255) / 256;
+    if (st && on_device) { // a caller may have written the model on the default stream: the build starts behind it
+        hipEvent_t ev = nullptr;
+        SLAM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(ev, nullptr);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
+        (void)hipEventDestroy(ev);
+        SLAM_HIP(e);
+    }
 
     // ---- the model in HBM (f64, as the caller holds it) and its extent
     BBox          bb;

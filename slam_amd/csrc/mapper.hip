@@ -15,11 +15,17 @@
 // Every rebuild_every chunks the target is rebuilt on the device (slam_icp_create_dev, icp_build.hip) from the
 // prior map (optional) plus the decimated points of the last window_chunks chunks whose registration has
 // finished: the newest chunk is not waited for, so the target lags by one chunk instead of stalling the pipeline
-// (the north-star's "sliding-window local map ... accepting staleness").
+// (the north-star's "sliding-window local map ... accepting staleness").  The rebuild's three host waits (the thinned
+// count, the list plan, the fullest cell) each queue behind ICP workgroups that hold every CU for 0.4 ms: they run on
+// a thread of the mapper's own (background_rebuild), the producer's thread keeps pushing against the old target and
+// adopts the new one at the first push after it is complete.
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "icp_model.hpp"
@@ -195,6 +201,18 @@ struct slam_mapper {
     bool               merge_pending = false;
     int                last_rows[2] = {0, -1};
     double             rebuild_ms = 0;
+    // background rebuild (prm.background_rebuild, not with strict_window): one job at a time
+    int                device = 0;
+    int                max_lag = 0;            // pushes a job may stay in flight: the window ring holds that many entries more
+    std::thread        worker;
+    std::mutex         mu;
+    std::condition_variable cv;
+    bool               job_posted = false, job_done = false, quit = false, job_in_flight = false;
+    long               job_chunk = 0;          // m->chunks when the job was posted
+    std::vector<WindowEntry> job_use;          // the window entries the job reads (by value)
+    slam_icp_t        *job_fresh = nullptr;
+    int                job_rc = SLAM_OK;
+    char               job_err[256] = "";
 };
 
 namespace {
@@ -266,22 +284,32 @@ int thin_class(slam_mapper *m, const std::vector<const WindowEntry *> &use, int 
     return SLAM_OK;
 }
 
-int rebuild_target(slam_mapper *m)
+// everything in the window whose registration has finished (the newest may still be running: skipped), newest W
+int collect_window(slam_mapper *m, std::vector<WindowEntry> &use)
 {
-    // everything in the window whose registration has finished (the newest may still be running: skipped)
-    std::vector<const WindowEntry *> use;
+    use.clear();
     for (const WindowEntry &w : m->window) {
         if (w.chunk < 0) continue;
         if (m->prm.strict_window) MAP_HIP(hipEventSynchronize(w.ready)); // reproducible: wait for the newest too
-        if (hipEventQuery(w.ready) == hipSuccess) use.push_back(&w);
+        if (hipEventQuery(w.ready) == hipSuccess) use.push_back(w);
     }
     (void)hipGetLastError();
-    std::sort(use.begin(), use.end(), [](const WindowEntry *a, const WindowEntry *b) { return a->chunk < b->chunk; });
+    std::sort(use.begin(), use.end(), [](const WindowEntry &a, const WindowEntry &b) { return a.chunk < b.chunk; });
     if ((int)use.size() > m->prm.window_chunks) use.erase(use.begin(), use.end() - m->prm.window_chunks); // the newest W
+    return SLAM_OK;
+}
+
+// The target for `use`: prior map (optional) + the window, thinned.  Runs on the caller's thread or on the mapper's
+// worker; touches only the rebuild's own buffers (d_model_*, d_thin*) and, read-only, the window entries in `use`.
+// *fresh stays null when there is nothing to build from.
+int build_target(slam_mapper *m, const std::vector<WindowEntry> &entries, slam_icp_t **fresh)
+{
+    *fresh = nullptr;
+    std::vector<const WindowEntry *> use;
+    for (const WindowEntry &w : entries) use.push_back(&w);
     if (use.empty()) return SLAM_OK; // nothing registered yet: keep the current target
-    const auto   t0 = std::chrono::steady_clock::now();
     const size_t p_ga = m->prm.keep_prior ? m->prior_ga.size() / 2 : 0, p_nga = m->prm.keep_prior ? m->prior_nga.size() / 2 : 0;
-    hipStream_t  st = nullptr; // the build runs on the default stream: everything it reads is complete by now
+    hipStream_t  st = build_stream(); // the stream slam_icp_create_dev builds on; everything read here is complete by now
     const bool   thin = m->prm.thin_res > 0;
     size_t       w_ga = 0, w_nga = 0;
     for (const WindowEntry *w : use) w_ga += (size_t)w->n_ga, w_nga += (size_t)w->n_nga;
@@ -322,16 +350,114 @@ int rebuild_target(slam_mapper *m)
             o_nga += (size_t)w->n_nga;
         }
     }
-    slam_icp_t *fresh = nullptr;
-    SLAM_TRY(slam_icp_create_dev(m->d_model_ga, (int)n_ga, m->d_model_nga, (int)n_nga, &m->prm.icp, &fresh));
+    // (slam_icp_create_dev returns with the index complete: every read of the window above has finished by then)
+    SLAM_TRY(slam_icp_create_dev(m->d_model_ga, (int)n_ga, m->d_model_nga, (int)n_nga, &m->prm.icp, fresh));
+    return SLAM_OK;
+}
+
+// the producer's thread: the new target replaces the current one; the one before last is destroyed
+void adopt_target(slam_mapper *m, slam_icp_t *fresh)
+{
+    if (!fresh) return;
     retire_now(m); // the handle before last: its launches ended chunks ago
     m->retired = m->target;
     std::swap(m->retired_used, m->target_used);
     m->target = fresh;
     ++m->rebuilds;
+}
+
+int rebuild_target(slam_mapper *m)
+{
+    std::vector<WindowEntry> use;
+    SLAM_TRY(collect_window(m, use));
+    if (use.empty()) return SLAM_OK;
+    const auto  t0 = std::chrono::steady_clock::now();
+    slam_icp_t *fresh = nullptr;
+    SLAM_TRY(build_target(m, use, &fresh));
+    adopt_target(m, fresh);
     m->last_rebuild = m->chunks;
     m->rebuild_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SLAM_OK;
+}
+
+// ---- the same on the mapper's own thread
+void worker_main(slam_mapper *m)
+{
+    (void)hipSetDevice(m->device);
+    std::unique_lock<std::mutex> lk(m->mu);
+    for (;;) {
+        m->cv.wait(lk, [&] { return m->job_posted || m->quit; });
+        if (m->quit) return;
+        m->job_posted = false;
+        lk.unlock();
+        const auto  t0 = std::chrono::steady_clock::now();
+        slam_icp_t *fresh = nullptr;
+        const int   rc = build_target(m, m->job_use, &fresh);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        lk.lock();
+        m->job_fresh = fresh;
+        m->job_rc = rc;
+        if (rc != SLAM_OK) snprintf(m->job_err, sizeof m->job_err, "%s", slam_last_error());
+        m->rebuild_ms += ms;
+        m->job_done = true;
+        m->cv.notify_all();
+    }
+}
+
+// adopts a finished job; block = wait for the one in flight
+int collect_job(slam_mapper *m, bool block)
+{
+    if (!m->job_in_flight) return SLAM_OK;
+    slam_icp_t *fresh = nullptr;
+    int         rc = SLAM_OK;
+    {
+        std::unique_lock<std::mutex> lk(m->mu);
+        if (block) m->cv.wait(lk, [&] { return m->job_done; });
+        if (!m->job_done) return SLAM_OK;
+        m->job_done = false;
+        fresh = m->job_fresh;
+        m->job_fresh = nullptr;
+        rc = m->job_rc;
+    }
+    m->job_in_flight = false;
+    if (rc != SLAM_OK) {
+        set_error("slam_mapper: background rebuild failed: %s", m->job_err);
+        return rc;
+    }
+    adopt_target(m, fresh);
+    return SLAM_OK;
+}
+
+int post_job(slam_mapper *m)
+{
+    std::vector<WindowEntry> use;
+    SLAM_TRY(collect_window(m, use));
+    m->last_rebuild = m->chunks; // the cadence counts from the post
+    if (use.empty()) return SLAM_OK;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->job_use.swap(use);
+        m->job_posted = true;
+        m->job_done = false;
+    }
+    m->job_chunk = m->chunks;
+    m->job_in_flight = true;
+    m->cv.notify_all();
+    return SLAM_OK;
+}
+
+void stop_worker(slam_mapper *m)
+{
+    if (!m->worker.joinable()) return;
+    {
+        std::unique_lock<std::mutex> lk(m->mu);
+        if (m->job_in_flight) m->cv.wait(lk, [&] { return m->job_done; });
+        m->quit = true;
+    }
+    m->cv.notify_all();
+    m->worker.join();
+    if (m->job_fresh) slam_icp_destroy(m->job_fresh), m->job_fresh = nullptr;
+    m->job_in_flight = false;
 }
 
 int finish_merge(slam_mapper *m)
@@ -373,6 +499,7 @@ void slam_mapper_default_params(slam_mapper_params *p)
     p->strict_window = 0;
     p->thin_res = 0.0;
     p->slots = 3;
+    p->background_rebuild = 1;
 }
 
 int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int n_ga, const double *m_nga, int n_nga,
@@ -432,8 +559,12 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
             hip(hipEventCreateWithFlags(&b.registered, hipEventDisableTiming));
             hip(hipEventCreateWithFlags(&b.mapped, hipEventDisableTiming));
         }
-        // the window keeps one entry more than it uses: the newest is still being written when a rebuild looks
-        m->window.resize(params->window_chunks ? (size_t)params->window_chunks + 1 : 0);
+        hip(hipGetDevice(&m->device));
+        // the window keeps one entry more than it uses: the newest is still being written when a rebuild looks -- and as
+        // many more as pushes may pass while a background rebuild reads its entries (it is waited for after max_lag)
+        const bool bg = params->window_chunks && params->background_rebuild && !params->strict_window;
+        m->max_lag = bg ? std::min(std::max(params->rebuild_every, 1), 4) : 0;
+        m->window.resize(params->window_chunks ? (size_t)params->window_chunks + 1 + (size_t)m->max_lag : 0);
         const size_t per = params->thin_res > 0 ? (size_t)params->max_points
                                                 : (size_t)std::max(64, params->target_points / std::max(2 * params->window_chunks, 1)) + 8;
         for (WindowEntry &w : m->window) {
@@ -446,6 +577,7 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
         slam_mapper_destroy(m);
         return rc;
     }
+    if (m->max_lag) m->worker = std::thread(worker_main, m);
     *out = m;
     return SLAM_OK;
 }
@@ -453,6 +585,7 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
 void slam_mapper_destroy(slam_mapper_t *m)
 {
     if (!m) return;
+    stop_worker(m);
     (void)hipDeviceSynchronize();
     for (Slot &b : m->slot) {
         for (void *p : {(void *)b.d_pts, (void *)b.d_off, (void *)b.d_nga, (void *)b.d_gab, (void *)b.d_R, (void *)b.d_t})
@@ -536,8 +669,15 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     const int n_ga = b.h_gab[n_scans], n_nga = n_points - n_ga;
 
     // ---- sliding target: rebuilt before this chunk's registration is enqueued
-    if (m->prm.window_chunks && m->chunks > 0 && m->chunks - std::max<long>(m->last_rebuild, 0) >= m->prm.rebuild_every)
+    const bool due = m->prm.window_chunks && m->chunks > 0 && m->chunks - std::max<long>(m->last_rebuild, 0) >= m->prm.rebuild_every;
+    if (m->max_lag) {
+        // a finished background build becomes the target of this chunk; one still running is waited for only when the
+        // pushes since its post are about to reach the window entries it reads, or when the next one is due
+        SLAM_TRY(collect_job(m, m->job_in_flight && (due || m->chunks - m->job_chunk >= m->max_lag)));
+        if (due && !m->job_in_flight) SLAM_TRY(post_job(m));
+    } else if (due) {
         SLAM_TRY(rebuild_target(m));
+    }
 
     // ---- copy
     MAP_HIP(hipMemcpyAsync(b.d_pts, b.h_pts, 16 * (size_t)n_points, hipMemcpyHostToDevice, m->copy));
@@ -606,6 +746,7 @@ int slam_mapper_wait(slam_mapper_t *m, int slot, double *R_out, double *t_out)
 int slam_mapper_finish(slam_mapper_t *m)
 {
     SLAM_REQUIRE(m, SLAM_E_INVALID, "null handle");
+    SLAM_TRY(collect_job(m, true));
     SLAM_TRY(finish_merge(m));
     if (m->merge_begin) { // whatever was added since the last merge
         int lo = 0, hi = -1;

@@ -137,6 +137,27 @@ void pool_trim()
     for (const PoolBlock &b : drop) (void)hipFree(b.p);
 }
 
+hipStream_t build_stream()
+{
+    static std::mutex  mu;
+    static hipStream_t streams[64] = {};
+    int                dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!streams[dev]) {
+        int lo = 0, hi = 0; // numerically lower = higher priority
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, lo) != hipSuccess) {
+            (void)hipGetLastError();
+            streams[dev] = nullptr;
+        }
+    }
+    return streams[dev];
+}
+
 // a small pinned host buffer per host thread for the build's read-back (allocated once, never freed: the
 // runtime may be gone when thread-local destructors run)
 void *pinned_scratch(size_t bytes)

@@ -184,3 +184,28 @@ def test_dirty_rows_are_the_touched_rows():
     ys = np.floor(obs[:, 1] / res + size // 2).astype(int)
     assert g.dirty_rows() == (ys.min(), ys.max())
     g.close()
+
+
+@pytest.mark.parametrize("background", [1, 0])
+def test_sliding_window_rebuilt_beside_the_stream(background):
+    """The production setting: the target is rebuilt from whatever has finished (not strict), on the mapper's own
+    thread (background_rebuild = 1) or inside the push (0), while chunks keep flowing.  Which chunk first meets a new
+    target depends on timing, so the poses are checked against the truth, not against a schedule; the grid is exact
+    whatever the poses: the oracle's Bresenham from the mapper's own poses."""
+    W, chunk, n_scans, size, res = 2, 6, 96, 1000, 0.05
+    m_ga, m_nga = synth.make_map(10000)
+    batch = synth.make_batch(n_scans, n_loop=256)
+    got = run_mapper(m_ga, m_nga, batch, chunk, rolling=0, grid_size_x=size, grid_size_y=size, resolution=res,
+                     window_chunks=W, rebuild_every=2, target_points=8000, merge_every=4, strict_window=0, keep_prior=1,
+                     thin_res=0.1, background_rebuild=background, icp=dict(max_iter=20, min_delta=1e-6))
+    st = got["stats"]
+    assert st["chunks"] == n_scans // chunk
+    assert 1 <= st["rebuilds"] <= n_scans // chunk // 2
+    R, t = got["R"], got["t"]
+    assert np.abs(t - batch.true_poses[:, :2]).max() < 0.05
+    gp = O.grid_params(size, size, res, min_cluster_points=20)
+    H, M = np.zeros(size * size, np.int32), np.zeros(size * size, np.int32)
+    for s in range(n_scans):
+        p = batch.pts[batch.scan_off[s]:batch.scan_off[s + 1]]
+        O.grid_raycast(gp, np.tile(t[s].astype(np.float32), (len(p), 1)), O.transform_points(p, R[s], t[s]), H, M)
+    assert np.array_equal(got["counts"][0], H) and np.array_equal(got["counts"][1], M)
