@@ -115,6 +115,10 @@ typedef struct {
     int    spread_scans;    /* batches of at most this many scans (one, in the reference's usage) run in the
                                spread form: every scan over many workgroups of one persistent launch, 64 lanes
                                per query (icp_single.hip); 0 = library default (CUs / 16), -1 = never */
+    int    pair_scans;      /* default schedule, batches: two scans per workgroup sharing one LDS index, each on half the
+                               wavefronts (icp_fit_pair_kernel): 1 = one lane per scan point in the ring search,
+                               2 = two lanes, 0 = library default (two lanes, for batches of at least two scans per
+                               CU), -1 = never (one scan per workgroup) */
 } slam_icp_params;
 
 typedef struct {

@@ -218,17 +218,40 @@ __device__ inline bool list_scan_coop(Best &b, float2 &m, const ListPtrs &lp, co
     return true;
 }
 
-// List-sweep kernel, one pass over kBlock points from p0, one lane per point.  A query the list cannot
+// The threads that work on one scan (TeamDims, icp_model.hpp).  sync() is the workgroup's s_barrier when the team is the
+// workgroup; a smaller team meets at a counter in LDS (gfx950 has no named barriers): every wavefront adds one and
+// sleeps until the count of the team's wavefronts times the barriers passed is reached.  LDS traffic of a wavefront
+// is complete before its add (release) and the others' is visible after the wait (acquire).
+template <int TB>
+struct Team {
+    int       tid;   // thread within the team
+    unsigned *bar;   // TB < kBlock: the team's barrier word in LDS
+    unsigned  epoch; // wavefront arrivals that end the next barrier
+    __device__ inline void sync()
+    {
+        if (TB == kBlock) {
+            __syncthreads();
+        } else {
+            epoch += (unsigned)(TB / 64);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if ((tid & 63) == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+};
+
+// List-sweep kernel, one pass over the team's TB points from p0, one lane per point.  A query the list cannot
 // decide is not searched by its own lane (the whole wavefront, and at the barrier the whole workgroup,
 // would wait for a few lanes): its offset goes to the wavefront's region of a queue in LDS (fixed regions:
 // the order does not depend on timing, so sums stay bitwise reproducible) that all wavefronts drain
 // together afterwards (drain_queue).
 __device__ inline void list_pass(const ListPtrs &lp, const ModelView &mv, const FitArgs &fa, const Pose &T, int n, int nga,
                                  int p0, const double2 P, double acc[kNumAcc], unsigned *wave_cnt, unsigned short *queue,
-                                 int &fell_back)
+                                 int &fell_back, int tid)
 {
-    const int  lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-    const int  p = p0 + (int)threadIdx.x;
+    const int  lane = tid & 63, wave = tid >> 6;
+    const int  p = p0 + tid;
     const int  cls = p < nga ? 0 : 1;
     const bool valid = p < n && mv.n_cls[cls] > 3; // icpPointToPoint.cpp:59,93
     bool       done = true;
@@ -243,35 +266,36 @@ __device__ inline void list_pass(const ListPtrs &lp, const ModelView &mv, const 
     }
     const unsigned long long need = __ballot(!done);
     if (lane == 0) wave_cnt[wave] = (unsigned)__popcll(need);
-    if (!done) queue[wave * 64 + __popcll(need & ((1ull << lane) - 1ull))] = (unsigned short)threadIdx.x;
+    if (!done) queue[wave * 64 + __popcll(need & ((1ull << lane) - 1ull))] = (unsigned short)tid;
 }
 
 // All wavefronts take kCoopPerWave points at a time and search each with kCoop lanes: first the `tail`
 // points past the pass (block_search, then the ring search if that does not decide), then the queued
 // ones (ring search).  Entry e of the queue lives in the region of the wavefront whose inclusive count
 // prefix first exceeds e.
-template <typename StartT, bool LISTS>
+template <typename StartT, bool LISTS, int TB>
 __device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ListPtrs &lp, const ModelView &mv, const FitArgs &fa,
                                    const Pose &T, int off, int n, int nga, int p0, double acc[kNumAcc], int tail,
-                                   const unsigned *wave_cnt, const unsigned short *queue)
+                                   const unsigned *wave_cnt, const unsigned short *queue, int tid)
 {
-    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-    const int mine = (int)wave_cnt[lane % kWaves];
+    constexpr int kW = TeamDims<TB>::kW, kCoopBlock = TeamDims<TB>::kCoopBlock; // kW <= 16: one count per lane of a DPP row
+    const int lane = tid & 63, wave = tid >> 6;
+    const int mine = (int)wave_cnt[lane % kW];
     int       incl = mine; // inclusive prefix over the 16 wavefronts, in every DPP row
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true); // row_shr:1
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, true);
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, true);
-    const int queued = __builtin_amdgcn_readlane(incl, kWaves - 1);
+    const int queued = __builtin_amdgcn_readlane(incl, kW - 1);
     const int total = tail + queued;
-    for (int base = 0; base < total; base += kCoopPerBlock) {
+    for (int base = 0; base < total; base += kCoopBlock) {
         const int g = lane / kCoop;
         const int e = base + wave * kCoopPerWave + g; // wavefront-major: a short round keeps few wavefronts busy (measured
                                                       // faster than dealing it round-robin over all sixteen)
         // wavefront region holding queue entry e - tail: the first whose inclusive prefix exceeds it
         int w = 0, excl = 0;
 #pragma unroll
-        for (int j = 0; j < kWaves; ++j) {
+        for (int j = 0; j < kW; ++j) {
             const int  incl_j = __builtin_amdgcn_readlane(incl, j); // the same in every lane: a scalar
             const bool below = incl_j <= e - tail;
             w += below ? 1 : 0;
@@ -279,7 +303,7 @@ __device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ListPtrs &
         }
         if (e < total) {
             const bool is_tail = e < tail;
-            const int  p = p0 + (is_tail ? kBlock + e : (int)queue[min(w, kWaves - 1) * 64 + (e - tail - excl)]);
+            const int  p = p0 + (is_tail ? TB + e : (int)queue[min(w, kW - 1) * 64 + (e - tail - excl)]);
             const int  cls = p < nga ? 0 : 1;
             if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
                 float qx, qy;
@@ -358,11 +382,11 @@ __device__ inline void accumulate_point(const IndexPtrs<StartT> &ix, const Model
 // One pass of the workgroup over kBlock/GG consecutive scene points from p0.
 template <int GG, typename StartT, int MODE>
 __device__ inline void point_pass(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
-                                  const Pose &T, int off, int n, int nga, int p0, double acc[kNumAcc])
+                                  const Pose &T, int off, int n, int nga, int p0, double acc[kNumAcc], int tid)
 {
-    const int p = p0 + (int)threadIdx.x / GG;
+    const int p = p0 + tid / GG;
     int       far = 0;
-    if (p < n) accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, fa.pts[off + p], p < nga, (int)threadIdx.x % GG, acc, far);
+    if (p < n) accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, fa.pts[off + p], p < nga, tid % GG, acc, far);
 }
 
 // The same with the lane's point already in registers (the first kHoist passes: a lane meets the same
@@ -370,14 +394,14 @@ __device__ inline void point_pass(const IndexPtrs<StartT> &ix, const ModelView &
 template <int GG, typename StartT, int MODE>
 __device__ inline void point_pass_reg(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
                                       const Pose &T, int n, int nga, int p0, const double2 P, double acc[kNumAcc],
-                                      int &far, int *seed = nullptr, float *empty = nullptr, float move_r = 0.f, float move_t = 0.f)
+                                      int &far, int tid, int *seed = nullptr, float *empty = nullptr, float move_r = 0.f, float move_t = 0.f)
 {
-    const int p = p0 + (int)threadIdx.x / GG;
+    const int p = p0 + tid / GG;
     if (p < n) {
         if (seed)
-            accumulate_point<GG, StartT, MODE, true>(ix, mv, fa, T, P, p < nga, (int)threadIdx.x % GG, acc, far, seed, empty, move_r, move_t);
+            accumulate_point<GG, StartT, MODE, true>(ix, mv, fa, T, P, p < nga, tid % GG, acc, far, seed, empty, move_r, move_t);
         else
-            accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, P, p < nga, (int)threadIdx.x % GG, acc, far);
+            accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, P, p < nga, tid % GG, acc, far);
     }
 }
 
@@ -389,16 +413,18 @@ __device__ inline void point_pass_reg(const IndexPtrs<StartT> &ix, const ModelVi
 // Iterations fs.iters .. max_iter-1 of the workgroup's scan in one search form (SWEEP 0: ring search with G lanes
 // per point on the cell index `ix`; SWEEP 2: list sweeps on the halo lists `lp`, the undecided few on `ix`).
 // phase 1 stops from fa.switch_iter on with fs.hand_over set as soon as the list form can take over (see the guard).
-template <int G, typename StartT, int MODE, int SWEEP>
+template <int G, typename StartT, int MODE, int SWEEP, int TB = kBlock>
 __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArgs &fa, const IndexPtrs<StartT> &ix,
-                                               const ListPtrs &lp, unsigned char *smem, int s, int off, int n, int nga,
-                                               int phase, FitState &fs)
+                                               const ListPtrs &lp, unsigned char *smem /* the team's scratch */, int s, int off,
+                                               int n, int nga, int phase, FitState &fs, Team<TB> &tm)
 {
+    constexpr int      kWaves = TeamDims<TB>::kW, kBlock = TB, kCoopPerBlock = TeamDims<TB>::kCoopBlock; // of the TEAM, from here on
+    constexpr unsigned kReduceBytes = TeamDims<TB>::kReduce;
     double *partial = reinterpret_cast<double *>(smem); // [2][kWaves][kNumAcc]
     double *bcast = partial + 2 * kWaves * kNumAcc;     // [2][8] new pose, delta, n_corr
     unsigned       *wave_cnt = reinterpret_cast<unsigned *>(smem + kReduceBytes); // [kWaves] undecided queries of the pass
     unsigned short *queue = reinterpret_cast<unsigned short *>(smem + kReduceBytes + 4 * kWaves); // [kWaves][64]
-    const int tid = threadIdx.x;
+    const int tid = tm.tid;
     const int lane = tid & 63, wave = tid >> 6;
     const int iter_begin = fs.iters;
     double    r00 = fs.r00, r01 = fs.r01, r10 = fs.r10, r11 = fs.r11, t0 = fs.t0, t1 = fs.t1, delta = fs.delta;
@@ -411,6 +437,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
         return (G > 0 && p < n) ? fa.pts[off + p] : make_double2(0.0, 0.0);
     };
     // named, not an array: stays in registers (the list-sweep kernel has one full pass per 1024 points: one is enough)
+    // (a team of half a workgroup sweeps a 1081-point scan in two full passes: both stay in registers)
     const double2 Pc0 = hoisted(0), Pc1 = SWEEP ? Pc0 : hoisted(1), Pc2 = SWEEP ? Pc0 : hoisted(2);
 
     int   sd0 = -1, sd1 = -1, sd2 = -1; // ring form: last iteration's neighbour of the lane's point in each hoisted pass
@@ -446,7 +473,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                     int tail = 0;
                     if (rem > kCoopPerBlock) {
                         const double2 P = pass == 0 ? Pc0 : (p0 + tid < n ? fa.pts[off + p0 + tid] : Pc0);
-                        list_pass(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back);
+                        list_pass(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back, tid);
                         tail = rem - kBlock;
                         tail = tail > 0 && tail <= kCoopPerBlock ? tail : 0;
                     } else { // a scan shorter than one cooperative round
@@ -454,11 +481,11 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                         tail = rem;
                         p0 -= kBlock; // the tail is addressed as p0 + kBlock + i
                     }
-                    __syncthreads();
+                    tm.sync();
                     if (SLAM_STAMPS(fa)) c_mid = __builtin_amdgcn_s_memtime();
-                    drain_queue<StartT, SWEEP == 2>(ix, lp, mv, fa, T, off, n, nga, p0, acc, tail, wave_cnt, queue);
+                    drain_queue<StartT, SWEEP == 2, TB>(ix, lp, mv, fa, T, off, n, nga, p0, acc, tail, wave_cnt, queue, tid);
                     p0 += kBlock + tail;
-                    if (p0 < n) __syncthreads(); // the queue is reused by the next pass
+                    if (p0 < n) tm.sync(); // the queue is reused by the next pass
                 } else if (G > 0) {
                     double2 P = pass == 0 ? Pc0 : (pass == 1 ? Pc1 : Pc2);
                     if (pass >= kHoist) {
@@ -469,27 +496,27 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                         // (the per-pass state is selected by value: a pointer into the three would put them on the stack)
                         int   sd = pass == 0 ? sd0 : (pass == 1 ? sd1 : sd2);
                         float em = pass == 0 ? em0 : (pass == 1 ? em1 : em2);
-                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc, far, &sd, &em, move_r, move_t);
+                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc, far, tid, &sd, &em, move_r, move_t);
                         sd0 = pass == 0 ? sd : sd0, sd1 = pass == 1 ? sd : sd1, sd2 = pass == 2 ? sd : sd2;
                         if (kSeedEmpty) em0 = pass == 0 ? em : em0, em1 = pass == 1 ? em : em1, em2 = pass == 2 ? em : em2;
                     } else {
-                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc, far);
+                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc, far, tid);
                     }
                     p0 += kBlock / (G > 0 ? G : 1);
                 } else if (rem * 2 > kBlock) {
-                    point_pass<1, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+                    point_pass<1, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc, tid);
                     p0 += kBlock;
                 } else if (rem * 4 > kBlock) {
-                    point_pass<2, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+                    point_pass<2, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc, tid);
                     p0 += kBlock / 2;
                 } else if (rem * 8 > kBlock) {
-                    point_pass<4, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+                    point_pass<4, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc, tid);
                     p0 += kBlock / 4;
                 } else if (rem * 16 > kBlock) {
-                    point_pass<8, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+                    point_pass<8, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc, tid);
                     p0 += kBlock / 8;
                 } else {
-                    point_pass<16, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc);
+                    point_pass<16, StartT, MODE>(ix, mv, fa, T, off, n, nga, p0, acc, tid);
                     p0 += kBlock / 16;
                 }
             }
@@ -508,7 +535,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                 if (lane == 0) my[8] = v9;
             }
             if (SLAM_STAMPS(fa)) c2 = __builtin_amdgcn_s_memtime();
-            __syncthreads();
+            tm.sync();
             if (SLAM_STAMPS(fa)) c3 = __builtin_amdgcn_s_memtime();
 
             // wavefront 0 alone adds the 16 partials (fixed order: bitwise reproducible)
@@ -567,7 +594,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                     if (lane == 0) partial[(iter & 1) * kWaves * kNumAcc] = (double)far_all;
                 }
             }
-            __syncthreads();
+            tm.sync();
             if (kSeedRing && kSeedEmpty && !SWEEP) { // |q_new - q_old| <= |dR|_F |p| + |dt| (rounded up)
                 const double n00 = uniform(bc[0]), n01 = uniform(bc[1]), n10 = uniform(bc[2]), n11 = uniform(bc[3]);
                 const double n4 = uniform(bc[4]), n5 = uniform(bc[5]);
@@ -587,7 +614,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                 for (int o = 32; o > 0; o >>= 1) fell_back += __shfl_xor(fell_back, o);
                 if ((tid & 63) == 0) {
                     const long long c4 = __builtin_amdgcn_s_memtime();
-                    long long *st = fa.stamps + ((size_t)s * kWaves + wave) * kStampSlots;
+                    long long *st = fa.stamps + ((size_t)s * icp::kWaves + wave) * kStampSlots;
                     st[0] += c1 - c0;
                     st[1] += c2 - c1;
                     st[2] += c3 - c2;
@@ -696,8 +723,9 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
         lp = make_list_ptrs(smem + kScratch, mv);
         __syncthreads();
     }
-    FitState fs = load_fit(fa, s, iter_begin);
-    fit_iterations<G, StartT, MODE, SWEEP>(mv, fa, ix, lp, smem, s, off, n, nga, fa.phase, fs);
+    FitState     fs = load_fit(fa, s, iter_begin);
+    Team<kBlock> tm = {(int)threadIdx.x, nullptr, 0u};
+    fit_iterations<G, StartT, MODE, SWEEP>(mv, fa, ix, lp, smem, s, off, n, nga, fa.phase, fs, tm);
     if (threadIdx.x == 0) store_fit(fa, s, fs, fa.phase);
 }
 
@@ -716,11 +744,12 @@ __global__ __launch_bounds__(kBlock) void icp_fit_fused_kernel(ModelView mv, Fit
     const int nga = fa.scan_nga[s];
     fill_lds(smem + kScratch, mv.blob, mv.blob_bytes);
     __syncthreads();
-    FitState fs = load_fit(fa, s, 0);
+    FitState     fs = load_fit(fa, s, 0);
+    Team<kBlock> tm = {(int)threadIdx.x, nullptr, 0u};
     {
         const IndexPtrs<uint16_t> ix = make_ptrs<uint16_t>(smem + kScratch, mv); // an index in LDS has 16-bit starts
         const ListPtrs            none = {};
-        fit_iterations<2, uint16_t, MODE, 0>(mv, fa, ix, none, smem, s, off, n, nga, 1, fs);
+        fit_iterations<2, uint16_t, MODE, 0>(mv, fa, ix, none, smem, s, off, n, nga, 1, fs, tm);
     }
     if (fs.hand_over) { // uniform for the workgroup
         __syncthreads();
@@ -728,9 +757,55 @@ __global__ __launch_bounds__(kBlock) void icp_fit_fused_kernel(ModelView mv, Fit
         const ListPtrs          lp = make_list_ptrs(smem + kScratch, mv);
         const IndexPtrs<StartT> ix = make_ptrs<StartT>(mv.blob, mv);
         __syncthreads();
-        fit_iterations<1, StartT, MODE, 2>(mv, fa, ix, lp, smem, s, off, n, nga, 2, fs);
+        fit_iterations<1, StartT, MODE, 2>(mv, fa, ix, lp, smem, s, off, n, nga, 2, fs, tm);
     }
     if (threadIdx.x == 0) store_fit(fa, s, fs, 0);
+}
+
+// TWO scans per workgroup, one LDS index: each half of the workgroup (a team of 8 wavefronts, Team<512>) runs the fused
+// schedule of icp_fit_fused_kernel on a scan of its own.  A scan spends a third (ring form) to a half (list form) of an
+// iteration in its serial part -- the slowest wavefront of the pass, the sums across wavefronts, the solve by one
+// wavefront -- with most of its wavefronts asleep at a barrier; here the other scan's wavefronts issue in those slots.
+// The teams meet only where the LDS changes hands: both must be through with the cell index before the halo lists
+// overwrite it.  GR = lanes per scene point in the ring form.
+template <typename StartT, int MODE, int GR>
+__global__ __launch_bounds__(kBlock) void icp_fit_pair_kernel(ModelView mv, FitArgs fa, int n_scans)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int      TB = kBlock / 2;
+    constexpr unsigned kTeamScratch = TeamDims<TB>::kScratch, kScratch = 2 * kTeamScratch;
+    __shared__ int     any_lists;
+    const int          team = (int)threadIdx.x / TB;
+    unsigned char     *tsm = smem + team * kTeamScratch;
+    Team<TB>           tm = {(int)threadIdx.x % TB, reinterpret_cast<unsigned *>(tsm + kTeamScratch - 16), 0u};
+    if (tm.tid == 0) *tm.bar = 0u;
+    if (threadIdx.x == 0) any_lists = 0;
+    const int  s = 2 * (int)blockIdx.x + team;
+    const bool active = s < n_scans; // an odd batch leaves the last workgroup one idle team
+    const int  off = active ? fa.scan_off[s] : 0;
+    const int  n = active ? fa.scan_off[s + 1] - off : 0;
+    const int  nga = active ? fa.scan_nga[s] : 0;
+    fill_lds(smem + kScratch, mv.blob, mv.blob_bytes);
+    __syncthreads();
+    FitState fs = load_fit(fa, active ? s : 0, 0);
+    if (active) {
+        const IndexPtrs<uint16_t> ix = make_ptrs<uint16_t>(smem + kScratch, mv); // an index in LDS has 16-bit starts
+        const ListPtrs            none = {};
+        fit_iterations<GR, uint16_t, MODE, 0, TB>(mv, fa, ix, none, tsm, s, off, n, nga, 1, fs, tm);
+    }
+    const bool lists = active && fs.hand_over; // uniform for the team
+    if (lists && tm.tid == 0) any_lists = 1;
+    __syncthreads(); // nobody reads the cell index in LDS any more
+    if (any_lists) {
+        fill_lds(smem + kScratch, mv.lblob, mv.lblob_bytes);
+        __syncthreads();
+    }
+    if (lists) {
+        const ListPtrs          lp = make_list_ptrs(smem + kScratch, mv);
+        const IndexPtrs<StartT> ix = make_ptrs<StartT>(mv.blob, mv);
+        fit_iterations<1, StartT, MODE, 2, TB>(mv, fa, ix, lp, tsm, s, off, n, nga, 2, fs, tm);
+    }
+    if (active && tm.tid == 0) store_fit(fa, s, fs, 0);
 }
 
 // Normals for the point-to-line mode, icpPointToPlane.cpp:279-305,340-349: for
@@ -1016,6 +1091,19 @@ int launch_fit(slam_icp *h, const FitArgs &fa_in, int n_scans, hipStream_t st)
         // first iterations by the ring search (index in LDS), the rest by the list sweeps (halo lists in LDS),
         // one launch: every workgroup swaps its LDS contents when its own scan gets there
         fa.switch_iter = h->switch_iter;
+        // two scans per workgroup where the batch leaves CUs to spare for it (slam_icp_params::pair_scans)
+        const size_t pair_lds = std::max(h->lds_bytes, h->list_lds_bytes) - kScratchBytes + 2 * TeamDims<kBlock / 2>::kScratch;
+        // Library default: from two scans per CU on.  Measured on config 2's scans (tools/pair_time.py): 256 scans on 256 CUs
+        // 0.39 ms alone against 0.61 in pairs (half the CUs idle); 512 scans 0.72 against 0.61; 1024 scans 1.31 against 1.16.
+        const int pair = h->pair > 0 ? h->pair : (h->pair == 0 && n_scans >= 2 * h->n_cu ? 2 : 0);
+        if (pair && pair_lds <= kLdsTotal && n_scans >= 2) {
+            auto kern = h->start32 ? (pair == 1 ? icp_fit_pair_kernel<uint32_t, SLAM_ICP_P2P, 1> : icp_fit_pair_kernel<uint32_t, SLAM_ICP_P2P, 2>)
+                                   : (pair == 1 ? icp_fit_pair_kernel<uint16_t, SLAM_ICP_P2P, 1> : icp_fit_pair_kernel<uint16_t, SLAM_ICP_P2P, 2>);
+            SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds));
+            hipLaunchKernelGGL(kern, dim3((n_scans + 1) / 2), dim3(kBlock), pair_lds, st, h->mv, fa, n_scans);
+            SLAM_HIP(hipGetLastError());
+            return SLAM_OK;
+        }
         auto         kern = h->start32 ? icp_fit_fused_kernel<uint32_t, SLAM_ICP_P2P> : icp_fit_fused_kernel<uint16_t, SLAM_ICP_P2P>;
         const size_t lds = std::max(h->lds_bytes, h->list_lds_bytes);
         SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1097,6 +1185,7 @@ void slam_icp_default_params(slam_icp_params *p)
     p->far_div = 0;
     p->split_launch = 0;
     p->spread_scans = 0;
+    p->pair_scans = 0;
 }
 
 } // extern "C"
@@ -1129,6 +1218,7 @@ int icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga, con
     if (h->prm.first_iterations > 0) h->switch_iter = h->prm.first_iterations;
     if (h->prm.far_div > 0) h->far_div = h->prm.far_div;
     h->split_launch = h->prm.split_launch != 0;
+    h->pair = h->prm.pair_scans > 0 ? std::min(h->prm.pair_scans, 2) : (h->prm.pair_scans < 0 ? -1 : 0);
     {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)

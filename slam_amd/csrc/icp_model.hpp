@@ -25,6 +25,20 @@ static_assert(kHoist == 3, "the pass loop selects Pc0, Pc1, Pc2 explicitly");
 static_assert(kWaves == 16 && 16 % kCoop == 0, "drain_queue keeps one wavefront count per lane of a 16-lane DPP row");
 constexpr unsigned kScratchBytes = (kReduceBytes + kQueueBytes + 15u) & ~15u;
 
+// A team = the TB threads (TB / 64 wavefronts) of a workgroup that work on ONE scan: the whole workgroup in the batch
+// kernels (TB = kBlock), half of it in the pair kernel, where two scans share one LDS index.  What of a workgroup's
+// scratch depends on the team's size:
+template <int TB>
+struct TeamDims {
+    static constexpr int      kW = TB / 64;                      // wavefronts
+    static constexpr int      kCoopBlock = kW * kCoopPerWave;    // queries of one cooperative round
+    static constexpr unsigned kReduce = (2u * kW * kNumAcc + 2u * 8u) * sizeof(double);
+    static constexpr unsigned kQueue = 4u * kW + 2u * TB;
+    // a team smaller than the workgroup keeps the word of its own barrier in the last 16 bytes
+    static constexpr unsigned kScratch = (kReduce + kQueue + (TB < kBlock ? 16u : 0u) + 15u) & ~15u;
+};
+static_assert(TeamDims<kBlock>::kScratch == kScratchBytes && TeamDims<kBlock>::kCoopBlock == kCoopPerBlock, "one team = the workgroup");
+
 struct Lattice {
     int   nx, ny;
     float x0, y0, h, inv_h;
@@ -144,6 +158,7 @@ struct slam_icp {
     int             spread_points_hint = 0; // points of the batch when the caller knows them (slam_icp_fit), else 0
     size_t          step_pose_off = 0;   // where in w_pts the pose of the last executed step lies
     bool            two_phase = false;   // ring search, then list sweeps (the point-to-point default)
+    int             pair = 0;             // two scans per workgroup in the fused schedule: lanes per point of its ring form; 0 = by batch size, -1 = never
     bool            split_launch = false; // SLAM_ICP_SPLIT=1: the two forms as two launches (measurements)
     bool            phase_events = false; // diagnostic: time the two launches separately (slam_icp_debug_phase_ms)
     hipEvent_t      ev[3] = {nullptr, nullptr, nullptr};

@@ -185,17 +185,21 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
 
 
 def _n_gpus():
-    import torch
-    return torch.cuda.device_count()       # counts devices without initialising the runtime
+    """devices visible to a torch process -- counted in a child: importing torch HERE would map a second HIP runtime
+    (torch's bundled one) beside the library's into the test process, and RCCL then finds no device"""
+    import subprocess
+    out = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=300)
+    return int(out.stdout.strip().splitlines()[-1]) if out.returncode == 0 and out.stdout.strip() else 0
 
 
 @pytest.mark.gpu
-@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: RCCL does not put two ranks on one device")
 def test_bench_two_ranks_rccl_merge():
     """Two ranks, one GPU each, the library's own RCCL communicator (slam_comm_create, slam_grid_merge_begin/_finish):
     bench.py itself asserts that the merged planes of the last step hold both ranks' updates exactly once."""
     import json
     import subprocess
+    if _n_gpus() < 2:
+        pytest.skip("needs two GPUs: RCCL does not put two ranks on one device")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--scans", "64", "--no-cpu-baseline"]
