@@ -29,6 +29,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The HIP runtime deals a process's streams over 4 hardware queues unless told otherwise, and two streams on one queue run
+# one after the other: this process holds up to eight that must overlap (registration x 2, grid, copy, index build, RCCL's).
+# Read by the runtime when it initialises: set before anything touches HIP.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 N_SCANS, N_ITERS, GRID, RES, MAP_POINTS = 256, 30, 2000, 0.05, 10000
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
@@ -312,33 +316,49 @@ def main():
         planes = torch.as_tensor(_Planes(), device=torch.device("cuda", local_rank)).view(2, GRID, GRID)
 
     # ---- how steps are launched
-    # pipeline (default): two streams over CONSECUTIVE steps.  A: initial poses in, ICP of step k (touches no plane).
-    #   B: count reset, raycast, [N>1: exchange of the touched rows, RCCL sum of those rows,] finalize of step k-1.  The
-    #   registration of a batch fills a CU with one workgroup for as long as its scan takes, and the launch ends with
-    #   the slowest scan: the grid update of the batch before takes the CUs that fall idle in that tail (0.53 -> 0.44 ms
-    #   per step on config 2).  Every step still does all of its work; K steps are timed to completion.  With N>1 the
-    #   host's wait for the 8-byte row range of step k-1 comes after step k's registration has been enqueued.
+    # pipeline (default): CONSECUTIVE steps on three streams.  A0 / A1 in turn: initial poses in, registration of step k
+    #   (touches no plane), two scans per workgroup (slam_icp_params::pair_scans: a batch of 256 then holds 128 CUs, and the
+    #   batch after it starts on the other 128 instead of waiting for this one's slowest scan).  B: count reset, raycast,
+    #   [N>1: exchange of the touched rows, RCCL sum of those rows,] finalize of step k-1, on the CUs the registrations
+    #   leave.  One scan per workgroup on one stream: 0.53 ms per step; registration beside the grid update of the step
+    #   before: 0.44; pairs on two registration streams: 0.36.  Every step still does all of its work; K steps are timed to
+    #   completion.  With N>1 the host's wait for the 8-byte row range of step k-1 comes after step k's registration has
+    #   been enqueued.
     # graph: one stream, one captured hipGraph replayed per step (N=1).  calls: one stream, call by call.
     launch = "pipeline" if not args.no_pipeline else ("calls" if (multi or args.no_graph or not args.warmup) else "graph")
-    sa, sb = api.Stream(), api.Stream(priority=1)   # two priority levels: never the same hardware queue (see mapper.hip)
-    pose = [d_pose, api.DeviceArray(d_pose0.shape, np.float64)]
+    n_cu = api.device_info()[1]
+    icp_one = icp                                       # library defaults: what the one-stream forms use
+    if launch == "pipeline" and S < 2 * n_cu and args.lanes == 0:
+        icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, cell_size=args.cell, pair_scans=2)
+    # three priority levels: never the same hardware queue (see mapper.hip)
+    SA, sb = [api.Stream(), api.Stream(priority=-1)], api.Stream(priority=1)
+    sa = SA[0]
+    NB = 4
+    pose = [d_pose] + [api.DeviceArray(d_pose0.shape, np.float64) for _ in range(NB - 1)]
     pR = [p_.view(0, batch.R.shape) for p_ in pose]
     pt = [p_.view(batch.R.size, batch.t.shape) for p_ in pose]
-    icp_done = [api.Event() for _ in range(2)]
-    grid_done = [api.Event() for _ in range(2)]
+    res = [d_res] + [api.DeviceArray((S,), api.RESULT_DTYPE) for _ in range(NB - 1)]
+    icp_done = [api.Event() for _ in range(NB)]
+    grid_done = [api.Event() for _ in range(NB)]
     merge_rows_seen = []
+    # (start, end) events around the registration launches of the timed region, on the stream of each
+    live = [(api.Event(), api.Event()) for _ in range(min(args.steps, 64))]
 
-    def enqueue_icp(k, a, e=None):
-        s_ = k % 2
-        a.wait_event(grid_done[s_])                    # the grid update two steps ago has read these poses
+    def enqueue_icp(k, a, e=None, handle=None, timed=False):
+        s_ = k % NB
+        a.wait_event(grid_done[s_])                    # the grid update NB steps ago has read these poses
         pose[s_].copy_from(d_pose0, a)
+        if timed and k < len(live):
+            live[k][0].record(a)
         if e: e[0].record(a)
-        icp.fit_batch_dev(d_pts, d_off, d_nga, S, pR[s_], pt[s_], 5.0, d_res, None, a)
+        (handle or icp).fit_batch_dev(d_pts, d_off, d_nga, S, pR[s_], pt[s_], 5.0, res[s_], None, a)
         if e: e[1].record(a)
+        if timed and k < len(live):
+            live[k][1].record(a)
         icp_done[s_].record(a)
 
     def enqueue_grid(k, b, e=None):
-        s_ = k % 2
+        s_ = k % NB
         b.wait_event(icp_done[s_])
         grid.reset_counts(b)
         grid.raycast_scans_dev(d_pts, d_off, S, P, pR[s_], pt[s_], b)
@@ -366,19 +386,21 @@ def main():
         if e: e[4].record(b)
         grid_done[s_].record(b)
 
-    def run_steps(n, events=None, pipelined=True):
+    def run_steps(n, events=None, pipelined=True, handle=None, timed=False):
         if n <= 0:
             return
         E = (lambda k: events[k]) if events else (lambda k: None)
         if pipelined:
+            # the host stays two registrations ahead of the grid update it enqueues (with N>1 that call waits for a row range)
             for k in range(n):
-                enqueue_icp(k, sa, E(k))
-                if k >= 1:
-                    enqueue_grid(k - 1, sb, E(k - 1))
-            enqueue_grid(n - 1, sb, E(n - 1))
+                enqueue_icp(k, SA[k % 2], E(k), handle, timed)
+                if k >= 2:
+                    enqueue_grid(k - 2, sb, E(k - 2))
+            for k in range(max(n - 2, 0), n):
+                enqueue_grid(k, sb, E(k))
         else:
             for k in range(n):
-                enqueue_icp(k, sa, E(k))
+                enqueue_icp(k, sa, E(k), handle, timed)
                 enqueue_grid(k, sa, E(k))
 
     for e_ in grid_done:
@@ -418,24 +440,27 @@ def main():
         for k in range(args.steps):
             graph.launch()
     else:
-        run_steps(args.steps, pipelined=launch == "pipeline")
+        run_steps(args.steps, pipelined=launch == "pipeline", timed=True)
     sync()
     barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    live_ms = [a_.elapsed_ms(b_) for a_, b_ in live] if (graph is None and args.steps > 0) else []
     # the same K steps one after the other on one stream (outside the timed region, N=1): what the pipelining buys
     seq_ms = None
     if launch == "pipeline" and not multi:
+        run_steps(2, pipelined=False, handle=icp_one)
         sync()
         t1 = time.perf_counter()
-        run_steps(args.steps, pipelined=False)
+        run_steps(args.steps, pipelined=False, handle=icp_one)
         sync()
         seq_ms = (time.perf_counter() - t1) / max(args.steps, 1) * 1e3
-    # per-kernel times from a few event-bracketed steps run one after the other, outside the timed region
+    # per-kernel times of the timed region's kernels, each alone on the chip: a few event-bracketed steps run one after
+    # the other on one stream, outside the timed region
     ev = [[api.Event() for _ in range(5)] for _ in range(min(max(args.steps, 1), 10))]
     run_steps(len(ev), ev, pipelined=False)
     sync()
-    d_R, d_t = pR[(len(ev) - 1) % 2], pt[(len(ev) - 1) % 2]
+    d_R, d_t, d_res = pR[(len(ev) - 1) % NB], pt[(len(ev) - 1) % NB], res[(len(ev) - 1) % NB]
 
     if upd_per_step is None:
         upd_per_step = grid.total_updates() // max(args.steps, 1)
@@ -473,10 +498,15 @@ def main():
         ray_bytes = 8 * upd_per_step + 16 * P           # 8 B RMW per cell update + 16 B per beam
         fin_bytes = GRID * GRID * 17                     # 2x4 B counts in, 8 B evidence + 1 B occupancy out
         fused = bool(info.get("two_forms")) and args.lanes == 0
-        icp_name = "icp_fit_fused_kernel" if fused else "icp_fit_kernel"
+        paired = fused and (icp is not icp_one or S >= 2 * n_cu)
+        icp_name = "icp_fit_pair_kernel" if paired else ("icp_fit_fused_kernel" if fused else "icp_fit_kernel")
+        # the registration launch as the timed region saw it (HIP events on its own stream around every launch; with two
+        # registration streams two launches share the chip); ms_icp below is the same kernel alone on the chip
+        ms_icp_live = float(np.mean(live_ms)) if live_ms else float(ms_icp)
         kernels = {
-            icp_name: {"ms": float(ms_icp), "alg_bytes": icp_bytes,
-                       "index_bytes_read_per_launch": S * (int(info.get("lds_bytes", 0)) + (int(info.get("list_bytes", 0)) if fused else 0))},
+            icp_name: {"ms": ms_icp_live, "ms_alone_on_the_chip": float(ms_icp), "alg_bytes": icp_bytes,
+                       "launches_in_flight": 2 if launch == "pipeline" else 1,
+                       "index_bytes_read_per_launch": (S // 2 if paired else S) * (int(info.get("lds_bytes", 0)) + (int(info.get("list_bytes", 0)) if fused else 0))},
             "raycast_tiled_kernel (+ beams, work list)": {"ms": float(ms_ray), "alg_bytes": ray_bytes},
             "finalize_kernel": {"ms": float(ms_fin), "alg_bytes": fin_bytes},
         }
@@ -499,15 +529,20 @@ def main():
                          "meaning": "busy_frac = SIMD cycles that issued a VALU instruction; active_lane_share = "
                                     "SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); their product is the share of "
                                     "VALU lane-slots that did work -- the bound this kernel runs against"},
-                "note": "the ICP kernel is VALU-issue bound (exact 1-NN search in LDS, one workgroup per scan, launch "
-                        "time = slowest scan), not HBM-bound: see DESIGN.md 4.1"}
+                "launches_in_flight": kernels[dom].get("launches_in_flight", 1),
+                "per_step_equivalent_GBps": (kernels[dom]["alg_bytes"] / (elapsed / max(args.steps, 1)) / 1e9) if dom == icp_name else None,
+                "note": "the ICP kernel is VALU-issue bound (exact 1-NN search in LDS, launch time = slowest scan), not "
+                        "HBM-bound: see DESIGN.md 4.1.  In the pipelined launch two registration launches are in flight on two "
+                        "streams, each on half the CUs (two scans per workgroup): avg_launch_ms is one launch's duration on "
+                        "its stream, per_step_equivalent_GBps the algorithmic bytes over the step time"}
         out = {
             "metric": "registered_scan_points_per_s", "value": total_pts * args.steps / elapsed,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 pose / f32 distance / int32 counts",
             "data": "synthetic",
-            "launch": {"pipeline": "two streams over consecutive steps: ICP of step k beside the grid update of step k-1",
+            "launch": {"pipeline": "consecutive steps on three streams: registrations (two scans per workgroup) alternate on two, "
+                                   "the grid update of the step before runs on the third",
                        "graph": "hipGraph replay of one captured step", "calls": "one stream, call by call"}[launch],
             "config": {"workload": "BASELINE config %s per GPU: %d x 1081-beam scans (%d points), %d ICP "
                                    "iterations vs %d-point map, Bresenham raycast into %dx%d @%.2f m, "
@@ -524,7 +559,8 @@ def main():
             "point_iterations_per_s": total_pts * N_ITERS * args.steps / elapsed,
             "one_stream": None if seq_ms is None else
             {"ms_per_step": seq_ms, "value": total_pts / (seq_ms * 1e-3),
-             "what": "the same steps call by call on ONE stream, nothing overlapped (measured after the timed region)"},
+             "what": "the same steps call by call on ONE stream, one scan per workgroup, nothing overlapped (measured after "
+                     "the timed region)"},
             "kernel_ms": {"icp": float(ms_icp), "raycast": float(ms_ray), "merge": float(ms_merge),
                           "finalize": float(ms_fin)},
             "kernels": kernels,

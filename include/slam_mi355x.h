@@ -135,7 +135,8 @@ void slam_icp_default_params(slam_icp_params *p);
 int  slam_icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga,
                      const slam_icp_params *params, slam_icp_t **out);
 /* The same with the model arrays resident in HBM (a target built from registered scans: the sliding local
- * map of a streaming mapper).  Synchronises the default stream; the arrays must be complete before the call. */
+ * map of a streaming mapper).  Builds on a stream of the library's own and returns with the index complete; the
+ * arrays must be complete when the call is made (it does not order itself behind any stream of the caller). */
 int  slam_icp_create_dev(const double *d_m_ga, int n_ga, const double *d_m_nga, int n_nga,
                          const slam_icp_params *params, slam_icp_t **out);
 void slam_icp_destroy(slam_icp_t *icp);
@@ -424,9 +425,11 @@ typedef struct {
     int    pipelined;          /* 1 = three streams; 0 = one stage after the other on one stream (same results) */
     int    strict_window;      /* 1 = a rebuild waits for the newest registered chunk (reproducible targets; the
                                   pipeline stalls for one registration); 0 = it takes what has finished */
-    int    slots;              /* chunks in flight (device + pinned buffers each): 2..4, default 3 -- with three the
-                                  host enqueues chunk k while k-1 registers and k-2 is mapped, so the ICP stream never
-                                  waits for the host (two: 0.53 ms per 256-scan chunk, three: 0.45) */
+    int    slots;              /* chunks in flight (device + pinned buffers each): 2..8; 0 = default: 5 with a fixed target -- the
+                                  host enqueues chunk k while two registrations run on the two registration streams and
+                                  the chunks before them are mapped and read back (256-scan chunks: two 0.54 ms per chunk,
+                                  three 0.43, four 0.38, five 0.37) -- and 3 with a sliding target, whose chunks register
+                                  one after the other (every chunk in flight is a chunk the window lags behind) */
     double thin_res;           /* > 0: the window is thinned to one point per cell of this pitch (metres) and class over
                                   the grid's extent, the oldest measurement of a cell kept (where pcl::VoxelGrid keeps a
                                   centroid, icpTools.cpp:620-633); 0: every stride-th point of a chunk instead */

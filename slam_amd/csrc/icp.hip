@@ -1168,6 +1168,22 @@ void destroy_unsynchronised(slam_icp *icp)
 } // namespace icp
 } // namespace slam
 
+namespace slam {
+namespace icp {
+
+// Batches of so few scans run in the spread form (icp_single.hip): one persistent launch whose workgroups of a scan wait
+// for one another, with scratch that belongs to the handle -- a handle takes ONE such call at a time (batches in the
+// workgroup-per-scan forms may be in flight on several streams at once: they keep nothing in the handle).
+bool takes_spread_form(const slam_icp *h, int n_scans)
+{
+    const int spread_max = h->prm.spread_scans > 0 ? std::min(h->prm.spread_scans, h->n_cu)
+                                                   : (h->prm.spread_scans < 0 ? 0 : h->n_cu / kSpreadMinParts);
+    return n_scans >= 1 && n_scans <= spread_max && h->prm.mode == SLAM_ICP_P2P && h->prm.lanes_per_point == 0;
+}
+
+} // namespace icp
+} // namespace slam
+
 extern "C" {
 
 void slam_icp_default_params(slam_icp_params *p)
@@ -1345,10 +1361,7 @@ int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *
     }
 #endif
     // few scans (one, in the reference's own usage): each scan spread over many workgroups of one persistent launch
-    const int spread_max = icp->prm.spread_scans > 0 ? std::min(icp->prm.spread_scans, icp->n_cu)
-                                                     : (icp->prm.spread_scans < 0 ? 0 : icp->n_cu / kSpreadMinParts);
-    if (n_scans >= 1 && n_scans <= spread_max && icp->prm.mode == SLAM_ICP_P2P && icp->prm.lanes_per_point == 0 && !fa.stamps)
-        return launch_fit_spread(icp, fa, n_scans, as_stream(stream));
+    if (takes_spread_form(icp, n_scans) && !fa.stamps) return launch_fit_spread(icp, fa, n_scans, as_stream(stream));
     return launch_fit(icp, fa, n_scans, as_stream(stream));
 }
 

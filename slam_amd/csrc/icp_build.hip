@@ -959,14 +959,9 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
     hipStream_t  st = build_stream();
     Workspace    ws;
     const int    pblocks = (n_all + 255) / 256;
-    if (st && on_device) { // a caller may have written the model on the default stream: the build starts behind it
-        hipEvent_t ev = nullptr;
-        SLAM_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        hipError_t e = hipEventRecord(ev, nullptr);
-        if (e == hipSuccess) e = hipStreamWaitEvent(st, ev, 0);
-        (void)hipEventDestroy(ev);
-        SLAM_HIP(e);
-    }
+    // (device arrays: complete when the call is made -- the build does not order itself behind the default stream: that
+    // stream shares a hardware queue with whatever the application runs, and an event on it can sit behind a whole
+    // registration launch)
 
     // ---- the model in HBM (f64, as the caller holds it) and its extent
     BBox          bb;

@@ -825,6 +825,7 @@ constexpr int kSpreadMinParts = 16; // the spread form takes batches that leave 
 // icp_single.hip: few scans (one, in the reference's own usage), each spread over many workgroups of one
 // persistent launch
 int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st);
+bool takes_spread_form(const slam_icp *h, int n_scans); // icp.hip
 
 } // namespace icp
 } // namespace slam

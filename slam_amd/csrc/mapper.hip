@@ -6,8 +6,9 @@
 // setSceneCloud -> doICPMatch against the target it keeps, :139-159; local_mapper.cpp:65-130: addToMap at
 // 50 Hz).  Per chunk k, with two device slots:
 //   copy stream : pinned chunk k -> HBM                                            -> event copied
-//   icp  stream : wait copied -> slam_icp_fit_batch_dev against the current target -> decimate the registered
-//                 points into the window ring                                       -> event registered
+//   icp  streams: wait copied -> slam_icp_fit_batch_dev against the current target -> decimate the registered
+//   (two, chunks  points into the window ring                                       -> event registered
+//    alternate)
 //   grid stream : wait registered -> slam_grid_set_pose (rolling window, mls.cpp:408-479) + Bresenham update
 //                 -> every merge_every chunks: dirty-row merge over the ranks (hook installed by
 //                 slam_mapper_use_comm, slam_mi355x_rccl.h), fold into the accumulator, finalize -> event mapped
@@ -29,6 +30,8 @@
 #include <vector>
 
 #include "icp_model.hpp"
+
+namespace slam { namespace icp { bool takes_spread_form(const slam_icp *h, int n_scans); } } // icp.hip
 
 using namespace slam;
 
@@ -166,7 +169,7 @@ struct Slot {
     int      n_scans = 0;
 };
 
-constexpr int kMaxSlots = 4;
+constexpr int kMaxSlots = 8;
 
 struct WindowEntry {
     double2 *ga = nullptr, *nga = nullptr; // device, room for max_points each
@@ -181,10 +184,11 @@ struct slam_mapper {
     slam_mapper_params prm;
     slam_grid_t       *grid = nullptr;
     slam_icp_t        *target = nullptr, *retired = nullptr;
-    hipEvent_t         target_used = nullptr, retired_used = nullptr; // behind the last launch that read the handle
-    hipStream_t        copy = nullptr, icp_s = nullptr, grid_s = nullptr;
+    hipEvent_t         target_used[2] = {nullptr, nullptr}, retired_used[2] = {nullptr, nullptr}; // behind the last launch on each
+                                                                                                  // registration stream that read the handle
+    hipStream_t        copy = nullptr, icp_s[2] = {nullptr, nullptr}, grid_s = nullptr; // chunks alternate over the two icp streams
     Slot               slot[kMaxSlots];
-    int                n_slots = 3;
+    int                n_slots = 5;
     int                next = 0;
     long               chunks = 0, merges = 0, rebuilds = 0, last_rebuild = -1;
     std::vector<WindowEntry> window;
@@ -222,7 +226,8 @@ namespace {
 void retire_now(slam_mapper *m)
 {
     if (!m->retired) return;
-    if (m->retired_used) (void)hipEventSynchronize(m->retired_used);
+    for (hipEvent_t e : m->retired_used)
+        if (e) (void)hipEventSynchronize(e);
     slam::icp::destroy_unsynchronised(m->retired);
     m->retired = nullptr;
 }
@@ -361,7 +366,8 @@ void adopt_target(slam_mapper *m, slam_icp_t *fresh)
     if (!fresh) return;
     retire_now(m); // the handle before last: its launches ended chunks ago
     m->retired = m->target;
-    std::swap(m->retired_used, m->target_used);
+    std::swap(m->retired_used[0], m->target_used[0]);
+    std::swap(m->retired_used[1], m->target_used[1]);
     m->target = fresh;
     ++m->rebuilds;
 }
@@ -498,7 +504,7 @@ void slam_mapper_default_params(slam_mapper_params *p)
     p->pipelined = 1;
     p->strict_window = 0;
     p->thin_res = 0.0;
-    p->slots = 3;
+    p->slots = 0;
     p->background_rebuild = 1;
 }
 
@@ -514,8 +520,18 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
     slam_mapper *m = new (std::nothrow) slam_mapper();
     SLAM_REQUIRE(m, SLAM_E_NOMEM, "slam_mapper_create: out of host memory");
     m->prm = *params;
+    {
+        // Two registrations are in flight (two streams): with two scans per workgroup a chunk of up to two scans per CU
+        // holds half the CUs it would hold otherwise, and the chunk after it starts beside it instead of behind its
+        // slowest scan (256-scan chunks: 0.41 -> 0.36 ms).  Below half a scan per CU two chunks fit side by side anyway.
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+            params->pipelined && !params->window_chunks && m->prm.icp.pair_scans == 0 && 2 * params->max_scans > cus)
+            m->prm.icp.pair_scans = 2;
+        (void)hipGetLastError();
+    }
     int rc = slam_grid_create(params->grid_size_x, params->grid_size_y, params->resolution, &params->grid, &m->grid);
-    if (rc == SLAM_OK) rc = slam_icp_create(m_ga, n_ga, m_nga, n_nga, &params->icp, &m->target); // the prior map: the first target
+    if (rc == SLAM_OK) rc = slam_icp_create(m_ga, n_ga, m_nga, n_nga, &m->prm.icp, &m->target); // the prior map: the first target
     auto hip = [&](hipError_t e) {
         if (rc == SLAM_OK && e != hipSuccess) rc = hip_fail(e, "slam_mapper_create", __FILE__, __LINE__);
     };
@@ -523,24 +539,33 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
         m->prior_ga.assign(m_ga, m_ga + 2 * (size_t)n_ga);
         m->prior_nga.assign(m_nga, m_nga + 2 * (size_t)n_nga);
         if (params->pipelined) {
-            // One priority level each.  HIP deals the streams of a process over a few hardware queues per priority level
-            // (four unless GPU_MAX_HW_QUEUES says otherwise), in an order that depends on what the application created
-            // before: two of these three on one queue run one after the other (measured: 0.42 ms per chunk alone, 0.54 and
-            // 0.65 ms with one and two idle application streams made first).  Queues of different levels are never
-            // shared, and the levels themselves make no measurable difference to the kernels (tools/pipeline_experiment.py).
+            // HIP deals the streams of a process over a few hardware queues: a handful for the default priority level,
+            // dealt in creation order over everything the application made before, and (as far as the timings tell) one
+            // each for the high and the low level.  Two streams on one queue run one after the other (measured: three
+            // default-level streams 0.42 ms per chunk alone, 0.54 and 0.65 ms with one and two idle application streams
+            // made first; the index build's stream on the registration stream's level: rebuilds 1.3 -> 3.2 ms).  So: the
+            // two registration streams on the default level, the copies on the high level (which they share with the
+            // index build's stream: both are short), the grid update on the low level.  The levels themselves make no
+            // measurable difference to the kernels (tools/pipeline_experiment.py).
             int lo = 0, hi = 0; // numerically lower = higher priority
             hip(hipDeviceGetStreamPriorityRange(&lo, &hi));
             hip(hipStreamCreateWithPriority(&m->copy, hipStreamNonBlocking, lo));
-            hip(hipStreamCreateWithPriority(&m->icp_s, hipStreamNonBlocking, (lo + hi) / 2));
+            hip(hipStreamCreateWithPriority(&m->icp_s[0], hipStreamNonBlocking, (lo + hi) / 2));
             hip(hipStreamCreateWithPriority(&m->grid_s, hipStreamNonBlocking, hi));
+            if (params->window_chunks)
+                m->icp_s[1] = m->icp_s[0]; // a sliding target registers its chunks one after the other (slam_mapper_push)
+            else
+                hip(hipStreamCreateWithPriority(&m->icp_s[1], hipStreamNonBlocking, (lo + hi) / 2));
         } else {
             hip(hipStreamCreateWithFlags(&m->copy, hipStreamNonBlocking));
-            m->icp_s = m->grid_s = m->copy;
+            m->icp_s[0] = m->icp_s[1] = m->grid_s = m->copy;
         }
-        hip(hipEventCreateWithFlags(&m->target_used, hipEventDisableTiming));
-        hip(hipEventCreateWithFlags(&m->retired_used, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) {
+            hip(hipEventCreateWithFlags(&m->target_used[k], hipEventDisableTiming));
+            hip(hipEventCreateWithFlags(&m->retired_used[k], hipEventDisableTiming));
+        }
         const size_t np = (size_t)params->max_points, ns = (size_t)params->max_scans;
-        m->n_slots = params->slots >= 2 && params->slots <= kMaxSlots ? params->slots : 3;
+        m->n_slots = params->slots >= 2 && params->slots <= kMaxSlots ? params->slots : (params->window_chunks ? 3 : 5);
         for (int k = 0; k < m->n_slots; ++k) {
             Slot &b = m->slot[k];
             hip(hipMalloc((void **)&b.d_pts, 16 * np));
@@ -606,11 +631,14 @@ void slam_mapper_destroy(slam_mapper_t *m)
     if (m->target) slam_icp_destroy(m->target);
     if (m->retired) slam_icp_destroy(m->retired);
     if (m->grid) slam_grid_destroy(m->grid);
-    if (m->target_used) (void)hipEventDestroy(m->target_used);
-    if (m->retired_used) (void)hipEventDestroy(m->retired_used);
-    const bool one = m->icp_s == m->copy;
+    for (int k = 0; k < 2; ++k) {
+        if (m->target_used[k]) (void)hipEventDestroy(m->target_used[k]);
+        if (m->retired_used[k]) (void)hipEventDestroy(m->retired_used[k]);
+    }
+    const bool one = m->icp_s[0] == m->copy;
     if (m->copy) (void)hipStreamDestroy(m->copy);
-    if (!one && m->icp_s) (void)hipStreamDestroy(m->icp_s);
+    if (!one && m->icp_s[0]) (void)hipStreamDestroy(m->icp_s[0]);
+    if (!one && m->icp_s[1] && m->icp_s[1] != m->icp_s[0]) (void)hipStreamDestroy(m->icp_s[1]);
     if (!one && m->grid_s) (void)hipStreamDestroy(m->grid_s);
     delete m;
 }
@@ -688,23 +716,28 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     MAP_HIP(hipMemcpyAsync(b.d_t, b.h_t, 16 * (size_t)n_scans, hipMemcpyHostToDevice, m->copy));
     MAP_HIP(hipEventRecord(b.copied, m->copy));
     // ---- register
-    MAP_HIP(hipStreamWaitEvent(m->icp_s, b.copied, 0));
+    // chunks alternate over the two registration streams; the spread form (a handful of scans) takes one call at a time
+    // (and so do the chunks of a sliding target: a chunk registered beside its predecessor would meet a window that is a
+    // chunk staler -- measured on config 5: 0.52 ms per chunk on one stream, 0.86 on two)
+    const int   lane = (m->prm.window_chunks || slam::icp::takes_spread_form(m->target, n_scans)) ? 0 : (int)(m->chunks & 1);
+    hipStream_t icp_s = m->icp_s[lane];
+    MAP_HIP(hipStreamWaitEvent(icp_s, b.copied, 0));
     SLAM_TRY(slam_icp_fit_batch_dev(m->target, b.d_pts, b.d_off, b.d_nga, n_scans, b.d_R, b.d_t, m->prm.indist, nullptr, nullptr,
-                                    (slam_stream_t)m->icp_s));
-    MAP_HIP(hipEventRecord(m->target_used, m->icp_s));
+                                    (slam_stream_t)icp_s));
+    MAP_HIP(hipEventRecord(m->target_used[lane], icp_s));
     if (m->prm.window_chunks) {
         WindowEntry &w = m->window[(size_t)(m->chunks % (long)m->window.size())];
         const int    sg = stride_for(m, n_ga), sn = stride_for(m, n_nga);
-        hipLaunchKernelGGL(window_points_kernel, dim3((n_points + 255) / 256), dim3(256), 0, m->icp_s,
+        hipLaunchKernelGGL(window_points_kernel, dim3((n_points + 255) / 256), dim3(256), 0, icp_s,
                            reinterpret_cast<const double2 *>(b.d_pts), b.d_off, b.d_nga, b.d_gab, n_scans, n_points, b.d_R, b.d_t, sg, sn,
                            w.ga, w.nga);
         MAP_HIP(hipGetLastError());
         w.n_ga = (n_ga + sg - 1) / sg;
         w.n_nga = (n_nga + sn - 1) / sn;
         w.chunk = m->chunks;
-        MAP_HIP(hipEventRecord(w.ready, m->icp_s));
+        MAP_HIP(hipEventRecord(w.ready, icp_s));
     }
-    MAP_HIP(hipEventRecord(b.registered, m->icp_s));
+    MAP_HIP(hipEventRecord(b.registered, icp_s));
     // ---- the previous chunk's merge, now that this chunk's registration is in the queue ahead of the wait
     SLAM_TRY(finish_merge(m));
     // ---- map
@@ -757,7 +790,8 @@ int slam_mapper_finish(slam_mapper_t *m)
         SLAM_TRY(slam_grid_finalize(m->grid, (slam_stream_t)m->grid_s));
     }
     MAP_HIP(hipStreamSynchronize(m->copy));
-    MAP_HIP(hipStreamSynchronize(m->icp_s));
+    MAP_HIP(hipStreamSynchronize(m->icp_s[0]));
+    MAP_HIP(hipStreamSynchronize(m->icp_s[1]));
     MAP_HIP(hipStreamSynchronize(m->grid_s));
     return SLAM_OK;
 }

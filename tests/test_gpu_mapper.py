@@ -42,7 +42,7 @@ def run_mapper(m_ga, m_nga, batch, chunk, rolling, comm=None, **kw):
     return out
 
 
-@pytest.mark.parametrize("n_scans,chunk,size,res,slots", [(48, 8, 600, 0.1, 3), (21, 5, 400, 0.15, 2), (40, 4, 400, 0.15, 4)])
+@pytest.mark.parametrize("n_scans,chunk,size,res,slots", [(48, 8, 600, 0.1, 3), (21, 5, 400, 0.15, 2), (40, 4, 400, 0.15, 7)])
 def test_fixed_target_rolling_window_matches_oracle(n_scans, chunk, size, res, slots):
     m_ga, m_nga = synth.make_map(10000)
     batch = synth.make_batch(n_scans, n_loop=64)

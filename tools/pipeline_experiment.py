@@ -65,7 +65,44 @@ def run_one():
     return (time.perf_counter() - t0) / K * 1e3
 
 
+def run_pairs(n_icp_streams, pair):
+    """registration with two scans per workgroup (half the CUs per batch) on n alternating streams, the grid on another"""
+    icp2 = api.Icp(m_ga, m_nga, max_iter=30, min_delta=-1.0, pair_scans=pair)
+    A = [api.Stream(-1 if i == 0 else None) for i in range(n_icp_streams)]
+    b = api.Stream(1)
+    NB = 2 * n_icp_streams
+    poses = [api.DeviceArray(d_pose0.shape, np.float64) for _ in range(NB)]
+    R_ = [p.view(0, batch.R.shape) for p in poses]
+    t_ = [p.view(batch.R.size, batch.t.shape) for p in poses]
+    icp_done = [api.Event() for _ in range(NB)]
+    grid_done = [api.Event() for _ in range(NB)]
+    def steps(n):
+        for k in range(n):
+            s, a = k % NB, A[k % n_icp_streams]
+            a.wait_event(grid_done[s])
+            poses[s].copy_from(d_pose0, a)
+            icp2.fit_batch_dev(d_pts, d_off, d_nga, S, R_[s], t_[s], 5.0, None, None, a)
+            icp_done[s].record(a)
+            b.wait_event(icp_done[s])
+            grid.reset_counts(b)
+            grid.raycast_scans_dev(d_pts, d_off, S, P, R_[s], t_[s], b)
+            grid.finalize(b)
+            grid_done[s].record(b)
+    for e in grid_done:
+        e.record(b)
+    steps(8)
+    api.synchronize()
+    t0 = time.perf_counter()
+    steps(K)
+    api.synchronize()
+    dt_ = (time.perf_counter() - t0) / K * 1e3
+    icp2.close()
+    return dt_
+
+
 print("one stream, call by call: %.4f ms/step" % run_one())
+for n, pair in ((2, 2), (2, -1), (3, 2), (1, 2)):
+    print("%d registration streams, pair_scans=%d: %.4f ms/step" % (n, pair, run_pairs(n, pair)))
 for pa, pb, name in ((None, None, "two streams, default priorities"), (1, -1, "ICP high, grid low"), (-1, 1, "ICP low, grid high")):
     print("%s: %.4f ms/step" % (name, run(pa, pb)))
 h, m = grid.read_counts()
