@@ -525,6 +525,11 @@ def main():
                 "alg_bytes_formula": "16*P + S*(8*M + 96) (SURVEY 8(d)); P=%d points, S=%d scans, M=%d model points" % (P, S, M),
                 "valu": {"busy_frac": busy, "active_lane_share": lanes,
                          "lane_slot_frac": (busy * lanes) if (busy is not None and lanes is not None) else None,
+                         # the counters are taken with the kernel alone on the chip: a launch of W workgroups of 1024 threads
+                         # holds min(W, CUs) CUs (pairs: half as many workgroups as scans)
+                         "cus_held_by_one_launch": min(n_cu, (S + 1) // 2 if paired else S) if dom == icp_name else None,
+                         "busy_frac_on_held_cus": (busy * n_cu / min(n_cu, (S + 1) // 2 if paired else S))
+                         if (busy is not None and dom == icp_name) else None,
                          "source": prof_file,
                          "meaning": "busy_frac = SIMD cycles that issued a VALU instruction; active_lane_share = "
                                     "SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); their product is the share of "
