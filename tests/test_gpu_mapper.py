@@ -42,11 +42,14 @@ def run_mapper(m_ga, m_nga, batch, chunk, rolling, comm=None, **kw):
     return out
 
 
-@pytest.mark.parametrize("n_scans,chunk,size,res,slots", [(48, 8, 600, 0.1, 3), (21, 5, 400, 0.15, 2), (40, 4, 400, 0.15, 7)])
-def test_fixed_target_rolling_window_matches_oracle(n_scans, chunk, size, res, slots):
+@pytest.mark.parametrize("n_scans,chunk,size,res,slots,pair", [(48, 8, 600, 0.1, 3, 0), (21, 5, 400, 0.15, 2, 0), (40, 4, 400, 0.15, 7, 0),
+                                                                (120, 20, 600, 0.1, 0, 0), (110, 22, 600, 0.1, 4, 2)])
+def test_fixed_target_rolling_window_matches_oracle(n_scans, chunk, size, res, slots, pair):
+    """chunks of up to 16 scans take the spread form (one registration stream); the chunks of 20 and 22 alternate over the
+    two registration streams, one scan or (pair = 2) two scans per workgroup, five chunks in flight by default"""
     m_ga, m_nga = synth.make_map(10000)
-    batch = synth.make_batch(n_scans, n_loop=64)
-    kw = dict(grid_size_x=size, grid_size_y=size, resolution=res, max_range=0.45 * size * res, slots=slots)
+    batch = synth.make_batch(n_scans, n_loop=128 if n_scans > 64 else 64)
+    kw = dict(grid_size_x=size, grid_size_y=size, resolution=res, max_range=0.45 * size * res, slots=slots, icp=dict(pair_scans=pair))
     a = run_mapper(m_ga, m_nga, batch, chunk, rolling=1, pipelined=1, **kw)
     b = run_mapper(m_ga, m_nga, batch, chunk, rolling=1, pipelined=0, **kw)
     assert np.array_equal(a["R"], b["R"]) and np.array_equal(a["t"], b["t"])             # pipelined == stage after stage
