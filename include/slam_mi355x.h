@@ -159,7 +159,11 @@ int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t
  *   d_result   n_scans slam_icp_result (nullable)
  *   d_trace    nullable; n_scans x max_iter x 8 doubles: R00 R01 R10 R11 t0 t1
  *              delta n_corr after each executed step
- * Scans with fewer than 5 points are left untouched (iters = 0). */
+ * Scans with fewer than 5 points are left untouched (iters = 0).
+ * Asynchronous on `stream`.  Batches in the workgroup-per-scan forms (more than CUs / 16 scans, or spread_scans = -1)
+ * keep nothing in the handle: calls on ONE handle may be in flight on several streams at once, and that is how a
+ * stream of batches should be run -- two registration streams with pair_scans = 2, the grid update on a third
+ * (DESIGN.md 4.6).  The spread form (few scans) uses scratch of the handle: one such call at a time per handle. */
 int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *d_scan_off,
                            const int32_t *d_scan_nga, int n_scans, double *d_R, double *d_t,
                            double indist, slam_icp_result *d_result, double *d_trace,
