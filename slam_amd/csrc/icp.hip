@@ -1096,7 +1096,7 @@ int launch_fit(slam_icp *h, const FitArgs &fa_in, int n_scans, hipStream_t st)
         // Library default: from two scans per CU on.  Measured on config 2's scans (tools/pair_time.py): 256 scans on 256 CUs
         // 0.39 ms alone against 0.61 in pairs (half the CUs idle); 512 scans 0.72 against 0.61; 1024 scans 1.31 against 1.16.
         const int pair = h->pair > 0 ? h->pair : (h->pair == 0 && n_scans >= 2 * h->n_cu ? 2 : 0);
-        if (pair && pair_lds <= kLdsTotal && n_scans >= 2) {
+        if (pair && pair_lds + 64 <= kLdsTotal && n_scans >= 2) { // (+ the kernel's one static word, with its alignment)
             auto kern = h->start32 ? (pair == 1 ? icp_fit_pair_kernel<uint32_t, SLAM_ICP_P2P, 1> : icp_fit_pair_kernel<uint32_t, SLAM_ICP_P2P, 2>)
                                    : (pair == 1 ? icp_fit_pair_kernel<uint16_t, SLAM_ICP_P2P, 1> : icp_fit_pair_kernel<uint16_t, SLAM_ICP_P2P, 2>);
             SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds));
