@@ -349,6 +349,9 @@ int  slam_gseg_split_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, 
  * or in its outermost cells).  GA/NGA are the two classes the ICP matches separately. */
 int  slam_gseg_classify_ga_dev(slam_gseg_t *h, const float *d_obstacle_xyz, int n, int stride,
                                uint8_t *d_flags, slam_stream_t stream);
+/* the same where the number of points is known on the device only (*d_n, at most n_capacity): no host round trip */
+int  slam_gseg_classify_ga_counted_dev(slam_gseg_t *h, const float *d_obstacle_xyz, const int32_t *d_n, int n_capacity,
+                                       int stride, uint8_t *d_flags, slam_stream_t stream);
 /* per polar bin (72 x 200): 1 = in the ground model (value = prototype height), 2 = candidate
  * that stayed out (value = GP mean), 0 = no signal point; INSAC iterations per sector */
 int  slam_gseg_read_model(slam_gseg_t *h, uint8_t *bin_state, double *bin_value, int32_t *sector_iterations);
@@ -402,6 +405,27 @@ int slam_ccicp_split_dev(slam_ccicp_t *h, const float *d_xyzg, int n, int stride
  * (optional) gets the four nearest indices. */
 int slam_ccicp_height_dev(slam_ccicp_t *h, const float *d_ground, int n, int stride, const double pose[7], double *z_out,
                           int *n_corr, int nn_idx[4], slam_stream_t stream);
+
+/* The steps above as ONE device-resident chain, for a caller that matches cloud after cloud (scan_registration.cpp:
+ * 109-199): CCICP::segmentGround + classifyPoints + setSceneCloud's voxel filter (voxel != 0; 0 = setTargetCloud's
+ * bin order) + doICPMatch's crop / class split / cap, stage after stage on `stream` with every count left on the device
+ * -- the stepwise entry points return each count to the host, seven round trips per cloud.  Same results, bit for bit.
+ *   d_pts    out: xy f64, the GA points then the NGA points (room for 2 * (cap - 1) points)
+ *   d_scan   out: int32[3] = {0, n_ga + n_nga, n_ga}: d_scan_off = d_scan, d_scan_nga = d_scan + 2 of a
+ *            slam_icp_fit_batch_dev call with n_scans = 1 that registers the cloud without the host knowing its size
+ *   d_ground out, nullable: the ground cloud as x,y,z,0 records (room for n)
+ *   d_counts out: int32[4] = {obstacle points, ground points, points after the filter, 1 if the voxel lattice did not
+ *            fit the chain's accumulator (2 M voxels; the stepwise entry point takes larger extents)}
+ * Nothing is read back and nothing waits: the caller reads d_counts when it needs them. */
+int slam_ccicp_scene_dev(slam_ccicp_t *h, slam_gseg_t *seg, const float *d_xyz, int n, int stride, int voxel, int crop,
+                         double cur_x, double cur_y, double crop_dist, int cap, double *d_pts, int32_t *d_scan,
+                         float *d_ground, int32_t *d_counts, slam_stream_t stream);
+/* doHeightInterpolate for the pose a registration left on the device (d_R 2x2, d_t of one scan; yaw = atan2(R10, R00),
+ * icpTools.cpp:195-197) against a ground cloud whose size is known on the device (*d_n_ground <= n_capacity):
+ * d_out[0] = z, d_out[1] = neighbours within 3 m.  Asynchronous. */
+int slam_ccicp_height_pose_dev(slam_ccicp_t *h, const float *d_ground, const int32_t *d_n_ground, int n_capacity,
+                               int stride, const double *d_R, const double *d_t, double z0, double *d_out,
+                               slam_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Streaming mapper (BASELINE config 5).  Stands where scan_registration (scan_registration.cpp:109-199: one

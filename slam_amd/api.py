@@ -95,9 +95,10 @@ EXPORTS = [
     "slam_grid_enable_accumulator", "slam_grid_fold",
     "slam_gseg_default_params", "slam_gseg_create", "slam_gseg_destroy", "slam_gseg_reserve",
     "slam_gseg_segment", "slam_gseg_segment_dev", "slam_gseg_split_dev", "slam_gseg_read_model",
-    "slam_gseg_classify_ga_dev",
+    "slam_gseg_classify_ga_dev", "slam_gseg_classify_ga_counted_dev",
     "slam_ccicp_create", "slam_ccicp_destroy", "slam_ccicp_voxel_downsample_dev", "slam_ccicp_split_dev",
-    "slam_ccicp_height_dev", "slam_ccicp_bin_order_dev", "slam_ccicp_select_dev",
+    "slam_ccicp_height_dev", "slam_ccicp_bin_order_dev", "slam_ccicp_select_dev", "slam_ccicp_scene_dev",
+    "slam_ccicp_height_pose_dev",
     "slam_mapper_default_params", "slam_mapper_create", "slam_mapper_destroy", "slam_mapper_next_slot", "slam_mapper_slots",
     "slam_mapper_chunk_buffers", "slam_mapper_push", "slam_mapper_wait", "slam_mapper_finish", "slam_mapper_grid",
     "slam_mapper_target", "slam_mapper_stats", "slam_mapper_set_merge",
@@ -128,6 +129,11 @@ def lib():
                                            C.c_void_p]
     L.slam_ccicp_height_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
+    L.slam_ccicp_scene_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
+                                       C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.slam_ccicp_height_pose_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                             C.c_double, C.c_void_p, C.c_void_p]
+    L.slam_gseg_classify_ga_counted_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.slam_grid_destroy.restype = None
     L.slam_icp_default_params.restype = None
     L.slam_grid_default_params.restype = None

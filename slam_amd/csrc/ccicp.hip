@@ -55,10 +55,15 @@ __host__ __device__ inline float unorder_f32(unsigned u)
 __device__ inline bool finite3(const float *p) { return isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]); }
 
 // getMinMax3D over finite points: wave reduction, one atomic per wavefront and bound
+// `n` is the launch's bound; where the number of points is only known on the device (the chain of slam_ccicp_scene_dev)
+// d_n holds it and n is the capacity the grid was sized for
+__device__ inline int bound(int n, const int *d_n) { return d_n ? min(*d_n, n) : n; }
+
 __global__ __launch_bounds__(256) void minmax_kernel(const float *xyz, const unsigned char *flag, int n, int stride,
-                                                     unsigned *mm /*[6]*/)
+                                                     unsigned *mm /*[6]*/, const int *d_n = nullptr)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    n = bound(n, d_n);
     unsigned  lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
     if (i < n) {
         const float *p = xyz + (size_t)i * stride;
@@ -87,10 +92,12 @@ __device__ inline long long voxel_of(const VoxelGridView &g, const float *p)
 }
 
 __global__ __launch_bounds__(256) void voxel_accumulate_kernel(VoxelGridView g, const float *xyz, const unsigned char *flag,
-                                                               int n, int stride, Voxel *vox)
+                                                               int n, int stride, Voxel *vox, const VoxelGridView *d_g = nullptr,
+                                                               const int *d_n = nullptr)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
+    if (d_g) g = *d_g; // the lattice worked out on the device (voxel_geometry_kernel)
+    if (i >= bound(n, d_n)) return;
     const float *p = xyz + (size_t)i * stride;
     if (!finite3(p) || (flag && flag[i] == 255)) return;
     const long long v = voxel_of(g, p);
@@ -105,9 +112,24 @@ __global__ __launch_bounds__(256) void voxel_accumulate_kernel(VoxelGridView g, 
 }
 
 // ---- stable compaction in three steps: per-block counts, scan of the block counts, ordered write
+// the domain of a compaction: n items, or fewer where a count on the device says so
+struct Domain {
+    long long        n;
+    const int       *d_n;   // nullable
+    const long long *d_n64; // nullable
+    __device__ long long size() const
+    {
+        long long m = n;
+        if (d_n) m = min(m, (long long)*d_n);
+        if (d_n64) m = min(m, *d_n64);
+        return m;
+    }
+};
+
 template <class Pred>
-__global__ __launch_bounds__(kScanThreads) void count_kernel(Pred pred, long long n, int *block_cnt)
+__global__ __launch_bounds__(kScanThreads) void count_kernel(Pred pred, Domain dom, int *block_cnt)
 {
+    const long long n = dom.size();
     const long long base = (long long)blockIdx.x * kItems;
     int             c = 0;
     for (int k = threadIdx.x; k < kItems; k += kScanThreads)
@@ -151,9 +173,10 @@ __global__ __launch_bounds__(1024) void scan_blocks_kernel(int *block_cnt, int n
 
 // positions of the block's selected items in index order: thread t owns items [t*16, t*16+16)
 template <class Pred, class Emit>
-__global__ __launch_bounds__(kScanThreads) void write_kernel(Pred pred, Emit emit, long long n, const int *block_off,
+__global__ __launch_bounds__(kScanThreads) void write_kernel(Pred pred, Emit emit, Domain dom, const int *block_off,
                                                             int limit)
 {
+    const long long n = dom.size();
     constexpr int   kPer = kItems / kScanThreads;
     const long long base = (long long)blockIdx.x * kItems + (long long)threadIdx.x * kPer;
     unsigned        mask = 0;
@@ -231,24 +254,28 @@ struct SplitEmit {
     const float *xyzg;
     int          stride;
     double      *out;
+    const int   *d_base; // nullable: points already in `out` (capped at `base_cap`): this class is written behind them
+    int          base_cap;
     __device__ void operator()(long long i, int pos) const
     {
         const float *p = xyzg + (size_t)i * stride;
-        out[2 * (size_t)pos] = (double)p[0]; // icpTools.cpp:252, 267: float coordinates widened
-        out[2 * (size_t)pos + 1] = (double)p[1];
+        const size_t o = (size_t)pos + (d_base ? (size_t)min(*d_base, base_cap) : 0);
+        out[2 * o] = (double)p[0]; // icpTools.cpp:252, 267: float coordinates widened
+        out[2 * o + 1] = (double)p[1];
     }
 };
 
 // four wheel points against all ground points: exact squared L2 in float (KdTreeFLANN, k = 1), packed
 // (distance bits, index) minimum -> lowest index on a tie
 __global__ __launch_bounds__(256) void height_nn_kernel(const float *ground, int n, int stride, float4 q0, float4 q1,
-                                                        float4 q2, float4 q3, unsigned long long *best /*[4]*/)
+                                                        float4 q2, float4 q3, unsigned long long *best /*[4]*/,
+                                                        const float4 *d_q = nullptr, const int *d_n = nullptr)
 {
     const int          i = blockIdx.x * 256 + threadIdx.x;
     unsigned long long b[4] = {~0ull, ~0ull, ~0ull, ~0ull};
-    if (i < n) {
+    if (i < bound(n, d_n)) {
         const float *c = ground + (size_t)i * stride;
-        const float4 q[4] = {q0, q1, q2, q3};
+        const float4 q[4] = {d_q ? d_q[0] : q0, d_q ? d_q[1] : q1, d_q ? d_q[2] : q2, d_q ? d_q[3] : q3};
         for (int k = 0; k < 4; ++k) {
             const float dx = c[0] - q[k].x, dy = c[1] - q[k].y, dz = c[2] - q[k].z;
             const float dd = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
@@ -269,10 +296,14 @@ __global__ __launch_bounds__(256) void height_nn_kernel(const float *ground, int
 // 1200 x 1200 lattice :60, edge cells :72-77 -- flag 255 from slam_gseg_classify_ga_dev) get the last key.
 constexpr int kGaBins = 1200; // icpTools.h:24-26
 __global__ __launch_bounds__(256) void bin_keys_kernel(const float *xyz, const unsigned char *flag, int n, int stride,
-                                                       unsigned long long *keys)
+                                                       unsigned long long *keys, const int *d_n = nullptr)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (i >= bound(n, d_n)) { // past the cloud's end (its size is known on the device only): sorts behind everything kept
+        keys[i] = (0x1fffffull << 32) | (unsigned)i;
+        return;
+    }
     const float *q = xyz + (size_t)i * stride;
     const double RES = 0.5, offset = (double)kGaBins * RES / 2;
     const double fx = floor(((double)q[0] + offset) / RES), fy = floor(((double)q[1] + offset) / RES); // :57-58
@@ -298,6 +329,168 @@ __global__ __launch_bounds__(256) void bin_gather_kernel(const float *xyz, const
     if (kept && !next_kept) *n_out = i + 1;
 }
 
+// ---- the chain of slam_ccicp_scene_dev: what the stepwise entry points work out on the host, on the device
+// the voxel lattice from the extent (slam_ccicp_voxel_downsample_dev's host code, PCL voxel_grid.hpp); err |= 1 when it
+// does not fit the accumulator (n_vox = 0 then: nothing is accumulated)
+__global__ void voxel_geometry_kernel(const unsigned *mm, float leaf_x, float leaf_y, float leaf_z, long long capacity,
+                                      VoxelGridView *g, int *err)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    VoxelGridView v;
+    const float   leaf[3] = {leaf_x, leaf_y, leaf_z};
+    long long     nv = 1;
+    bool          bad = mm[0] == 0xffffffffu; // no finite point
+    for (int d = 0; d < 3; ++d) {
+        v.inv[d] = 1.0f / leaf[d];
+        const double lo = floor((double)(unorder_f32(mm[d]) * v.inv[d]));
+        const double hi = floor((double)(unorder_f32(mm[3 + d]) * v.inv[d]));
+        if (bad || !(fabs(lo) < 1e9) || !(hi - lo + 1.0 <= (double)capacity)) {
+            bad = true;
+            v.min_b[d] = 0;
+            v.div_b[d] = 0;
+            continue;
+        }
+        v.min_b[d] = (int)lo;
+        v.div_b[d] = (int)(hi - lo) + 1;
+        nv *= v.div_b[d];
+        if (nv <= 0 || nv > capacity) bad = true;
+    }
+    v.n_vox = bad ? 0 : nv;
+    if (bad && mm[0] != 0xffffffffu) atomicOr(err, 1);
+    *g = v;
+}
+
+__global__ __launch_bounds__(256) void voxel_zero_kernel(const VoxelGridView *g, Voxel *vox)
+{
+    const long long nv = g->n_vox;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long long)gridDim.x * 256) {
+        Voxel z;
+        z.sx = z.sy = z.sz = 0;
+        z.sflag = z.count = 0;
+        vox[i] = z;
+    }
+}
+
+// {0, n_ga + n_nga, n_ga}: scan_off[0..1] and scan_nga[0] of the one scan slam_icp_fit_batch_dev then registers; the
+// class totals are capped as CCICP::doICPMatch caps them (ICP_MAX_PTS - 1, icpTools.cpp:256,259)
+__global__ void scene_scan_kernel(const int *tot /*[2]*/, int cap, const int *n_obs, const int *n_gnd, const int *n_flt, int *scan,
+                                  int *counts)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const int ga = min(tot[0], cap - 1), nga = min(tot[1], cap - 1);
+    scan[0] = 0;
+    scan[1] = ga + nga;
+    scan[2] = ga;
+    counts[0] = *n_obs;
+    counts[1] = *n_gnd;
+    counts[2] = *n_flt;
+}
+
+// doHeightInterpolate's four wheel points from a pose held on the device: R (2 x 2), t of the match and z0; the
+// quaternion of the yaw (qz = sin(yaw / 2), qw = cos(yaw / 2)) goes through the same arithmetic as the host form
+__host__ __device__ inline void wheel_points(const double pose[7], float4 q[4])
+{
+    const double ROBO_HEIGHT = 1.45, wheel = 0.5; // icpTools.cpp:303-305
+    const double x = pose[3], y = pose[4], z = pose[5], w = pose[6];
+    const double d = x * x + y * y + z * z + w * w, s = 2.0 / d;
+    const double xs = x * s, ys = y * s, zs = z * s, wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys,
+                 xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
+    const float M[3][4] = {{(float)(1.0 - (yy + zz)), (float)(xy - wz), (float)(xz + wy), (float)pose[0]},
+                           {(float)(xy + wz), (float)(1.0 - (xx + zz)), (float)(yz - wx), (float)pose[1]},
+                           {(float)(xz - wy), (float)(yz + wx), (float)(1.0 - (xx + yy)), (float)pose[2]}};
+    int k = 0;
+    for (int i = -1; i <= 1; i += 2)
+        for (int j = -1; j <= 1; j += 2, ++k) { // :311-318
+            const float p[3] = {(float)(i * wheel), (float)(j * wheel), (float)(-1.0 * ROBO_HEIGHT)};
+            float       t[3];
+            for (int r = 0; r < 3; ++r) t[r] = M[r][0] * p[0] + M[r][1] * p[1] + M[r][2] * p[2] + M[r][3];
+            q[k] = make_float4(t[0], t[1], t[2], 0.f);
+        }
+}
+
+__global__ void height_pose_kernel(const double *R, const double *t, double z0, float4 *q /*[4]*/, unsigned long long *best)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    const double yaw = atan2(R[2], R[0]); // icpTools.cpp:195-197
+    const double pose[7] = {t[0], t[1], z0, 0.0, 0.0, sin(0.5 * yaw), cos(0.5 * yaw)};
+    wheel_points(pose, q);
+    for (int k = 0; k < 4; ++k) best[k] = ~0ull;
+}
+
+// 3x3 symmetric: eigenvector of the smallest eigenvalue by Jacobi sweeps (four points: one thread, host or device)
+__host__ __device__ inline void smallest_eigvec3(double A[3][3], double v[3])
+{
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        if (fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]) < 1e-300) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (fabs(A[p][q]) < 1e-300) continue;
+                const double th = 0.5 * (A[q][q] - A[p][p]) / A[p][q];
+                const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq;
+                    A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk;
+                    A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq;
+                    V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    int m = 0;
+    for (int k = 1; k < 3; ++k)
+        if (A[k][k] < A[m][m]) m = k;
+    for (int k = 0; k < 3; ++k) v[k] = V[k][m];
+}
+
+
+// the plane under the wheel points and the height it gives (icpTools.cpp:345-376), from the four packed nearest
+// neighbours; *n_corr = neighbours within 3 m, z stays z0 below four of them
+__host__ __device__ inline double height_from_neighbours(const float corr[4][3], int nc, double z0)
+{
+    const double ROBO_HEIGHT = 1.45;
+    if (nc < 4) return z0; // :351,:379 "Height could not be determined"
+    double mean[3] = {0, 0, 0};
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 3; ++r) mean[r] += (double)corr[i][r];
+    for (int r = 0; r < 3; ++r) mean[r] /= 4.0;
+    double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int i = 0; i < 4; ++i)
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) C[r][c] += ((double)corr[i][r] - mean[r]) * ((double)corr[i][c] - mean[c]);
+    double nrm[3];
+    smallest_eigvec3(C, nrm); // computePointNormal -> solvePlaneParameters (:361-365)
+    if (nrm[0] != nrm[0] || nrm[1] != nrm[1] || nrm[2] != nrm[2]) return z0; // :367
+    if (nrm[2] < 0) nrm[2] = -nrm[2];                                          // :369-372
+    return (double)(float)((float)nrm[2] * ROBO_HEIGHT + (float)mean[2]);      // :376
+}
+
+__global__ void height_fit_kernel(const float *ground, int stride, const unsigned long long *best, double z0, double *out /*[2]*/)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    float corr[4][3];
+    int   nc = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (best[k] == ~0ull) continue;
+        const unsigned idx = (unsigned)(best[k] & 0xffffffffu);
+        if (__uint_as_float((unsigned)(best[k] >> 32)) < 9.0f) { // :345
+            for (int r = 0; r < 3; ++r) corr[nc][r] = ground[(size_t)idx * stride + r];
+            ++nc;
+        }
+    }
+    out[0] = height_from_neighbours(corr, nc, z0);
+    out[1] = (double)nc;
+}
+
 struct DevBuf {
     void  *p = nullptr;
     size_t cap = 0;
@@ -318,14 +511,20 @@ struct DevBuf {
 };
 
 template <class Pred, class Emit>
-int compact(Pred pred, Emit emit, long long n, int limit, DevBuf &blocks, int *d_total, hipStream_t st)
+int compact(Pred pred, Emit emit, long long n, int limit, DevBuf &blocks, int *d_total, hipStream_t st, const int *d_n = nullptr,
+            const long long *d_n64 = nullptr)
 {
+    if (n <= 0) { // nothing to select from: the total is zero all the same
+        SLAM_HIP(hipMemsetAsync(d_total, 0, sizeof(int), st));
+        return SLAM_OK;
+    }
     const int n_blocks = (int)((n + kItems - 1) / kItems);
     SLAM_TRY(blocks.reserve(sizeof(int) * (size_t)(n_blocks + 1)));
-    int *bc = static_cast<int *>(blocks.p);
-    hipLaunchKernelGGL((count_kernel<Pred>), dim3(n_blocks), dim3(kScanThreads), 0, st, pred, n, bc);
+    int         *bc = static_cast<int *>(blocks.p);
+    const Domain dom = {n, d_n, d_n64};
+    hipLaunchKernelGGL((count_kernel<Pred>), dim3(n_blocks), dim3(kScanThreads), 0, st, pred, dom, bc);
     hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, bc, n_blocks, d_total);
-    hipLaunchKernelGGL((write_kernel<Pred, Emit>), dim3(n_blocks), dim3(kScanThreads), 0, st, pred, emit, n, bc, limit);
+    hipLaunchKernelGGL((write_kernel<Pred, Emit>), dim3(n_blocks), dim3(kScanThreads), 0, st, pred, emit, dom, bc, limit);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
@@ -336,6 +535,9 @@ struct slam_ccicp {
     DevBuf vox, blocks, blocks2, small; // small: 6 min/max words, totals, 4 packed NN results
     DevBuf keys, sort_tmp;
     long long max_voxels = 1ll << 26;
+    // the chain (slam_ccicp_scene_dev): per-point scratch for the cloud's capacity, the lattice and the counts on the device
+    DevBuf labels, obs, flags, filtered, chain; // chain: VoxelGridView, counts, wheel points, packed neighbours
+    long long chain_voxels = 1ll << 21;         // accumulator capacity of the chain (64 MB): 0.5 x 0.5 x 2 m over 360 x 360 x 30 m
 };
 
 extern "C" {
@@ -469,9 +671,9 @@ int slam_ccicp_split_dev(slam_ccicp_t *h, const float *d_xyzg, int n, int stride
     p.y_lo = (float)(-crop_dist + cur_y);
     p.y_hi = (float)(crop_dist + cur_y);
     p.want_ga = 1;
-    SLAM_TRY(compact(p, SplitEmit{d_xyzg, stride, d_ga_xy}, n, cap - 1, h->blocks, d_tot, st)); // ICP_MAX_PTS-1 (:256,:259)
+    SLAM_TRY(compact(p, SplitEmit{d_xyzg, stride, d_ga_xy, nullptr, 0}, n, cap - 1, h->blocks, d_tot, st)); // ICP_MAX_PTS-1 (:256,:259)
     p.want_ga = 0;
-    SLAM_TRY(compact(p, SplitEmit{d_xyzg, stride, d_nga_xy}, n, cap - 1, h->blocks2, d_tot + 1, st));
+    SLAM_TRY(compact(p, SplitEmit{d_xyzg, stride, d_nga_xy, nullptr, 0}, n, cap - 1, h->blocks2, d_tot + 1, st));
     int tot[2];
     SLAM_HIP(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st));
     SLAM_HIP(hipStreamSynchronize(st));
@@ -480,68 +682,19 @@ int slam_ccicp_split_dev(slam_ccicp_t *h, const float *d_xyzg, int n, int stride
     return SLAM_OK;
 }
 
-// 3x3 symmetric: eigenvector of the smallest eigenvalue by Jacobi sweeps (four points: host side)
-static void smallest_eigvec3(double A[3][3], double v[3])
-{
-    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        if (std::fabs(A[0][1]) + std::fabs(A[0][2]) + std::fabs(A[1][2]) < 1e-300) break;
-        for (int p = 0; p < 2; ++p)
-            for (int q = p + 1; q < 3; ++q) {
-                if (std::fabs(A[p][q]) < 1e-300) continue;
-                const double th = 0.5 * (A[q][q] - A[p][p]) / A[p][q];
-                const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
-                const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-                for (int k = 0; k < 3; ++k) {
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = c * akp - s * akq;
-                    A[k][q] = s * akp + c * akq;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = c * apk - s * aqk;
-                    A[q][k] = s * apk + c * aqk;
-                }
-                for (int k = 0; k < 3; ++k) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = c * vkp - s * vkq;
-                    V[k][q] = s * vkp + c * vkq;
-                }
-            }
-    }
-    int m = 0;
-    for (int k = 1; k < 3; ++k)
-        if (A[k][k] < A[m][m]) m = k;
-    for (int k = 0; k < 3; ++k) v[k] = V[k][m];
-}
-
 int slam_ccicp_height_dev(slam_ccicp_t *h, const float *d_ground, int n, int stride, const double pose[7], double *z_out,
                           int *n_corr, int nn_idx[4], slam_stream_t stream)
 {
     SLAM_REQUIRE(h && pose && z_out && n >= 0 && stride >= 3 && (d_ground || n == 0), SLAM_E_INVALID,
                  "slam_ccicp_height_dev: bad arguments");
-    const double ROBO_HEIGHT = 1.45, wheel = 0.5; // icpTools.cpp:303-305
     *z_out = pose[2];
     if (n_corr) *n_corr = 0;
     if (nn_idx) nn_idx[0] = nn_idx[1] = nn_idx[2] = nn_idx[3] = -1;
     if (n == 0) return SLAM_OK;
     // tf::Matrix3x3(q) stored to an Eigen::Matrix4f (:321-329), then pcl::transformPointCloud in float (:332)
-    const double x = pose[3], y = pose[4], z = pose[5], w = pose[6];
-    const double d = x * x + y * y + z * z + w * w, s = 2.0 / d;
-    const double xs = x * s, ys = y * s, zs = z * s, wx = w * xs, wy = w * ys, wz = w * zs, xx = x * xs, xy = x * ys,
-                 xz = x * zs, yy = y * ys, yz = y * zs, zz = z * zs;
-    const float M[3][4] = {{(float)(1.0 - (yy + zz)), (float)(xy - wz), (float)(xz + wy), (float)pose[0]},
-                           {(float)(xy + wz), (float)(1.0 - (xx + zz)), (float)(yz - wx), (float)pose[1]},
-                           {(float)(xz - wy), (float)(yz + wx), (float)(1.0 - (xx + yy)), (float)pose[2]}};
     float4 q[4];
-    int    k = 0;
-    for (int i = -1; i <= 1; i += 2)
-        for (int j = -1; j <= 1; j += 2, ++k) { // :311-318
-            const float p[3] = {(float)(i * wheel), (float)(j * wheel), (float)(-1.0 * ROBO_HEIGHT)};
-            float       t[3];
-            for (int r = 0; r < 3; ++r) t[r] = M[r][0] * p[0] + M[r][1] * p[1] + M[r][2] * p[2] + M[r][3];
-            q[k] = make_float4(t[0], t[1], t[2], 0.f);
-        }
+    wheel_points(pose, q);
+    int k = 0;
     hipStream_t         st = as_stream(stream);
     unsigned long long *best = reinterpret_cast<unsigned long long *>(static_cast<unsigned *>(h->small.p) + 16);
     SLAM_HIP(hipMemsetAsync(best, 0xff, 4 * sizeof(unsigned long long), st));
@@ -565,20 +718,112 @@ int slam_ccicp_height_dev(slam_ccicp_t *h, const float *d_ground, int n, int str
     }
     SLAM_HIP(hipStreamSynchronize(st));
     if (n_corr) *n_corr = nc;
-    if (nc < 4) return SLAM_OK; // :351,:379 "Height could not be determined"
-    double mean[3] = {0, 0, 0};
-    for (int i = 0; i < 4; ++i)
-        for (int r = 0; r < 3; ++r) mean[r] += (double)corr[i][r];
-    for (int r = 0; r < 3; ++r) mean[r] /= 4.0;
-    double C[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-    for (int i = 0; i < 4; ++i)
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 3; ++c) C[r][c] += ((double)corr[i][r] - mean[r]) * ((double)corr[i][c] - mean[c]);
-    double nrm[3];
-    smallest_eigvec3(C, nrm); // computePointNormal -> solvePlaneParameters (:361-365)
-    if (std::isnan(nrm[0]) || std::isnan(nrm[1]) || std::isnan(nrm[2])) return SLAM_OK; // :367
-    if (nrm[2] < 0) nrm[2] = -nrm[2];                                                      // :369-372
-    *z_out = (double)(float)((float)nrm[2] * ROBO_HEIGHT + (float)mean[2]);                // :376
+    *z_out = height_from_neighbours(corr, nc, pose[2]);
+    return SLAM_OK;
+}
+
+// ---- the device-resident chain
+namespace {
+struct ChainSmall { // layout of slam_ccicp::chain
+    VoxelGridView      g;
+    unsigned           mm[8];
+    int                n_obs, n_gnd, n_flt, tot[2], err, pad[2];
+    float4             q[4];
+    unsigned long long best[4];
+};
+
+__global__ void chain_init_kernel(ChainSmall *c)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    for (int d = 0; d < 3; ++d) c->mm[d] = 0xffffffffu, c->mm[3 + d] = 0u;
+    c->n_obs = c->n_gnd = c->n_flt = c->tot[0] = c->tot[1] = c->err = 0;
+    c->g.n_vox = 0;
+}
+} // namespace
+
+int slam_ccicp_scene_dev(slam_ccicp_t *h, slam_gseg_t *seg, const float *d_xyz, int n, int stride, int voxel, int crop,
+                         double cur_x, double cur_y, double crop_dist, int cap, double *d_pts, int32_t *d_scan, float *d_ground,
+                         int32_t *d_counts, slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && seg && n >= 0 && stride >= 3 && cap >= 1 && d_pts && d_scan && d_counts && (d_xyz || n == 0), SLAM_E_INVALID,
+                 "slam_ccicp_scene_dev: bad arguments");
+    hipStream_t st = as_stream(stream);
+    const size_t np = (size_t)std::max(n, 1);
+    SLAM_TRY(h->labels.reserve(np));
+    SLAM_TRY(h->obs.reserve(16 * np));
+    SLAM_TRY(h->flags.reserve(np));
+    SLAM_TRY(h->filtered.reserve(16 * np));
+    SLAM_TRY(h->chain.reserve(sizeof(ChainSmall)));
+    ChainSmall    *c = static_cast<ChainSmall *>(h->chain.p);
+    unsigned char *lab = static_cast<unsigned char *>(h->labels.p), *flg = static_cast<unsigned char *>(h->flags.p);
+    float         *obs = static_cast<float *>(h->obs.p), *flt = static_cast<float *>(h->filtered.p);
+    hipLaunchKernelGGL(chain_init_kernel, dim3(1), dim3(64), 0, st, c);
+    // segmentGround (icpTools.cpp:106-119): the outcloud CCICP classifies and the ground cloud
+    SLAM_TRY(slam_gseg_segment_dev(seg, d_xyz, n, stride, lab, stream));
+    SLAM_TRY(compact(LabelPred{lab, (1u << 2) | (1u << 3)}, Xyz4Emit{d_xyz, stride, reinterpret_cast<float4 *>(obs)}, n, n, h->blocks,
+                     &c->n_obs, st));
+    if (d_ground)
+        SLAM_TRY(compact(LabelPred{lab, 1u << 1}, Xyz4Emit{d_xyz, stride, reinterpret_cast<float4 *>(d_ground)}, n, n, h->blocks2,
+                         &c->n_gnd, st));
+    // classifyPoints (:36-103) on however many obstacle points there are
+    SLAM_TRY(slam_gseg_classify_ga_counted_dev(seg, obs, &c->n_obs, n, 4, flg, stream));
+    if (n > 0) {
+        if (voxel) { // setSceneCloud's voxel filter (:620-633), leaf 0.5, 0.5, 2
+            hipLaunchKernelGGL(minmax_kernel, dim3((n + 255) / 256), dim3(256), 0, st, obs, flg, n, 4, c->mm, &c->n_obs);
+            hipLaunchKernelGGL(voxel_geometry_kernel, dim3(1), dim3(64), 0, st, c->mm, 0.5f, 0.5f, 2.0f, h->chain_voxels, &c->g, &c->err);
+            SLAM_TRY(h->vox.reserve(sizeof(Voxel) * (size_t)h->chain_voxels));
+            Voxel *vox = static_cast<Voxel *>(h->vox.p);
+            hipLaunchKernelGGL(voxel_zero_kernel, dim3(1024), dim3(256), 0, st, &c->g, vox);
+            hipLaunchKernelGGL(voxel_accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, st, VoxelGridView(), obs, flg, n, 4, vox,
+                               &c->g, &c->n_obs);
+            // (there are never more occupied voxels than points: n bounds the output)
+            SLAM_TRY(compact(VoxelUsed{vox}, VoxelEmit{vox, flt}, h->chain_voxels, n, h->blocks, &c->n_flt, st, nullptr, &c->g.n_vox));
+        } else { // setTargetCloud: classified, bin by bin, no voxel filter (:591-595)
+            SLAM_TRY(h->keys.reserve(2 * sizeof(unsigned long long) * (size_t)n));
+            unsigned long long *k_in = static_cast<unsigned long long *>(h->keys.p), *k_out = k_in + n;
+            hipLaunchKernelGGL(bin_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, st, obs, flg, n, 4, k_in, &c->n_obs);
+            size_t tmp = 0;
+            SLAM_HIP(rocprim::radix_sort_keys(nullptr, tmp, k_in, k_out, (size_t)n, 0u, 53u, st));
+            SLAM_TRY(h->sort_tmp.reserve(tmp));
+            SLAM_HIP(rocprim::radix_sort_keys(h->sort_tmp.p, tmp, k_in, k_out, (size_t)n, 0u, 53u, st));
+            hipLaunchKernelGGL(bin_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, obs, flg, 4, k_out, n,
+                               reinterpret_cast<float4 *>(flt), &c->n_flt);
+        }
+        // doICPMatch marshalling (:225-276): crop, split by class with the cap, GA in front of NGA
+        SplitPred p;
+        p.xyzg = flt;
+        p.stride = 4;
+        p.crop = crop;
+        p.x_lo = (float)(-crop_dist + cur_x);
+        p.x_hi = (float)(crop_dist + cur_x);
+        p.y_lo = (float)(-crop_dist + cur_y);
+        p.y_hi = (float)(crop_dist + cur_y);
+        p.want_ga = 1;
+        SLAM_TRY(compact(p, SplitEmit{flt, 4, d_pts, nullptr, 0}, n, cap - 1, h->blocks, &c->tot[0], st, &c->n_flt));
+        p.want_ga = 0;
+        SLAM_TRY(compact(p, SplitEmit{flt, 4, d_pts, &c->tot[0], cap - 1}, n, cap - 1, h->blocks2, &c->tot[1], st, &c->n_flt));
+    }
+    hipLaunchKernelGGL(scene_scan_kernel, dim3(1), dim3(64), 0, st, c->tot, cap, &c->n_obs, &c->n_gnd, &c->n_flt, d_scan, d_counts);
+    SLAM_HIP(hipMemcpyAsync(d_counts + 3, &c->err, sizeof(int), hipMemcpyDeviceToDevice, st));
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+int slam_ccicp_height_pose_dev(slam_ccicp_t *h, const float *d_ground, const int32_t *d_n_ground, int n_capacity, int stride,
+                               const double *d_R, const double *d_t, double z0, double *d_out, slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && d_n_ground && d_R && d_t && d_out && n_capacity >= 0 && stride >= 3 && (d_ground || n_capacity == 0),
+                 SLAM_E_INVALID, "slam_ccicp_height_pose_dev: bad arguments");
+    hipStream_t st = as_stream(stream);
+    SLAM_TRY(h->chain.reserve(sizeof(ChainSmall)));
+    ChainSmall *c = static_cast<ChainSmall *>(h->chain.p);
+    hipLaunchKernelGGL(height_pose_kernel, dim3(1), dim3(64), 0, st, d_R, d_t, z0, c->q, c->best);
+    if (n_capacity > 0)
+        hipLaunchKernelGGL(height_nn_kernel, dim3((n_capacity + 255) / 256), dim3(256), 0, st, d_ground, n_capacity, stride,
+                           make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), c->best,
+                           c->q, d_n_ground);
+    hipLaunchKernelGGL(height_fit_kernel, dim3(1), dim3(64), 0, st, d_ground, stride, c->best, z0, d_out);
+    SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
 

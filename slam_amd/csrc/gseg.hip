@@ -315,18 +315,21 @@ __device__ inline int ga_bin(const float *q)
     return (int)fx * kGaBins + (int)fy;
 }
 
-__global__ __launch_bounds__(256) void ga_mark_kernel(const float *xyz, int n, int stride, unsigned char *occ)
+// (d_n: the number of points where only the device knows it; n is then the capacity the launch was sized for)
+__global__ __launch_bounds__(256) void ga_mark_kernel(const float *xyz, int n, int stride, unsigned char *occ, const int *d_n)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (d_n) n = min(n, *d_n);
     if (i >= n) return;
     const int b = ga_bin(xyz + (size_t)i * stride);
     if (b >= 0) occ[b] = 1;
 }
 
 __global__ __launch_bounds__(256) void ga_flag_kernel(const float *xyz, int n, int stride, const unsigned char *occ,
-                                                      unsigned char *flags)
+                                                      unsigned char *flags, const int *d_n)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (d_n) n = min(n, *d_n);
     if (i >= n) return;
     const int     b = ga_bin(xyz + (size_t)i * stride);
     unsigned char f = 255;
@@ -496,21 +499,35 @@ int slam_gseg_split_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, c
     return SLAM_OK;
 }
 
-int slam_gseg_classify_ga_dev(slam_gseg_t *h, const float *d_obstacle_xyz, int n, int stride, uint8_t *d_flags,
-                              slam_stream_t stream)
+static int classify_ga(slam_gseg_t *h, const float *d_obstacle_xyz, int n, const int32_t *d_n, int stride, uint8_t *d_flags,
+                       slam_stream_t stream)
 {
-    SLAM_REQUIRE(h && n >= 0 && stride >= 2 && (n == 0 || (d_obstacle_xyz && d_flags)), SLAM_E_INVALID,
-                 "slam_gseg_classify_ga_dev: bad arguments");
     SLAM_TRY(require_device());
     if (n == 0) return SLAM_OK;
     if (!h->d_ga_occ) SLAM_HIP(hipMalloc((void **)&h->d_ga_occ, (size_t)kGaBins * kGaBins));
     hipStream_t st = as_stream(stream);
     SLAM_HIP(hipMemsetAsync(h->d_ga_occ, 0, (size_t)kGaBins * kGaBins, st));
-    hipLaunchKernelGGL(ga_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_obstacle_xyz, n, stride, h->d_ga_occ);
+    hipLaunchKernelGGL(ga_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_obstacle_xyz, n, stride, h->d_ga_occ, d_n);
     hipLaunchKernelGGL(ga_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_obstacle_xyz, n, stride, h->d_ga_occ,
-                       d_flags);
+                       d_flags, d_n);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
+}
+
+int slam_gseg_classify_ga_dev(slam_gseg_t *h, const float *d_obstacle_xyz, int n, int stride, uint8_t *d_flags,
+                              slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && n >= 0 && stride >= 2 && (n == 0 || (d_obstacle_xyz && d_flags)), SLAM_E_INVALID,
+                 "slam_gseg_classify_ga_dev: bad arguments");
+    return classify_ga(h, d_obstacle_xyz, n, nullptr, stride, d_flags, stream);
+}
+
+int slam_gseg_classify_ga_counted_dev(slam_gseg_t *h, const float *d_obstacle_xyz, const int32_t *d_n, int n_capacity, int stride,
+                                      uint8_t *d_flags, slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && d_n && n_capacity >= 0 && stride >= 2 && (n_capacity == 0 || (d_obstacle_xyz && d_flags)), SLAM_E_INVALID,
+                 "slam_gseg_classify_ga_counted_dev: bad arguments");
+    return classify_ga(h, d_obstacle_xyz, n_capacity, d_n, stride, d_flags, stream);
 }
 
 int slam_gseg_read_model(slam_gseg_t *h, uint8_t *bin_state, double *bin_value, int32_t *sector_iterations)
