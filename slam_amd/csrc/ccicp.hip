@@ -70,14 +70,25 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float *xyz, const uns
         if (finite3(p) && !(flag && flag[i] == 255)) // 255: dropped by classifyPoints (icpTools.cpp:60,72-77)
             for (int d = 0; d < 3; ++d) lo[d] = hi[d] = order_f32(p[d]);
     }
+    // wavefront, then block (LDS), then one atomic per block and bound -- and only where it would change the value: all
+    // six words share a cache line, and every same-line atomic costs ~5-10 ns (1100 wavefronts x 6 took 35 us)
+    __shared__ unsigned red[4][6];
     for (int d = 0; d < 3; ++d) {
         for (int off = 32; off > 0; off >>= 1) {
             lo[d] = min(lo[d], (unsigned)__shfl_xor((int)lo[d], off));
             hi[d] = max(hi[d], (unsigned)__shfl_xor((int)hi[d], off));
         }
-        if ((threadIdx.x & 63) == 0) {
-            if (lo[d] != 0xffffffffu) atomicMin(&mm[d], lo[d]);
-            if (hi[d] != 0u) atomicMax(&mm[3 + d], hi[d]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][d] = lo[d], red[threadIdx.x >> 6][3 + d] = hi[d];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int d = threadIdx.x;
+        unsigned  v = red[0][d];
+        for (int w = 1; w < 4; ++w) v = d < 3 ? min(v, red[w][d]) : max(v, red[w][d]);
+        if (d < 3) {
+            if (v != 0xffffffffu && v < __hip_atomic_load(&mm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mm[d], v);
+        } else {
+            if (v != 0u && v > __hip_atomic_load(&mm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mm[d], v);
         }
     }
 }
@@ -282,12 +293,20 @@ __global__ __launch_bounds__(256) void height_nn_kernel(const float *ground, int
             if (dd == dd) b[k] = ((unsigned long long)__float_as_uint(dd) << 32) | (unsigned)i; // dd >= 0: bits order as values
         }
     }
+    __shared__ unsigned long long red[4][4];
     for (int k = 0; k < 4; ++k) {
         for (int off = 32; off > 0; off >>= 1) {
             const unsigned long long o = __shfl_xor(b[k], off);
             b[k] = o < b[k] ? o : b[k];
         }
-        if ((threadIdx.x & 63) == 0 && b[k] != ~0ull) atomicMin(&best[k], b[k]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = b[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) { // one atomic per block and wheel point, where it improves on what is there (see minmax_kernel)
+        const int          k = threadIdx.x;
+        unsigned long long v = red[0][k];
+        for (int w = 1; w < 4; ++w) v = red[w][k] < v ? red[w][k] : v;
+        if (v != ~0ull && v < __hip_atomic_load(&best[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&best[k], v);
     }
 }
 
@@ -422,7 +441,10 @@ __host__ __device__ inline void smallest_eigvec3(double A[3][3], double v[3])
 {
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int sweep = 0; sweep < 60; ++sweep) {
-        if (fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]) < 1e-300) break;
+        // converged to rounding: the off-diagonal part is 1e-22 of the diagonal (a sweep squares it; waiting for it to
+        // underflow took five sweeps more, 50 us of one GPU thread's f64 divisions and square roots)
+        const double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+        if (off < 1e-300 || off <= 1e-22 * (fabs(A[0][0]) + fabs(A[1][1]) + fabs(A[2][2]))) break;
         for (int p = 0; p < 2; ++p)
             for (int q = p + 1; q < 3; ++q) {
                 if (fabs(A[p][q]) < 1e-300) continue;
@@ -477,16 +499,19 @@ __host__ __device__ inline double height_from_neighbours(const float corr[4][3],
 __global__ void height_fit_kernel(const float *ground, int stride, const unsigned long long *best, double z0, double *out /*[2]*/)
 {
     if (threadIdx.x || blockIdx.x) return;
+    const unsigned long long b[4] = {best[0], best[1], best[2], best[3]};
+    float                    all[4][3];
+    for (int k = 0; k < 4; ++k) { // four independent gathers (index 0 where there is no neighbour: read, not used)
+        const size_t idx = b[k] == ~0ull ? 0 : (size_t)(unsigned)(b[k] & 0xffffffffu);
+        for (int r = 0; r < 3; ++r) all[k][r] = ground ? ground[idx * stride + r] : 0.0f; // (an empty cloud has no buffer)
+    }
     float corr[4][3];
     int   nc = 0;
-    for (int k = 0; k < 4; ++k) {
-        if (best[k] == ~0ull) continue;
-        const unsigned idx = (unsigned)(best[k] & 0xffffffffu);
-        if (__uint_as_float((unsigned)(best[k] >> 32)) < 9.0f) { // :345
-            for (int r = 0; r < 3; ++r) corr[nc][r] = ground[(size_t)idx * stride + r];
+    for (int k = 0; k < 4; ++k)
+        if (b[k] != ~0ull && __uint_as_float((unsigned)(b[k] >> 32)) < 9.0f) { // :345
+            for (int r = 0; r < 3; ++r) corr[nc][r] = all[k][r];
             ++nc;
         }
-    }
     out[0] = height_from_neighbours(corr, nc, z0);
     out[1] = (double)nc;
 }

@@ -84,22 +84,67 @@ def measure(n_clouds=50, cell=0.0, dump_case=None):
         icp.close()
         return t_model, t_create, t_front, t_icp, t_h, errs, iters, len(m_ga) + len(m_nga), n_scene
 
+    def run_chain():
+        """the same sequence through the device-resident chain: per cloud one H2D of the cloud, slam_ccicp_scene_dev ->
+        slam_icp_fit_batch_dev (the cloud's size never leaves the device) -> slam_ccicp_height_pose_dev, one read-back"""
+        m_ga, m_nga, n_gnd_t = front_end(clouds[0], False, (0.0, 0.0))
+        icp = api.Icp(m_ga, m_nga, cell_size=cell)
+        d_gt = api.DeviceArray((max(n_gnd_t, 1), 4), np.float32)
+        api.check(L.slam_memcpy_d2d(d_gt.ptr, d_gnd.ptr, 16 * n_gnd_t, None))
+        d_ngt = api.DeviceArray.from_host(np.array([n_gnd_t], np.int32))
+        d_pts = api.DeviceArray((2 * 20000, 2), np.float64)
+        d_scan, d_counts = api.DeviceArray((3,), np.int32), api.DeviceArray((4,), np.int32)
+        d_pose = api.DeviceArray((6,), np.float64)
+        d_R, d_t = d_pose.view(0, (1, 4)), d_pose.view(4, (1, 2))
+        d_res = api.DeviceArray((1,), api.RESULT_DTYPE)
+        d_z = api.DeviceArray((2,), np.float64)
+        h_pose = np.zeros(6)
+        st = api.Stream()
+        errs, iters, t_all = [], [], 0.0
+        for k in range(1, n_clouds):
+            rel = relative(poses[0], poses[k])
+            R0, t0_ = synth.pose_to_Rt(rel[0] + 0.1, rel[1] - 0.1, rel[2] + 0.02)
+            xyz = clouds[k]
+            a = time.perf_counter()
+            h_pose[:4], h_pose[4:] = R0.reshape(4), t0_
+            api.check(L.slam_memcpy_h2d(d_xyz.ptr, xyz.ctypes.data, xyz.nbytes, None))
+            api.check(L.slam_memcpy_h2d_async(d_pose.ptr, h_pose.ctypes.data, 48, st.ptr))
+            api.check(L.slam_ccicp_scene_dev(cc.h, seg.h, d_xyz.ptr, len(xyz), 3, 1, 0, 0.0, 0.0, 75.0, 20000, d_pts.ptr, d_scan.ptr,
+                                             None, d_counts.ptr, st.ptr))
+            icp.fit_batch_dev(d_pts, d_scan, d_scan.view(2, (1,)), 1, d_R, d_t, 5.0, d_res, None, st)
+            api.check(L.slam_ccicp_height_pose_dev(cc.h, d_gt.ptr, d_ngt.ptr, n_gnd_t, 4, d_R.ptr, d_t.ptr, 0.0, d_z.ptr, st.ptr))
+            st.synchronize()
+            pose, res, z = d_pose.download(), d_res.download()[0], d_z.download()
+            t_all += time.perf_counter() - a
+            errs.append(np.hypot(pose[4] - rel[0], pose[5] - rel[1])); iters.append(int(res["iters"]))
+        icp.close()
+        return t_all, errs, iters
+
     run()                                                                    # warm-up: buffers, code objects
     t_model, t_create, t_front, t_icp, t_h, errs, iters, n_model, n_scene = run()
+    run_chain()
+    t_chain, errs_c, iters_c = run_chain()
+    assert iters_c == iters, "the chain and the stepwise path ran different iteration counts"
+    assert np.abs(np.array(errs_c) - np.array(errs)).max() < 1e-9
     n = n_clouds - 1
     total = t_front + t_icp + t_h
     return {
-        "metric": "registered_clouds_per_s", "value": n / total, "unit": "clouds/s", "steps": n, "warmup": n,
-        "ms_per_step": total / n * 1e3,
+        "metric": "registered_clouds_per_s", "value": n / t_chain, "unit": "clouds/s", "steps": n, "warmup": n,
+        "ms_per_step": t_chain / n * 1e3,
+        "ms_per_cloud_chain": round(t_chain / n * 1e3, 3),
+        "chain": "slam_ccicp_scene_dev -> slam_icp_fit_batch_dev -> slam_ccicp_height_pose_dev on one stream: one H2D of the cloud "
+                 "(pageable host memory), one read-back of pose / result / height per cloud; identical results to the stepwise path",
+        "stepwise_clouds_per_s": n / total,
         "config": {"workload": "BASELINE config 3: %d clouds x %d rays registered against the first through the CCICP chain "
                                "(ground segmentation, GA/NGA classification, voxel filter, crop + split, class-constrained "
-                               "ICP max_iter 20 / min_delta 1e-6, height recovery), one match at a time through the host API"
+                               "ICP max_iter 20 / min_delta 1e-6, height recovery), one match at a time, device-resident chain; ms_per_cloud = the same "
+                               "through the stepwise host API"
                                % (n, len(clouds[0]))},
         "workload": "config 3: %d clouds x %d rays registered against the first through the CCICP chain" % (n, len(clouds[0])),
         "ms_per_cloud": {"front end (segment, classify, voxel, split)": round(t_front / n * 1e3, 3),
                          "icp fit (one scan, host API)": round(t_icp / n * 1e3, 3), "height": round(t_h / n * 1e3, 3),
                          "total": round(total / n * 1e3, 3)},
-        "clouds_per_s": n / total, "rays_per_s": n * len(clouds[0]) / total,
+        "clouds_per_s": n / t_chain, "rays_per_s": n * len(clouds[0]) / t_chain,
         "scene_points_per_match": n_scene / n, "registered_scene_points_per_s": n_scene / t_icp,
         "target_model_ms": round(t_model * 1e3, 3), "target_index_build_ms": round(t_create * 1e3, 3), "model_points": n_model,
         "mean_icp_iterations": float(np.mean(iters)),
