@@ -45,29 +45,52 @@ __device__ inline unsigned orderable(float z)
 }
 
 // :110-162.  bin_of[i] = sector*200 + bin, or -1 beyond RMAX
+// (adjacent lanes are adjacent azimuth steps of one ring: a 5-degree sector is a run of ~28 lanes in one bin -- the run
+// is counted and its minimum taken inside the wavefront, its last lane issues the two atomics)
 __global__ __launch_bounds__(256) void gseg_bin_kernel(GsegParams p, const float *xyz, int n, int stride, int *bin_of,
                                                        int *count, unsigned long long *proto)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const float *q = xyz + (size_t)i * stride;
-    const double px = q[0], py = q[1], pz = q[2];
-    int          b = -1;
-    if (sqrt(px * px + py * py + pz * pz) < p.rmax) { // :126
-        const double bsize_rad = 360.0 / NA, bsize_lin = p.rmax / NL;
-        double       ph = atan2(py, px) * (180 / M_PI);
-        if (ph < 0) ph = 360.0 + ph;
-        unsigned bind_rad = (unsigned)floor(ph / bsize_rad);
-        if (bind_rad >= (unsigned)NA) bind_rad = NA - 1; // the reference asserts (:136)
-        const double xy = sqrt(px * px + py * py);
-        unsigned     bind_lin = (unsigned)floor(xy / bsize_lin);
-        if (bind_lin >= (unsigned)NL) bind_lin = NL - 1;
-        b = (int)bind_rad * NL + (int)bind_lin;
-        atomicAdd(&count[b], 1);                                       // binPoints.push_back :145
-        if (q[2] < kInvalid)                                           // :149 against INVALID; NaN never passes
-            atomicMin(&proto[b], ((unsigned long long)orderable(q[2]) << 32) | (unsigned)i);
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+    int                b = -1;
+    int                cnt = 0;
+    unsigned long long key = ~0ull; // (orderable z, index): the prototype is the minimum
+    if (i < n) {
+        const float *q = xyz + (size_t)i * stride;
+        const double px = q[0], py = q[1], pz = q[2];
+        if (sqrt(px * px + py * py + pz * pz) < p.rmax) { // :126
+            const double bsize_rad = 360.0 / NA, bsize_lin = p.rmax / NL;
+            double       ph = atan2(py, px) * (180 / M_PI);
+            if (ph < 0) ph = 360.0 + ph;
+            unsigned bind_rad = (unsigned)floor(ph / bsize_rad);
+            if (bind_rad >= (unsigned)NA) bind_rad = NA - 1; // the reference asserts (:136)
+            const double xy = sqrt(px * px + py * py);
+            unsigned     bind_lin = (unsigned)floor(xy / bsize_lin);
+            if (bind_lin >= (unsigned)NL) bind_lin = NL - 1;
+            b = (int)bind_rad * NL + (int)bind_lin;
+            cnt = 1;                                                       // binPoints.push_back :145
+            if (q[2] < kInvalid)                                           // :149 against INVALID; NaN never passes
+                key = ((unsigned long long)orderable(q[2]) << 32) | (unsigned)i;
+        }
+        bin_of[i] = b;
     }
-    bin_of[i] = b;
+    const int  prev = __shfl_up(b, 1), next = __shfl_down(b, 1);
+    bool       head = lane == 0 || prev != b;
+    const bool last = lane == 63 || next != b;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { // segmented inclusive scan over the runs of equal bins
+        const int                uc = __shfl_up(cnt, d);
+        const unsigned long long uk = __shfl_up(key, d);
+        const bool               uh = __shfl_up((int)head, d) != 0;
+        if (lane >= d && !head) {
+            cnt += uc;
+            key = uk < key ? uk : key;
+            head = uh;
+        }
+    }
+    if (last && b >= 0) {
+        atomicAdd(&count[b], cnt);
+        if (key != ~0ull) atomicMin(&proto[b], key);
+    }
 }
 
 // :165-185 with sig_f, p_l narrowed to float as the reference's signature does
