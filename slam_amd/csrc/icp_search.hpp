@@ -481,6 +481,13 @@ __device__ inline Best nn_search_rows_impl(const IndexPtrs<StartT> &ix, const Mo
     // (2) Last iteration's neighbour is a candidate from the start: the disk of its distance prunes the first level.
     if (seed.empty > 0.0f && fx >= 0.0f && fx < (float)L.nx && fy >= 0.0f && fy < (float)L.ny) {
         const float D = seed.empty - move - 2.0f * L.margin;
+        if (D > 0.0f && (double)D * (double)D >= gate) {
+            // nothing of the class within D, and D is beyond the inlier gate (icpPointToPoint.cpp:76): whatever the
+            // nearest point is, the caller drops it -- no read at all.  (Half of config 3's scene queries: a cloud seen
+            // from the next pose has parts the target never saw; they cost two ring levels of ~2000 cells per iteration.)
+            empty_out = D;
+            return b;
+        }
         if (D > 0.0f) {
             const float cells = fminf(D * L.inv_h * 0.70710677f, (float)(L.nx + L.ny)); // (rp + 1) h sqrt(2) <= D
             rp = (int)floorf(cells) - 1;
