@@ -450,7 +450,8 @@ typedef struct {
     int    target_points;      /* points the sliding target holds at most, both classes (2 x 19999: icpTools.h:21) */
     int    keep_prior;         /* 1 = the model given at create stays part of every rebuilt target */
     int    merge_every;        /* chunks between merges over the GPUs + finalize; 0 = only at slam_mapper_finish */
-    int    pipelined;          /* 1 = three streams; 0 = one stage after the other on one stream (same results) */
+    int    pipelined;          /* 1 = copy, registration (two in turn for a fixed target) and grid update on streams of their
+                                  own; 0 = one stage after the other on one stream (same results) */
     int    strict_window;      /* 1 = a rebuild waits for the newest registered chunk (reproducible targets; the
                                   pipeline stalls for one registration); 0 = it takes what has finished */
     int    slots;              /* chunks in flight (device + pinned buffers each): 2..8; 0 = default: 5 with a fixed target -- the
