@@ -305,15 +305,23 @@ def main():
     d_R, d_t = d_pose.view(0, batch.R.shape), d_pose.view(batch.R.size, batch.t.shape)
     d_res = api.DeviceArray((S,), api.RESULT_DTYPE)
 
+    # N>1: consecutive steps alternate over two grids (each step resets, ray-casts, merges and finalizes its own), so that
+    # the raycast of step k+1 runs on one grid stream while the rows of step k are summed over the GPUs on the other
+    grids = [grid]
+    if multi and not args.no_pipeline:
+        grids.append(api.Grid(GRID, GRID, RES, rolling=0, min_cluster_points=20,
+                              raycast_impl={"tiled": api.RAYCAST_TILED, "merge": api.RAYCAST_TILED_MERGE, "global": api.RAYCAST_GLOBAL}[args.raycast]))
     planes = None
     if multi and comm is None:
         # rehearsal (gloo, several ranks on one GPU): a zero-copy torch view of the library's [hits | misses] planes
-        ptr, n_ints = grid.counts_dev()
+        planes = []
+        for g_ in grids:
+            ptr, n_ints = g_.counts_dev()
 
-        class _Planes:
-            __cuda_array_interface__ = {"shape": (n_ints,), "typestr": "<i4", "data": (ptr, False),
-                                        "version": 2, "strides": None}
-        planes = torch.as_tensor(_Planes(), device=torch.device("cuda", local_rank)).view(2, GRID, GRID)
+            class _Planes:
+                __cuda_array_interface__ = {"shape": (n_ints,), "typestr": "<i4", "data": (ptr, False),
+                                            "version": 2, "strides": None}
+            planes.append(torch.as_tensor(_Planes(), device=torch.device("cuda", local_rank)).view(2, GRID, GRID))
 
     # ---- how steps are launched
     # pipeline (default): CONSECUTIVE steps on three streams.  A0 / A1 in turn: initial poses in, registration of step k
@@ -332,6 +340,7 @@ def main():
         icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, cell_size=args.cell, pair_scans=2)
     # three priority levels: never the same hardware queue (see mapper.hip)
     SA, sb = [api.Stream(), api.Stream(priority=-1)], api.Stream(priority=1)
+    SB = [sb] + [api.Stream(priority=1) for _ in grids[1:]]      # one grid stream per grid
     sa = SA[0]
     NB = 4
     pose = [d_pose] + [api.DeviceArray(d_pose0.shape, np.float64) for _ in range(NB - 1)]
@@ -357,32 +366,33 @@ def main():
             live[k][1].record(a)
         icp_done[s_].record(a)
 
-    def enqueue_grid(k, b, e=None):
+    def enqueue_grid(k, b, e=None, g=None):
         s_ = k % NB
+        g = g or grid
         b.wait_event(icp_done[s_])
-        grid.reset_counts(b)
-        grid.raycast_scans_dev(d_pts, d_off, S, P, pR[s_], pt[s_], b)
+        g.reset_counts(b)
+        g.raycast_scans_dev(d_pts, d_off, S, P, pR[s_], pt[s_], b)
         if e: e[2].record(b)
         if multi:
             if comm is not None:
-                comm.merge_begin(grid, b)
-                merge_rows_seen.append(comm.merge_finish(grid, b))      # waits for the 8-byte range, then the row all-reduce
+                comm.merge_begin(g, b)
+                merge_rows_seen.append(comm.merge_finish(g, b))         # waits for the 8-byte range, then the row all-reduce
             else:                                                       # gloo rehearsal on one GPU
                 b.synchronize()
-                lo, hi = grid.dirty_rows()
+                lo, hi = g.dirty_rows()
                 rng = torch.tensor([lo if hi >= lo else 1 << 30, -hi if hi >= lo else 1 << 30], dtype=torch.int64)
                 dist.all_reduce(rng, op=dist.ReduceOp.MIN)
                 lo, hi = int(rng[0]), -int(rng[1])
                 merge_rows_seen.append((lo, hi))
                 if hi >= lo:
                     for j in range(2):
-                        part = planes[j, lo:hi + 1]
+                        part = planes[grids.index(g)][j, lo:hi + 1]
                         host = part.cpu()
                         dist.all_reduce(host)
                         part.copy_(host)
                     torch.cuda.synchronize()
         if e: e[3].record(b)
-        grid.finalize(b)
+        g.finalize(b)
         if e: e[4].record(b)
         grid_done[s_].record(b)
 
@@ -395,24 +405,26 @@ def main():
             for k in range(n):
                 enqueue_icp(k, SA[k % 2], E(k), handle, timed)
                 if k >= 2:
-                    enqueue_grid(k - 2, sb, E(k - 2))
+                    enqueue_grid(k - 2, SB[(k - 2) % len(SB)], E(k - 2), grids[(k - 2) % len(grids)])
             for k in range(max(n - 2, 0), n):
-                enqueue_grid(k, sb, E(k))
+                enqueue_grid(k, SB[k % len(SB)], E(k), grids[k % len(grids)])
         else:
             for k in range(n):
                 enqueue_icp(k, sa, E(k), handle, timed)
-                enqueue_grid(k, sa, E(k))
+                enqueue_grid(k, sa, E(k), grids[k % len(grids)])
 
     for e_ in grid_done:
         e_.record(sb)
-    grid.clear()
+    for g_ in grids:
+        g_.clear()
     run_steps(args.warmup, pipelined=launch == "pipeline")
     sync()
     upd_per_step = None
     if args.warmup:
         # every step starts from reset counts, but the update counter keeps running
-        upd_per_step = grid.total_updates() // args.warmup
-    grid.clear()
+        upd_per_step = sum(g_.total_updates() for g_ in grids) // args.warmup
+    for g_ in grids:
+        g_.clear()
     sync()
     barrier()
     sync()
@@ -445,6 +457,8 @@ def main():
     barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    if upd_per_step is None:      # no warm-up to count them in: the timed steps' own updates, before anything else runs
+        upd_per_step = sum(g_.total_updates() for g_ in grids) // max(args.steps, 1)
     live_ms = [a_.elapsed_ms(b_) for a_, b_ in live] if (graph is None and args.steps > 0) else []
     # the same K steps one after the other on one stream (outside the timed region, N=1): what the pipelining buys
     seq_ms = None
@@ -461,9 +475,8 @@ def main():
     run_steps(len(ev), ev, pipelined=False)
     sync()
     d_R, d_t, d_res = pR[(len(ev) - 1) % NB], pt[(len(ev) - 1) % NB], res[(len(ev) - 1) % NB]
+    grid = grids[(len(ev) - 1) % len(grids)]            # the grid of the last step: what the checks below read
 
-    if upd_per_step is None:
-        upd_per_step = grid.total_updates() // max(args.steps, 1)
     if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
