@@ -65,3 +65,49 @@ def test_full_batch_matches_oracle(n_scans, size, min_delta):
         assert np.array_equal(g.read_occupancy(), occ)
         assert np.array_equal(g.read_num_pts(), num)
         g.close()
+
+
+def test_config5_stream_of_10240_scans_matches_oracle():
+    """BASELINE config 5 at full length through slam_mapper_*: 40 chunks of 256 scans from pinned host memory, two
+    registration streams with two scans per workgroup, five chunks in flight, finalize every 8 chunks -- with the prior
+    map as a fixed target, so that every scan has ONE right answer: the oracle's registration of every scan (poses within
+    tolerance, correspondence-exact by the same tests at batch size) and the oracle's Bresenham of all 11 M beams from
+    the mapper's own poses (counts bit-exact).  (The sliding-window form takes whatever chunks have finished when a
+    rebuild looks -- timing-dependent by design -- and is held against the oracle with strict_window in
+    tests/test_gpu_mapper.py.)"""
+    n_scans, chunk, size = 10240, 256, 2000
+    m_ga, m_nga = synth.make_map()
+    batch = synth.make_batch(n_scans, n_loop=n_scans)
+    mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=size, grid_size_y=size, resolution=0.05,
+                    max_scans=chunk, max_points=chunk * 1100, icp=dict(max_iter=30, min_delta=-1.0), merge_every=8)
+    assert mp.n_slots == 5
+    R, t = np.zeros((n_scans, 4)), np.zeros((n_scans, 2))
+    pending = []
+    for k in range(n_scans // chunk):
+        if len(pending) == mp.n_slots:
+            slot, a = pending.pop(0)
+            R[a:a + chunk], t[a:a + chunk] = mp.wait(slot)
+        pending.append((mp.push(batch.shard(k, n_scans // chunk)), k * chunk))
+    for slot, a in pending:
+        R[a:a + chunk], t[a:a + chunk] = mp.wait(slot)
+    mp.finish()
+    hits, misses = mp.grid.read_counts()
+    occ = mp.grid.read_occupancy()
+    assert mp.stats()["chunks"] == n_scans // chunk
+    mp.close()
+    model = O.IcpModel(m_ga, m_nga)
+    Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R, batch.t,
+                                                  O.icp_params(30, -1.0, 5.0), n_threads=THREADS)
+    assert np.abs(t - to).max() < 1e-4 and ang_diff(yaw(R), yaw(Ro)).max() < 1e-5
+    assert np.abs(t - batch.true_poses[:, :2]).max() < 0.03
+    gp = O.grid_params(size, size, 0.05, min_cluster_points=20)
+    ends, origins = [], []
+    for s in range(n_scans):
+        o, e = batch.scan_off[s], batch.scan_off[s + 1]
+        ends.append(O.transform_points(batch.pts[o:e], R[s], t[s]))
+        origins.append(np.tile(t[s].astype(np.float32), (e - o, 1)))
+    H, M, upd = O.grid_raycast(gp, np.concatenate(origins), np.concatenate(ends), n_threads=THREADS)
+    assert np.array_equal(hits, H) and np.array_equal(misses, M)
+    num, eocc = np.zeros(size * size), np.full(size * size, -1, np.int8)
+    O.grid_finalize(gp, H, M, num, eocc)
+    assert np.array_equal(occ, eocc)
