@@ -293,6 +293,10 @@ int slam_grid_raycast_stats(slam_grid_t *g, int *n_tiles, int *n_items, int *n_s
 /* the two int32 planes ([hits | misses], 2*size_x*size_y ints, toroidal
  * storage order) for a collective merge; see slam_mi355x_rccl.h */
 int slam_grid_counts_dev(slam_grid_t *g, int32_t **d_planes, size_t *n_ints);
+/* Whoever writes the planes through those pointers says which storage rows it wrote: the grid resets and finalizes
+ * only the rows it knows to be touched (slam_grid_reset_counts, slam_grid_finalize).  The merges of
+ * slam_mi355x_rccl.h do; asynchronous on `stream`, after the writes. */
+int slam_grid_mark_rows(slam_grid_t *g, int row_lo, int row_hi, slam_stream_t stream);
 /* Rows of the planes (storage order) that received counts since the planes were last reset or folded, tracked
  * on the device by the update kernels: a merge moves only these.  row_hi < row_lo = none.  The host form
  * synchronises; d_range = two ints {lowest row, -(highest row)} (0x7f7f7f7f each when none). */

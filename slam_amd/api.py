@@ -91,7 +91,7 @@ EXPORTS = [
     "slam_grid_raycast", "slam_grid_raycast_dev", "slam_grid_raycast_scans_dev",
     "slam_grid_finalize", "slam_grid_add_scan_inorder", "slam_grid_add_scan_inorder_dev", "slam_grid_read_counts",
     "slam_grid_read_occupancy", "slam_grid_read_num_pts", "slam_grid_total_updates",
-    "slam_grid_info", "slam_grid_counts_dev", "slam_grid_raycast_stats", "slam_grid_dirty_rows", "slam_grid_dirty_rows_dev",
+    "slam_grid_info", "slam_grid_counts_dev", "slam_grid_mark_rows", "slam_grid_raycast_stats", "slam_grid_dirty_rows", "slam_grid_dirty_rows_dev",
     "slam_grid_enable_accumulator", "slam_grid_fold",
     "slam_gseg_default_params", "slam_gseg_create", "slam_gseg_destroy", "slam_gseg_reserve",
     "slam_gseg_segment", "slam_gseg_segment_dev", "slam_gseg_split_dev", "slam_gseg_read_model",
@@ -205,6 +205,7 @@ def lib():
     L.slam_grid_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.slam_grid_counts_dev.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]
+    L.slam_grid_mark_rows.argtypes = [_vp, C.c_int, C.c_int, _vp]
     L.slam_grid_dirty_rows.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.slam_grid_dirty_rows_dev.argtypes = [_vp, C.POINTER(_vp)]
     L.slam_grid_enable_accumulator.argtypes = [_vp]
@@ -691,6 +692,10 @@ class Grid:
 
     def fold(self, row_lo, row_hi, stream=None):
         check(lib().slam_grid_fold(self.h, int(row_lo), int(row_hi), _sp(stream)))
+
+    def mark_rows(self, lo, hi, stream=None):
+        """storage rows lo..hi of the planes were written through counts_dev()'s pointer"""
+        check(lib().slam_grid_mark_rows(self.h, int(lo), int(hi), _sp(stream)))
 
     def counts_dev(self):
         p, n = _vp(), C.c_size_t()

@@ -103,7 +103,9 @@ int slam_grid_allreduce(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stre
     size_t   n = 0;
     SLAM_TRY(slam_grid_counts_dev(grid, &planes, &n));
     SLAM_NCCL(ncclAllReduce(planes, planes, n, ncclInt32, ncclSum, comm->comm, as_stream(stream)));
-    return SLAM_OK;
+    int sy = 0;
+    SLAM_TRY(slam_grid_info(grid, nullptr, &sy, nullptr, nullptr, nullptr));
+    return slam_grid_mark_rows(grid, 0, sy - 1, stream); // every row may hold another rank's counts now
 }
 
 int slam_grid_allreduce_rows(slam_grid_t *grid, slam_comm_t *comm, int row_lo, int row_hi, slam_stream_t stream)
@@ -124,7 +126,7 @@ int slam_grid_allreduce_rows(slam_grid_t *grid, slam_comm_t *comm, int row_lo, i
     const ncclResult_t e = ncclGroupEnd();
     SLAM_NCCL(r);
     SLAM_NCCL(e);
-    return SLAM_OK;
+    return slam_grid_mark_rows(grid, row_lo, row_hi, stream); // rows this rank did not touch hold the others' counts now
 }
 
 int slam_grid_merge_begin(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream)
