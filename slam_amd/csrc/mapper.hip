@@ -816,7 +816,10 @@ int slam_mapper_stats(slam_mapper_t *m, long *chunks, long *merges, long *rebuil
     if (chunks) *chunks = m->chunks;
     if (merges) *merges = m->merges;
     if (rebuilds) *rebuilds = m->rebuilds;
-    if (rebuild_ms) *rebuild_ms = m->rebuild_ms;
+    if (rebuild_ms) {
+        std::lock_guard<std::mutex> lk(m->mu); // the worker adds to it
+        *rebuild_ms = m->rebuild_ms;
+    }
     if (last_merge_rows) last_merge_rows[0] = m->last_rows[0], last_merge_rows[1] = m->last_rows[1];
     return SLAM_OK;
 }
