@@ -33,6 +33,10 @@ void *pinned_scratch(size_t bytes);
 // waits queued behind whatever registration shared that queue (0.4 ms each).  Null on failure (callers fall back to
 // the default stream).
 hipStream_t build_stream();
+// ... unless the calling thread has named a stream of its own for its builds (the mapper's rebuild thread: the mapper's
+// copy stream, where only short operations live -- which hardware queue a further stream would land on is the runtime's
+// choice, and one rebuild in five landed behind the registrations)
+void build_stream_for_this_thread(hipStream_t s);
 
 } // namespace slam
 

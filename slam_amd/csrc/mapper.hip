@@ -390,6 +390,7 @@ int rebuild_target(slam_mapper *m)
 void worker_main(slam_mapper *m)
 {
     (void)hipSetDevice(m->device);
+    build_stream_for_this_thread(m->copy); // the rebuild's kernels and read-backs go between the chunk copies
     std::unique_lock<std::mutex> lk(m->mu);
     for (;;) {
         m->cv.wait(lk, [&] { return m->job_posted || m->quit; });
