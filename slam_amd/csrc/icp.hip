@@ -8,7 +8,7 @@
 //
 // MI355X design (DESIGN.md "ICP kernel"):
 //   * one workgroup (16 wavefronts) per scan, resident for ALL iterations: the
-//     pose never leaves registers, one s_barrier per iteration, no host round
+//     pose never leaves registers, two s_barriers per iteration, no host round
 //     trip (the reference's loop-carried dependency is per scan, scans are
 //     independent: SURVEY 8(a) I6);
 //   * the model is held in LDS as a uniform-cell index (points sorted by cell,
@@ -17,10 +17,15 @@
 //     consecutive float2 (conflict-free ds_read_b64) with no pointer chasing;
 //   * G lanes of a wavefront cooperate on one scene point (G = 64 is the
 //     north-star "one wavefront per scan point"; the default is measured);
-//   * the per-iteration normal-equation sums (9 doubles) are reduced with
-//     cross-lane shuffles inside the wavefront and once through LDS across the
-//     16 wavefronts; every thread then solves the 2x2 (or 3x3) system
-//     redundantly, so no broadcast and no second barrier is needed;
+//   * the per-iteration normal-equation sums (9 doubles) are reduced on the DPP
+//     cross-lane path inside the wavefront and once through LDS across the
+//     wavefronts (fixed order: bitwise reproducible); wavefront 0 solves the 2x2
+//     (or 3x3) system and broadcasts the pose through LDS (every wavefront
+//     solving for itself was measured slower: DESIGN.md 4.1);
+//   * batches pick their form by size: a handful of scans are each spread over
+//     many workgroups of one persistent launch (icp_single.hip), from two scans
+//     per CU on two scans share a workgroup and its LDS index
+//     (icp_fit_pair_kernel), one workgroup per scan in between;
 //   * the float distance is fl(fl(dx*dx)+fl(dy*dy)) with contraction off and
 //     the query is (float)(double transform), as icpPointToPoint.cpp:69-70 and
 //     kdtree.cpp:610-612 compute them, so the correspondence set is the
