@@ -90,3 +90,31 @@ def test_python_binding_declares_pointer_signatures():
     assert undeclared <= {"slam_last_error", "slam_version", "slam_device_count", "slam_set_device",
                           "slam_device_synchronize", "slam_icp_default_params", "slam_grid_default_params",
                           "slam_ccicp_create"}
+
+
+def test_python_structs_mirror_the_header(tmp_path):
+    """slam_amd/api.py restates the parameter structs of include/slam_mi355x.h for ctypes: a field added on one side only
+    would shift everything behind it.  A C program prints sizeof and every field's offset; ctypes must agree."""
+    import ctypes as C
+    import subprocess
+    from slam_amd import api
+    structs = {"slam_icp_params": api.IcpParams, "slam_grid_params": api.GridParams, "slam_mapper_params": api.MapperParams,
+               "slam_gseg_params": api.GsegParams, "slam_icp_result": api.IcpResult}
+    lines = ["#include <stddef.h>", "#include <stdio.h>", '#include "slam_mi355x.h"', "int main(void) {"]
+    for name, cls in structs.items():
+        lines.append('printf("%s %%zu", sizeof(%s));' % (name, name))
+        for f, _ in cls._fields_:
+            lines.append('printf(" %s=%%zu", offsetof(%s, %s));' % (f, name, f))
+        lines.append('printf("\\n");')
+    lines += ["return 0;", "}"]
+    src, exe = tmp_path / "sizes.c", tmp_path / "sizes"
+    src.write_text("\n".join(lines))
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True)
+    for line in out.strip().splitlines():
+        parts = line.split()
+        cls = structs[parts[0]]
+        assert int(parts[1]) == C.sizeof(cls), (parts[0], parts[1], C.sizeof(cls))
+        for p in parts[2:]:
+            f, off = p.split("=")
+            assert getattr(cls, f).offset == int(off), (parts[0], f, off, getattr(cls, f).offset)
