@@ -718,8 +718,9 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     MAP_HIP(hipEventRecord(b.copied, m->copy));
     // ---- register
     // chunks alternate over the two registration streams; the spread form (a handful of scans) takes one call at a time
-    // (and so do the chunks of a sliding target: a chunk registered beside its predecessor would meet a window that is a
-    // chunk staler -- measured on config 5: 0.52 ms per chunk on one stream, 0.86 on two)
+    // (and so do the chunks of a sliding target: a chunk registered beside its predecessor meets a window that is a chunk
+    // staler, and every further chunk in flight costs more than the overlap gains -- config 5: 0.54 ms per chunk on one
+    // stream, 0.51 / 0.53 / 0.56 on two with three / four / five chunks in flight)
     const int   lane = (m->prm.window_chunks || slam::icp::takes_spread_form(m->target, n_scans)) ? 0 : (int)(m->chunks & 1);
     hipStream_t icp_s = m->icp_s[lane];
     MAP_HIP(hipStreamWaitEvent(icp_s, b.copied, 0));
