@@ -206,6 +206,10 @@ def main():
     ap.add_argument("--raycast", choices=["tiled", "merge", "global"], default="tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip model build, single scan, streaming and config-3 legs")
+    ap.add_argument("--raycast-seg", type=int, default=None,
+                    help="slam_grid_params::raycast_seg_items (default: 48 when the raycast runs beside registrations, "
+                         "0 = sized from the work list with --no-pipeline)")
+    ap.add_argument("--raycast-wg", type=int, default=0, help="slam_grid_params::raycast_wg_per_cu (0 = library default)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the grid update of step k-1 with the registration of step k (one stream: a captured "
                          "hipGraph per step at N=1, call by call otherwise)")
@@ -294,8 +298,10 @@ def main():
     batch = synth.make_batch(S, n_loop=S * world, first=rank * S)
     P = batch.n_points
     icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, lanes_per_point=args.lanes, cell_size=args.cell)
-    grid = api.Grid(GRID, GRID, RES, rolling=0, min_cluster_points=20,
-                    raycast_impl={"tiled": api.RAYCAST_TILED, "merge": api.RAYCAST_TILED_MERGE, "global": api.RAYCAST_GLOBAL}[args.raycast])
+    # (a raycast that runs beside registrations wants longer segments than one that has the chip to itself: slam_grid_params)
+    grid_kw = dict(rolling=0, min_cluster_points=20, raycast_wg_per_cu=args.raycast_wg, raycast_seg_items=args.raycast_seg if args.raycast_seg is not None else (0 if args.no_pipeline else 48),
+                   raycast_impl={"tiled": api.RAYCAST_TILED, "merge": api.RAYCAST_TILED_MERGE, "global": api.RAYCAST_GLOBAL}[args.raycast])
+    grid = api.Grid(GRID, GRID, RES, **grid_kw)
     d_pts = api.DeviceArray.from_host(batch.pts, np.float64)
     d_off = api.DeviceArray.from_host(batch.scan_off, np.int32)
     d_nga = api.DeviceArray.from_host(batch.scan_nga, np.int32)
@@ -309,8 +315,7 @@ def main():
     # the raycast of step k+1 runs on one grid stream while the rows of step k are summed over the GPUs on the other
     grids = [grid]
     if multi and not args.no_pipeline:
-        grids.append(api.Grid(GRID, GRID, RES, rolling=0, min_cluster_points=20,
-                              raycast_impl={"tiled": api.RAYCAST_TILED, "merge": api.RAYCAST_TILED_MERGE, "global": api.RAYCAST_GLOBAL}[args.raycast]))
+        grids.append(api.Grid(GRID, GRID, RES, **grid_kw))
     planes = None
     if multi and comm is None:
         # rehearsal (gloo, several ranks on one GPU): a zero-copy torch view of the library's [hits | misses] planes

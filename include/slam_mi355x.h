@@ -217,8 +217,12 @@ typedef struct {
     int    rolling;             /* MLS(..., bool roll) mls.h:154 */
     int    raycast_impl;        /* SLAM_RAYCAST_* */
     int    raycast_seg_items;   /* tiled raycast: 64-beam blocks of one tile a workgroup accumulates before it
-                                   writes the tile back; 0 = sized from the work list; at most 1023 */
-    int    raycast_wg_per_cu;   /* tiled raycast: persistent workgroups per CU; 0 = library default (2) */
+                                   writes the tile back; 0 = sized from the work list (about five segments per workgroup:
+                                   best when the raycast has the chip to itself); a raycast that runs BESIDE registrations,
+                                   on the CUs they leave, wants longer segments -- fewer tile flushes, and its tail is
+                                   somebody else's head: 48 (the mapper and bench.py set that); at most 1023 */
+    int    raycast_wg_per_cu;   /* tiled raycast: persistent workgroups per CU; 0 = library default (one while the grid has
+                                   no more 128 x 128-cell tiles than the chip has CUs, two beyond) */
 } slam_grid_params;
 
 void slam_grid_default_params(slam_grid_params *p);

@@ -969,7 +969,7 @@ struct slam_grid {
     int              seg_items = 0;  // 64-beam blocks of one tile a workgroup accumulates before writing back; 0 = adaptive_seg
     int              last_chunks = 0;
     int              ablate = 0;     // debug: SLAM_RAYCAST_ABLATE bit mask (timing experiments only)
-    int              wg_per_cu = 2;
+    int              wg_per_cu = 0;  // persistent raycast workgroups per CU; 0 = by the number of tiles (raycast_wg_per_cu)
     bool             merge = false;  // tiled raycast: lanes on one cell add once (SLAM_RAYCAST_TILED_MERGE)
     void            *d_stage = nullptr;   // host-API staging
     size_t           cap_stage = 0;
@@ -1019,6 +1019,12 @@ int reserve_beams(slam_grid *g, size_t n)
     return SLAM_OK;
 }
 
+// Persistent raycast workgroups per CU where the caller did not say: one (sixteen wavefronts) while there are no more tiles
+// than CUs, two beyond.  tools/raycast_time.py and bench.py --raycast-wg: config 2 (256 tiles) 0.115 ms with one against
+// 0.124 with two, alone; config 4's share (1024 tiles) 1.30 ms per step with two against 1.40 with one, beside the
+// registrations.
+int raycast_wg_per_cu(const slam_grid *g, int n_tiles) { return g->wg_per_cu > 0 ? g->wg_per_cu : (n_tiles > g->n_cu ? 2 : 1); }
+
 int walk_beams(slam_grid *g, int n, hipStream_t st)
 {
     const int n_chunks = (n + kBlock - 1) / kBlock; // culling blocks
@@ -1032,7 +1038,7 @@ int walk_beams(slam_grid *g, int n, hipStream_t st)
             // one pass over the block boxes; the raycast workgroups derive the segment offsets themselves
             hipLaunchKernelGGL(tile_items_wg_kernel, dim3(n_tiles), dim3(1024), 0, st, g->d_chunk_box, n_chunks, tiles_x,
                                g->gv.sx, g->gv.sy, g->d_tile_cnt, g->d_items, g->d_queue);
-            hipLaunchKernelGGL(g->merge ? raycast_tiled_kernel<true> : raycast_tiled_kernel<false>, dim3(g->wg_per_cu * g->n_cu),
+            hipLaunchKernelGGL(g->merge ? raycast_tiled_kernel<true> : raycast_tiled_kernel<false>, dim3(raycast_wg_per_cu(g, n_tiles) * g->n_cu),
                                dim3(kTileThreads), 0, st, g->gv, g->d_beams, n, g->d_items, item_off, seg_off, n_tiles, g->d_queue,
                                tiles_x, g->seg_items, g->ablate, g->d_tile_cnt, n_chunks);
         } else {
@@ -1044,7 +1050,7 @@ int walk_beams(slam_grid *g, int n, hipStream_t st)
             hipLaunchKernelGGL((tile_items_kernel<1>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
                                n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items, g->d_queue);
             // persistent workgroups, two per CU (66 KB of LDS each); each drains the queue and exits
-            hipLaunchKernelGGL(g->merge ? raycast_tiled_kernel<true> : raycast_tiled_kernel<false>, dim3(g->wg_per_cu * g->n_cu),
+            hipLaunchKernelGGL(g->merge ? raycast_tiled_kernel<true> : raycast_tiled_kernel<false>, dim3(raycast_wg_per_cu(g, n_tiles) * g->n_cu),
                                dim3(kTileThreads), 0, st, g->gv, g->d_beams, n, g->d_items, item_off, seg_off, n_tiles, g->d_queue,
                                tiles_x, seg_items, g->ablate, (const int *)nullptr, 0);
         }
@@ -1525,7 +1531,7 @@ int slam_grid_raycast_stats(slam_grid_t *g, int *n_tiles, int *n_items, int *n_s
         SLAM_HIP(hipMemcpy(cnt.data(), g->d_tile_cnt, sizeof(int) * (size_t)tiles, hipMemcpyDeviceToHost));
         long items = 0, segs = 0;
         for (int c : cnt) items += c;
-        const int seg = g->seg_items > 0 ? g->seg_items : adaptive_seg(items, g->wg_per_cu * g->n_cu);
+        const int seg = g->seg_items > 0 ? g->seg_items : adaptive_seg(items, raycast_wg_per_cu(g, tiles) * g->n_cu);
         for (int c : cnt) segs += (c + seg - 1) / seg;
         if (n_items) *n_items = (int)items;
         if (n_segments) *n_segments = (int)segs;

@@ -12,7 +12,8 @@ m_ga, m_nga = synth.make_map()
 batch = synth.make_batch(S)
 P = batch.n_points
 icp = api.Icp(m_ga, m_nga, max_iter=30, min_delta=-1.0)
-grid = api.Grid(2000, 2000, 0.05, rolling=0, min_cluster_points=20)
+grid = api.Grid(2000, 2000, 0.05, rolling=0, min_cluster_points=20, raycast_seg_items=int(os.environ.get('X_SEG', 0)),
+                raycast_wg_per_cu=int(os.environ.get('X_WG', 0)))
 d_pts = api.DeviceArray.from_host(batch.pts, np.float64)
 d_off = api.DeviceArray.from_host(batch.scan_off, np.int32)
 d_nga = api.DeviceArray.from_host(batch.scan_nga, np.int32)

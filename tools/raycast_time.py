@@ -11,7 +11,7 @@ sweep = {"wg_per_cu": [0], "seg": [0], "impl": [api.RAYCAST_TILED]}
 for a in sys.argv[1:]:
     k, v = a.split("=")
     sweep[k] = [int(x) for x in v.split(",")]
-S, GRID = 256, 2000
+S, GRID = int(sweep.pop('scans', [256])[0]), int(sweep.pop('grid', [2000])[0])
 batch = synth.make_batch(S)
 R = np.stack([np.array([[np.cos(p[2]), -np.sin(p[2])], [np.sin(p[2]), np.cos(p[2])]]) for p in batch.true_poses])
 t = batch.true_poses[:, :2].copy()
