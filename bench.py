@@ -9,6 +9,7 @@ does that for its own 256 scans (weak scaling) and the rows of the int32 hit/mis
 merged with one RCCL all-reduce per step (slam_grid_merge_begin / _finish of the library) before finalize.
 
     python bench.py --gpus 1 --steps 50 --warmup 5
+    python bench.py --gpus N ...    # starts its own N ranks (the launch below) before touching a GPU; --dry-launch prints it
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
     python bench.py --config 3      # 64-ring clouds through the CCICP chain, one scan at a time (the reference's usage)
     python bench.py --config 4      # one GPU's share of config 4: 1024 scans, 4000 x 4000 grid
@@ -183,6 +184,63 @@ def run_config3(n_clouds):
     return bench_config3.measure(n_clouds)
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_command(n_ranks, argv, port=None):
+    """The launch the driver makes for N > 1 (one rank per GPU over RCCL), built here when bench.py is started by itself."""
+    argv = [a for a in argv if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+            "--master-addr", "127.0.0.1", "--master-port", str(port or _free_port()), os.path.abspath(__file__)] + argv
+
+
+def visible_devices():
+    """GPUs this process could use, counted without initialising HIP (torch.cuda.device_count() does not, on this
+    image): the launcher itself must stay off the GPU."""
+    try:
+        import torch
+        return int(torch.cuda.device_count())
+    except Exception as ex:
+        log("could not count the devices (%s)" % ex)
+        return -1
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child `python -m torch.distributed.run ...
+    bench.py --gpus N ...` BEFORE this process makes any HIP call, hand its one JSON line on, and fail loudly (the
+    child's stderr tail, a non-zero exit) when it fails.  Returns the exit code."""
+    import subprocess
+    cmd = launch_command(args.gpus, argv)
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd, "n_ranks": args.gpus, "env": {"HSA_ENABLE_IPC_MODE_LEGACY": "0"}}), flush=True)
+        return 0
+    if not args.one_device:
+        n_dev = visible_devices()
+        if 0 <= n_dev < args.gpus:
+            log("bench.py --gpus %d: %d ranks need %d devices, this machine shows %d (one process per GPU over RCCL; "
+                "--backend gloo --one-device rehearses the N > 1 path on one GPU)" % (args.gpus, args.gpus, args.gpus, n_dev))
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC: RCCL between processes needs it on this driver
+    log("launching %d ranks: %s" % (args.gpus, " ".join(cmd)))
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    out, err = p.communicate()
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        log("the %d-rank launch failed (exit code %d); the end of its stderr:" % (args.gpus, p.returncode))
+        log(err[-4000:])
+        return p.returncode or 1
+    sys.stderr.write(err[-2000:])
+    print(lines[-1], flush=True)
+    return 0
+
+
 def main():
     global GRID
     ap = argparse.ArgumentParser()
@@ -217,23 +275,26 @@ def main():
                     help="with --no-pipeline at N=1: launch every step call by call instead of replaying one captured hipGraph")
     ap.add_argument("--no-torch", action="store_true", help="N=1 only: do not import torch at all")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="N>1 data plane: nccl = the library's RCCL merge (slam_grid_merge_begin/_finish); gloo = a "
-                         "torch.distributed all-reduce of the same rows, only to rehearse the N>1 path with several "
-                         "ranks on ONE GPU (--one-device), where RCCL cannot run")
+                    help="N>1 data plane: nccl = the library's merge (slam_grid_merge_begin/_finish) over RCCL; gloo = the same "
+                         "entry points over the library's host-staged communicator with gloo carrying the host buffers, "
+                         "only to rehearse the N>1 path with several ranks on ONE GPU (--one-device), where RCCL cannot run")
     ap.add_argument("--one-device", action="store_true", help="all ranks use GPU 0 (rehearsal with --backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearse the N>1 code path (communicator + row merge) with one rank")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="print the launch `python bench.py --gpus N` would make of its N ranks (one JSON line) and exit")
     args = ap.parse_args()
     S = args.scans or (1024 if args.config == 4 else N_SCANS)
     GRID = args.grid or (4000 if args.config == 4 else GRID)
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.dry_launch):
+        # `python bench.py --gpus N` by itself: this process becomes the launcher of N ranks and touches no GPU
+        raise SystemExit(self_launch(args, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs a launch through torch.distributed.run" % args.gpus)
-        args.gpus = world
+    args.gpus = world
 
     if args.config == 3:
         assert world == 1, "config 3 is a single-GPU sequence"
@@ -265,6 +326,12 @@ def main():
         # control plane (rendezvous, barriers, the maximum over the ranks' clocks) over gloo; the data plane -- the
         # planes' rows -- goes through the library's own RCCL communicator, whose id rank 0 hands out here
         dist.init_process_group("gloo")
+        if args.backend == "gloo":
+            # rehearsal (several ranks on ONE GPU, where RCCL cannot run): the library's own merge entry points over its
+            # host-staged communicator (slam_comm_create_host), gloo carrying the host buffers
+            def gloo_allreduce(a, op):
+                dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM if op == api.COMM_SUM else dist.ReduceOp.MIN)
+            comm = api.Comm.host(rank, world, gloo_allreduce)
         if args.backend == "nccl":
             ids = [api.Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
@@ -316,17 +383,6 @@ def main():
     grids = [grid]
     if multi and not args.no_pipeline:
         grids.append(api.Grid(GRID, GRID, RES, **grid_kw))
-    planes = None
-    if multi and comm is None:
-        # rehearsal (gloo, several ranks on one GPU): a zero-copy torch view of the library's [hits | misses] planes
-        planes = []
-        for g_ in grids:
-            ptr, n_ints = g_.counts_dev()
-
-            class _Planes:
-                __cuda_array_interface__ = {"shape": (n_ints,), "typestr": "<i4", "data": (ptr, False),
-                                            "version": 2, "strides": None}
-            planes.append(torch.as_tensor(_Planes(), device=torch.device("cuda", local_rank)).view(2, GRID, GRID))
 
     # ---- how steps are launched
     # pipeline (default): CONSECUTIVE steps on three streams.  A0 / A1 in turn: initial poses in, registration of step k
@@ -379,24 +435,8 @@ def main():
         g.raycast_scans_dev(d_pts, d_off, S, P, pR[s_], pt[s_], b)
         if e: e[2].record(b)
         if multi:
-            if comm is not None:
-                comm.merge_begin(g, b)
-                merge_rows_seen.append(comm.merge_finish(g, b))         # waits for the 8-byte range, then the row all-reduce
-            else:                                                       # gloo rehearsal on one GPU
-                b.synchronize()
-                lo, hi = g.dirty_rows()
-                rng = torch.tensor([lo if hi >= lo else 1 << 30, -hi if hi >= lo else 1 << 30], dtype=torch.int64)
-                dist.all_reduce(rng, op=dist.ReduceOp.MIN)
-                lo, hi = int(rng[0]), -int(rng[1])
-                merge_rows_seen.append((lo, hi))
-                if hi >= lo:
-                    for j in range(2):
-                        part = planes[grids.index(g)][j, lo:hi + 1]
-                        host = part.cpu()
-                        dist.all_reduce(host)
-                        part.copy_(host)
-                    torch.cuda.synchronize()
-                    g.mark_rows(lo, hi, b)          # written behind the library's back: tell it
+            comm.merge_begin(g, b)
+            merge_rows_seen.append(comm.merge_finish(g, b))         # waits for the united range, then the row all-reduce
         if e: e[3].record(b)
         g.finalize(b)
         if e: e[4].record(b)
@@ -580,7 +620,7 @@ def main():
                                    "finalize%s" % ("2" if (S, GRID) == (256, 2000) else ("4" if (S, GRID) == (1024, 4000) else "2 (resized)"),
                                                    S, P, N_ITERS, M, GRID, GRID, RES,
                                                    ", all-reduce of the touched rows of the int32 planes (%s)" %
-                                                   ("slam_grid_merge_begin/_finish over RCCL" if comm is not None else "gloo rehearsal") if multi else ""),
+                                                   ("slam_grid_merge_begin/_finish over RCCL" if args.backend == "nccl" else "slam_grid_merge_begin/_finish over the host-staged communicator, gloo rehearsal") if multi else ""),
                        "scans_per_gpu": S, "icp_iters": N_ITERS, "grid": [GRID, GRID], "resolution": RES,
                        "map_points": M, "icp_index": info, "raycast": args.raycast,
                        "raycast_worklist": grid.raycast_stats(),

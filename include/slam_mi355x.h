@@ -289,6 +289,10 @@ int slam_grid_read_num_pts(slam_grid_t *g, double *num_pts);
 int slam_grid_total_updates(slam_grid_t *g, uint64_t *n);       /* counter increments so far */
 int slam_grid_info(slam_grid_t *g, int *size_x, int *size_y, double *resolution,
                    int *origin_x, int *origin_y);
+/* where a rolling window sits: the cells it has moved since creation (the sum of MLS::setPose's dx, dy,
+ * mls.cpp:419-431; 0, 0 for a non-rolling grid).  Two grids hold the same world cells in the same storage rows
+ * exactly when these agree (what a merge over the GPUs requires: slam_mi355x_rccl.h). */
+int slam_grid_window_cell(slam_grid_t *g, int *cell_x, int *cell_y);
 
 /* work-list size of the last tiled raycast: tiles of the window, (tile, 64-beam block)
  * items and workgroup segments (for reporting) */

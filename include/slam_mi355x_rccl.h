@@ -29,6 +29,15 @@ typedef struct slam_comm slam_comm_t;
 int  slam_comm_unique_id(char id[SLAM_COMM_ID_BYTES]);                       /* rank 0: ncclGetUniqueId */
 int  slam_comm_create(const char id[SLAM_COMM_ID_BYTES], int rank, int n_ranks, slam_comm_t **out);
 int  slam_comm_adopt(void *nccl_comm, slam_comm_t **out);                     /* wrap an ncclComm_t (not owned) */
+/* A communicator whose collectives go through the HOST: for ranks RCCL cannot connect (several processes on ONE GPU:
+ * rehearsals of the N > 1 path on a one-GPU box) or for a transport of the caller's own (MPI, gloo).  Every entry point
+ * below works the same way on it; the library stages the rows through pinned memory and calls `allreduce` on host
+ * buffers of int32 (in place, over all ranks, blocking; op = SLAM_COMM_SUM or SLAM_COMM_MIN; returns 0 or non-zero
+ * on failure).  slam_grid_merge_finish and the all-reduces synchronise `stream` on such a communicator. */
+#define SLAM_COMM_SUM 0
+#define SLAM_COMM_MIN 1
+typedef int (*slam_host_allreduce_fn)(void *ctx, int32_t *buf, size_t count, int op);
+int  slam_comm_create_host(int rank, int n_ranks, slam_host_allreduce_fn allreduce, void *ctx, slam_comm_t **out);
 void slam_comm_destroy(slam_comm_t *comm);
 int  slam_comm_info(slam_comm_t *comm, int *rank, int *n_ranks);
 
@@ -38,10 +47,13 @@ int  slam_grid_allreduce(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t str
 int  slam_grid_allreduce_rows(slam_grid_t *grid, slam_comm_t *comm, int row_lo, int row_hi, slam_stream_t stream);
 /* Merge of the rows ANY rank touched, without the host knowing them in advance:
  *   begin : on `stream`, the ranks' device-tracked dirty ranges (slam_grid_dirty_rows_dev) are united with
- *           one 8-byte all-reduce and start travelling to the host; returns at once -- enqueue other work
+ *           one 24-byte all-reduce and start travelling to the host; returns at once -- enqueue other work
  *           (the next batch's registration) before calling finish;
  *   finish: waits for that range on the host, then enqueues the all-reduce of those rows on `stream`;
- *           *row_lo / *row_hi (optional) receive the range (row_hi < row_lo: nothing to merge). */
+ *           *row_lo / *row_hi (optional) receive the range (row_hi < row_lo: nothing to merge).
+ * Storage rows mean the same world cells on every rank only while the ranks' windows sit on the same cells: the same
+ * all-reduce carries every rank's window position (in cells, MLS::setPose mls.cpp:419-431) and finish fails with
+ * SLAM_E_INVALID, merging nothing, when rolling grids were moved apart. */
 int  slam_grid_merge_begin(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream);
 int  slam_grid_merge_finish(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream, int *row_lo, int *row_hi);
 /* the streaming mapper's periodic merge (slam_mapper_params::merge_every) over this communicator */

@@ -91,7 +91,7 @@ EXPORTS = [
     "slam_grid_raycast", "slam_grid_raycast_dev", "slam_grid_raycast_scans_dev",
     "slam_grid_finalize", "slam_grid_add_scan_inorder", "slam_grid_add_scan_inorder_dev", "slam_grid_read_counts",
     "slam_grid_read_occupancy", "slam_grid_read_num_pts", "slam_grid_total_updates",
-    "slam_grid_info", "slam_grid_counts_dev", "slam_grid_mark_rows", "slam_grid_raycast_stats", "slam_grid_dirty_rows", "slam_grid_dirty_rows_dev",
+    "slam_grid_info", "slam_grid_window_cell", "slam_grid_counts_dev", "slam_grid_mark_rows", "slam_grid_raycast_stats", "slam_grid_dirty_rows", "slam_grid_dirty_rows_dev",
     "slam_grid_enable_accumulator", "slam_grid_fold",
     "slam_gseg_default_params", "slam_gseg_create", "slam_gseg_destroy", "slam_gseg_reserve",
     "slam_gseg_segment", "slam_gseg_segment_dev", "slam_gseg_split_dev", "slam_gseg_read_model",
@@ -204,6 +204,7 @@ def lib():
     L.slam_grid_total_updates.argtypes = [_vp, C.POINTER(C.c_uint64)]
     L.slam_grid_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.slam_grid_window_cell.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.slam_grid_counts_dev.argtypes = [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t)]
     L.slam_grid_mark_rows.argtypes = [_vp, C.c_int, C.c_int, _vp]
     L.slam_grid_dirty_rows.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -677,6 +678,11 @@ class Grid:
         return dict(size_x=sx.value, size_y=sy.value, resolution=res.value, origin_x=ox.value,
                     origin_y=oy.value)
 
+    def window_cell(self):
+        x, y = C.c_int(), C.c_int()
+        check(lib().slam_grid_window_cell(self.h, C.byref(x), C.byref(y)))
+        return x.value, y.value
+
     def raycast_stats(self):
         t, i, s = C.c_int(), C.c_int(), C.c_int()
         check(lib().slam_grid_raycast_stats(self.h, C.byref(t), C.byref(i), C.byref(s)))
@@ -952,9 +958,13 @@ class Ccicp:
 
 # ------------------------------------------------------------------ RCCL merge
 _rccl = None
-RCCL_EXPORTS = ["slam_comm_unique_id", "slam_comm_create", "slam_comm_adopt", "slam_comm_destroy",
+RCCL_EXPORTS = ["slam_comm_unique_id", "slam_comm_create", "slam_comm_create_host", "slam_comm_adopt", "slam_comm_destroy",
                 "slam_comm_info", "slam_grid_allreduce", "slam_grid_allreduce_rows", "slam_grid_merge_begin",
                 "slam_grid_merge_finish", "slam_mapper_use_comm"]
+
+
+COMM_SUM, COMM_MIN = 0, 1
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, C.POINTER(C.c_int32), C.c_size_t, C.c_int)
 
 
 def rccl_lib():
@@ -969,6 +979,7 @@ def rccl_lib():
     R.slam_comm_unique_id.argtypes = [C.c_char_p]
     R.slam_comm_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]
     R.slam_comm_adopt.argtypes = [_vp, C.POINTER(_vp)]
+    R.slam_comm_create_host.argtypes = [C.c_int, C.c_int, HOST_ALLREDUCE_FN, _vp, C.POINTER(_vp)]
     R.slam_comm_destroy.argtypes = [_vp]
     R.slam_comm_destroy.restype = None
     R.slam_comm_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -997,6 +1008,26 @@ class Comm:
         h = _vp()
         check(rccl_lib().slam_comm_create(id_bytes, int(rank), int(n_ranks), C.byref(h)))
         self.h = h.value
+
+    @classmethod
+    def host(cls, rank, n_ranks, allreduce):
+        """slam_comm_create_host: a communicator over a host transport.  allreduce(array, op) reduces a numpy int32
+        array in place over all ranks (op = COMM_SUM / COMM_MIN) -- e.g. a gloo all_reduce of torch.from_numpy(array)."""
+        self = object.__new__(cls)
+
+        def thunk(_ctx, buf, count, op):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(count,)), op)
+                return 0
+            except Exception as ex:   # an exception must not unwind through the C frames
+                import sys
+                print("host all-reduce failed: %r" % (ex,), file=sys.stderr)
+                return 1
+        self._thunk = HOST_ALLREDUCE_FN(thunk)      # kept alive as long as the communicator
+        h = _vp()
+        check(rccl_lib().slam_comm_create_host(int(rank), int(n_ranks), self._thunk, None, C.byref(h)))
+        self.h = h.value
+        return self
 
     def info(self):
         r, n = C.c_int(), C.c_int()

@@ -974,6 +974,7 @@ struct slam_grid {
     void            *d_stage = nullptr;   // host-API staging
     size_t           cap_stage = 0;
     bool             state_from_inorder = false;
+    long             shift_x = 0, shift_y = 0; // cells the rolling window has moved since creation (sum of setPose's dx, dy)
 };
 
 namespace {
@@ -1298,6 +1299,8 @@ int slam_grid_set_pose(slam_grid_t *g, double x, double y, slam_stream_t stream)
     v.oy = wrap(v.oy, dy, v.sy);
     v.pose_x += dx * v.res; // mls.cpp:430-431
     v.pose_y += dy * v.res;
+    g->shift_x += dx;
+    g->shift_y += dy;
     hipLaunchKernelGGL(roll_clear_kernel, grid2d(g), dim3(256), 0, as_stream(stream), v, dx, dy, g->d_num_s,
                        g->d_occ_s);
     // the window moved over the storage: every row of the evidence / occupancy planes (window order) is due
@@ -1514,6 +1517,14 @@ int slam_grid_info(slam_grid_t *g, int *size_x, int *size_y, double *resolution,
     if (resolution) *resolution = g->gv.res;
     if (origin_x) *origin_x = g->gv.ox;
     if (origin_y) *origin_y = g->gv.oy;
+    return SLAM_OK;
+}
+
+int slam_grid_window_cell(slam_grid_t *g, int *cell_x, int *cell_y)
+{
+    SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
+    if (cell_x) *cell_x = (int)g->shift_x;
+    if (cell_y) *cell_y = (int)g->shift_y;
     return SLAM_OK;
 }
 

@@ -9,15 +9,69 @@
 
 using namespace slam;
 
+// What the ranks agree on before rows move: {lowest dirty row, -(highest), window cell x, -x, window cell y, -y}.  One
+// MIN all-reduce unites the ranges (the union of {lo, -hi} is their minimum) and shows whether the windows sit on the same
+// cells (min(x) == -min(-x) exactly when every rank holds the same x).
+constexpr int kKeyInts = 6;
+
 struct slam_comm {
-    ncclComm_t comm = nullptr;
+    ncclComm_t comm = nullptr;      // null for a host-staged communicator
     bool       owned = false;
     int        rank = 0, n_ranks = 1;
-    int       *d_range = nullptr;   // [2] united dirty range of a merge in flight
+    slam_host_allreduce_fn host_fn = nullptr; // host-staged transport (slam_comm_create_host)
+    void      *host_ctx = nullptr;
+    int       *d_key = nullptr;     // [kKeyInts] this rank's key of a merge in flight
+    int       *d_range = nullptr;   // [kKeyInts] the minimum over the ranks
     int       *h_range = nullptr;   // pinned copy
     hipEvent_t ev_range = nullptr;
     bool       pending = false;
+    int32_t   *h_stage = nullptr;   // pinned staging of the host-staged transport
+    size_t     cap_stage = 0;       // ints
 };
+
+namespace {
+
+__global__ void merge_key_kernel(const int *dirty, int cell_x, int cell_y, int *key)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    key[0] = dirty[0];
+    key[1] = dirty[1];
+    key[2] = cell_x;
+    key[3] = -cell_x;
+    key[4] = cell_y;
+    key[5] = -cell_y;
+}
+
+bool usable(const slam_comm *c) { return c && (c->comm || c->host_fn); }
+
+int stage_reserve(slam_comm *c, size_t ints)
+{
+    if (ints <= c->cap_stage) return SLAM_OK;
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr;
+    c->cap_stage = 0;
+    SLAM_HIP(hipHostMalloc((void **)&c->h_stage, ints * sizeof(int32_t), hipHostMallocDefault));
+    c->cap_stage = ints;
+    return SLAM_OK;
+}
+
+// host-staged sum of `count` ints at planes + first and planes + cells + first: both parts down, one all-reduce of the
+// two together, both back.  Synchronises the stream (the caller's transport blocks anyway).
+int host_sum_rows(slam_comm *c, int32_t *planes, size_t cells, size_t first, size_t count, hipStream_t st)
+{
+    SLAM_TRY(stage_reserve(c, 2 * count));
+    SLAM_HIP(hipMemcpyAsync(c->h_stage, planes + first, count * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SLAM_HIP(hipMemcpyAsync(c->h_stage + count, planes + cells + first, count * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    SLAM_HIP(hipStreamSynchronize(st));
+    SLAM_REQUIRE(c->host_fn(c->host_ctx, c->h_stage, 2 * count, SLAM_COMM_SUM) == 0, SLAM_E_HIP,
+                 "the host transport's all-reduce (sum of %zu ints) failed", 2 * count);
+    SLAM_HIP(hipMemcpyAsync(planes + first, c->h_stage, count * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    SLAM_HIP(hipMemcpyAsync(planes + cells + first, c->h_stage + count, count * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    SLAM_HIP(hipStreamSynchronize(st)); // the staging buffer is free again
+    return SLAM_OK;
+}
+
+} // namespace
 
 #define SLAM_NCCL(expr)                                                                   \
     do {                                                                                  \
@@ -65,6 +119,22 @@ int slam_comm_create(const char id[SLAM_COMM_ID_BYTES], int rank, int n_ranks, s
     return SLAM_OK;
 }
 
+int slam_comm_create_host(int rank, int n_ranks, slam_host_allreduce_fn allreduce, void *ctx, slam_comm_t **out)
+{
+    SLAM_REQUIRE(allreduce && out && n_ranks >= 1 && rank >= 0 && rank < n_ranks, SLAM_E_INVALID,
+                 "slam_comm_create_host: bad arguments");
+    *out = nullptr;
+    SLAM_TRY(require_device());
+    slam_comm *c = new (std::nothrow) slam_comm();
+    SLAM_REQUIRE(c, SLAM_E_NOMEM, "slam_comm_create_host: out of host memory");
+    c->host_fn = allreduce;
+    c->host_ctx = ctx;
+    c->rank = rank;
+    c->n_ranks = n_ranks;
+    *out = c;
+    return SLAM_OK;
+}
+
 int slam_comm_adopt(void *nccl_comm, slam_comm_t **out)
 {
     SLAM_REQUIRE(nccl_comm && out, SLAM_E_INVALID, "slam_comm_adopt: bad arguments");
@@ -82,7 +152,9 @@ void slam_comm_destroy(slam_comm_t *comm)
 {
     if (!comm) return;
     if (comm->d_range) (void)hipFree(comm->d_range);
+    if (comm->d_key) (void)hipFree(comm->d_key);
     if (comm->h_range) (void)hipHostFree(comm->h_range);
+    if (comm->h_stage) (void)hipHostFree(comm->h_stage);
     if (comm->ev_range) (void)hipEventDestroy(comm->ev_range);
     if (comm->owned && comm->comm) (void)ncclCommDestroy(comm->comm);
     delete comm;
@@ -98,11 +170,14 @@ int slam_comm_info(slam_comm_t *comm, int *rank, int *n_ranks)
 
 int slam_grid_allreduce(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream)
 {
-    SLAM_REQUIRE(grid && comm && comm->comm, SLAM_E_INVALID, "slam_grid_allreduce: bad arguments");
+    SLAM_REQUIRE(grid && usable(comm), SLAM_E_INVALID, "slam_grid_allreduce: bad arguments");
     int32_t *planes = nullptr;
     size_t   n = 0;
     SLAM_TRY(slam_grid_counts_dev(grid, &planes, &n));
-    SLAM_NCCL(ncclAllReduce(planes, planes, n, ncclInt32, ncclSum, comm->comm, as_stream(stream)));
+    if (comm->comm)
+        SLAM_NCCL(ncclAllReduce(planes, planes, n, ncclInt32, ncclSum, comm->comm, as_stream(stream)));
+    else
+        SLAM_TRY(host_sum_rows(comm, planes, n / 2, 0, n / 2, as_stream(stream)));
     int sy = 0;
     SLAM_TRY(slam_grid_info(grid, nullptr, &sy, nullptr, nullptr, nullptr));
     return slam_grid_mark_rows(grid, 0, sy - 1, stream); // every row may hold another rank's counts now
@@ -110,7 +185,7 @@ int slam_grid_allreduce(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stre
 
 int slam_grid_allreduce_rows(slam_grid_t *grid, slam_comm_t *comm, int row_lo, int row_hi, slam_stream_t stream)
 {
-    SLAM_REQUIRE(grid && comm && comm->comm, SLAM_E_INVALID, "slam_grid_allreduce_rows: bad arguments");
+    SLAM_REQUIRE(grid && usable(comm), SLAM_E_INVALID, "slam_grid_allreduce_rows: bad arguments");
     if (row_hi < row_lo) return SLAM_OK;
     int32_t *planes = nullptr;
     size_t   n = 0;
@@ -119,44 +194,68 @@ int slam_grid_allreduce_rows(slam_grid_t *grid, slam_comm_t *comm, int row_lo, i
     SLAM_TRY(slam_grid_info(grid, &sx, &sy, nullptr, nullptr, nullptr));
     SLAM_REQUIRE(row_lo >= 0 && row_hi < sy, SLAM_E_INVALID, "slam_grid_allreduce_rows: rows %d..%d outside the grid", row_lo, row_hi);
     const size_t cells = n / 2, first = (size_t)row_lo * sx, count = (size_t)(row_hi - row_lo + 1) * sx;
-    SLAM_NCCL(ncclGroupStart());
-    ncclResult_t r = ncclAllReduce(planes + first, planes + first, count, ncclInt32, ncclSum, comm->comm, as_stream(stream));
-    if (r == ncclSuccess)
-        r = ncclAllReduce(planes + cells + first, planes + cells + first, count, ncclInt32, ncclSum, comm->comm, as_stream(stream));
-    const ncclResult_t e = ncclGroupEnd();
-    SLAM_NCCL(r);
-    SLAM_NCCL(e);
+    if (comm->comm) {
+        SLAM_NCCL(ncclGroupStart());
+        ncclResult_t r = ncclAllReduce(planes + first, planes + first, count, ncclInt32, ncclSum, comm->comm, as_stream(stream));
+        if (r == ncclSuccess)
+            r = ncclAllReduce(planes + cells + first, planes + cells + first, count, ncclInt32, ncclSum, comm->comm, as_stream(stream));
+        const ncclResult_t e = ncclGroupEnd();
+        SLAM_NCCL(r);
+        SLAM_NCCL(e);
+    } else {
+        SLAM_TRY(host_sum_rows(comm, planes, cells, first, count, as_stream(stream)));
+    }
     return slam_grid_mark_rows(grid, row_lo, row_hi, stream); // rows this rank did not touch hold the others' counts now
 }
 
 int slam_grid_merge_begin(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream)
 {
-    SLAM_REQUIRE(grid && comm && comm->comm, SLAM_E_INVALID, "slam_grid_merge_begin: bad arguments");
+    SLAM_REQUIRE(grid && usable(comm), SLAM_E_INVALID, "slam_grid_merge_begin: bad arguments");
     SLAM_REQUIRE(!comm->pending, SLAM_E_INVALID, "slam_grid_merge_begin: the previous merge was not finished");
     if (!comm->d_range) {
-        SLAM_HIP(hipMalloc((void **)&comm->d_range, 2 * sizeof(int)));
-        SLAM_HIP(hipHostMalloc((void **)&comm->h_range, 2 * sizeof(int), hipHostMallocDefault));
+        SLAM_HIP(hipMalloc((void **)&comm->d_range, kKeyInts * sizeof(int)));
+        SLAM_HIP(hipMalloc((void **)&comm->d_key, kKeyInts * sizeof(int)));
+        SLAM_HIP(hipHostMalloc((void **)&comm->h_range, kKeyInts * sizeof(int), hipHostMallocDefault));
         SLAM_HIP(hipEventCreateWithFlags(&comm->ev_range, hipEventDisableTiming));
     }
     int32_t *d_dirty = nullptr;
+    int      cell_x = 0, cell_y = 0;
     SLAM_TRY(slam_grid_dirty_rows_dev(grid, &d_dirty));
-    // {lowest row, -(highest row)}: the union over the ranks is one minimum
-    SLAM_NCCL(ncclAllReduce(d_dirty, comm->d_range, 2, ncclInt32, ncclMin, comm->comm, as_stream(stream)));
-    SLAM_HIP(hipMemcpyAsync(comm->h_range, comm->d_range, 2 * sizeof(int), hipMemcpyDeviceToHost, as_stream(stream)));
-    SLAM_HIP(hipEventRecord(comm->ev_range, as_stream(stream)));
+    SLAM_TRY(slam_grid_window_cell(grid, &cell_x, &cell_y)); // as of the updates enqueued so far (slam_grid_set_pose keeps it on the host)
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(merge_key_kernel, dim3(1), dim3(64), 0, st, d_dirty, cell_x, cell_y, comm->d_key);
+    SLAM_HIP(hipGetLastError());
+    if (comm->comm) {
+        SLAM_NCCL(ncclAllReduce(comm->d_key, comm->d_range, kKeyInts, ncclInt32, ncclMin, comm->comm, st));
+        SLAM_HIP(hipMemcpyAsync(comm->h_range, comm->d_range, kKeyInts * sizeof(int), hipMemcpyDeviceToHost, st));
+    } else { // host-staged: this rank's key travels to the host now, the minimum over the ranks is taken in finish
+        SLAM_HIP(hipMemcpyAsync(comm->h_range, comm->d_key, kKeyInts * sizeof(int), hipMemcpyDeviceToHost, st));
+    }
+    SLAM_HIP(hipEventRecord(comm->ev_range, st));
     comm->pending = true;
     return SLAM_OK;
 }
 
 int slam_grid_merge_finish(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream, int *row_lo, int *row_hi)
 {
-    SLAM_REQUIRE(grid && comm && comm->comm && comm->pending, SLAM_E_INVALID, "slam_grid_merge_finish: no merge in flight");
+    SLAM_REQUIRE(grid && usable(comm) && comm->pending, SLAM_E_INVALID, "slam_grid_merge_finish: no merge in flight");
     comm->pending = false;
     SLAM_HIP(hipEventSynchronize(comm->ev_range));
+    int *k = comm->h_range;
+    if (!comm->comm)
+        SLAM_REQUIRE(comm->host_fn(comm->host_ctx, k, kKeyInts, SLAM_COMM_MIN) == 0, SLAM_E_HIP,
+                     "the host transport's all-reduce (minimum of %d ints) failed", kKeyInts);
+    if (row_lo) *row_lo = 0;
+    if (row_hi) *row_hi = -1;
+    // every rank sees the same six numbers, so every rank takes the same branch: nobody is left waiting in a collective
+    SLAM_REQUIRE(k[2] == -k[3] && k[4] == -k[5], SLAM_E_INVALID,
+                 "slam_grid_merge_finish: the ranks' rolling windows sit on different cells (x %d..%d, y %d..%d): storage rows "
+                 "do not mean the same world cells; move every rank's grid to the same pose before a merge",
+                 k[2], -k[3], k[4], -k[5]);
     int sy = 0;
     SLAM_TRY(slam_grid_info(grid, nullptr, &sy, nullptr, nullptr, nullptr));
-    const bool none = comm->h_range[0] > sy;
-    const int  lo = none ? 0 : comm->h_range[0], hi = none ? -1 : -comm->h_range[1];
+    const bool none = k[0] > sy;
+    const int  lo = none ? 0 : k[0], hi = none ? -1 : -k[1];
     if (row_lo) *row_lo = lo;
     if (row_hi) *row_hi = hi;
     return slam_grid_allreduce_rows(grid, comm, lo, hi, stream);
@@ -173,7 +272,7 @@ static int mapper_merge_finish(void *ctx, slam_grid_t *grid, slam_stream_t strea
 
 int slam_mapper_use_comm(slam_mapper_t *mapper, slam_comm_t *comm)
 {
-    SLAM_REQUIRE(mapper && comm && comm->comm, SLAM_E_INVALID, "slam_mapper_use_comm: bad arguments");
+    SLAM_REQUIRE(mapper && usable(comm), SLAM_E_INVALID, "slam_mapper_use_comm: bad arguments");
     return slam_mapper_set_merge(mapper, mapper_merge_begin, mapper_merge_finish, comm);
 }
 

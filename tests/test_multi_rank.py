@@ -131,6 +131,29 @@ def test_two_rank_periodic_merge_equals_single_process(tmp_path):
     assert np.array_equal(merged[0], hits) and np.array_equal(merged[1], misses)
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher around it builds the driver's own launch (one rank per GPU through
+    torch.distributed.run on 127.0.0.1) and hands its arguments on; --dry-launch prints it instead of running it."""
+    import json
+    import subprocess
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup", "3", "--dry-launch"],
+                       capture_output=True, text=True, timeout=120, env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    cmd = d["launch"]
+    assert d["n_ranks"] == 4
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert 1024 < int(cmd[cmd.index("--master-port") + 1]) < 65536
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "3"]            # the ranks get the same arguments
+    # on a machine with fewer devices than ranks the launcher says so and starts nothing (this container has none)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
+    if p.returncode != 0 and "ranks need" in p.stderr:
+        assert "2 ranks need 2 devices" in p.stderr and p.stdout.strip() == ""
+
+
 def test_rccl_library_exports_header_symbols():
     import re
     from slam_amd import api, build
