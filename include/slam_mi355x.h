@@ -119,6 +119,10 @@ typedef struct {
                                wavefronts (icp_fit_pair_kernel): 1 = one lane per scan point in the ring search,
                                2 = two lanes, 0 = library default (two lanes, for batches of at least two scans per
                                CU), -1 = never (one scan per workgroup) */
+    int    spread_wait_us;  /* spread form: how long a scan's workgroups wait at their FIRST exchange for one another to
+                               become resident before the scan is handed to the one-workgroup form instead (another
+                               spread launch, another process or a persistent kernel may hold the CUs they need; a fit
+                               never fails for it, icp.cpp:80-114); 0 = library default (5000), < 0 = hand over at once */
 } slam_icp_params;
 
 typedef struct {
@@ -163,7 +167,10 @@ int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t
  * Asynchronous on `stream`.  Batches in the workgroup-per-scan forms (more than CUs / 16 scans, or spread_scans = -1)
  * keep nothing in the handle: calls on ONE handle may be in flight on several streams at once, and that is how a
  * stream of batches should be run -- two registration streams with pair_scans = 2, the grid update on a third
- * (DESIGN.md 4.6).  The spread form (few scans) uses scratch of the handle: one such call at a time per handle. */
+ * (DESIGN.md 4.6).  The spread form (few scans) uses scratch of the handle: one such call at a time per handle; calls
+ * on DIFFERENT handles and streams are fine -- the library runs a process's spread launches one after the other on the
+ * device, and a scan whose workgroups cannot become resident together (another process's launch, a persistent kernel
+ * on the CUs) is redone by the workgroup-per-scan form inside the same call: every scan comes back registered. */
 int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *d_scan_off,
                            const int32_t *d_scan_nga, int n_scans, double *d_R, double *d_t,
                            double indist, slam_icp_result *d_result, double *d_trace,

@@ -32,7 +32,8 @@ class IcpParams(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("min_delta", C.c_double), ("mode", C.c_int),
                 ("normals_k", C.c_int), ("lanes_per_point", C.c_int), ("cell_size", C.c_double),
                 ("force_global", C.c_int), ("build_on_host", C.c_int), ("first_iterations", C.c_int),
-                ("far_div", C.c_int), ("split_launch", C.c_int), ("spread_scans", C.c_int), ("pair_scans", C.c_int)]
+                ("far_div", C.c_int), ("split_launch", C.c_int), ("spread_scans", C.c_int), ("pair_scans", C.c_int),
+                ("spread_wait_us", C.c_int)]
 
 
 class IcpResult(C.Structure):

@@ -707,6 +707,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
     constexpr unsigned kScratch = kScratchBytes;
     static_assert(kScratch % 16 == 0, "scratch keeps the blob 16-B aligned");
     const int s = blockIdx.x;
+    if (fa.only && fa.only[s] == 0) return; // uniform for the workgroup
     const int off = fa.scan_off[s];
     const int n = fa.scan_off[s + 1] - off;
     const int nga = fa.scan_nga[s];
@@ -744,6 +745,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_fused_kernel(ModelView mv, Fit
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr unsigned kScratch = kScratchBytes;
     const int s = blockIdx.x;
+    if (fa.only && fa.only[s] == 0) return; // uniform for the workgroup
     const int off = fa.scan_off[s];
     const int n = fa.scan_off[s + 1] - off;
     const int nga = fa.scan_nga[s];
@@ -789,7 +791,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_pair_kernel(ModelView mv, FitA
     if (tm.tid == 0) *tm.bar = 0u;
     if (threadIdx.x == 0) any_lists = 0;
     const int  s = 2 * (int)blockIdx.x + team;
-    const bool active = s < n_scans; // an odd batch leaves the last workgroup one idle team
+    const bool active = s < n_scans && !(fa.only && fa.only[s] == 0); // an odd batch leaves the last workgroup one idle team
     const int  off = active ? fa.scan_off[s] : 0;
     const int  n = active ? fa.scan_off[s + 1] - off : 0;
     const int  nga = active ? fa.scan_nga[s] : 0;
@@ -1210,6 +1212,7 @@ void slam_icp_default_params(slam_icp_params *p)
     p->split_launch = 0;
     p->spread_scans = 0;
     p->pair_scans = 0;
+    p->spread_wait_us = 0;
 }
 
 } // extern "C"
@@ -1369,7 +1372,14 @@ int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *
     }
 #endif
     // few scans (one, in the reference's own usage): each scan spread over many workgroups of one persistent launch
-    if (takes_spread_form(icp, n_scans) && !fa.stamps) return launch_fit_spread(icp, fa, n_scans, as_stream(stream));
+    fa.only = nullptr;
+    if (takes_spread_form(icp, n_scans) && !fa.stamps) {
+        // ... and behind it the workgroup-per-scan form for the scans whose workgroups did not all become resident together
+        // (another spread launch or a persistent kernel holding CUs: icp_single.hip): its workgroups find their scan's flag
+        // clear and exit -- a few microseconds -- unless the scan has to be redone.  A fit always completes (icp.cpp:80-114).
+        SLAM_TRY(launch_fit_spread(icp, fa, n_scans, as_stream(stream), &fa.only));
+        return launch_fit(icp, fa, n_scans, as_stream(stream));
+    }
     return launch_fit(icp, fa, n_scans, as_stream(stream));
 }
 
@@ -1425,10 +1435,9 @@ int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t
     SLAM_HIP(hipStreamSynchronize(st));
     slam_icp_result res;
     memcpy(&res, hp + o_res, sizeof res);
-    if (res.iters < 0) { // the spread form's exchange gave up (icp_single.hip): nothing was written back
-        set_error("slam_icp_fit: the scan's workgroups lost each other (the GPU is oversubscribed by other persistent kernels?)");
-        return SLAM_E_HIP;
-    }
+    // (a scan whose spread-form workgroups did not become resident together was redone by the one-workgroup form inside the
+    // call above: there is no outcome without a pose)
+    SLAM_REQUIRE(res.iters >= 0, SLAM_E_HIP, "slam_icp_fit: the registration kernels left no result (iters = %d)", res.iters);
     memcpy(R, hp + o_pose_in, 32);
     memcpy(t, hp + o_pose_in + 32, 16);
     if (result) *result = res;

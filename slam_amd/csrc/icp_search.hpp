@@ -808,6 +808,8 @@ struct FitArgs {
     int            phase;  // icp_fit_kernel: 0 = the only launch, 1 = ring search of two launches, 2 = list sweeps of two
     int            switch_iter;
     int            far_div;       // hand over once at most n / far_div queries are beyond the lists' certified radius
+    const int     *only;          // nullable; per scan: the workgroup-per-scan kernels run scan s only if only[s] != 0 (the
+                                  // scans a spread launch could not finish, icp_single.hip)
 };
 
 
@@ -831,7 +833,9 @@ constexpr int kSpreadMinParts = 16; // the spread form takes batches that leave 
 
 // icp_single.hip: few scans (one, in the reference's own usage), each spread over many workgroups of one
 // persistent launch
-int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st);
+// *redo_flags: device array [n_scans], non-zero for a scan the launch could not finish (its R, t untouched): the caller
+// enqueues the workgroup-per-scan form behind it with FitArgs::only = that array
+int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st, const int **redo_flags);
 bool takes_spread_form(const slam_icp *h, int n_scans); // icp.hip
 
 } // namespace icp

@@ -16,11 +16,17 @@
 //   * granules are double-buffered by iteration parity: a workgroup can run at most one exchange ahead of the
 //     slowest (it needs everyone's granules of iteration k to start k + 1);
 //   * a model that fits LDS is copied there by every workgroup once (the cell index of icp.hip, 16-bit starts).
-// Every spin is bounded by the wall clock (s_memrealtime); a workgroup that gives up flags the scan's result
-// (iters = -1) instead of hanging the queue.  All workgroups of a launch must be resident together: the grid is
-// at most one workgroup per CU.
+// All workgroups of a scan must be resident together (the grid is at most one workgroup per CU), and nothing guarantees
+// that: a second spread launch (another handle, another process on the GPU) or a persistent kernel that holds the CUs
+// can leave each launch with a share of its workgroups, spinning on the ones that never start.  So every spin is bounded
+// by the wall clock (s_memrealtime) -- the FIRST exchange, which is what proves the scan's workgroups resident together,
+// by milliseconds -- a workgroup that gives up raises the scan's abort word, which every other spin of the scan looks
+// at, and workgroup 0 of a scan that did not finish flags it in redo[]: the caller enqueues the one-workgroup-per-scan
+// form behind this launch for exactly the flagged scans (icp.hip: no dependency between workgroups there), from the
+// initial pose the spread form has left untouched.  A fit always returns a pose (Icp::fit, icp.cpp:80-114).
 #include <algorithm>
 #include <cstdlib>
+#include <mutex>
 
 #include "icp_search.hpp"
 
@@ -32,7 +38,8 @@ namespace {
 constexpr int      kSB = 512, kSW = kSB / 64;      // threads / wavefronts of a spread workgroup (256 VGPRs per lane: no spills)
 constexpr int      kDenseCell = 64;                // points in the fullest cell from which a query gets 64 lanes instead of 16
 constexpr int      kGranPerWg = 2 * kNumAcc;       // 18 granules: hi and lo half of nine doubles
-constexpr unsigned long long kSpinTicks = 200000000ull; // 2 s of the 100 MHz wall clock
+constexpr int      kFirstWaitUs = 5000;                 // the first exchange of a scan (slam_icp_params::spread_wait_us)
+constexpr unsigned long long kSpinTicks = 200000000ull; // 2 s: later exchanges (everyone was resident at the first)
 
 typedef unsigned long long __attribute__((address_space(1))) gu64;
 
@@ -57,7 +64,8 @@ __host__ __device__ inline int active_parts(int n, int G, int parts)
 template <int G, typename StartT>
 __device__ inline bool spread_iterations(const ModelView &mv, const FitArgs &fa, const IndexPtrs<StartT> &ix,
                                          unsigned char *smem, unsigned long long *gran /* [2][parts][18] of this scan */,
-                                         float2 *qstate, int qcap, int parts, int s, int off, int n, int nga, FitState &fs)
+                                         int *abort_word, unsigned long long first_ticks, float2 *qstate, int qcap, int parts, int s,
+                                         int off, int n, int nga, FitState &fs)
 {
     double   *partial = reinterpret_cast<double *>(smem);   // [kSW][kNumAcc]
     double   *bc = partial + kSW * kNumAcc;                  // [8] new pose, delta, n_corr
@@ -138,8 +146,9 @@ __device__ inline bool spread_iterations(const ModelView &mv, const FitArgs &fa,
                         v[k] = granule_load(g + k);
                         all &= (unsigned)(v[k] >> 32) == tag;
                     }
-                    if (all) break;
-                    if (__builtin_amdgcn_s_memrealtime() - t_begin > kSpinTicks) {
+                    if (all && !(iter == 0 && first_ticks == 0)) break; // (spread_wait_us < 0: every scan is handed over, for the tests)
+                    if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                        __builtin_amdgcn_s_memrealtime() - t_begin >= (iter == 0 ? first_ticks : kSpinTicks)) {
                         ok = false;
                         break;
                     }
@@ -149,6 +158,7 @@ __device__ inline bool spread_iterations(const ModelView &mv, const FitArgs &fa,
                 for (int k = 0; k < kNumAcc; ++k) tot[k] += __hiloint2double((int)(unsigned)v[2 * k], (int)(unsigned)v[2 * k + 1]);
             }
             ok = __all(ok);
+            if (!ok && lane == 0) __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the others stop spinning
             const double v8 = wave_sum8(tot), v9 = wave_sum(tot[8]);
             double       S[kNumAcc];
 #pragma unroll
@@ -202,8 +212,8 @@ __device__ inline bool spread_iterations(const ModelView &mv, const FitArgs &fa,
 
 // grid (parts, n_scans); a workgroup whose scan does not need it exits at once
 template <typename StartT, bool LDS>
-__global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitArgs fa, unsigned long long *gran, float2 *qstate,
-                                                                int qcap, int wide_max)
+__global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitArgs fa, unsigned long long *gran, int *flags /* [2][n_scans] abort | redo */,
+                                                                unsigned long long first_ticks, float2 *qstate, int qcap, int wide_max)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = blockIdx.y, parts = (int)gridDim.x, part = blockIdx.x;
@@ -234,9 +244,11 @@ __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitAr
     fs.n_corr = 0;
     fs.hand_over = false;
     unsigned long long *g = gran + (size_t)s * 2 * parts * kGranPerWg;
-    const bool          ok = wide ? spread_iterations<64, StartT>(mv, fa, ix, smem, g, qstate, qcap, parts, s, off, n, nga, fs)
-                                  : spread_iterations<16, StartT>(mv, fa, ix, smem, g, qstate, qcap, parts, s, off, n, nga, fs);
+    const bool          ok = wide ? spread_iterations<64, StartT>(mv, fa, ix, smem, g, flags + s, first_ticks, qstate, qcap, parts, s, off, n, nga, fs)
+                                  : spread_iterations<16, StartT>(mv, fa, ix, smem, g, flags + s, first_ticks, qstate, qcap, parts, s, off, n, nga, fs);
     if (part == 0 && threadIdx.x == 0) {
+        // workgroup 0 decides: if IT saw every exchange through, the pose is complete whatever the others did afterwards
+        if (!ok) flags[gridDim.y + s] = 1; // redo: the one-workgroup form takes this scan, from the pose left untouched here
         if (ok) {
             fa.R[4 * s + 0] = fs.r00;
             fa.R[4 * s + 1] = fs.r01;
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitAr
             fa.t[2 * s + 1] = fs.t1;
         }
         if (fa.result) {
-            fa.result[s].iters = ok ? fs.iters : -1; // -1: the exchange between the scan's workgroups timed out
+            fa.result[s].iters = ok ? fs.iters : -1; // -1: an exchange gave up; overwritten by the launch that redoes the scan
             fa.result[s].n_corr = fs.n_corr;
             fa.result[s].delta = fs.delta;
         }
@@ -262,21 +274,41 @@ namespace icp {
 // workgroups per scan), and how many workgroups each scan gets
 int spread_parts(int n_scans, int n_cu) { return std::max(1, n_cu / std::max(n_scans, 1)); }
 
-int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
+// Spread launches of one process run one after the other on the device, whatever streams and handles they come from: two
+// of them in flight would each hold a share of the CUs and wait for workgroups that cannot start (they would give up after
+// kFirstTicks and be redone -- correct, and milliseconds late).  The order costs the host an event wait and an event record per
+// launch; launches of other processes are beyond it, the give-up path is what covers those.
+namespace {
+std::mutex  g_spread_mu;
+hipEvent_t  g_spread_done[16] = {};
+} // namespace
+
+int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st, const int **redo_flags)
 {
     int dev = 0, n_cu = 0;
     SLAM_HIP(hipGetDevice(&dev));
     SLAM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     const int    parts = spread_parts(n_scans, std::max(n_cu, 1));
     const size_t gran_bytes = sizeof(unsigned long long) * 2 * (size_t)parts * kGranPerWg * (size_t)n_scans;
-    SLAM_TRY(h->w_single.reserve(gran_bytes));
-    SLAM_HIP(hipMemsetAsync(h->w_single.p, 0, gran_bytes, st)); // tag 0 = nothing published
+    const size_t flag_bytes = sizeof(int) * 2 * (size_t)n_scans;
+    SLAM_TRY(h->w_single.reserve(gran_bytes + flag_bytes));
+    SLAM_HIP(hipMemsetAsync(h->w_single.p, 0, gran_bytes + flag_bytes, st)); // tag 0 = nothing published; no abort, no redo
     unsigned long long *gran = static_cast<unsigned long long *>(h->w_single.p);
+    int                *flags = reinterpret_cast<int *>(static_cast<unsigned char *>(h->w_single.p) + gran_bytes);
+    *redo_flags = flags + n_scans;
+    std::lock_guard<std::mutex> lk(g_spread_mu);
+    hipEvent_t &done = g_spread_done[dev & 15];
+    if (!done)
+        SLAM_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    else
+        SLAM_HIP(hipStreamWaitEvent(st, done, 0)); // behind the spread launch before this one, on whatever stream it went
     // per scene point, what its last search left for the next (positions beyond the buffer search unseeded)
     const int qcap = std::max(h->spread_points_hint, 1 << 16);
     SLAM_TRY(h->w_state.reserve(sizeof(float2) * (size_t)qcap));
     float2    *qstate = static_cast<float2 *>(h->w_state.p);
     const dim3 grid(parts, n_scans);
+    const int                wait_us = h->prm.spread_wait_us > 0 ? h->prm.spread_wait_us : (h->prm.spread_wait_us < 0 ? 0 : kFirstWaitUs);
+    const unsigned long long first_ticks = 100ull * (unsigned long long)wait_us; // s_memrealtime counts at 100 MHz
     // Lanes per query.  A 2-D map holds a handful of points per cell: 16 lanes take a query's cells in one or two
     // steps, a 1081-point scan is 34 workgroups, and the exchange between them is the larger part of an iteration --
     // fewer workgroups, cheaper exchange (0.17 against 0.22 ms for 20 iterations).  A lidar cloud holds hundreds of
@@ -288,13 +320,14 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
     if (h->in_lds) {
         auto kern = icp_fit_spread_kernel<uint16_t, true>;
         SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-        hipLaunchKernelGGL(kern, grid, dim3(kSB), h->lds_bytes, st, h->mv, fa, gran, qstate, qcap, wide_max);
+        hipLaunchKernelGGL(kern, grid, dim3(kSB), h->lds_bytes, st, h->mv, fa, gran, flags, first_ticks, qstate, qcap, wide_max);
     } else if (h->start32) {
-        hipLaunchKernelGGL((icp_fit_spread_kernel<uint32_t, false>), grid, dim3(kSB), kScratchBytes, st, h->mv, fa, gran, qstate, qcap, wide_max);
+        hipLaunchKernelGGL((icp_fit_spread_kernel<uint32_t, false>), grid, dim3(kSB), kScratchBytes, st, h->mv, fa, gran, flags, first_ticks, qstate, qcap, wide_max);
     } else {
-        hipLaunchKernelGGL((icp_fit_spread_kernel<uint16_t, false>), grid, dim3(kSB), kScratchBytes, st, h->mv, fa, gran, qstate, qcap, wide_max);
+        hipLaunchKernelGGL((icp_fit_spread_kernel<uint16_t, false>), grid, dim3(kSB), kScratchBytes, st, h->mv, fa, gran, flags, first_ticks, qstate, qcap, wide_max);
     }
     SLAM_HIP(hipGetLastError());
+    SLAM_HIP(hipEventRecord(done, st));
     return SLAM_OK;
 }
 

@@ -139,3 +139,94 @@ def test_host_fit_goes_through_the_spread_form_and_keeps_edge_weights():
     eW = icp.edge_weight()
     assert np.isfinite(eW).all() and eW[0, 0] > 0
     icp.close()
+
+
+# ---- a fit always returns a pose (Icp::fit, icp.cpp:80-114): the spread form needs all workgroups of a scan resident
+# together, and when that does not happen the scan is redone by the one-workgroup form inside the same call
+
+@pytest.mark.parametrize("n_scans,big", [(1, False), (5, False), (2, True)])
+def test_spread_hand_over_redoes_the_scans(n_scans, big):
+    """spread_wait_us < 0: every scan is handed over at its first exchange.  What comes back is the one-workgroup form's
+    result, bit for bit, and the oracle's; model in LDS and (big) in HBM."""
+    m_ga, m_nga = synth.make_map(39998 if big else 10000)
+    batch = synth.make_batch(n_scans, n_loop=256)
+    icp, R, t, res, tr = check_against_oracle(m_ga, m_nga, batch, 20, 1e-6, spread_wait_us=-1)
+    icp.close()
+    ref = api.Icp(m_ga, m_nga, max_iter=20, min_delta=1e-6, spread_scans=-1)
+    Rb, tb, resb, trb = ref.fit_batch(batch, indist=5.0, trace=True)
+    assert np.array_equal(R, Rb) and np.array_equal(t, tb) and np.array_equal(res, resb)
+    ref.close()
+    # the host API of one scan (slam_icp_fit): the same
+    t_ga, t_nga = batch.scan(0)
+    a = api.Icp(m_ga, m_nga, max_iter=20, min_delta=1e-6, spread_wait_us=-1)
+    Ra, ta, ra = a.fit(t_ga, t_nga, batch.R[0], batch.t[0], 5.0)
+    assert np.array_equal(Ra.reshape(4), R[0]) and np.array_equal(ta, t[0]) and ra.iters == res["iters"][0]
+    assert np.isfinite(a.edge_weight()).all()
+    a.close()
+
+
+def test_two_handles_fit_from_two_threads():
+    """The reference runs two CCICP objects in one process (scan_registration.cpp:57, graphSlamTools.cpp:14): two handles,
+    two host threads, one fit after the other each.  Every fit equals the oracle and nothing stalls."""
+    import threading
+    import time
+    m_ga, m_nga = synth.make_map(10000)
+    batch = synth.make_batch(8, n_loop=256)
+    model = O.IcpModel(m_ga, m_nga)
+    Ro, to, iters, ncorr, _ = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R, batch.t, O.icp_params(20, 1e-6, 5.0))
+    handles = [api.Icp(m_ga, m_nga, max_iter=20, min_delta=1e-6) for _ in range(2)]
+    out = [[], []]
+
+    def work(k):
+        for rep in range(6):
+            for s in range(k, batch.n_scans, 2):
+                t_ga, t_nga = batch.scan(s)
+                out[k].append((s,) + tuple(handles[k].fit(t_ga, t_nga, batch.R[s], batch.t[s], 5.0)))
+    for h in handles:                                      # warm-up: buffers, code objects
+        h.fit(*batch.scan(0), batch.R[0], batch.t[0], 5.0)
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    dt = time.perf_counter() - t0
+    assert len(out[0]) + len(out[1]) == 6 * batch.n_scans
+    for k in range(2):
+        for s, R, t, r in out[k]:
+            assert r.iters == iters[s] and r.n_corr == ncorr[s]
+            assert np.abs(t - to[s]).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro[s]))[0] < ANG_TOL
+    assert dt < 1.0, "48 fits took %.3f s: a spread launch waited out its time limit" % dt
+    [h.close() for h in handles]
+
+
+def test_fit_beside_a_running_grid_update():
+    """local_mapper runs beside scan_registration on the same machine: single fits while a stream of config 4's share of
+    raycasts (1024 scans into 4000 x 4000, persistent workgroups on every CU) keeps the chip busy.  Every fit equals the
+    oracle, none waits out a time limit."""
+    import time
+    m_ga, m_nga = synth.make_map(10000)
+    big = synth.make_batch(1024, n_loop=1024)
+    R = np.stack([synth.pose_to_Rt(*p)[0].reshape(4) for p in big.true_poses])
+    t = np.stack([synth.pose_to_Rt(*p)[1] for p in big.true_poses])
+    d = [api.DeviceArray.from_host(a, dt) for a, dt in ((big.pts, np.float64), (big.scan_off, np.int32), (R, np.float64), (t, np.float64))]
+    g = api.Grid(4000, 4000, 0.05, rolling=0, min_cluster_points=20)
+    st = api.Stream()
+    batch = synth.make_batch(6, n_loop=256)
+    model = O.IcpModel(m_ga, m_nga)
+    Ro, to, iters, ncorr, _ = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R, batch.t, O.icp_params(20, 1e-6, 5.0))
+    icp = api.Icp(m_ga, m_nga, max_iter=20, min_delta=1e-6)
+    icp.fit(*batch.scan(0), batch.R[0], batch.t[0], 5.0)
+    g.raycast_scans_dev(d[0], d[1], big.n_scans, big.n_points, d[2], d[3], st)
+    st.synchronize()
+    t0 = time.perf_counter()
+    for rep in range(4):
+        for k in range(8):
+            g.raycast_scans_dev(d[0], d[1], big.n_scans, big.n_points, d[2], d[3], st)     # ~0.35 ms of persistent workgroups each
+        for s in range(batch.n_scans):
+            Rs, ts, r = icp.fit(*batch.scan(s), batch.R[s], batch.t[s], 5.0)
+            assert r.iters == iters[s] and r.n_corr == ncorr[s]
+            assert np.abs(ts - to[s]).max() < POS_TOL and ang_diff(yaw(Rs), yaw(Ro[s]))[0] < ANG_TOL
+    st.synchronize()
+    dt = time.perf_counter() - t0
+    assert dt < 1.0, "24 fits beside 32 raycasts took %.3f s" % dt
+    icp.close()
+    g.close()
