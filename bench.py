@@ -241,6 +241,25 @@ def self_launch(args, argv):
     return 0
 
 
+def side_run(argv, keys, timeout=420):
+    """One of the other configs as a child `python bench.py ...` (never under the profiler's exec rules: a plain child);
+    returns the chosen keys of its JSON line plus its workload, or {"error": ...} -- the headline must not depend on it."""
+    import subprocess
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv, capture_output=True, text=True, timeout=timeout, cwd=ROOT,
+                           env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not lines:
+            return {"error": "exit code %d: %s" % (p.returncode, p.stderr[-400:])}
+        d = json.loads(lines[-1])
+        r = {k: d.get(k) for k in keys}
+        r["workload"] = d.get("config", {}).get("workload")
+        r["command"] = "python bench.py " + " ".join(argv)
+        return r
+    except Exception as ex:
+        return {"error": repr(ex)}
+
+
 def main():
     global GRID
     ap = argparse.ArgumentParser()
@@ -548,6 +567,19 @@ def main():
     pose_err = float(np.abs(t_fin - batch.true_poses[:, :2]).max())
     assert pose_err < 0.05, "registered poses are off by %.3f m" % pose_err
 
+    # the storage rows one step's finalize (and count reset) covers: the rows the step's raycast touched -- with N>1 the
+    # rows any rank touched (the merge's united range); read back from the device-tracked range, outside the timed region
+    if multi and merge_rows_seen:
+        rows_lo, rows_hi = merge_rows_seen[-1]
+    else:
+        grid.reset_counts(sa)
+        grid.raycast_scans_dev(d_pts, d_off, S, P, d_R, d_t, sa)
+        sync()
+        rows_lo, rows_hi = grid.dirty_rows()
+        grid.finalize(sa)
+        sync()
+    rows_cov = max(rows_hi - rows_lo + 1, 0)
+
     if rank == 0:
         info = icp.index_info()
         M = len(m_ga) + len(m_nga)
@@ -555,61 +587,67 @@ def main():
         # library builds for itself are NOT algorithmic bytes (reported beside, as index_bytes_read_per_launch)
         icp_bytes = 16 * P + S * (8 * M + 96)
         ray_bytes = 8 * upd_per_step + 16 * P           # 8 B RMW per cell update + 16 B per beam
-        fin_bytes = GRID * GRID * 17                     # 2x4 B counts in, 8 B evidence + 1 B occupancy out
+        fin_bytes = rows_cov * GRID * 17                # per cell of the rows covered: 2x4 B counts in, 8 B evidence + 1 B occupancy out
         fused = bool(info.get("two_forms")) and args.lanes == 0
         paired = fused and (icp is not icp_one or S >= 2 * n_cu)
         icp_name = "icp_fit_pair_kernel" if paired else ("icp_fit_fused_kernel" if fused else "icp_fit_kernel")
+        step_ms = elapsed / max(args.steps, 1) * 1e3
         # the registration launch as the timed region saw it (HIP events on its own stream around every launch; with two
-        # registration streams two launches share the chip); ms_icp below is the same kernel alone on the chip
+        # registration streams two launches share the chip); ms_icp is the same kernel alone on the chip
         ms_icp_live = float(np.mean(live_ms)) if live_ms else float(ms_icp)
+        ATOMIC_CEILING_GBS = 1300.0   # MI355X_MICROARCH.md, global atomics: ~1.3 TB/s of added bytes
         kernels = {
             icp_name: {"ms": ms_icp_live, "ms_alone_on_the_chip": float(ms_icp), "alg_bytes": icp_bytes,
                        "launches_in_flight": 2 if launch == "pipeline" else 1,
                        "index_bytes_read_per_launch": (S // 2 if paired else S) * (int(info.get("lds_bytes", 0)) + (int(info.get("list_bytes", 0)) if fused else 0))},
-            "raycast_tiled_kernel (+ beams, work list)": {"ms": float(ms_ray), "alg_bytes": ray_bytes},
-            "finalize_rows_kernel": {"ms": float(ms_fin), "alg_bytes": fin_bytes,
-                                     "note": "alg_bytes = 17 B for every cell of the grid; the kernel covers the touched rows only"},
+            "raycast_tiled_kernel (+ count reset, beams, work list)": {
+                "ms": float(ms_ray), "alg_bytes": ray_bytes,
+                "global_atomic_ceiling_GBps": ATOMIC_CEILING_GBS,
+                "note": "alg_bytes = 8 B RMW per cell update + 16 B per beam; against the ceiling of one GLOBAL atomic per "
+                        "update (SURVEY 8(d)): the updates are binned in LDS tiles and reach HBM as one atomic per touched "
+                        "cell and segment, which is how the rate can exceed that ceiling"},
+            "finalize_rows_kernel": {"ms": float(ms_fin), "alg_bytes": fin_bytes, "rows_covered": rows_cov, "rows_of_the_grid": GRID,
+                                     "note": "alg_bytes = 17 B x the cells of the storage rows the kernel covers (the touched "
+                                             "rows, read back from the device-tracked range)"},
         }
         for k in kernels.values():
             k["GBps"] = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
+            k["frac_of_hbm_peak"] = k["GBps"] / HBM_PEAK_GBS
+        kr = kernels["raycast_tiled_kernel (+ count reset, beams, work list)"]
+        kr["vs_global_atomic_ceiling"] = kr["GBps"] / ATOMIC_CEILING_GBS
         dom = max(kernels, key=lambda n: kernels[n]["ms"])
         prof_file, prof = pmc_profile()
         pk = prof.get(dom.split(" ")[0], {})
         busy, lanes = pk.get("valu_busy_frac"), pk.get("valu_active_lane_share")
-        # two launches of the registration kernel share the chip in the pipelined step (half the CUs each): the chip-level
-        # rate of the kernel is the bytes of the launches in flight over one launch's duration
-        in_flight = kernels[dom].get("launches_in_flight", 1) if (dom == icp_name and paired) else 1
-        roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"] * in_flight, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kernels[dom]["GBps"] * in_flight / HBM_PEAK_GBS,
-                "achieved_per_launch": kernels[dom]["GBps"],
+        held = min(n_cu, (S + 1) // 2 if paired else S) if dom == icp_name else n_cu
+        roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": kernels[dom]["GBps"] / HBM_PEAK_GBS,
                 "traffic": pk.get("hbm_bytes_per_launch"),
-                "traffic_source": ("%s (rocprofv3 --pmc passes of this command, committed; not measured in this run)" % prof_file)
+                "traffic_source": ("%s (rocprofv3 --pmc passes of this command, committed; not measured in this run; the "
+                                   "profiler runs one dispatch at a time, so these are the kernel alone on the chip)" % prof_file)
                 if prof_file else None,
                 "alg_bytes_per_launch": kernels[dom]["alg_bytes"], "avg_launch_ms": kernels[dom]["ms"],
                 "alg_bytes_formula": "16*P + S*(8*M + 96) (SURVEY 8(d)); P=%d points, S=%d scans, M=%d model points" % (P, S, M),
-                "valu": {"busy_frac": busy, "active_lane_share": lanes,
-                         "lane_slot_frac": (busy * lanes) if (busy is not None and lanes is not None) else None,
-                         # the counters are taken with the kernel alone on the chip: a launch of W workgroups of 1024 threads
-                         # holds min(W, CUs) CUs (pairs: half as many workgroups as scans)
-                         "cus_held_by_one_launch": min(n_cu, (S + 1) // 2 if paired else S) if dom == icp_name else None,
-                         "busy_frac_on_held_cus": (busy * n_cu / min(n_cu, (S + 1) // 2 if paired else S))
-                         if (busy is not None and dom == icp_name) else None,
+                "per_step": {"GBps": kernels[dom]["alg_bytes"] / (step_ms * 1e-3) / 1e9,
+                             "frac": kernels[dom]["alg_bytes"] / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "what": "alg_bytes_per_launch / ms_per_step: one launch of this kernel per step, whatever overlaps it"},
+                # the bound this kernel actually runs against: the share of the chip's VALU lane-slots that do work
+                "valu": {"bound": "valu", "frac": (busy * lanes) if (busy is not None and lanes is not None) else None,
+                         "busy_frac": busy, "active_lane_share": lanes,
+                         "cus_held_by_one_launch": held,
+                         "frac_on_held_cus": (busy * lanes * n_cu / held) if (busy is not None and lanes is not None) else None,
                          "source": prof_file,
-                         "meaning": "busy_frac = SIMD cycles that issued a VALU instruction; active_lane_share = "
-                                    "SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); their product is the share of "
-                                    "VALU lane-slots that did work -- the bound this kernel runs against"},
-                "launches_in_flight": in_flight,
-                "per_step_equivalent_GBps": (kernels[dom]["alg_bytes"] / (elapsed / max(args.steps, 1)) / 1e9) if dom == icp_name else None,
-                "note": "the ICP kernel is VALU-issue bound (exact 1-NN search in LDS, launch time = slowest scan), not "
-                        "HBM-bound: see DESIGN.md 4.1.  In the pipelined launch two registration launches are in flight on two "
-                        "streams, each on half the CUs (two scans per workgroup): avg_launch_ms is one launch's duration on "
-                        "its stream (HIP events around every launch of the timed region), achieved = launches_in_flight x "
-                        "alg_bytes_per_launch / avg_launch_ms, achieved_per_launch the same for one launch, "
-                        "per_step_equivalent_GBps the algorithmic bytes over the whole step time"}
+                         "meaning": "busy_frac = SIMD cycles (all 1024 SIMDs) that issued a VALU instruction; active_lane_share = "
+                                    "SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); frac = their product = the share of the "
+                                    "chip's VALU lane-slots that did work during a launch"},
+                "note": "frac = alg_bytes_per_launch / avg_launch_ms / peak, avg_launch_ms = HIP events around every launch of the "
+                        "timed region on its own stream (profiles/: the kernel's AverageNs in the kernel-trace summary of the same "
+                        "command).  The kernel is VALU-issue bound (exact 1-NN search in LDS, DESIGN.md 4.1), not HBM-bound: "
+                        "`valu` is the bound it runs against; the HBM fraction is reported because the contract asks for it."}
         out = {
             "metric": "registered_scan_points_per_s", "value": total_pts * args.steps / elapsed,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / max(args.steps, 1) * 1e3, "higher_is_better": True,
+            "ms_per_step": step_ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 pose / f32 distance / int32 counts",
             "data": "synthetic",
             "launch": {"pipeline": "consecutive steps on three streams: registrations (two scans per workgroup) alternate on two, "
@@ -656,6 +694,13 @@ def main():
                                                      "mean_icp_iterations", "target_model_ms")}
             except Exception as ex:   # the headline line must not depend on the extra leg
                 out["config3"] = {"error": str(ex)}
+            # short runs of the other GPU configs of BASELINE.json, each in a process of its own (this one stays idle):
+            # one GPU's share of config 4 (1024 scans into 4000 x 4000, pipelined steps) and config 5 (the streaming mapper
+            # with its sliding-window target, PCIe inclusive)
+            out["config4_share"] = side_run(["--config", "4", "--steps", "12", "--warmup", "3", "--no-extras", "--no-cpu-baseline"],
+                                            ("value", "ms_per_step", "grid_cell_updates_per_s", "cell_updates_per_step", "kernel_ms", "max_pose_error_m"))
+            out["config5"] = side_run(["--config", "5", "--stream-scans", "4096"],
+                                      ("value", "ms_per_step", "steps", "grid_cell_updates_per_s", "max_pose_error_m"))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(m_ga, m_nga, batch, GRID, RES)
         print(json.dumps(out), flush=True)
@@ -689,6 +734,7 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, ba
     for s in [mp.push(base) for _ in range(mp.n_slots)]:
         mp.wait(s)
     sync()
+    upd_warm = mp.grid.total_updates()       # the warm-up chunks' updates are not the timed chunks'
     barrier()
     t0 = time.perf_counter()
     pending, worst = [], 0.0
@@ -705,7 +751,7 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, ba
     sync()
     barrier()
     elapsed = time.perf_counter() - t0
-    upd = mp.grid.total_updates()
+    upd = mp.grid.total_updates() - upd_warm
     st = mp.stats()
     if dist is not None:
         import torch
@@ -719,9 +765,12 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, ba
             "steps": n_chunks, "warmup": mp.n_slots, "ms_per_step": elapsed / n_chunks * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 pose / f32 distance / int32 counts", "data": "synthetic",
             "config": {"workload": "BASELINE config 5 per GPU: %d scans streamed in chunks of %d from pinned host memory, %d ICP "
-                                   "iterations against a sliding-window target (5 k-point prior map + 5 k points of the last 4 chunks, rebuilt on "
-                                   "the device every 4), Bresenham raycast into %dx%d @%.2f m, merge over the GPUs + finalize every 8 chunks"
-                                   % (n_chunks * chunk, chunk, N_ITERS, GRID, GRID, RES),
+                                   "iterations against %s, Bresenham raycast into %dx%d @%.2f m, merge over the GPUs + finalize every %d chunks"
+                                   % (n_chunks * chunk, chunk, N_ITERS,
+                                      ("a sliding-window target (5 k-point prior map + at most 5 k points of the last %d chunks thinned at %.2f m, "
+                                       "rebuilt on the device every %d)" % (args.window, args.thin, args.rebuild_every)) if args.window
+                                      else "the fixed 5 k-point prior map",
+                                      GRID, GRID, RES, args.merge_every),
                        "pcie_inclusive": True, "mapper": st, "target_index": mp.target_index_info()},
             "grid_cell_updates_per_s": upd * world / elapsed, "max_pose_error_m": worst, "device": api.device_info()[0]}), flush=True)
     mp.close()

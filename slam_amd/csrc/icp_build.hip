@@ -937,6 +937,7 @@ double ms_since(std::chrono::steady_clock::time_point t0)
 
 struct Workspace { // pool blocks of one build, returned when it ends
     std::vector<void *> blocks;
+    hipStream_t         st = nullptr; // the stream the build's kernels run on
     void *get(size_t bytes)
     {
         void *p = pool_alloc(bytes);
@@ -945,7 +946,21 @@ struct Workspace { // pool blocks of one build, returned when it ends
     }
     ~Workspace()
     {
+        // on EVERY way out, error returns included: kernels already enqueued may still write these blocks, and the pool
+        // hands a freed block to the next caller (another thread's rebuild) without synchronising
+        if (!blocks.empty()) {
+            (void)hipStreamSynchronize(st);
+            (void)hipGetLastError();
+        }
         for (void *p : blocks) pool_free(p);
+    }
+};
+
+struct EventGuard { // an event of one build, destroyed on every way out
+    hipEvent_t ev = nullptr;
+    ~EventGuard()
+    {
+        if (ev) (void)hipEventDestroy(ev);
     }
 };
 
@@ -958,6 +973,7 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
     const int    cnt[2] = {n_ga, n_nga};
     hipStream_t  st = build_stream();
     Workspace    ws;
+    ws.st = st;
     const int    pblocks = (n_all + 255) / 256;
     // (device arrays: complete when the call is made -- the build does not order itself behind the default stream: that
     // stream shares a hardware queue with whatever the application runs, and an event on it can sit behind a whole
@@ -1064,7 +1080,8 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
     // the first candidates' entry counts travel back while the cell index is finished
     ListGeom           *d_geom = nullptr;
     unsigned long long *h_ent = nullptr;
-    hipEvent_t          ev_ent = nullptr;
+    EventGuard          ent_done;
+    hipEvent_t         &ev_ent = ent_done.ev;
     const int           nc_first = std::min(nc, kCandFirst);
     if (nc) {
         d_geom = static_cast<ListGeom *>(ws.get(sizeof(ListGeom) * (size_t)nc));
@@ -1085,9 +1102,7 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
     // ---- halo lists
     if (nc) {
         const auto t_plan = std::chrono::steady_clock::now();
-        hipError_t e = hipEventSynchronize(ev_ent); // the build's one read-back
-        (void)hipEventDestroy(ev_ent);
-        SLAM_HIP(e);
+        SLAM_HIP(hipEventSynchronize(ev_ent)); // the build's one read-back
         int    pick = -1;
         size_t n_ent[2] = {0, 0};
         auto   choose = [&](int k0, int k1) {
@@ -1144,7 +1159,8 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
         }
     }
     // the workspace goes back to the pool when this returns: the device must be done with it
-    unsigned *h_most = reinterpret_cast<unsigned *>(static_cast<unsigned char *>(pinned_scratch(16 * (size_t)std::max(nc, 1) + 64)) + 16 * (size_t)std::max(nc, 1));
+    unsigned char *h_tail = static_cast<unsigned char *>(pinned_scratch(16 * (size_t)std::max(nc, 1) + 64));
+    unsigned      *h_most = h_tail ? reinterpret_cast<unsigned *>(h_tail + 16 * (size_t)std::max(nc, 1)) : nullptr;
     if (h_most) SLAM_HIP(hipMemcpyAsync(h_most, d_most, 4, hipMemcpyDeviceToHost, st));
     SLAM_HIP(hipStreamSynchronize(st));
     if (h_most) h->max_cell_points = (int)*h_most;

@@ -427,8 +427,8 @@ int collect_job(slam_mapper *m, bool block)
         rc = m->job_rc;
     }
     m->job_in_flight = false;
-    if (rc != SLAM_OK) {
-        set_error("slam_mapper: background rebuild failed: %s", m->job_err);
+    if (rc != SLAM_OK) { // the old target stays; the push that finds this out is refused before it has consumed anything
+        set_error("slam_mapper: the background rebuild of the sliding target failed (the previous target stays in use): %s", m->job_err);
         return rc;
     }
     adopt_target(m, fresh);
@@ -552,15 +552,16 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
             // two registration streams on the default level, the copies on the high level (which they share with the
             // index build's stream: both are short), the grid update on the low level.  The levels themselves make no
             // measurable difference to the kernels (tools/pipeline_experiment.py).
-            int lo = 0, hi = 0; // numerically lower = higher priority
-            hip(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            hip(hipStreamCreateWithPriority(&m->copy, hipStreamNonBlocking, lo));
-            hip(hipStreamCreateWithPriority(&m->icp_s[0], hipStreamNonBlocking, (lo + hi) / 2));
-            hip(hipStreamCreateWithPriority(&m->grid_s, hipStreamNonBlocking, hi));
+            int least = 0, greatest = 0;
+            hip(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            const int mid = (least + greatest) / 2;
+            hip(hipStreamCreateWithPriority(&m->copy, hipStreamNonBlocking, greatest));
+            hip(hipStreamCreateWithPriority(&m->icp_s[0], hipStreamNonBlocking, mid));
+            hip(hipStreamCreateWithPriority(&m->grid_s, hipStreamNonBlocking, least));
             if (params->window_chunks)
                 m->icp_s[1] = m->icp_s[0]; // a sliding target registers its chunks one after the other (slam_mapper_push)
             else
-                hip(hipStreamCreateWithPriority(&m->icp_s[1], hipStreamNonBlocking, (lo + hi) / 2));
+                hip(hipStreamCreateWithPriority(&m->icp_s[1], hipStreamNonBlocking, mid));
         } else {
             hip(hipStreamCreateWithFlags(&m->copy, hipStreamNonBlocking));
             m->icp_s[0] = m->icp_s[1] = m->grid_s = m->copy;
@@ -691,8 +692,9 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     SLAM_REQUIRE(n_scans <= m->prm.max_scans && n_points <= m->prm.max_points, SLAM_E_INVALID,
                  "slam_mapper_push: chunk of %d scans / %d points exceeds the reservation (%d / %d)", n_scans, n_points,
                  m->prm.max_scans, m->prm.max_points);
+    // (everything that can refuse the chunk comes before anything is consumed: a push that fails leaves the slot, its
+    // pinned buffers and slam_mapper_next_slot() as they were, and the caller may push the same chunk again)
     const int s = m->next;
-    m->next = (m->next + 1) % m->n_slots;
     Slot &b = m->slot[s];
     SLAM_REQUIRE(!b.busy, SLAM_E_INVALID, "slam_mapper_push: slot %d still holds a chunk that was not waited for", s);
     SLAM_REQUIRE(b.h_off[0] == 0 && b.h_off[n_scans] == n_points, SLAM_E_INVALID, "slam_mapper_push: scan_off does not span the chunk");
@@ -764,6 +766,7 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     MAP_HIP(hipEventRecord(b.mapped, m->grid_s));
     b.busy = true;
     b.n_scans = n_scans;
+    m->next = (s + 1) % m->n_slots;
     if (slot_out) *slot_out = s;
     return SLAM_OK;
 }

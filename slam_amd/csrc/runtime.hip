@@ -152,9 +152,9 @@ hipStream_t build_stream()
     }
     std::lock_guard<std::mutex> lk(mu);
     if (!streams[dev]) {
-        int lo = 0, hi = 0; // numerically lower = higher priority
-        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess ||
-            hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, lo) != hipSuccess) {
+        int least = 0, greatest = 0; // hipDeviceGetStreamPriorityRange(&least, &greatest): greatest is the numerically LOWER one
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess ||
+            hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, greatest) != hipSuccess) {
             (void)hipGetLastError();
             streams[dev] = nullptr;
         }
@@ -328,9 +328,9 @@ int slam_stream_create_with_priority(slam_stream_t *stream, int priority)
 {
     SLAM_REQUIRE(stream, SLAM_E_INVALID, "slam_stream_create_with_priority: null out pointer");
     SLAM_TRY(require_device());
-    int lo = 0, hi = 0; // numerically lower = higher priority
-    SLAM_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    const int   p = priority > 0 ? hi : (priority < 0 ? lo : (lo + hi) / 2);
+    int least = 0, greatest = 0;
+    SLAM_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int   p = priority > 0 ? greatest : (priority < 0 ? least : (least + greatest) / 2);
     hipStream_t s;
     SLAM_HIP(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, p));
     *stream = (slam_stream_t)s;
