@@ -442,7 +442,10 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
         return (G > 0 && p < n) ? fa.pts[off + p] : make_double2(0.0, 0.0);
     };
     // named, not an array: stays in registers (the list-sweep kernel has one full pass per 1024 points: one is enough)
-    // (a team of half a workgroup sweeps a 1081-point scan in two full passes: both stay in registers)
+    // (round 3, measured and not kept: a team of half a workgroup needs five ring passes for a 1081-point scan and seeds only
+    // the three it keeps in registers; one pass of points kept and the seeds of all five -- nine registers instead of fifteen
+    // -- made no difference with two lanes per point (0.620 / 0.630 / 1.195 ms for 256 / 512 / 1024 scans against 0.627 /
+    // 0.626 / 1.199) and cost 3 % with one)
     const double2 Pc0 = hoisted(0), Pc1 = SWEEP ? Pc0 : hoisted(1), Pc2 = SWEEP ? Pc0 : hoisted(2);
 
     int   sd0 = -1, sd1 = -1, sd2 = -1; // ring form: last iteration's neighbour of the lane's point in each hoisted pass
@@ -456,7 +459,10 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
             for (int k = 0; k < kNumAcc; ++k) acc[k] = 0.0;
             const Pose T = {r00, r01, r10, r11, t0, t1};
             if (fa.step_pose && tid == 0) {
-                double *sp = fa.step_pose + 6 * (size_t)s;
+                // (the scan index is the same in every lane of a wavefront; said so HERE, the address is formed in scalar
+                // registers inside this rarely taken block -- left to itself the compiler forms it once per kernel in vector
+                // registers, which in the pair kernel, where the scan depends on the team, was what went to scratch)
+                double *sp = fa.step_pose + 6 * (size_t)__builtin_amdgcn_readfirstlane(s);
                 sp[0] = r00;
                 sp[1] = r01;
                 sp[2] = r10;
@@ -632,7 +638,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                 }
             }
             if (fa.trace && tid == 0) {
-                double *tr = fa.trace + ((size_t)s * fa.max_iter + iter) * 8;
+                double *tr = fa.trace + ((size_t)__builtin_amdgcn_readfirstlane(s) * fa.max_iter + iter) * 8;
                 tr[0] = r00;
                 tr[1] = r01;
                 tr[2] = r10;
