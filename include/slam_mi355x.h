@@ -223,11 +223,9 @@ typedef struct {
     int    min_cluster_points;  /* mls.h:165 (10); local_mapper.cpp:86 sets 20 */
     int    rolling;             /* MLS(..., bool roll) mls.h:154 */
     int    raycast_impl;        /* SLAM_RAYCAST_* */
-    int    raycast_seg_items;   /* tiled raycast: 64-beam blocks of one tile a workgroup accumulates before it
-                                   writes the tile back; 0 = sized from the work list (about five segments per workgroup:
-                                   best when the raycast has the chip to itself); a raycast that runs BESIDE registrations,
-                                   on the CUs they leave, wants longer segments -- fewer tile flushes, and its tail is
-                                   somebody else's head: 48 (the mapper and bench.py set that); at most 1023 */
+    int    raycast_seg_items;   /* tiled raycast: 64-beam blocks a workgroup takes from a tile's work list at a time (it goes
+                                   on accumulating in the same LDS tile while the tile has blocks left and writes the tile
+                                   back when it leaves it); 0 = library default (32); 8 ... 511 */
     int    raycast_wg_per_cu;   /* tiled raycast: persistent workgroups per CU; 0 = library default (one while the grid has
                                    no more 128 x 128-cell tiles than the chip has CUs, two beyond) */
 } slam_grid_params;
@@ -301,8 +299,8 @@ int slam_grid_info(slam_grid_t *g, int *size_x, int *size_y, double *resolution,
  * exactly when these agree (what a merge over the GPUs requires: slam_mi355x_rccl.h). */
 int slam_grid_window_cell(slam_grid_t *g, int *cell_x, int *cell_y);
 
-/* work-list size of the last tiled raycast: tiles of the window, (tile, 64-beam block)
- * items and workgroup segments (for reporting) */
+/* work list of the last tiled raycast: tiles of the window, (tile, 64-beam block) items, and how many times a
+ * workgroup wrote a tile back (for reporting) */
 int slam_grid_raycast_stats(slam_grid_t *g, int *n_tiles, int *n_items, int *n_segments);
 
 /* the two int32 planes ([hits | misses], 2*size_x*size_y ints, toroidal

@@ -687,7 +687,7 @@ class Grid:
     def raycast_stats(self):
         t, i, s = C.c_int(), C.c_int(), C.c_int()
         check(lib().slam_grid_raycast_stats(self.h, C.byref(t), C.byref(i), C.byref(s)))
-        return dict(tiles=t.value, items=i.value, segments=s.value)
+        return dict(tiles=t.value, items=i.value, tile_write_backs=s.value)
 
     def dirty_rows(self):
         lo, hi = C.c_int(), C.c_int()

@@ -305,9 +305,9 @@ __global__ __launch_bounds__(256) void raycast_global_kernel(GridView g, const B
 // Work list for the tiled raycast, built without atomics (so its order is
 // deterministic): for every tile the 64-beam blocks whose bounding box overlaps it.
 //   tile_items_wg : one workgroup per tile, ballot + popcount over the block boxes; the ids go to the tile's own
-//                row of `items` (n_blocks ids wide, so no prefix sum is needed first), the count to cnt[]
-//   the raycast workgroups turn cnt[] into segment offsets themselves (a prefix over a few hundred tiles
-//   in LDS): a segment = <= kSeg items of ONE tile, the unit a workgroup takes.
+//                row of `items` (n_blocks ids wide, so no prefix sum is needed first), the count to cnt[], and the
+//                tile's cursor (the next block of its list to hand out) back to 0
+//   the raycast workgroups take blocks from a tile's list through that cursor, a chunk at a time.
 //   Grids of more than kMaxLdsTiles tiles keep the three-kernel form (count, scan, fill).
 
 __device__ inline bool box_overlaps_tile(const int4 cb, int tx0, int ty0, int tx1, int ty1)
@@ -321,7 +321,7 @@ constexpr int kMaxLdsTiles = 2048; // segment offsets of that many tiles fit bes
 template <int FILL>
 __global__ __launch_bounds__(256) void tile_items_kernel(const int4 *block_box, int n_blocks, int tiles_x,
                                                          int n_tiles, int sx, int sy, int *cnt,
-                                                         const int *item_off, int *items, int *queue)
+                                                         const int *item_off, int *items)
 {
     const int t = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (t >= n_tiles) return;
@@ -351,12 +351,15 @@ __global__ __launch_bounds__(256) void tile_items_kernel(const int4 *block_box, 
 // trip (all loads in flight at once), the wavefronts' match counts go through LDS, and the ids land in the tile's row
 // in ascending block order as before (17 dependent trips of one wavefront per tile took 11 us on config 2).
 __global__ __launch_bounds__(1024) void tile_items_wg_kernel(const int4 *block_box, int n_blocks, int tiles_x, int sx,
-                                                             int sy, int *cnt, int *items, int *queue)
+                                                             int sy, int *cnt, int *items, int *cursor)
 {
     __shared__ int s_cnt[4][16], s_base;
     const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (t == 0 && tid == 0) queue[0] = 0; // next segment to take
-    if (tid == 0) s_base = 0;
+    if (tid == 0) {
+        s_base = 0;
+        cursor[t] = 0;                       // the tile's list is handed out from its start
+        if (t == 0) cursor[gridDim.x] = 0;   // behind the cursors: tile write-backs of the launch (slam_grid_raycast_stats)
+    }
     const int tx0 = (t % tiles_x) * kTile, ty0 = (t / tiles_x) * kTile;
     const int tx1 = min(tx0 + kTile, sx) - 1, ty1 = min(ty0 + kTile, sy) - 1;
     const int base_out = t * n_blocks;
@@ -400,53 +403,39 @@ __global__ __launch_bounds__(1024) void tile_items_wg_kernel(const int4 *block_b
     if (tid == 0) cnt[t] = s_base;
 }
 
-__global__ __launch_bounds__(1024) void tile_scan_kernel(const int *cnt, int n_tiles, int *item_off, int *seg_off,
-                                                         int *queue, int kSeg)
+// grids of more than kMaxLdsTiles tiles: exclusive prefix of the tile counts (where each tile's list starts, the total
+// behind the last), and the cursors back to 0
+__global__ __launch_bounds__(1024) void tile_scan_kernel(const int *cnt, int n_tiles, int *item_off, int *cursor)
 {
-    __shared__ int carry[2];
-    __shared__ int wsum[2][16];
+    __shared__ int carry;
+    __shared__ int wsum[16];
     const int tid = threadIdx.x;
-    if (tid == 0) carry[0] = carry[1] = 0;
+    if (tid == 0) carry = 0;
     __syncthreads();
     for (int base = 0; base < n_tiles; base += 1024) {
         const int i = base + tid;
         const int v0 = i < n_tiles ? cnt[i] : 0;
-        const int v1 = (v0 + kSeg - 1) / kSeg;
-        int       x0 = v0, x1 = v1;
+        int       x0 = v0;
         for (int off = 1; off < 64; off <<= 1) {
-            const int y0 = __shfl_up(x0, off), y1 = __shfl_up(x1, off);
-            if ((tid & 63) >= off) {
-                x0 += y0;
-                x1 += y1;
-            }
+            const int y0 = __shfl_up(x0, off);
+            if ((tid & 63) >= off) x0 += y0;
         }
-        if ((tid & 63) == 63) {
-            wsum[0][tid >> 6] = x0;
-            wsum[1][tid >> 6] = x1;
-        }
+        if ((tid & 63) == 63) wsum[tid >> 6] = x0;
         __syncthreads();
-        int w0 = 0, w1 = 0;
-        for (int w = 0; w < (tid >> 6); ++w) {
-            w0 += wsum[0][w];
-            w1 += wsum[1][w];
-        }
-        const int in0 = carry[0] + w0 + x0, in1 = carry[1] + w1 + x1;
+        int w0 = 0;
+        for (int w = 0; w < (tid >> 6); ++w) w0 += wsum[w];
+        const int in0 = carry + w0 + x0;
         if (i < n_tiles) {
             item_off[i] = in0 - v0;
-            seg_off[i] = in1 - v1;
+            cursor[i] = 0;
         }
         __syncthreads();
-        if (tid == 1023) {
-            carry[0] = in0;
-            carry[1] = in1;
-        }
+        if (tid == 1023) carry = in0;
         __syncthreads();
     }
     if (tid == 0) {
-        item_off[n_tiles] = carry[0];
-        seg_off[n_tiles] = carry[1];
-        queue[0] = 0;        // next segment to take
-        queue[1] = carry[1]; // number of segments
+        item_off[n_tiles] = carry;
+        cursor[n_tiles] = 0; // tile write-backs of the launch
     }
 }
 
@@ -465,11 +454,15 @@ __device__ inline int floor_div_small(int num, int den, float rden)
     return q;
 }
 
-// Tiled raycast.  Persistent workgroups take SEGMENTS (<= kSeg chunks of one
-// tile) from a global queue.  For a segment the workgroup zeroes a 128x128
-// tile of packed (hits<<16 | misses) counters in LDS, its 16 wavefronts pull
-// (chunk, 64-beam block) pairs from an LDS counter, and the tile is written
-// back once with coalesced global atomics.
+// Tiled raycast.  A persistent workgroup works on ONE tile at a time: it zeroes a 128x128 tile of packed
+// (hits<<16 | misses) counters in LDS, takes 64-beam blocks from the tile's work list a chunk at a time (the tile's
+// cursor: one global atomic per chunk), its 16 wavefronts pull the chunk's blocks from an LDS counter, and it keeps
+// accumulating in the same LDS tile for as long as the tile has blocks left -- the tile is written back (coalesced
+// global atomics) once, when the workgroup leaves it.  Workgroups start spread over the tiles in proportion to the
+// tiles' lists (a prefix over the tile counts in LDS) and, when their tile runs dry, move to the tile with the most
+// blocks left.  (Round 2 cut the lists into fixed segments of one tile, each zeroed and written back by whoever took it:
+// 8.5 write-backs per tile on config 2 -- 30 % of the kernel's instructions and 40 MB of atomic traffic per launch;
+// a workgroup that stays is one write-back per workgroup and tile.)
 // Within a block every lane owns one beam: it clips the beam's Bresenham step
 // range [0, du] to the tile exactly -- the cell of step i has the closed form
 //   (u0 + su*i, v0 + sv*floor((2*i*dv + du) / (2*du))),
@@ -478,21 +471,15 @@ __device__ inline int floor_div_small(int num, int den, float rden)
 // lock-step with the integer error update (4 integer ops + one ds_add per
 // cell).  Clipping by closed form is what makes the tiling invisible in the
 // result: the cells are exactly those of the unclipped line.
-// Blocks of one tile a workgroup accumulates before it writes the tile back (a segment), when the caller leaves the
-// choice to the library: about five segments per persistent workgroup, at least 20 blocks -- fewer segments leave
-// workgroups idle at the end, shorter ones pay the tile's zeroing and write-back too often (SLAM_RAYCAST_SEG sweeps
-// on configs 2 and 4).
-__host__ __device__ inline int adaptive_seg(long total_items, int n_workgroups)
-{
-    const long per = (total_items + 5L * n_workgroups - 1) / (5L * n_workgroups);
-    return (int)(per < 20 ? 20 : (per > 128 ? 128 : per));
-}
+constexpr int kChunkMin = 8;      // (the visit's chunk log in LDS is sized for it)
+constexpr int kChunkDefault = 32; // blocks a workgroup takes from a tile's list at a time, where the caller leaves it to the library
+constexpr int kMaxAccBlocks = 1023; // blocks accumulated in the packed LDS counters before a write-back is forced: 64 * 1023 misses of the
+                                    // sensor's cell cannot carry into the hit half
 
 template <bool MERGE>
 __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView g, const Beam *beams, int n,
                                                                         const int *items, const int *item_off,
-                                                                        const int *seg_off, int n_tiles,
-                                                                        int *queue, int tiles_x, int kSeg,
+                                                                        int n_tiles, int *cursor, int tiles_x, int chunk,
                                                                         int ablate_arg, const int *cnt, int item_stride)
 {
 #ifdef SLAM_MEASURE // timing experiments only (tools/ablate.sh): bits switch parts of the kernel off -- wrong counts
@@ -502,29 +489,21 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
     (void)ablate_arg;
 #endif
     __shared__ __attribute__((aligned(16))) unsigned tile[kTile * kTileStride];
-    __shared__ int s_seg, s_pair;
-    __shared__ int s_segoff[kMaxLdsTiles + 1], s_wsum[kTileThreads / 64], s_carry;
+    __shared__ int s_ticket, s_done, s_end;
+    __shared__ unsigned long long s_desc[kMaxAccBlocks / kChunkMin]; // the visit's chunk log
+    __shared__ int s_off[kMaxLdsTiles + 1], s_wsum[kTileThreads / 64], s_carry;
+    __shared__ unsigned long long s_best[kTileThreads / 64];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    // single-pass work list (cnt != null): every workgroup turns the tile counts into segment offsets itself
-    const bool own_prefix = cnt != nullptr;
-    if (own_prefix) {
-        if (kSeg <= 0) { // segment length from the total number of (tile, block) items
-            int v = 0;
-            for (int i = tid; i < n_tiles; i += kTileThreads) v += cnt[i];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0) s_wsum[tid >> 6] = v;
-            __syncthreads();
-            long total = 0;
-            for (int k = 0; k < kTileThreads / 64; ++k) total += s_wsum[k];
-            kSeg = adaptive_seg(total, (int)gridDim.x);
-            __syncthreads();
-        }
+    // (item_off != null: a grid of more than kMaxLdsTiles tiles; its lists lie one behind the other and their starts were
+    // scanned by tile_scan_kernel.  Otherwise every tile has a row of its own and the prefix is worked out here.)
+    const bool in_lds = item_off == nullptr;
+    if (in_lds) {
         if (tid == 0) s_carry = 0;
         __syncthreads();
         for (int base = 0; base < n_tiles; base += kTileThreads) {
             const int i = base + tid;
-            const int v = i < n_tiles ? (cnt[i] + kSeg - 1) / kSeg : 0;
+            const int v = i < n_tiles ? cnt[i] : 0;
             int       x = v;
             for (int off = 1; off < 64; off <<= 1) {
                 const int y = __shfl_up(x, off);
@@ -535,62 +514,144 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
             int w = 0;
             for (int k = 0; k < (tid >> 6); ++k) w += s_wsum[k];
             const int incl = s_carry + w + x;
-            if (i < n_tiles) s_segoff[i] = incl - v;
+            if (i < n_tiles) s_off[i] = incl - v;
             __syncthreads();
             if (tid == kTileThreads - 1) s_carry = incl;
             __syncthreads();
         }
-        if (tid == 0) s_segoff[n_tiles] = s_carry;
+        if (tid == 0) s_off[n_tiles] = s_carry;
         __syncthreads();
     }
-    const int n_segs = own_prefix ? s_segoff[n_tiles] : queue[1];
-    unsigned  did = 0;
-    int       d_lo = 0x7fffffff, d_hi = -1; // storage rows this lane wrote back
-
-    for (;;) {
-        __syncthreads(); // the previous segment's write-back has read the tile
-        if (tid == 0) {
-            s_seg = atomicAdd(&queue[0], 1);
-            s_pair = 0;
-        }
-        for (int i = tid * 4; i < kTile * kTileStride; i += kTileThreads * 4)
-            *reinterpret_cast<uint4 *>(&tile[i]) = make_uint4(0u, 0u, 0u, 0u);
-        __syncthreads();
-        const int seg = s_seg;
-        if (seg >= n_segs) break;
-
-        int lo = 0, hi = n_tiles - 1; // tile of the segment: last t with seg_off[t] <= seg
+    const auto list_start = [&](int t) { return in_lds ? s_off[t] : item_off[t]; };
+    const int  total = list_start(n_tiles);
+    unsigned   did = 0;
+    int        d_lo = 0x7fffffff, d_hi = -1; // storage rows this lane wrote back
+    if (total <= 0 || (ablate & 8)) {
+        mark_dirty_rows(g.dirty, d_lo, d_hi);
+        block_add_updates(g.updates, did);
+        return;
+    }
+    // where this workgroup starts: the tile that holds its share of all blocks (the last t with list_start(t) <= pos)
+    int cur;
+    {
+        const int pos = (int)(((long long)blockIdx.x * total) / gridDim.x);
+        int       lo = 0, hi = n_tiles - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if ((own_prefix ? s_segoff[mid] : seg_off[mid]) <= seg)
+            if (list_start(mid) <= pos)
                 lo = mid;
             else
                 hi = mid - 1;
         }
-        const int t = lo;
-        const int tile_base = own_prefix ? t * item_stride : item_off[t];
-        const int tile_end = own_prefix ? tile_base + cnt[t] : item_off[t + 1];
-        const int it0 = tile_base + (seg - (own_prefix ? s_segoff[t] : seg_off[t])) * kSeg;
-        const int n_pairs = (ablate & 8) ? 0 : min(it0 + kSeg, tile_end) - it0; // 64-beam blocks in this segment
+        cur = lo;
+    }
+    for (int i = tid * 4; i < kTile * kTileStride; i += kTileThreads * 4)
+        *reinterpret_cast<uint4 *>(&tile[i]) = make_uint4(0u, 0u, 0u, 0u);
+
+    // writes the LDS tile of tile t back (coalesced: consecutive lanes -> consecutive x of one row) and zeroes it
+    const auto flush = [&](int t) {
+        const int tx0 = (t % tiles_x) * kTile, ty0 = (t / tiles_x) * kTile;
+        for (int i = (ablate & 2) ? kTile * kTile : tid; i < kTile * kTile; i += kTileThreads) {
+            const int      lx = i & (kTile - 1), ly = i / kTile;
+            const unsigned v = tile[ly * kTileStride + lx];
+            if (!v) continue;
+            tile[ly * kTileStride + lx] = 0u;
+            const int s = storage_index(g, tx0 + lx, ty0 + ly);
+            if (v & 0xffffu) atomicAdd(&g.misses[s], (int)(v & 0xffffu));
+            if (v >> 16) atomicAdd(&g.hits[s], (int)(v >> 16));
+            int row = ty0 + ly + g.oy; // the storage row of s (storage_index without its division)
+            row -= row >= g.sy ? g.sy : 0;
+            d_lo = min(d_lo, row);
+            d_hi = max(d_hi, row);
+        }
+        if (tid == 0) atomicAdd(&cursor[n_tiles], 1); // statistics: tile write-backs of the launch
+    };
+
+    // One VISIT = the stay of this workgroup on one tile between two write-backs.  Within a visit there is no barrier: a
+    // wavefront draws a ticket T from an LDS counter; ticket T is block T % chunk of the visit's chunk T / chunk, and chunk c
+    // is the range [base_c, base_c + np_c) of the tile's list that a global atomic on the tile's cursor handed out,
+    // published as one 64-bit LDS word {1, np, base}.  Chunks 0 and 1 come from one atomic at the start of the visit; the
+    // wavefront that draws the first ticket of chunk c fetches chunk c + 2 -- two chunks of walks ahead of its use, the
+    // atomic in flight while the wavefront walks its own block -- once it has seen chunks c and c + 1 full: fetches are
+    // therefore issued one after the other's return, the bases grow with c, and the first chunk that is not full ends the
+    // list for every later ticket (s_end).  Descriptors are a log, not a ring (one per chunk of the visit: never overwritten
+    // while anybody may read them); a visit ends where the log does (kMaxAccBlocks blocks, the limit of the packed LDS
+    // counters) or where the tile's list does.  A wavefront never waits while it owes a publication (settle).
+    const int  kMaxChunks = kMaxAccBlocks / chunk; // chunks per visit (host: chunk <= kMaxAccBlocks / 2, so at least two)
+    const auto publish = [&](int c, int base, int np) { // lane 0 of the fetching wavefront
+        __hip_atomic_store(&s_desc[c], (1ull << 48) | ((unsigned long long)(unsigned)np << 32) | (unsigned)base, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (np < chunk) { // the tile's list ends in (np > 0) or before (np == 0) this chunk
+            atomicMin(&s_end, np > 0 ? c + 1 : c);
+            s_done = 1;
+        }
+    };
+    for (;;) {
+        __syncthreads(); // the last visit's walks are in the tile and written back; nobody reads its descriptors any more
+        for (int c = tid; c < kMaxChunks; c += kTileThreads) s_desc[c] = 0ull;
+        if (tid == 0) {
+            s_ticket = 0;
+            s_done = 0;
+            s_end = kMaxChunks;
+        }
+        __syncthreads();
+        const int t = cur;
+        if (tid == 0) { // the visit's first two chunks
+            const int have_t = cnt[t];
+            const int k = atomicAdd(&cursor[t], 2 * chunk);
+            const int np0 = max(0, min(chunk, have_t - k));
+            publish(0, k, np0);
+            if (np0 == chunk) publish(1, k + chunk, max(0, min(chunk, have_t - k - chunk)));
+        }
+        const int tile_base = in_lds ? t * item_stride : item_off[t];
         const int tx0 = (t % tiles_x) * kTile, ty0 = (t / tiles_x) * kTile;
         const int tx1 = min(tx0 + kTile, g.sx) - 1, ty1 = min(ty0 + kTile, g.sy) - 1;
 
-        // each wavefront pulls blocks from the segment; the next block's beams are
-        // requested before the current one is walked (hides the two dependent loads)
-        auto grab = [&](int2 *raw) {
-            int p = 0;
-            if (lane == 0) p = atomicAdd(&s_pair, 1);
-            p = __builtin_amdgcn_readfirstlane(p);
-            if (p < n_pairs) {
-                const int bi = items[it0 + p] * kBlock + lane;
-                *raw = bi < n ? *reinterpret_cast<const int2 *>(&beams[bi]) : make_int2(-1, 0);
+        int  fetch_c = -1, fetch_k = 0; // this wavefront owes the publication of chunk fetch_c; lane 0's atomic returned fetch_k
+        auto settle = [&]() {
+            if (fetch_c >= 0 && lane == 0) publish(fetch_c, fetch_k, max(0, min(chunk, cnt[t] - fetch_k)));
+            fetch_c = -1;
+        };
+        // descriptor of chunk c, or 0 when the list ends before it
+        auto wait_desc = [&](int c) -> unsigned long long {
+            for (;;) {
+                if (c >= __hip_atomic_load(&s_end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return 0ull;
+                const unsigned long long d = __hip_atomic_load(&s_desc[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (d != 0ull) return d;
+                if (fetch_c >= 0)
+                    settle(); // never wait while owing: the chunk awaited may hang on this very publication
+                else
+                    __builtin_amdgcn_s_sleep(1);
             }
-            return p;
+        };
+        // a wavefront's next block: its beams are requested before the current block is walked (hides the two dependent
+        // loads).  Returns false at the end of the visit.
+        auto grab = [&](int2 *raw) -> bool {
+            int T = 0;
+            if (lane == 0) T = atomicAdd(&s_ticket, 1);
+            T = __builtin_amdgcn_readfirstlane(T);
+            const int c = T / chunk, idx = T - c * chunk;
+            if (c >= kMaxChunks) return false; // the visit's log is full: write back, then the same tile again
+            const unsigned long long d = wait_desc(c);
+            const int np = (int)((d >> 32) & 0xffffu), base = (int)(unsigned)(d & 0xffffffffull);
+            if (idx >= np) return false; // the tile's list ends before this block
+            if (idx == 0 && np == chunk && c + 2 < kMaxChunks) {
+                // first ticket of a full chunk: if the next chunk is full too, fetch the one after it
+                const unsigned long long d1 = wait_desc(c + 1);
+                if ((int)((d1 >> 32) & 0xffffu) == chunk) {
+                    settle(); // (one fetch at a time per wavefront)
+                    if (lane == 0) fetch_k = atomicAdd(&cursor[t], chunk);
+                    fetch_c = c + 2;
+                }
+            }
+            const int bi = items[tile_base + base + idx] * kBlock + lane;
+            *raw = bi < n ? *reinterpret_cast<const int2 *>(&beams[bi]) : make_int2(-1, 0);
+            return true;
         };
         int2 raw = make_int2(-1, 0), raw_next = make_int2(-1, 0);
-        int  p = grab(&raw);
-        while (p < n_pairs) {
-            const int p_next = grab(&raw_next);
+        bool have = grab(&raw);
+        while (have) {
+            const bool have_next = grab(&raw_next);
 
             // ---- clip this lane's beam to the tile
             int rem = 0, a = 0, e = 0, dv2 = 0, den = 1, step_u = 0, step_v = 0, to_end = 0;
@@ -694,23 +755,33 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
                 if (miss > k) add_miss();
                 advance(); // a finished lane's cell is not used again
             }
-            p = p_next;
+            settle(); // (after the walk: the fetch's round trip is behind it by now)
+            have = have_next;
             raw = raw_next;
         }
-        __syncthreads();
-        // coalesced write-back: consecutive lanes -> consecutive x of one row
-        for (int i = (ablate & 2) ? kTile * kTile : tid; i < kTile * kTile; i += kTileThreads) {
-            const int      lx = i & (kTile - 1), ly = i / kTile;
-            const unsigned v = tile[ly * kTileStride + lx];
-            if (!v) continue;
-            const int s = storage_index(g, tx0 + lx, ty0 + ly);
-            if (v & 0xffffu) atomicAdd(&g.misses[s], (int)(v & 0xffffu));
-            if (v >> 16) atomicAdd(&g.hits[s], (int)(v >> 16));
-            int row = ty0 + ly + g.oy; // the storage row of s (storage_index without its division)
-            row -= row >= g.sy ? g.sy : 0;
-            d_lo = min(d_lo, row);
-            d_hi = max(d_hi, row);
+        settle(); // nothing fetched may stay unpublished: others wait for it
+        __syncthreads(); // every wavefront has found the end of the visit
+        flush(t);
+        if (s_done == 0) continue; // the visit's log was full and the tile has blocks left: the same tile again, fresh counters
+        // this tile has nothing left to hand out: on to the tile with the most blocks left, if any
+        unsigned long long best = 0ull;
+        for (int u = tid; u < n_tiles; u += kTileThreads) {
+            const int have_u = cnt[u];
+            const int taken = __hip_atomic_load(&cursor[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int left = have_u - min(have_u, taken);
+            const unsigned long long key = ((unsigned long long)(unsigned)left << 32) | (unsigned)u;
+            best = left > 0 && key > best ? key : best;
         }
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long o = __shfl_xor(best, off);
+            best = o > best ? o : best;
+        }
+        if (lane == 0) s_best[tid >> 6] = best;
+        __syncthreads();
+        best = 0ull;
+        for (int w = 0; w < kTileThreads / 64; ++w) best = s_best[w] > best ? s_best[w] : best;
+        if (best == 0ull) break; // every list is handed out (what is still being walked belongs to others)
+        cur = (int)(unsigned)(best & 0xffffffffull);
     }
     mark_dirty_rows(g.dirty, d_lo, d_hi);
     block_add_updates(g.updates, did);
@@ -961,12 +1032,12 @@ struct slam_grid {
     int4            *d_chunk_box = nullptr;
     size_t           cap_chunks = 0;
     int             *d_tile_cnt = nullptr; // [n_tiles] overlapping chunks per tile
-    int             *d_tile_fill = nullptr; // [2][n_tiles+1] item_off | seg_off
-    int             *d_queue = nullptr;    // [2] next segment, number of segments
+    int             *d_tile_fill = nullptr; // [n_tiles+1] item_off: where each tile's list starts (grids beyond kMaxLdsTiles tiles)
+    int             *d_cursor = nullptr;   // [n_tiles+1] blocks of each tile's list handed out so far; behind them, the launch's tile write-backs
     int             *d_items = nullptr;    // chunk ids bucketed by tile
     size_t           cap_items = 0;
     int              n_cu = 256;
-    int              seg_items = 0;  // 64-beam blocks of one tile a workgroup accumulates before writing back; 0 = adaptive_seg
+    int              seg_items = 0;  // 64-beam blocks a workgroup takes from a tile's list at a time; 0 = kChunkDefault
     int              last_chunks = 0;
     int              ablate = 0;     // debug: SLAM_RAYCAST_ABLATE bit mask (timing experiments only)
     int              wg_per_cu = 0;  // persistent raycast workgroups per CU; 0 = by the number of tiles (raycast_wg_per_cu)
@@ -1008,8 +1079,8 @@ int reserve_beams(slam_grid *g, size_t n)
         const size_t n_tiles = (size_t)((g->gv.sx + kTile - 1) / kTile) * ((g->gv.sy + kTile - 1) / kTile);
         if (!g->d_tile_cnt) {
             SLAM_HIP(hipMalloc((void **)&g->d_tile_cnt, n_tiles * sizeof(int)));
-            SLAM_HIP(hipMalloc((void **)&g->d_tile_fill, 2 * (n_tiles + 1) * sizeof(int)));
-            SLAM_HIP(hipMalloc((void **)&g->d_queue, 2 * sizeof(int)));
+            SLAM_HIP(hipMalloc((void **)&g->d_tile_fill, (n_tiles + 1) * sizeof(int)));
+            SLAM_HIP(hipMalloc((void **)&g->d_cursor, (n_tiles + 1) * sizeof(int)));
         }
         size_t ci = g->cap_items * sizeof(int);
         p = g->d_items;
@@ -1032,28 +1103,27 @@ int walk_beams(slam_grid *g, int n, hipStream_t st)
     if (g->prm.raycast_impl != SLAM_RAYCAST_GLOBAL) {
         const int tiles_x = (g->gv.sx + kTile - 1) / kTile, tiles_y = (g->gv.sy + kTile - 1) / kTile;
         const int n_tiles = tiles_x * tiles_y;
-        int      *item_off = g->d_tile_fill, *seg_off = g->d_tile_fill + (n_tiles + 1);
+        int       *item_off = g->d_tile_fill;
         const dim3 tgrid((n_tiles * 64 + 255) / 256);
+        const int  chunk = g->seg_items > 0 ? g->seg_items : kChunkDefault;
+        const dim3 rgrid(raycast_wg_per_cu(g, n_tiles) * g->n_cu); // persistent workgroups (66 KB of LDS each)
         g->last_chunks = n_chunks;
         if (n_tiles <= kMaxLdsTiles) {
-            // one pass over the block boxes; the raycast workgroups derive the segment offsets themselves
+            // one pass over the block boxes; the raycast workgroups work the prefix of the tile counts out themselves
             hipLaunchKernelGGL(tile_items_wg_kernel, dim3(n_tiles), dim3(1024), 0, st, g->d_chunk_box, n_chunks, tiles_x,
-                               g->gv.sx, g->gv.sy, g->d_tile_cnt, g->d_items, g->d_queue);
-            hipLaunchKernelGGL(g->merge ? raycast_tiled_kernel<true> : raycast_tiled_kernel<false>, dim3(raycast_wg_per_cu(g, n_tiles) * g->n_cu),
-                               dim3(kTileThreads), 0, st, g->gv, g->d_beams, n, g->d_items, item_off, seg_off, n_tiles, g->d_queue,
-                               tiles_x, g->seg_items, g->ablate, g->d_tile_cnt, n_chunks);
+                               g->gv.sx, g->gv.sy, g->d_tile_cnt, g->d_items, g->d_cursor);
+            hipLaunchKernelGGL(g->merge ? raycast_tiled_kernel<true> : raycast_tiled_kernel<false>, rgrid, dim3(kTileThreads), 0, st,
+                               g->gv, g->d_beams, n, g->d_items, (const int *)nullptr, n_tiles, g->d_cursor, tiles_x, chunk, g->ablate,
+                               g->d_tile_cnt, n_chunks);
         } else {
             hipLaunchKernelGGL((tile_items_kernel<0>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
-                               n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items, g->d_queue);
-            const int seg_items = g->seg_items > 0 ? g->seg_items : 32; // the total is not known on the host here
-            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, g->d_tile_cnt, n_tiles, item_off, seg_off,
-                               g->d_queue, seg_items);
+                               n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items);
+            hipLaunchKernelGGL(tile_scan_kernel, dim3(1), dim3(1024), 0, st, g->d_tile_cnt, n_tiles, item_off, g->d_cursor);
             hipLaunchKernelGGL((tile_items_kernel<1>), tgrid, dim3(256), 0, st, g->d_chunk_box, n_chunks, tiles_x,
-                               n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items, g->d_queue);
-            // persistent workgroups, two per CU (66 KB of LDS each); each drains the queue and exits
-            hipLaunchKernelGGL(g->merge ? raycast_tiled_kernel<true> : raycast_tiled_kernel<false>, dim3(raycast_wg_per_cu(g, n_tiles) * g->n_cu),
-                               dim3(kTileThreads), 0, st, g->gv, g->d_beams, n, g->d_items, item_off, seg_off, n_tiles, g->d_queue,
-                               tiles_x, seg_items, g->ablate, (const int *)nullptr, 0);
+                               n_tiles, g->gv.sx, g->gv.sy, g->d_tile_cnt, item_off, g->d_items);
+            hipLaunchKernelGGL(g->merge ? raycast_tiled_kernel<true> : raycast_tiled_kernel<false>, rgrid, dim3(kTileThreads), 0, st,
+                               g->gv, g->d_beams, n, g->d_items, item_off, n_tiles, g->d_cursor, tiles_x, chunk, g->ablate,
+                               g->d_tile_cnt, 0);
         }
     } else {
         hipLaunchKernelGGL(raycast_global_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g->gv, g->d_beams, n);
@@ -1102,14 +1172,13 @@ int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
             g->n_cu = std::max(1, prop.multiProcessorCount);
     }
-    // a segment adds up to 64 * seg_items misses to one 16-bit packed LDS counter (the sensor cell): 1023 is the
-    // most that cannot carry into the hit half
-    g->seg_items = std::min(std::max(g->prm.raycast_seg_items, 0), 1023);
+    // (a visit's log holds at least two chunks and at most kMaxAccBlocks / kChunkMin)
+    g->seg_items = g->prm.raycast_seg_items > 0 ? std::min(std::max(g->prm.raycast_seg_items, kChunkMin), kMaxAccBlocks / 2) : 0;
     if (g->prm.raycast_wg_per_cu > 0) g->wg_per_cu = std::min(g->prm.raycast_wg_per_cu, 8);
     g->merge = g->prm.raycast_impl == SLAM_RAYCAST_TILED_MERGE;
 #ifdef SLAM_MEASURE
     if (const char *e = getenv("SLAM_RAYCAST_MERGE")) g->merge = atoi(e) != 0;
-    if (const char *e = getenv("SLAM_RAYCAST_SEG")) g->seg_items = std::min(std::max(0, atoi(e)), 1023);
+    if (const char *e = getenv("SLAM_RAYCAST_SEG")) g->seg_items = std::min(std::max(kChunkMin, atoi(e)), kMaxAccBlocks / 2);
     if (const char *e = getenv("SLAM_RAYCAST_ABLATE")) g->ablate = atoi(e);
     if (const char *e = getenv("SLAM_RAYCAST_WGPCU")) g->wg_per_cu = std::max(1, atoi(e));
 #endif
@@ -1160,7 +1229,7 @@ void slam_grid_destroy(slam_grid_t *g)
     if (!g) return;
     void *ptrs[] = {g->d_planes, g->d_num_w, g->d_occ_w, g->d_num_s,     g->d_occ_s, g->d_delta,
                     g->d_touched, g->d_updates, g->d_beams, g->d_chunk_box, g->d_stage,
-                    g->d_tile_cnt, g->d_tile_fill, g->d_queue, g->d_items, g->d_dirty, g->d_acc};
+                    g->d_tile_cnt, g->d_tile_fill, g->d_cursor, g->d_items, g->d_dirty, g->d_acc};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     delete g;
@@ -1537,19 +1606,12 @@ int slam_grid_raycast_stats(slam_grid_t *g, int *n_tiles, int *n_items, int *n_s
     if (n_segments) *n_segments = 0;
     if (!g->d_tile_fill) return SLAM_OK; // no tiled raycast has run yet
     SLAM_HIP(hipDeviceSynchronize());
-    if (tiles <= kMaxLdsTiles) { // single-pass work list: the counts are all there is
-        std::vector<int> cnt((size_t)tiles);
-        SLAM_HIP(hipMemcpy(cnt.data(), g->d_tile_cnt, sizeof(int) * (size_t)tiles, hipMemcpyDeviceToHost));
-        long items = 0, segs = 0;
-        for (int c : cnt) items += c;
-        const int seg = g->seg_items > 0 ? g->seg_items : adaptive_seg(items, raycast_wg_per_cu(g, tiles) * g->n_cu);
-        for (int c : cnt) segs += (c + seg - 1) / seg;
-        if (n_items) *n_items = (int)items;
-        if (n_segments) *n_segments = (int)segs;
-        return SLAM_OK;
-    }
-    if (n_items) SLAM_HIP(hipMemcpy(n_items, g->d_tile_fill + tiles, sizeof(int), hipMemcpyDeviceToHost));
-    if (n_segments) SLAM_HIP(hipMemcpy(n_segments, g->d_queue + 1, sizeof(int), hipMemcpyDeviceToHost));
+    std::vector<int> cnt((size_t)tiles);
+    SLAM_HIP(hipMemcpy(cnt.data(), g->d_tile_cnt, sizeof(int) * (size_t)tiles, hipMemcpyDeviceToHost));
+    long items = 0;
+    for (int c : cnt) items += c;
+    if (n_items) *n_items = (int)items;
+    if (n_segments) SLAM_HIP(hipMemcpy(n_segments, g->d_cursor + tiles, sizeof(int), hipMemcpyDeviceToHost));
     return SLAM_OK;
 }
 
