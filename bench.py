@@ -283,9 +283,7 @@ def main():
     ap.add_argument("--raycast", choices=["tiled", "merge", "global"], default="tiled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip model build, single scan, streaming and config-3 legs")
-    ap.add_argument("--raycast-seg", type=int, default=None,
-                    help="slam_grid_params::raycast_seg_items (default: 48 when the raycast runs beside registrations, "
-                         "0 = sized from the work list with --no-pipeline)")
+    ap.add_argument("--raycast-seg", type=int, default=0, help="slam_grid_params::raycast_seg_items (0 = library default)")
     ap.add_argument("--raycast-wg", type=int, default=0, help="slam_grid_params::raycast_wg_per_cu (0 = library default)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the grid update of step k-1 with the registration of step k (one stream: a captured "
@@ -384,8 +382,7 @@ def main():
     batch = synth.make_batch(S, n_loop=S * world, first=rank * S)
     P = batch.n_points
     icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, lanes_per_point=args.lanes, cell_size=args.cell)
-    # (a raycast that runs beside registrations wants longer segments than one that has the chip to itself: slam_grid_params)
-    grid_kw = dict(rolling=0, min_cluster_points=20, raycast_wg_per_cu=args.raycast_wg, raycast_seg_items=args.raycast_seg if args.raycast_seg is not None else (0 if args.no_pipeline else 48),
+    grid_kw = dict(rolling=0, min_cluster_points=20, raycast_wg_per_cu=args.raycast_wg, raycast_seg_items=args.raycast_seg or 0,
                    raycast_impl={"tiled": api.RAYCAST_TILED, "merge": api.RAYCAST_TILED_MERGE, "global": api.RAYCAST_GLOBAL}[args.raycast])
     grid = api.Grid(GRID, GRID, RES, **grid_kw)
     d_pts = api.DeviceArray.from_host(batch.pts, np.float64)
@@ -450,14 +447,14 @@ def main():
         s_ = k % NB
         g = g or grid
         b.wait_event(icp_done[s_])
-        g.reset_counts(b)
+        # (every step starts from zero counts: the step before ended with slam_grid_finalize_reset)
         g.raycast_scans_dev(d_pts, d_off, S, P, pR[s_], pt[s_], b)
         if e: e[2].record(b)
         if multi:
             comm.merge_begin(g, b)
             merge_rows_seen.append(comm.merge_finish(g, b))         # waits for the united range, then the row all-reduce
         if e: e[3].record(b)
-        g.finalize(b)
+        g.finalize_reset(b)          # evidence + occupancy of this batch, count planes zero again: one launch
         if e: e[4].record(b)
         grid_done[s_].record(b)
 
@@ -500,9 +497,9 @@ def main():
             with graph:      # the warm-up ran the same calls: every scratch buffer exists
                 pose[0].copy_from(d_pose0, sa)
                 icp.fit_batch_dev(d_pts, d_off, d_nga, S, pR[0], pt[0], 5.0, d_res, None, sa)
-                grid.reset_counts(sa)
                 grid.raycast_scans_dev(d_pts, d_off, S, P, pR[0], pt[0], sa)
-                grid.finalize(sa)
+                grid.finalize(sa)            # (a captured graph replays fixed kernel arguments: finalize_reset alternates
+                grid.reset_counts(sa)        # between two range buffers from call to call, so the graph keeps the two-call form)
             sync()
             graph.launch()   # one replay outside the timed region: a graph that cannot run must not cost the bench
             sync()
@@ -549,10 +546,17 @@ def main():
         cnt = torch.tensor([P, upd_per_step], dtype=torch.int64)
         dist.all_reduce(cnt)
         total_pts, total_upd = int(cnt[0].item()), int(cnt[1].item())
-        # the merged planes of the last step hold every rank's updates of that step, once
+        # one more update, merged but not yet folded away (a step ends with finalize_reset, which zeroes the counts): the
+        # merged planes hold every rank's updates of a step, once
+        grid.raycast_scans_dev(d_pts, d_off, S, P, d_R, d_t, sb)
+        comm.merge_begin(grid, sb)
+        merge_rows_seen.append(comm.merge_finish(grid, sb))
+        sync()
         hits, misses = grid.read_counts()
         merged = int(hits.astype(np.int64).sum() + misses.astype(np.int64).sum())
         assert merged == total_upd, "merged planes hold %d updates, the ranks made %d" % (merged, total_upd)
+        grid.finalize_reset(sb)
+        sync()
     else:
         total_pts, total_upd = P, upd_per_step
 
@@ -572,11 +576,10 @@ def main():
     if multi and merge_rows_seen:
         rows_lo, rows_hi = merge_rows_seen[-1]
     else:
-        grid.reset_counts(sa)
         grid.raycast_scans_dev(d_pts, d_off, S, P, d_R, d_t, sa)
         sync()
         rows_lo, rows_hi = grid.dirty_rows()
-        grid.finalize(sa)
+        grid.finalize_reset(sa)
         sync()
     rows_cov = max(rows_hi - rows_lo + 1, 0)
 
@@ -600,20 +603,21 @@ def main():
             icp_name: {"ms": ms_icp_live, "ms_alone_on_the_chip": float(ms_icp), "alg_bytes": icp_bytes,
                        "launches_in_flight": 2 if launch == "pipeline" else 1,
                        "index_bytes_read_per_launch": (S // 2 if paired else S) * (int(info.get("lds_bytes", 0)) + (int(info.get("list_bytes", 0)) if fused else 0))},
-            "raycast_tiled_kernel (+ count reset, beams, work list)": {
+            "raycast_tiled_kernel (+ beams, work list)": {
                 "ms": float(ms_ray), "alg_bytes": ray_bytes,
                 "global_atomic_ceiling_GBps": ATOMIC_CEILING_GBS,
                 "note": "alg_bytes = 8 B RMW per cell update + 16 B per beam; against the ceiling of one GLOBAL atomic per "
                         "update (SURVEY 8(d)): the updates are binned in LDS tiles and reach HBM as one atomic per touched "
                         "cell and segment, which is how the rate can exceed that ceiling"},
-            "finalize_rows_kernel": {"ms": float(ms_fin), "alg_bytes": fin_bytes, "rows_covered": rows_cov, "rows_of_the_grid": GRID,
-                                     "note": "alg_bytes = 17 B x the cells of the storage rows the kernel covers (the touched "
-                                             "rows, read back from the device-tracked range)"},
+            "finalize_reset_rows_kernel": {"ms": float(ms_fin), "alg_bytes": fin_bytes, "rows_covered": rows_cov, "rows_of_the_grid": GRID,
+                                     "note": "alg_bytes = 17 B x the cells of the storage rows the kernel covers (the touched rows, read "
+                                             "back from the device-tracked range): counts in, evidence + occupancy out; the zeroes it "
+                                             "writes back into the counts it has folded are not counted"},
         }
         for k in kernels.values():
             k["GBps"] = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
             k["frac_of_hbm_peak"] = k["GBps"] / HBM_PEAK_GBS
-        kr = kernels["raycast_tiled_kernel (+ count reset, beams, work list)"]
+        kr = kernels["raycast_tiled_kernel (+ beams, work list)"]
         kr["vs_global_atomic_ceiling"] = kr["GBps"] / ATOMIC_CEILING_GBS
         dom = max(kernels, key=lambda n: kernels[n]["ms"])
         prof_file, prof = pmc_profile()

@@ -225,9 +225,8 @@ typedef struct {
     int    raycast_impl;        /* SLAM_RAYCAST_* */
     int    raycast_seg_items;   /* tiled raycast: 64-beam blocks a workgroup takes from a tile's work list at a time (it goes
                                    on accumulating in the same LDS tile while the tile has blocks left and writes the tile
-                                   back when it leaves it); 0 = library default (32); 8 ... 511 */
-    int    raycast_wg_per_cu;   /* tiled raycast: persistent workgroups per CU; 0 = library default (one while the grid has
-                                   no more 128 x 128-cell tiles than the chip has CUs, two beyond) */
+                                   back when it leaves it); 0 = library default (16); 8 ... 511 */
+    int    raycast_wg_per_cu;   /* tiled raycast: persistent workgroups per CU; 0 = library default (two) */
 } slam_grid_params;
 
 void slam_grid_default_params(slam_grid_params *p);
@@ -277,6 +276,10 @@ int slam_grid_raycast_scans_dev(slam_grid_t *g, const double *d_pts, const int32
  *   c += inc*h; if (h>0 && c>min) occ=100;  c -= dec*m; if (m>0 && c<min) occ=0.
  * The count planes keep accumulating (they are the bit-exact contract). */
 int slam_grid_finalize(slam_grid_t *g, slam_stream_t stream);
+/* slam_grid_finalize followed by slam_grid_reset_counts, in one pass over the rows and one launch: what a batch step
+ * ends with (fold this batch's counts into evidence and occupancy, leave the count planes zero for the next batch;
+ * the accumulator planes, if any, are not touched).  Same evidence and occupancy as the two calls. */
+int slam_grid_finalize_reset(slam_grid_t *g, slam_stream_t stream);
 
 /* One scan with the reference's own ordering and rounding (mls.cpp:73-142):
  * sequential += / -= on the per-cell double, thresholds after every point. */

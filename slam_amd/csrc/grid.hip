@@ -472,7 +472,7 @@ __device__ inline int floor_div_small(int num, int den, float rden)
 // cell).  Clipping by closed form is what makes the tiling invisible in the
 // result: the cells are exactly those of the unclipped line.
 constexpr int kChunkMin = 8;      // (the visit's chunk log in LDS is sized for it)
-constexpr int kChunkDefault = 32; // blocks a workgroup takes from a tile's list at a time, where the caller leaves it to the library
+constexpr int kChunkDefault = 16; // blocks a workgroup takes from a tile's list at a time, where the caller leaves it to the library
 constexpr int kMaxAccBlocks = 1023; // blocks accumulated in the packed LDS counters before a write-back is forced: 64 * 1023 misses of the
                                     // sensor's cell cannot carry into the hit half
 
@@ -894,6 +894,37 @@ __global__ __launch_bounds__(256) void finalize_rows_kernel(GridView g, double i
     }
 }
 
+// slam_grid_finalize_reset: finalize_rows_kernel that also zeroes the counts it has just folded (what slam_grid_reset_counts
+// would do next) and retires the ranges -- one launch where the batch step had four (finalize_rows, ranges_set, reset_rows,
+// ranges_retire).  The rows it covers are the hull of the touched and the changed rows, as in finalize_rows_kernel.  Afterwards
+// the touched rows are "changed" (their counts are zero again while their evidence still shows this batch: the next finalize
+// must visit them) and nothing is touched: that state goes into the OTHER range buffer (`next`; every workgroup reads `ranges`,
+// nobody reads `next` during this launch), which the host makes the grid's current one for everything enqueued behind.
+__global__ __launch_bounds__(256) void finalize_reset_rows_kernel(GridView g, double inc, double dec, double minp, double *num_pts,
+                                                                  int8_t *occ, const int *ranges, int *next)
+{
+    const int t_lo = ranges[0], t_nhi = ranges[1];
+    const int lo = max(min(t_lo, ranges[2]), 0), hi = min(max(-t_nhi, -ranges[3]), g.sy - 1);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        next[0] = next[1] = 0x7f7f7f7f;
+        next[2] = t_lo;
+        next[3] = t_nhi;
+    }
+    if (hi < lo) return;
+    const int  per_row = (g.sx + 255) / 256;
+    const long items = (long)(hi - lo + 1) * per_row;
+    for (long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int srow = lo + (int)(it / per_row), x = (int)(it % per_row) * 256 + threadIdx.x;
+        if (x >= g.sx) continue;
+        int y = srow - g.oy; // the window row stored there (storage_index's inverse)
+        y += y < 0 ? g.sy : 0;
+        finalize_cell(g, x, y, inc, dec, minp, num_pts, occ);
+        const int s = storage_index(g, x, y);
+        if (g.hits[s]) g.hits[s] = 0;
+        if (g.misses[s]) g.misses[s] = 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void gather_counts_kernel(GridView g, int32_t *hits_w, int32_t *misses_w)
 {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -1025,7 +1056,7 @@ struct slam_grid {
     int             *d_touched = nullptr; // [2*cap_points] + counter
     size_t           cap_touched = 0;
     unsigned long long *d_updates = nullptr;
-    int             *d_dirty = nullptr;    // [2] see GridView::dirty
+    int             *d_dirty = nullptr;    // [2][4] see GridView::dirty; two buffers: slam_grid_finalize_reset reads one and starts the other
     int32_t         *d_acc = nullptr;      // [hits | misses] accumulator planes (slam_grid_enable_accumulator)
     Beam            *d_beams = nullptr;
     size_t           cap_beams = 0;
@@ -1091,11 +1122,11 @@ int reserve_beams(slam_grid *g, size_t n)
     return SLAM_OK;
 }
 
-// Persistent raycast workgroups per CU where the caller did not say: one (sixteen wavefronts) while there are no more tiles
-// than CUs, two beyond.  tools/raycast_time.py and bench.py --raycast-wg: config 2 (256 tiles) 0.115 ms with one against
-// 0.124 with two, alone; config 4's share (1024 tiles) 1.30 ms per step with two against 1.40 with one, beside the
-// registrations.
-int raycast_wg_per_cu(const slam_grid *g, int n_tiles) { return g->wg_per_cu > 0 ? g->wg_per_cu : (n_tiles > g->n_cu ? 2 : 1); }
+// Persistent raycast workgroups per CU where the caller did not say: two (thirty-two wavefronts, 2 x 75 KB of LDS).  A
+// workgroup's walk is a chain of dependent integer steps and LDS adds: the second workgroup's wavefronts issue in its gaps
+// (tools/raycast_time.py, chunks of 16 blocks: config 2 0.110 ms per call with two against 0.131 with one; config 4's share
+// 0.274 against 0.322).
+int raycast_wg_per_cu(const slam_grid *g, int n_tiles) { return g->wg_per_cu > 0 ? g->wg_per_cu : 2; }
 
 int walk_beams(slam_grid *g, int n, hipStream_t st)
 {
@@ -1196,7 +1227,7 @@ int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_
     alloc((void **)&g->d_num_s, g->cells * sizeof(double));
     alloc((void **)&g->d_occ_s, g->cells);
     alloc((void **)&g->d_updates, kUpdateSlots * sizeof(unsigned long long));
-    alloc((void **)&g->d_dirty, 4 * sizeof(int));
+    alloc((void **)&g->d_dirty, 8 * sizeof(int));
     if (rc != SLAM_OK) {
         slam_grid_destroy(g);
         return rc;
@@ -1245,7 +1276,7 @@ int slam_grid_clear(slam_grid_t *g, slam_stream_t stream)
     SLAM_HIP(hipMemsetAsync(g->d_occ_w, 0xff, g->cells, st)); // -1 = unknown (mls.cpp:26)
     SLAM_HIP(hipMemsetAsync(g->d_occ_s, 0xff, g->cells, st));
     SLAM_HIP(hipMemsetAsync(g->d_updates, 0, kUpdateSlots * sizeof(unsigned long long), st));
-    SLAM_HIP(hipMemsetAsync(g->d_dirty, 0x7f, 4 * sizeof(int), st)); // {lowest, -highest} = "no row", twice
+    SLAM_HIP(hipMemsetAsync(g->d_dirty, 0x7f, 8 * sizeof(int), st)); // {lowest, -highest} = "no row", twice (both buffers)
     if (g->d_acc) SLAM_HIP(hipMemsetAsync(g->d_acc, 0, 2 * g->cells * sizeof(int32_t), st));
     g->state_from_inorder = false;
     return SLAM_OK;
@@ -1255,8 +1286,8 @@ int slam_grid_reset_counts(slam_grid_t *g, slam_stream_t stream)
 {
     SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(reset_rows_kernel, dim3(kRangeBlocks), dim3(256), 0, st, g->d_planes, g->cells, g->gv.sx, g->gv.sy, g->d_dirty);
-    hipLaunchKernelGGL(ranges_retire_kernel, dim3(1), dim3(64), 0, st, g->d_dirty);
+    hipLaunchKernelGGL(reset_rows_kernel, dim3(kRangeBlocks), dim3(256), 0, st, g->d_planes, g->cells, g->gv.sx, g->gv.sy, g->gv.dirty);
+    hipLaunchKernelGGL(ranges_retire_kernel, dim3(1), dim3(64), 0, st, g->gv.dirty);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
@@ -1286,9 +1317,9 @@ int slam_grid_fold(slam_grid_t *g, int row_lo, int row_hi, slam_stream_t stream)
     // the folded rows have changed since the last finalize (by updates, by a merge): they and whatever else was touched
     // stay due for it; the touched range starts again
     if (row_hi >= row_lo)
-        hipLaunchKernelGGL(ranges_fold_kernel, dim3(1), dim3(64), 0, st, g->d_dirty, row_lo, row_hi);
+        hipLaunchKernelGGL(ranges_fold_kernel, dim3(1), dim3(64), 0, st, g->gv.dirty, row_lo, row_hi);
     else // nothing to fold: as before, the touched range starts again (there is nothing in it that holds counts... or the caller said so)
-        hipLaunchKernelGGL(ranges_retire_kernel, dim3(1), dim3(64), 0, st, g->d_dirty);
+        hipLaunchKernelGGL(ranges_retire_kernel, dim3(1), dim3(64), 0, st, g->gv.dirty);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
@@ -1298,7 +1329,7 @@ int slam_grid_mark_rows(slam_grid_t *g, int row_lo, int row_hi, slam_stream_t st
     SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
     if (row_hi < row_lo) return SLAM_OK;
     SLAM_REQUIRE(row_lo >= 0 && row_hi < g->gv.sy, SLAM_E_INVALID, "slam_grid_mark_rows: rows %d..%d outside the grid", row_lo, row_hi);
-    hipLaunchKernelGGL(ranges_set_kernel, dim3(1), dim3(64), 0, as_stream(stream), g->d_dirty, 2, row_lo, row_hi, g->gv.sy);
+    hipLaunchKernelGGL(ranges_set_kernel, dim3(1), dim3(64), 0, as_stream(stream), g->gv.dirty, 2, row_lo, row_hi, g->gv.sy);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
@@ -1306,7 +1337,7 @@ int slam_grid_mark_rows(slam_grid_t *g, int row_lo, int row_hi, slam_stream_t st
 int slam_grid_dirty_rows_dev(slam_grid_t *g, int32_t **d_range)
 {
     SLAM_REQUIRE(g && d_range, SLAM_E_INVALID, "slam_grid_dirty_rows_dev: bad arguments");
-    *d_range = g->d_dirty;
+    *d_range = g->gv.dirty; // (the buffer in use as of the calls enqueued so far: slam_grid_finalize_reset alternates between two)
     return SLAM_OK;
 }
 
@@ -1314,7 +1345,7 @@ int slam_grid_dirty_rows(slam_grid_t *g, int *row_lo, int *row_hi)
 {
     SLAM_REQUIRE(g && row_lo && row_hi, SLAM_E_INVALID, "slam_grid_dirty_rows: bad arguments");
     int r[2];
-    SLAM_HIP(hipMemcpy(r, g->d_dirty, sizeof r, hipMemcpyDeviceToHost));
+    SLAM_HIP(hipMemcpy(r, g->gv.dirty, sizeof r, hipMemcpyDeviceToHost));
     *row_lo = r[0] > g->gv.sy ? 0 : r[0];
     *row_hi = r[0] > g->gv.sy ? -1 : -r[1];
     return SLAM_OK;
@@ -1325,7 +1356,7 @@ int slam_grid_set_min_cluster_points(slam_grid_t *g, int v)
     SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
     g->prm.min_cluster_points = v;
     // the threshold enters every cell's occupancy: all rows are due at the next finalize
-    hipLaunchKernelGGL(ranges_set_kernel, dim3(1), dim3(64), 0, nullptr, g->d_dirty, 1, 0, 0, g->gv.sy);
+    hipLaunchKernelGGL(ranges_set_kernel, dim3(1), dim3(64), 0, nullptr, g->gv.dirty, 1, 0, 0, g->gv.sy);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
@@ -1373,7 +1404,7 @@ int slam_grid_set_pose(slam_grid_t *g, double x, double y, slam_stream_t stream)
     hipLaunchKernelGGL(roll_clear_kernel, grid2d(g), dim3(256), 0, as_stream(stream), v, dx, dy, g->d_num_s,
                        g->d_occ_s);
     // the window moved over the storage: every row of the evidence / occupancy planes (window order) is due
-    hipLaunchKernelGGL(ranges_set_kernel, dim3(1), dim3(64), 0, as_stream(stream), g->d_dirty, 1, 0, 0, v.sy);
+    hipLaunchKernelGGL(ranges_set_kernel, dim3(1), dim3(64), 0, as_stream(stream), g->gv.dirty, 1, 0, 0, v.sy);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
@@ -1471,10 +1502,25 @@ int slam_grid_finalize(slam_grid_t *g, slam_stream_t stream)
                            g->prm.occupancy_decrement, (double)g->prm.min_cluster_points, g->d_num_w, g->d_occ_w);
     else
         hipLaunchKernelGGL(finalize_rows_kernel, dim3(kRangeBlocks), dim3(256), 0, as_stream(stream), g->gv, g->prm.occupancy_increment,
-                           g->prm.occupancy_decrement, (double)g->prm.min_cluster_points, g->d_num_w, g->d_occ_w, g->d_dirty);
-    hipLaunchKernelGGL(ranges_set_kernel, dim3(1), dim3(64), 0, as_stream(stream), g->d_dirty, 0, 0, 0, g->gv.sy);
+                           g->prm.occupancy_decrement, (double)g->prm.min_cluster_points, g->d_num_w, g->d_occ_w, g->gv.dirty);
+    hipLaunchKernelGGL(ranges_set_kernel, dim3(1), dim3(64), 0, as_stream(stream), g->gv.dirty, 0, 0, 0, g->gv.sy);
     SLAM_HIP(hipGetLastError());
     g->state_from_inorder = false;
+    return SLAM_OK;
+}
+
+int slam_grid_finalize_reset(slam_grid_t *g, slam_stream_t stream)
+{
+    SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
+    if (g->state_from_inorder) { // the in-order mode keeps its evidence in planes of its own: the two steps as they are
+        SLAM_TRY(slam_grid_finalize(g, stream));
+        return slam_grid_reset_counts(g, stream);
+    }
+    int *cur = g->gv.dirty, *next = cur == g->d_dirty ? g->d_dirty + 4 : g->d_dirty;
+    hipLaunchKernelGGL(finalize_reset_rows_kernel, dim3(kRangeBlocks), dim3(256), 0, as_stream(stream), g->gv, g->prm.occupancy_increment,
+                       g->prm.occupancy_decrement, (double)g->prm.min_cluster_points, g->d_num_w, g->d_occ_w, cur, next);
+    SLAM_HIP(hipGetLastError());
+    g->gv.dirty = next; // for every call enqueued from here on (one stream at a time per handle: the header's contract)
     return SLAM_OK;
 }
 

@@ -531,10 +531,6 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
             m->prm.icp.pair_scans = 2;
         (void)hipGetLastError();
     }
-    // the map update runs beside the registrations, on the CUs they leave: longer raycast segments (fewer tile flushes;
-    // the tail is filled by the next registration) -- 256-scan batches: 0.379 -> 0.363 ms per step with 48 blocks
-    // against the length sized for a raycast that has the chip to itself (bench.py --raycast-seg / --raycast-wg)
-    if (params->pipelined && m->prm.grid.raycast_seg_items == 0) m->prm.grid.raycast_seg_items = 48;
     int rc = slam_grid_create(params->grid_size_x, params->grid_size_y, params->resolution, &m->prm.grid, &m->grid);
     if (rc == SLAM_OK) rc = slam_icp_create(m_ga, n_ga, m_nga, n_nga, &m->prm.icp, &m->target); // the prior map: the first target
     auto hip = [&](hipError_t e) {

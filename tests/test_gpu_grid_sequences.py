@@ -1,4 +1,4 @@
-"""slam_grid_reset_counts and slam_grid_finalize work on the rows the grid knows to be touched or changed, not on the
+"""slam_grid_reset_counts, slam_grid_finalize and slam_grid_finalize_reset work on the rows the grid knows to be touched or changed, not on the
 whole planes.  Random sequences of every operation that writes counts (raycast, endpoints, writes through the raw
 plane pointer followed by slam_grid_mark_rows -- what a merge over the GPUs does), clears them (reset, fold into the
 accumulator, clear), moves the window (set_pose on a rolling grid) or changes the rule (min_cluster_points) against
@@ -55,7 +55,8 @@ def test_random_sequences_against_a_host_shadow(rolling, seed):
     L = api.lib()
     log = []
     for step in range(120):
-        op = rs.choice(["raycast", "raycast", "endpoints", "reset", "fold", "finalize", "finalize", "external", "minp", "clear", "roll"])
+        op = rs.choice(["raycast", "raycast", "endpoints", "reset", "fold", "finalize", "finalize", "external", "minp", "clear", "roll",
+                        "finalize_reset", "finalize_reset"])
         if op == "roll" and not rolling:
             op = "raycast"
         if op == "external" and rolling:      # (the raw pointer is in storage order: the shadow would need the torus too)
@@ -77,6 +78,15 @@ def test_random_sequences_against_a_host_shadow(rolling, seed):
             g.reset_counts()
             sh.H[:] = 0
             sh.M[:] = 0
+        elif op == "finalize_reset":   # one launch: evidence and occupancy of the counts so far, then the count planes zero
+            num, occ = sh.expected()
+            g.finalize_reset()
+            api.synchronize()
+            assert np.array_equal(g.read_occupancy(), occ) and np.array_equal(g.read_num_pts(), num), "finalize_reset after %s" % " ".join(log[-12:])
+            sh.H[:] = 0
+            sh.M[:] = 0
+            hits, misses = g.read_counts()
+            assert np.array_equal(hits, sh.AH.reshape(-1)) and np.array_equal(misses, sh.AM.reshape(-1))
         elif op == "fold":        # the rows that hold counts (what a merge returns) -- or, sometimes, only some of them
             rows = np.flatnonzero((sh.H != 0).any(1) | (sh.M != 0).any(1))
             if len(rows) == 0:
