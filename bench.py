@@ -693,9 +693,9 @@ def main():
                                              "streams -> poses D2H; 48 chunks, three in flight, filling and draining included"}
             out["single_scan"] = single_scan_times(api, synth, m_ga, m_nga)
             try:
-                c3 = run_config3(8)
-                out["config3"] = {k: c3[k] for k in ("workload", "ms_per_cloud_chain", "ms_per_cloud", "clouds_per_s", "stepwise_clouds_per_s", "model_points",
-                                                     "mean_icp_iterations", "target_model_ms")}
+                c3 = run_config3(args.clouds)
+                out["config3"] = {k: c3[k] for k in ("workload", "ms_per_cloud_chain", "cpp_adapter", "ms_per_cloud", "clouds_per_s", "stepwise_clouds_per_s",
+                                                     "model_points", "mean_icp_iterations", "target_model_ms")}
             except Exception as ex:   # the headline line must not depend on the extra leg
                 out["config3"] = {"error": str(ex)}
             # short runs of the other GPU configs of BASELINE.json, each in a process of its own (this one stays idle):

@@ -11,14 +11,22 @@
 //   doICPMatch(target, scene, pose)  :571-578               doICPMatch(target..., scene..., initPose)
 //   getResidual()                    :637-641 (returns -1)  getResidual()
 //
-// The clouds stay on the device between the steps (ground segmentation, GA/NGA classification, voxel
-// filter, crop + split, ICP, height recovery); PCL and tf types are replaced by plain arrays and the
-// Pose struct below (the pose part of geometry_msgs::PoseStamped).  The tf calls (getYaw, getEulerYPR,
-// createQuaternionFromRPY: icpTools.cpp:174,205-212) are restated here as tf defines them.
+// PCL and tf types are replaced by plain arrays and the Pose struct below (the pose part of
+// geometry_msgs::PoseStamped); the tf calls (getYaw, getEulerYPR, createQuaternionFromRPY: icpTools.cpp:174,205-212)
+// are restated here as tf defines them.
+//
+// What runs per scan (scan_registration.cpp:139-159: setSceneCloud, doICPMatch) is ONE device-resident chain on one
+// stream: the cloud goes up once, slam_ccicp_scene_dev (segmentGround + classifyPoints + voxel filter + class split
+// with the cap) -> slam_icp_fit_batch_dev -> slam_ccicp_height_rpy_pose_dev run without the host learning a single count,
+// and one 128-byte block comes back (pose, result, height, counts).  The target's index is built when the target
+// changes -- setTargetCloud, or a crop window (icpTools.cpp:225-239) that selects other points than the last one did --
+// not once per match as the reference constructs its matcher (icpTools.cpp:187).
 #pragma once
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
+#include <utility>
 #include <vector>
 
 #include "slam_mi355x.h"
@@ -81,51 +89,83 @@ public:
     {
         if (slam_gseg_create(nullptr, &gseg_) != SLAM_OK || slam_ccicp_create(&cc_) != SLAM_OK)
             std::fprintf(stderr, "CCICP: %s\n", slam_last_error());
+        ok(slam_stream_create(&stream_));
         ok(slam_malloc((void **)&d_ga_, 16 * (size_t)ICP_MAX_PTS));
         ok(slam_malloc((void **)&d_nga_, 16 * (size_t)ICP_MAX_PTS));
-        ok(slam_malloc((void **)&d_cnt_, 16));
+        ok(slam_malloc((void **)&d_scene_pts_, 16 * 2 * (size_t)ICP_MAX_PTS));
+        ok(slam_malloc((void **)&d_io_, kIoBytes));
+        ok(slam_host_alloc((void **)&h_io_, kIoBytes));
+        if (h_io_) std::memset(h_io_, 0, kIoBytes);
+        if (d_io_) ok(slam_memset(d_io_, 0, kIoBytes, stream_));
+        reset_box();
     }
     ~CCICP()
     {
         slam_device_synchronize();
-        for (Cloud *c : {&raw_, &labels_, &obs_, &flags_, &seg_target_, &seg_scene_, &ground_target_, &ground_scene_, &tmp_})
+        if (icp_) slam_icp_destroy(icp_);
+        for (Cloud *c : {&raw_, &scene_raw_, &labels_, &obs_, &flags_, &seg_target_, &seg_scene_, &ground_target_, &ground_scene_, &scene_ground_})
             slam_free(c->p);
         slam_free(d_ga_);
         slam_free(d_nga_);
-        slam_free(d_cnt_);
+        slam_free(d_scene_pts_);
+        slam_free(d_io_);
+        slam_host_free(h_io_);
         slam_ccicp_destroy(cc_);
         slam_gseg_destroy(gseg_);
+        slam_stream_destroy(stream_);
     }
     CCICP(const CCICP &) = delete;
     CCICP &operator=(const CCICP &) = delete;
 
     // icpTools.cpp:585-608.  SCAN_TO_MAP: the target is an obstacle cloud already (the global map):
     // classifyPoints only.  SCAN_TO_SCAN: segmentGround first; its ground cloud becomes ground_target.
+    // (Called when the map changes, not per scan: it may wait for the device.)
     void setTargetCloud(const float *xyz, int n, int stride, const Pose & /*initPose*/)
     {
+        extent_of(xyz, n, stride);
         if (type == SCAN_TO_MAP) {
-            upload(xyz, n, stride);
+            upload(raw_, xyz, n, stride);
             select(0xffu, obs_, obs_n_); // copyPointCloud(*target, *seg_target) (:592)
             classify_into(seg_target_, seg_target_n_, false);
         } else {
-            segment(xyz, n, stride, ground_target_, ground_target_n_);
-            classify_into(seg_target_, seg_target_n_, false);
+            // segmentGround + classifyPoints in bin order (no voxel filter) as one chain; the ground cloud is the new ground_target
+            upload(raw_, xyz, n, stride);
+            reserve(seg_target_, 16 * (size_t)(n + 1));
+            reserve(ground_target_, 16 * (size_t)(n + 1));
+            seg_target_n_ = 0;
+            set_ground_target_count(0);
+            if (n > 0) {
+                ok(slam_ccicp_scene_dev(cc_, gseg_, (const float *)raw_.p, n, stride, 0, 0, 0.0, 0.0, 0.0, ICP_MAX_PTS, d_scene_pts_, io_scan(),
+                                        (float *)ground_target_.p, io_counts(), stream_));
+                ok(slam_ccicp_scene_cloud_dev(cc_, (float *)seg_target_.p, n, stream_));
+                fetch_io();
+                seg_target_n_ = h_counts()[2];
+                set_ground_target_count(h_counts()[1]);
+            }
+            scene_ready_ = false; // (the chain's scene outputs were borrowed)
         }
+        target_dirty_ = true;
+        reset_box();
     }
     void setTargetGndCloud(const float *xyz, int n, int stride) // :580-583
     {
-        upload(xyz, n, stride);
-        select(0xffu, ground_target_, ground_target_n_); // copyPointCloud
+        upload(raw_, xyz, n, stride);
+        int n_out = 0;
+        select(0xffu, ground_target_, n_out); // copyPointCloud
+        set_ground_target_count(n_out);
     }
-    void setSceneCloud(const float *xyz, int n, int stride) // :611-634
+    // :611-634: segmentGround, classifyPoints, VoxelGrid 0.5 x 0.5 x 2 -- enqueued, nothing waited for
+    void setSceneCloud(const float *xyz, int n, int stride)
     {
-        segment(xyz, n, stride, tmp_, tmp_n_);
-        classify_into(seg_scene_, seg_scene_n_, true); // voxel filter 0.5, 0.5, 2
-        reserve(ground_scene_, 16 * (size_t)(tmp_n_ + 1));
-        ground_scene_n_ = 0;
-        if (tmp_n_ > 0)
-            ok(slam_ccicp_voxel_downsample_dev(cc_, (const float *)tmp_.p, nullptr, tmp_n_, 4, 0.5f, 0.5f, 5.0f,
-                                               (float *)ground_scene_.p, tmp_n_, &ground_scene_n_, nullptr));
+        upload(scene_raw_, xyz, n, stride);
+        scene_n_in_ = n;
+        scene_stride_ = stride;
+        reserve(scene_ground_, 16 * (size_t)(n + 1));
+        ok(slam_ccicp_scene_dev(cc_, gseg_, (const float *)scene_raw_.p, n, stride, 1, 0, 0.0, 0.0, 0.0, ICP_MAX_PTS, d_scene_pts_, io_scan(),
+                                (float *)scene_ground_.p, io_counts(), stream_));
+        scene_ready_ = true;
+        scene_known_ = false;
+        seg_scene_valid_ = ground_scene_valid_ = false;
     }
 
     Pose doICPMatch(const float *target, int n_target, const float *scene, int n_scene, int stride, const Pose &initPose)
@@ -137,74 +177,77 @@ public:
 
     Pose doICPMatch(const Pose &initPose) // :222-298
     {
-        int mc[2] = {0, 0}, sc[2] = {0, 0};
-        std::vector<double> m_ga, m_nga, s_ga, s_nga;
-        // target: crop +-75 m around the pose (:225-239), split with the cap (:263-276)
-        ok(slam_ccicp_split_dev(cc_, (const float *)seg_target_.p, seg_target_n_, 4, 1, initPose.x, initPose.y, 75.0,
-                                ICP_MAX_PTS, d_ga_, d_nga_, mc, nullptr));
-        download(m_ga, d_ga_, mc[0]);
-        download(m_nga, d_nga_, mc[1]);
-        ok(slam_ccicp_split_dev(cc_, (const float *)seg_scene_.p, seg_scene_n_, 4, 0, 0, 0, 0, ICP_MAX_PTS, d_ga_,
-                                d_nga_, sc, nullptr)); // :248-261
-        download(s_ga, d_ga_, sc[0]);
-        download(s_nga, d_nga_, sc[1]);
-        n_model_[0] = mc[0], n_model_[1] = mc[1], n_scene_[0] = sc[0], n_scene_[1] = sc[1];
-
+        ensure_target(initPose); // crop +-75 m around the pose (:225-239), split with the cap (:263-276), index
         Pose   result;
         double yaw0, pitch0, roll0;
         detail::euler_ypr(initPose, yaw0, pitch0, roll0); // tf::getYaw (:174)
-        double R[4] = {std::cos(yaw0), -std::sin(yaw0), std::sin(yaw0), std::cos(yaw0)};
-        double t[2] = {initPose.x, initPose.y};
-        if (sc[0] + sc[1] < 5) { // :179-184
-            std::fprintf(stderr, "ERROR: Total Scene has %d points\n", sc[0] + sc[1]);
+        double *hp = reinterpret_cast<double *>(h_io_);
+        hp[0] = std::cos(yaw0), hp[1] = -std::sin(yaw0), hp[2] = std::sin(yaw0), hp[3] = std::cos(yaw0); // :168-176
+        hp[4] = initPose.x, hp[5] = initPose.y;
+        std::memset(h_io_ + kOffRes, 0, 32); // result and height: a scan below 5 points leaves them untouched
+        hp[kOffZ / 8] = initPose.z;
+        if (!scene_ready_) { // no scene cloud: an empty one
+            std::memset(h_io_ + kOffScan, 0, 32);
+            ok(slam_memcpy_h2d_async(d_io_, h_io_, kOffNgt, stream_));
+        } else {
+            ok(slam_memcpy_h2d_async(d_io_, h_io_, kOffScan, stream_));
+        }
+        // IcpPointToPoint icp(refPts...) + icp.fit(...) (:187-188): the scene's size stays on the device
+        if (icp_)
+            ok(slam_icp_fit_batch_dev(icp_, d_scene_pts_, io_scan(), io_scan() + 2, 1, io_R(), io_t(), 5.0,
+                                      reinterpret_cast<slam_icp_result *>(d_io_ + kOffRes), nullptr, stream_));
+        // doHeightInterpolate(ground_target, result_2d) (:295, :301-381) for the pose the fit left on the device
+        ok(slam_ccicp_height_rpy_pose_dev(cc_, (const float *)ground_target_.p, reinterpret_cast<const int32_t *>(d_io_ + kOffNgt),
+                                          ground_target_n_, 4, io_R(), io_t(), initPose.z, roll0, pitch0,
+                                          reinterpret_cast<double *>(d_io_ + kOffZ), stream_));
+        fetch_io(); // the one read-back of the match
+        scene_known_ = scene_ready_;
+        const int32_t *scan = h_scan();
+        n_scene_[0] = scan[2], n_scene_[1] = scan[1] - scan[2];
+        if (scene_ready_ && h_counts()[3] != 0) return match_stepwise(initPose, yaw0, pitch0, roll0); // lattice beyond the chain's accumulator
+        if (scan[1] < 5) { // :179-184
+            std::fprintf(stderr, "ERROR: Total Scene has %d points\n", scan[1]);
+            num_corr_ = 0;
             result = Pose();
             result.qw = 9999;
             return result;
         }
-        slam_icp_t *icp = nullptr; // IcpPointToPoint icp(refPts_GA, refPts_NGA, ...) (:187)
-        num_corr_ = 0;
-        if (slam_icp_create(m_ga.data(), mc[0], m_nga.data(), mc[1], nullptr, &icp) == SLAM_OK) {
-            slam_icp_result res;
-            if (slam_icp_fit(icp, s_ga.data(), sc[0], s_nga.data(), sc[1], R, t, 5.0, &res) == SLAM_OK) // :188
-                num_corr_ = res.n_corr;
-            else
-                std::fprintf(stderr, "%s\n", slam_last_error());
-            slam_icp_destroy(icp);
-        } else {
-            std::fprintf(stderr, "%s\n", slam_last_error()); // fewer than 5 model points: R,t stay (icp.cpp:38-43)
-        }
-        const double corr_yaw = std::atan2(R[2], R[0]); // :197
-        result.x = t[0];
-        result.y = t[1];
-        result.z = initPose.z;
-        detail::quat_from_rpy(roll0, pitch0, corr_yaw, result); // :205-212
-        // doHeightInterpolate(ground_target, result_2d) (:295, :301-381)
-        double z = result.z;
-        const double pose7[7] = {result.x, result.y, result.z, result.qx, result.qy, result.qz, result.qw};
-        ok(slam_ccicp_height_dev(cc_, (const float *)ground_target_.p, ground_target_n_, 4, pose7, &z, nullptr, nullptr,
-                                 nullptr));
-        result.z = z;
-        return result;
+        return result_from_io(initPose, pitch0, roll0);
     }
 
     double getResidual() const { return -1; } // :637-641 ("TODO: calculate this somehow")
     // :644-650: copies of seg_target, seg_scene, ground_target, ground_scene as x, y, z per point
     void getSegmentedClouds(std::vector<float> &target, std::vector<float> &scene, std::vector<float> &g_target,
-                            std::vector<float> &g_scene) const
+                            std::vector<float> &g_scene)
     {
-        copy_out(seg_target_, seg_target_n_, target);
-        copy_out(seg_scene_, seg_scene_n_, scene);
-        copy_out(ground_target_, ground_target_n_, g_target);
-        copy_out(ground_scene_, ground_scene_n_, g_scene);
+        copy_out(seg_target_, seg_target_n_, target, box_); // doICPMatch has filtered seg_target in place (:226-239)
+        materialise_scene();
+        copy_out(seg_scene_, seg_scene_n_, scene, nullptr);
+        copy_out(ground_target_, ground_target_n_, g_target, nullptr);
+        copy_out(ground_scene_, ground_scene_n_, g_scene, nullptr);
     }
-    int    getNumberCorrespondences() const { return num_corr_; }
+    int getNumberCorrespondences() const { return num_corr_; }
     // sizes of what getSegmentedClouds would copy out (:644-650)
-    int targetSize() const { return seg_target_n_; }
-    int sceneSize() const { return seg_scene_n_; }
+    int targetSize() { return target_dirty_ ? seg_target_n_ : target_in_box_; }
+    int sceneSize()
+    {
+        know_scene();
+        return h_counts()[2];
+    }
     int groundTargetSize() const { return ground_target_n_; }
-    int groundSceneSize() const { return ground_scene_n_; }
+    int groundSceneSize()
+    {
+        materialise_scene();
+        return ground_scene_n_;
+    }
     const int *modelCounts() const { return n_model_; }
-    const int *sceneCounts() const { return n_scene_; }
+    const int *sceneCounts()
+    {
+        know_scene();
+        return n_scene_;
+    }
+    int lastIterations() const { return last_iters_; }
+    int targetBuilds() const { return target_builds_; } // how often the target's index was built (it is kept across matches)
 
     RegistrationType type;
 
@@ -213,6 +256,27 @@ private:
         void  *p = nullptr;
         size_t cap = 0;
     };
+    // one device block and its pinned mirror: [R t | result | z, neighbours | scan {0, n, n_ga, -} | counts {obs, gnd, flt, err} | n ground target]
+    static constexpr size_t kOffRes = 48, kOffZ = 64, kOffScan = 80, kOffCounts = 96, kOffNgt = 112, kIoBytes = 128;
+    double  *io_R() { return reinterpret_cast<double *>(d_io_); }
+    double  *io_t() { return reinterpret_cast<double *>(d_io_) + 4; }
+    int32_t *io_scan() { return reinterpret_cast<int32_t *>(d_io_ + kOffScan); }
+    int32_t *io_counts() { return reinterpret_cast<int32_t *>(d_io_ + kOffCounts); }
+    const int32_t *h_scan() const { return reinterpret_cast<const int32_t *>(h_io_ + kOffScan); }
+    const int32_t *h_counts() const { return reinterpret_cast<const int32_t *>(h_io_ + kOffCounts); }
+    void fetch_io()
+    {
+        ok(slam_memcpy_d2h_async(h_io_, d_io_, kIoBytes, stream_));
+        ok(slam_stream_synchronize(stream_));
+    }
+    void know_scene()
+    {
+        if (scene_ready_ && !scene_known_) {
+            fetch_io();
+            scene_known_ = true;
+            n_scene_[0] = h_scan()[2], n_scene_[1] = h_scan()[1] - h_scan()[2];
+        }
+    }
     static void ok(int rc)
     {
         if (rc != SLAM_OK) std::fprintf(stderr, "CCICP: %s\n", slam_last_error());
@@ -220,17 +284,82 @@ private:
     static void reserve(Cloud &c, size_t bytes)
     {
         if (bytes <= c.cap) return;
+        slam_device_synchronize(); // (the old block may be in use by enqueued work)
         slam_free(c.p);
         c.p = nullptr;
         c.cap = 0;
         if (slam_malloc(&c.p, bytes) == SLAM_OK) c.cap = bytes;
     }
-    void upload(const float *xyz, int n, int stride)
+    void upload(Cloud &dst, const float *xyz, int n, int stride)
     {
-        reserve(raw_, sizeof(float) * (size_t)(n + 1) * stride);
-        raw_n_ = n;
-        raw_stride_ = stride;
-        if (n > 0) ok(slam_memcpy_h2d(raw_.p, xyz, sizeof(float) * (size_t)n * stride, nullptr));
+        reserve(dst, sizeof(float) * (size_t)(n + 1) * stride);
+        if (&dst == &raw_) raw_n_ = n, raw_stride_ = stride;
+        if (n > 0) ok(slam_memcpy_h2d(dst.p, xyz, sizeof(float) * (size_t)n * stride, stream_));
+    }
+    void set_ground_target_count(int n)
+    {
+        ground_target_n_ = n;
+        *reinterpret_cast<int32_t *>(h_io_ + kOffNgt) = n;
+        ok(slam_memcpy_h2d(d_io_ + kOffNgt, h_io_ + kOffNgt, 4, stream_));
+    }
+    // extent of the finite points of the cloud the target is made of (a superset of seg_target's): what a crop window must
+    // cover to select everything
+    void extent_of(const float *xyz, int n, int stride)
+    {
+        ext_[0] = ext_[2] = INFINITY, ext_[1] = ext_[3] = -INFINITY;
+        for (int i = 0; i < n; ++i) {
+            const float *p = xyz + (size_t)i * stride;
+            if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;
+            ext_[0] = std::fmin(ext_[0], p[0]), ext_[1] = std::fmax(ext_[1], p[0]);
+            ext_[2] = std::fmin(ext_[2], p[1]), ext_[3] = std::fmax(ext_[3], p[1]);
+        }
+    }
+    void reset_box() { box_[0] = box_[2] = -INFINITY, box_[1] = box_[3] = INFINITY; }
+    bool covers(const float b[4]) const { return ext_[0] >= b[0] && ext_[1] <= b[1] && ext_[2] >= b[2] && ext_[3] <= b[3]; }
+    // The model of this match: seg_target inside the intersection of every crop window since setTargetCloud (the reference
+    // filters seg_target in place, :226-239), split by class with the cap (:263-276).  The index is rebuilt only when that
+    // selects other points than it was built from.
+    void ensure_target(const Pose &initPose)
+    {
+        const double crop_dist = 75;
+        const float  win[4] = {(float)(-crop_dist + initPose.x), (float)(crop_dist + initPose.x), (float)(-crop_dist + initPose.y),
+                               (float)(crop_dist + initPose.y)}; // setFilterLimits takes floats (:231,:236)
+        const float  nb[4] = {std::fmax(box_[0], win[0]), std::fmin(box_[1], win[1]), std::fmax(box_[2], win[2]), std::fmin(box_[3], win[3])};
+        const bool   same = !target_dirty_ && ((covers(nb) && covers(built_box_)) ||
+                                             (nb[0] == built_box_[0] && nb[1] == built_box_[1] && nb[2] == built_box_[2] && nb[3] == built_box_[3]));
+        for (int k = 0; k < 4; ++k) box_[k] = nb[k];
+        if (same) return;
+        if (icp_) {
+            slam_icp_destroy(icp_);
+            icp_ = nullptr;
+        }
+        int mc[2] = {0, 0}, tot[2] = {0, 0};
+        ok(slam_ccicp_split_box_dev(cc_, (const float *)seg_target_.p, seg_target_n_, 4, box_, ICP_MAX_PTS, d_ga_, d_nga_, mc, tot, stream_));
+        n_model_[0] = mc[0], n_model_[1] = mc[1];
+        target_in_box_ = tot[0] + tot[1];
+        // IcpPointToPoint icp(refPts_GA, refPts_NGA, ...) (:187): fewer than 5 model points -> error, R,t stay (icp.cpp:38-43)
+        if (slam_icp_create_dev(d_ga_, mc[0], d_nga_, mc[1], nullptr, &icp_) != SLAM_OK) {
+            std::fprintf(stderr, "%s\n", slam_last_error());
+            icp_ = nullptr;
+        }
+        for (int k = 0; k < 4; ++k) built_box_[k] = box_[k];
+        target_dirty_ = false;
+        ++target_builds_;
+    }
+    Pose result_from_io(const Pose &initPose, double pitch0, double roll0)
+    {
+        const double          *hp = reinterpret_cast<const double *>(h_io_);
+        const slam_icp_result *res = reinterpret_cast<const slam_icp_result *>(h_io_ + kOffRes);
+        num_corr_ = icp_ ? res->n_corr : 0;
+        last_iters_ = icp_ ? res->iters : 0;
+        Pose         result;
+        const double corr_yaw = std::atan2(hp[2], hp[0]); // :197
+        result.x = hp[4];
+        result.y = hp[5];
+        detail::quat_from_rpy(roll0, pitch0, corr_yaw, result); // :205-212
+        result.z = hp[kOffZ / 8];
+        (void)initPose;
+        return result;
     }
     // the points of raw_ whose label is in `mask`, in cloud order, as (x, y, z, 0) records; 0xff = every point
     void select(unsigned mask, Cloud &dst, int &n_dst)
@@ -240,22 +369,11 @@ private:
         if (raw_n_ == 0) return;
         if (mask == 0xffu) {
             reserve(labels_, (size_t)raw_n_ + 16);
-            ok(slam_memset(labels_.p, 0, (size_t)raw_n_, nullptr));
+            ok(slam_memset(labels_.p, 0, (size_t)raw_n_, stream_));
             mask = 1u;
         }
         ok(slam_ccicp_select_dev(cc_, (const float *)raw_.p, raw_n_, raw_stride_, (const uint8_t *)labels_.p, mask,
-                                 (float *)dst.p, &n_dst, nullptr));
-    }
-    // segmentGround (:106-119): labels, then outcloud (obstacle + overhead) into obs_ and the ground cloud
-    void segment(const float *xyz, int n, int stride, Cloud &ground, int &n_ground)
-    {
-        upload(xyz, n, stride);
-        reserve(labels_, (size_t)n + 16);
-        obs_n_ = n_ground = 0;
-        if (n == 0) return;
-        ok(slam_gseg_segment_dev(gseg_, (const float *)raw_.p, n, stride, (uint8_t *)labels_.p, nullptr));
-        select((1u << SLAM_GSEG_OBSTACLE) | (1u << SLAM_GSEG_OVERHEAD), obs_, obs_n_);
-        select(1u << SLAM_GSEG_GROUND, ground, n_ground);
+                                 (float *)dst.p, &n_dst, stream_));
     }
     // classifyPoints over obs_ (:36-103) into x,y,z,ground_adj records: through the voxel filter
     // (setSceneCloud) or in classifyPoints' own bin order (setTargetCloud)
@@ -265,36 +383,109 @@ private:
         reserve(dst, 16 * (size_t)(obs_n_ + 1));
         n_dst = 0;
         if (obs_n_ == 0) return;
-        ok(slam_gseg_classify_ga_dev(gseg_, (const float *)obs_.p, obs_n_, 4, (uint8_t *)flags_.p, nullptr));
+        ok(slam_gseg_classify_ga_dev(gseg_, (const float *)obs_.p, obs_n_, 4, (uint8_t *)flags_.p, stream_));
         if (voxel)
             ok(slam_ccicp_voxel_downsample_dev(cc_, (const float *)obs_.p, (const uint8_t *)flags_.p, obs_n_, 4, 0.5f, 0.5f,
-                                               2.0f, (float *)dst.p, obs_n_, &n_dst, nullptr));
+                                               2.0f, (float *)dst.p, obs_n_, &n_dst, stream_));
         else
             ok(slam_ccicp_bin_order_dev(cc_, (const float *)obs_.p, (const uint8_t *)flags_.p, obs_n_, 4, (float *)dst.p,
-                                        &n_dst, nullptr));
+                                        &n_dst, stream_));
     }
-    static void copy_out(const Cloud &c, int n, std::vector<float> &xyz)
+    // seg_scene and ground_scene as clouds (getSegmentedClouds): not needed by a match, made when asked for
+    void materialise_scene()
+    {
+        if (!scene_ready_) {
+            seg_scene_n_ = ground_scene_n_ = 0;
+            return;
+        }
+        know_scene();
+        if (!seg_scene_valid_) {
+            seg_scene_n_ = h_counts()[2];
+            reserve(seg_scene_, 16 * (size_t)(scene_n_in_ + 1));
+            ok(slam_ccicp_scene_cloud_dev(cc_, (float *)seg_scene_.p, scene_n_in_, stream_));
+            seg_scene_valid_ = true;
+        }
+        if (!ground_scene_valid_) { // VoxelGrid 0.5 x 0.5 x 5 of the scene's ground cloud (:628-633)
+            const int n_gnd = h_counts()[1];
+            reserve(ground_scene_, 16 * (size_t)(n_gnd + 1));
+            ground_scene_n_ = 0;
+            if (n_gnd > 0)
+                ok(slam_ccicp_voxel_downsample_dev(cc_, (const float *)scene_ground_.p, nullptr, n_gnd, 4, 0.5f, 0.5f, 5.0f,
+                                                   (float *)ground_scene_.p, n_gnd, &ground_scene_n_, stream_));
+            ground_scene_valid_ = true;
+        }
+    }
+    // The scene through the stepwise entry points, which take voxel lattices of any extent (the chain's accumulator holds
+    // 2 M voxels: d_counts[3] said that this cloud's lattice does not fit)
+    Pose match_stepwise(const Pose &initPose, double yaw0, double pitch0, double roll0)
+    {
+        raw_n_ = scene_n_in_, raw_stride_ = scene_stride_;
+        std::swap(raw_, scene_raw_);
+        reserve(labels_, (size_t)raw_n_ + 16);
+        int n_gnd = 0, sc[2] = {0, 0};
+        ok(slam_gseg_segment_dev(gseg_, (const float *)raw_.p, raw_n_, raw_stride_, (uint8_t *)labels_.p, stream_));
+        select((1u << SLAM_GSEG_OBSTACLE) | (1u << SLAM_GSEG_OVERHEAD), obs_, obs_n_);
+        select(1u << SLAM_GSEG_GROUND, scene_ground_, n_gnd);
+        std::swap(raw_, scene_raw_);
+        classify_into(seg_scene_, seg_scene_n_, true);
+        seg_scene_valid_ = true;
+        ok(slam_ccicp_split_box_dev(cc_, (const float *)seg_scene_.p, seg_scene_n_, 4, nullptr, ICP_MAX_PTS, d_scene_pts_, d_nga_, sc, nullptr, stream_));
+        if (sc[1]) ok(slam_memcpy_d2d(d_scene_pts_ + 2 * (size_t)sc[0], d_nga_, 16 * (size_t)sc[1], stream_)); // NGA behind GA
+        int32_t *hs = reinterpret_cast<int32_t *>(h_io_ + kOffScan), *hc = reinterpret_cast<int32_t *>(h_io_ + kOffCounts);
+        hs[0] = 0, hs[1] = sc[0] + sc[1], hs[2] = sc[0], hs[3] = 0;
+        hc[0] = obs_n_, hc[1] = n_gnd, hc[2] = seg_scene_n_, hc[3] = 0;
+        n_scene_[0] = sc[0], n_scene_[1] = sc[1];
+        double *hp = reinterpret_cast<double *>(h_io_);
+        hp[0] = std::cos(yaw0), hp[1] = -std::sin(yaw0), hp[2] = std::sin(yaw0), hp[3] = std::cos(yaw0);
+        hp[4] = initPose.x, hp[5] = initPose.y;
+        std::memset(h_io_ + kOffRes, 0, 32);
+        hp[kOffZ / 8] = initPose.z;
+        ok(slam_memcpy_h2d_async(d_io_, h_io_, kOffNgt, stream_));
+        if (hs[1] >= 5 && icp_)
+            ok(slam_icp_fit_batch_dev(icp_, d_scene_pts_, io_scan(), io_scan() + 2, 1, io_R(), io_t(), 5.0,
+                                      reinterpret_cast<slam_icp_result *>(d_io_ + kOffRes), nullptr, stream_));
+        ok(slam_ccicp_height_rpy_pose_dev(cc_, (const float *)ground_target_.p, reinterpret_cast<const int32_t *>(d_io_ + kOffNgt),
+                                          ground_target_n_, 4, io_R(), io_t(), initPose.z, roll0, pitch0,
+                                          reinterpret_cast<double *>(d_io_ + kOffZ), stream_));
+        fetch_io();
+        if (hs[1] < 5) {
+            std::fprintf(stderr, "ERROR: Total Scene has %d points\n", hs[1]);
+            Pose bad;
+            bad.qw = 9999;
+            num_corr_ = 0;
+            return bad;
+        }
+        return result_from_io(initPose, pitch0, roll0);
+    }
+    // n records (x, y, z, .) as x, y, z triples; box (optional): only the points a PassThrough of these limits keeps
+    void copy_out(const Cloud &c, int n, std::vector<float> &xyz, const float *box)
     {
         std::vector<float> rec(4 * (size_t)n + 4);
-        if (n > 0) ok(slam_memcpy_d2h(rec.data(), c.p, 16 * (size_t)n, nullptr));
-        xyz.resize(3 * (size_t)n);
-        for (int i = 0; i < n; ++i)
-            for (int k = 0; k < 3; ++k) xyz[3 * (size_t)i + k] = rec[4 * (size_t)i + k];
-    }
-    static void download(std::vector<double> &v, const double *d, int n)
-    {
-        v.resize(2 * (size_t)n + 2);
-        if (n > 0) ok(slam_memcpy_d2h(v.data(), d, 16 * (size_t)n, nullptr));
+        if (n > 0) ok(slam_memcpy_d2h(rec.data(), c.p, 16 * (size_t)n, stream_));
+        xyz.clear();
+        xyz.reserve(3 * (size_t)n);
+        for (int i = 0; i < n; ++i) {
+            const float *p = &rec[4 * (size_t)i];
+            if (box && !(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]) && p[0] >= box[0] && p[0] <= box[1] &&
+                         p[1] >= box[2] && p[1] <= box[3]))
+                continue;
+            xyz.insert(xyz.end(), p, p + 3);
+        }
     }
 
     slam_gseg_t  *gseg_ = nullptr;
     slam_ccicp_t *cc_ = nullptr;
-    Cloud         raw_, labels_, obs_, flags_, seg_target_, seg_scene_, ground_target_, ground_scene_, tmp_;
+    slam_icp_t   *icp_ = nullptr;   // the target's index, kept across matches
+    slam_stream_t stream_ = nullptr;
+    Cloud         raw_, scene_raw_, labels_, obs_, flags_, seg_target_, seg_scene_, ground_target_, ground_scene_, scene_ground_;
     int           raw_n_ = 0, raw_stride_ = 3, obs_n_ = 0, seg_target_n_ = 0, seg_scene_n_ = 0, ground_target_n_ = 0,
-        ground_scene_n_ = 0, tmp_n_ = 0, num_corr_ = 0;
+        ground_scene_n_ = 0, num_corr_ = 0, last_iters_ = 0, scene_n_in_ = 0, scene_stride_ = 3, target_in_box_ = 0, target_builds_ = 0;
     int     n_model_[2] = {0, 0}, n_scene_[2] = {0, 0};
-    double *d_ga_ = nullptr, *d_nga_ = nullptr;
-    void   *d_cnt_ = nullptr;
+    bool    target_dirty_ = true, scene_ready_ = false, scene_known_ = false, seg_scene_valid_ = false, ground_scene_valid_ = false;
+    float   ext_[4] = {0, 0, 0, 0};       // x_lo, x_hi, y_lo, y_hi of the target's finite points
+    float   box_[4], built_box_[4] = {0, 0, 0, 0}; // the crop so far (intersection of the windows); the one the index was built for
+    double *d_ga_ = nullptr, *d_nga_ = nullptr, *d_scene_pts_ = nullptr;
+    unsigned char *d_io_ = nullptr, *h_io_ = nullptr;
 };
 
 } // namespace slam_amd

@@ -419,6 +419,13 @@ int slam_ccicp_split_dev(slam_ccicp_t *h, const float *d_xyzg, int n, int stride
                          double crop_dist, int cap, double *d_ga_xy, double *d_nga_xy, int counts[2],
                          slam_stream_t stream);
 
+/* The same with the crop given as the box itself, box = {x_lo, x_hi, y_lo, y_hi} (closed intervals of floats, as
+ * pcl::PassThrough compares them; null = no crop): CCICP::doICPMatch filters seg_target IN PLACE (icpTools.cpp:226-239), so the
+ * points a later match sees are those inside the intersection of every window since setTargetCloud -- a box again.
+ * totals (optional) = points of each class inside the box before the cap (what the reference's seg_target keeps). */
+int slam_ccicp_split_box_dev(slam_ccicp_t *h, const float *d_xyzg, int n, int stride, const float box[4], int cap, double *d_ga_xy,
+                             double *d_nga_xy, int counts[2], int totals[2], slam_stream_t stream);
+
 /* CCICP::doHeightInterpolate, icpTools.cpp:301-381: the four wheel points of the pose (x,y,z,qx,qy,qz,qw)
  * find their nearest ground point (exact, squared distance < 9); with four of them the new z is
  * n_z * 1.45 + mean z of the four (n = their plane normal, n_z >= 0); otherwise z stays.  nn_idx
@@ -446,6 +453,14 @@ int slam_ccicp_scene_dev(slam_ccicp_t *h, slam_gseg_t *seg, const float *d_xyz, 
 int slam_ccicp_height_pose_dev(slam_ccicp_t *h, const float *d_ground, const int32_t *d_n_ground, int n_capacity,
                                int stride, const double *d_R, const double *d_t, double z0, double *d_out,
                                slam_stream_t stream);
+/* ... with the roll and pitch of the initial pose, which doICPMatch keeps beside the matched yaw (tf::createQuaternionFromRPY,
+ * icpTools.cpp:205-212) and doHeightInterpolate turns the wheel points by (:321-332) */
+int slam_ccicp_height_rpy_pose_dev(slam_ccicp_t *h, const float *d_ground, const int32_t *d_n_ground, int n_capacity,
+                                   int stride, const double *d_R, const double *d_t, double z0, double roll, double pitch,
+                                   double *d_out, slam_stream_t stream);
+/* The filtered cloud of the last slam_ccicp_scene_dev call (x, y, z, ground_adj records: seg_scene / seg_target of
+ * icpTools.h:77-78; d_counts[2] of that call says how many are valid) copied to d_out_xyzg, at most `capacity` records. */
+int slam_ccicp_scene_cloud_dev(slam_ccicp_t *h, float *d_out_xyzg, int capacity, slam_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Streaming mapper (BASELINE config 5).  Stands where scan_registration (scan_registration.cpp:109-199: one

@@ -459,11 +459,16 @@ __host__ __device__ inline void wheel_points(const double pose[7], float4 q[4])
         }
 }
 
-__global__ void height_pose_kernel(const double *R, const double *t, double z0, float4 *q /*[4]*/, unsigned long long *best)
+__global__ void height_pose_kernel(const double *R, const double *t, double z0, double roll, double pitch, float4 *q /*[4]*/,
+                                   unsigned long long *best)
 {
     if (threadIdx.x || blockIdx.x) return;
     const double yaw = atan2(R[2], R[0]); // icpTools.cpp:195-197
-    const double pose[7] = {t[0], t[1], z0, 0.0, 0.0, sin(0.5 * yaw), cos(0.5 * yaw)};
+    // tf::createQuaternionFromRPY(roll, pitch, yaw): the matched yaw with the roll and pitch the initial pose carried (:205-212)
+    const double hy = yaw * 0.5, hp = pitch * 0.5, hr = roll * 0.5;
+    const double cy = cos(hy), sy = sin(hy), cp = cos(hp), sp = sin(hp), cr = cos(hr), sr = sin(hr);
+    const double pose[7] = {t[0], t[1], z0, sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy,
+                            cr * cp * cy + sr * sp * sy};
     wheel_points(pose, q);
     for (int k = 0; k < 4; ++k) best[k] = ~0ull;
 }
@@ -709,24 +714,24 @@ int slam_ccicp_bin_order_dev(slam_ccicp_t *h, const float *d_xyz, const uint8_t 
     return SLAM_OK;
 }
 
-int slam_ccicp_split_dev(slam_ccicp_t *h, const float *d_xyzg, int n, int stride, int crop, double cur_x, double cur_y,
-                         double crop_dist, int cap, double *d_ga_xy, double *d_nga_xy, int counts[2],
-                         slam_stream_t stream)
+int slam_ccicp_split_box_dev(slam_ccicp_t *h, const float *d_xyzg, int n, int stride, const float box[4], int cap, double *d_ga_xy,
+                             double *d_nga_xy, int counts[2], int totals[2], slam_stream_t stream)
 {
     SLAM_REQUIRE(h && n >= 0 && stride >= 4 && cap >= 1 && d_ga_xy && d_nga_xy && counts && (d_xyzg || n == 0),
-                 SLAM_E_INVALID, "slam_ccicp_split_dev: bad arguments");
+                 SLAM_E_INVALID, "slam_ccicp_split_box_dev: bad arguments");
     counts[0] = counts[1] = 0;
+    if (totals) totals[0] = totals[1] = 0;
     if (n == 0) return SLAM_OK;
     hipStream_t st = as_stream(stream);
     int        *d_tot = reinterpret_cast<int *>(static_cast<unsigned *>(h->small.p) + 12);
     SplitPred   p;
     p.xyzg = d_xyzg;
     p.stride = stride;
-    p.crop = crop;
-    p.x_lo = (float)(-crop_dist + cur_x); // setFilterLimits takes floats (icpTools.cpp:231,236)
-    p.x_hi = (float)(crop_dist + cur_x);
-    p.y_lo = (float)(-crop_dist + cur_y);
-    p.y_hi = (float)(crop_dist + cur_y);
+    p.crop = box ? 1 : 0;
+    p.x_lo = box ? box[0] : 0.f;
+    p.x_hi = box ? box[1] : 0.f;
+    p.y_lo = box ? box[2] : 0.f;
+    p.y_hi = box ? box[3] : 0.f;
     p.want_ga = 1;
     SLAM_TRY(compact(p, SplitEmit{d_xyzg, stride, d_ga_xy, nullptr, 0}, n, cap - 1, h->blocks, d_tot, st)); // ICP_MAX_PTS-1 (:256,:259)
     p.want_ga = 0;
@@ -736,7 +741,17 @@ int slam_ccicp_split_dev(slam_ccicp_t *h, const float *d_xyzg, int n, int stride
     SLAM_HIP(hipStreamSynchronize(st));
     counts[0] = tot[0] < cap - 1 ? tot[0] : cap - 1;
     counts[1] = tot[1] < cap - 1 ? tot[1] : cap - 1;
+    if (totals) totals[0] = tot[0], totals[1] = tot[1];
     return SLAM_OK;
+}
+
+int slam_ccicp_split_dev(slam_ccicp_t *h, const float *d_xyzg, int n, int stride, int crop, double cur_x, double cur_y,
+                         double crop_dist, int cap, double *d_ga_xy, double *d_nga_xy, int counts[2],
+                         slam_stream_t stream)
+{
+    // setFilterLimits takes floats (icpTools.cpp:231,236)
+    const float box[4] = {(float)(-crop_dist + cur_x), (float)(crop_dist + cur_x), (float)(-crop_dist + cur_y), (float)(crop_dist + cur_y)};
+    return slam_ccicp_split_box_dev(h, d_xyzg, n, stride, crop ? box : nullptr, cap, d_ga_xy, d_nga_xy, counts, nullptr, stream);
 }
 
 int slam_ccicp_height_dev(slam_ccicp_t *h, const float *d_ground, int n, int stride, const double pose[7], double *z_out,
@@ -869,12 +884,27 @@ int slam_ccicp_scene_dev(slam_ccicp_t *h, slam_gseg_t *seg, const float *d_xyz, 
 int slam_ccicp_height_pose_dev(slam_ccicp_t *h, const float *d_ground, const int32_t *d_n_ground, int n_capacity, int stride,
                                const double *d_R, const double *d_t, double z0, double *d_out, slam_stream_t stream)
 {
+    return slam_ccicp_height_rpy_pose_dev(h, d_ground, d_n_ground, n_capacity, stride, d_R, d_t, z0, 0.0, 0.0, d_out, stream);
+}
+
+int slam_ccicp_scene_cloud_dev(slam_ccicp_t *h, float *d_out_xyzg, int capacity, slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && capacity >= 0 && (d_out_xyzg || capacity == 0), SLAM_E_INVALID, "slam_ccicp_scene_cloud_dev: bad arguments");
+    const size_t have = h->filtered.cap / 16, n = std::min((size_t)capacity, have);
+    if (n) SLAM_HIP(hipMemcpyAsync(d_out_xyzg, h->filtered.p, 16 * n, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return SLAM_OK;
+}
+
+int slam_ccicp_height_rpy_pose_dev(slam_ccicp_t *h, const float *d_ground, const int32_t *d_n_ground, int n_capacity, int stride,
+                                   const double *d_R, const double *d_t, double z0, double roll, double pitch, double *d_out,
+                                   slam_stream_t stream)
+{
     SLAM_REQUIRE(h && d_n_ground && d_R && d_t && d_out && n_capacity >= 0 && stride >= 3 && (d_ground || n_capacity == 0),
-                 SLAM_E_INVALID, "slam_ccicp_height_pose_dev: bad arguments");
+                 SLAM_E_INVALID, "slam_ccicp_height_rpy_pose_dev: bad arguments");
     hipStream_t st = as_stream(stream);
     SLAM_TRY(h->chain.reserve(sizeof(ChainSmall)));
     ChainSmall *c = static_cast<ChainSmall *>(h->chain.p);
-    hipLaunchKernelGGL(height_pose_kernel, dim3(1), dim3(64), 0, st, d_R, d_t, z0, c->q, c->best);
+    hipLaunchKernelGGL(height_pose_kernel, dim3(1), dim3(64), 0, st, d_R, d_t, z0, roll, pitch, c->q, c->best);
     if (n_capacity > 0)
         hipLaunchKernelGGL(height_nn_kernel, dim3((n_capacity + 255) / 256), dim3(256), 0, st, d_ground, n_capacity, stride,
                            make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), c->best,

@@ -1,0 +1,92 @@
+// BASELINE config 3 as scan_registration runs it (scan_registration.cpp:57,73-104,109-173), over the adapter
+// include/slam_amd/ccicp.hpp: a sequence of 64-ring clouds, each registered against the current target with
+// setSceneCloud + doICPMatch; every `advance` clouds the cloud just matched becomes the new target (setTargetCloud,
+// SCAN_TO_SCAN: what the target callbacks :73-104 do when graph_slam publishes a new map).
+//   ccicp_sequence <dir> <n_clouds> <advance> [passes]
+// <dir>/cloud<k>.f32 (x y z per point), <dir>/init.f64 (per match k = 1..n-1: x y z qx qy qz qw of the initial pose of
+// cloud k in the frame of ITS target), <dir>/truth.f64 (x y yaw of the same).  Prints one JSON line; the last pass is
+// the one reported (the first warms buffers and code objects).
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "slam_amd/ccicp.hpp"
+
+template <class T>
+static std::vector<T> read_all(const std::string &path)
+{
+    std::vector<T> v;
+    FILE *f = std::fopen(path.c_str(), "rb");
+    if (!f) { std::fprintf(stderr, "cannot open %s\n", path.c_str()); std::exit(2); }
+    std::fseek(f, 0, SEEK_END);
+    const long n = std::ftell(f);
+    std::fseek(f, 0, SEEK_SET);
+    v.resize((size_t)n / sizeof(T));
+    if (n && std::fread(v.data(), 1, (size_t)n, f) != (size_t)n) std::exit(2);
+    std::fclose(f);
+    return v;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 4) return 2;
+    const std::string dir = argv[1];
+    const int n_clouds = std::atoi(argv[2]), advance = std::atoi(argv[3]), passes = argc > 4 ? std::atoi(argv[4]) : 2;
+    std::vector<std::vector<float>> clouds;
+    for (int k = 0; k < n_clouds; ++k) clouds.push_back(read_all<float>(dir + "/cloud" + std::to_string(k) + ".f32"));
+    const auto init = read_all<double>(dir + "/init.f64"), truth = read_all<double>(dir + "/truth.f64");
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+
+    slam_amd::CCICP icp(slam_amd::SCAN_TO_SCAN);
+    double t_match = 0, t_target = 0, worst = 0, sum_err = 0, iters = 0, corr = 0;
+    int    n_match = 0, n_target = 0, builds0 = 0;
+    std::vector<double> poses;
+    for (int pass = 0; pass < passes; ++pass) {
+        t_match = t_target = worst = sum_err = iters = corr = 0;
+        n_match = n_target = 0;
+        poses.clear();
+        builds0 = icp.targetBuilds();
+        slam_amd::Pose p0;
+        auto a = clk::now();
+        icp.setTargetCloud(clouds[0].data(), (int)clouds[0].size() / 3, 3, p0);
+        t_target += ms(a, clk::now());
+        ++n_target;
+        for (int k = 1; k < n_clouds; ++k) {
+            const double  *q = &init[7 * (size_t)(k - 1)], *tr = &truth[3 * (size_t)(k - 1)];
+            slam_amd::Pose pose;
+            pose.x = q[0], pose.y = q[1], pose.z = q[2], pose.qx = q[3], pose.qy = q[4], pose.qz = q[5], pose.qw = q[6];
+            a = clk::now();
+            icp.setSceneCloud(clouds[k].data(), (int)clouds[k].size() / 3, 3); // scan_registration.cpp:139
+            const slam_amd::Pose r = icp.doICPMatch(pose);                       // :159
+            t_match += ms(a, clk::now());
+            ++n_match;
+            if (r.qw == 9999) { std::fprintf(stderr, "match %d: scene too small\n", k); return 3; }
+            const double err = std::hypot(r.x - tr[0], r.y - tr[1]);
+            worst = err > worst ? err : worst;
+            sum_err += err;
+            iters += icp.lastIterations();
+            corr += icp.getNumberCorrespondences();
+            poses.insert(poses.end(), {r.x, r.y, r.z, r.qx, r.qy, r.qz, r.qw});
+            if (advance > 0 && k % advance == 0 && k + 1 < n_clouds) { // the map moved on: this cloud is the target from here
+                a = clk::now();
+                icp.setTargetCloud(clouds[k].data(), (int)clouds[k].size() / 3, 3, r);
+                t_target += ms(a, clk::now());
+                ++n_target;
+            }
+        }
+    }
+    if (FILE *f = std::fopen((dir + "/poses_out.f64").c_str(), "wb")) {
+        std::fwrite(poses.data(), 8, poses.size(), f);
+        std::fclose(f);
+    }
+    std::printf("{\"matches\": %d, \"ms_per_match\": %.4f, \"clouds_per_s\": %.1f, \"target_updates\": %d, \"ms_per_target_update\": %.4f, "
+                "\"target_index_builds\": %d, \"ms_per_cloud_with_target_updates\": %.4f, \"mean_icp_iterations\": %.2f, "
+                "\"mean_correspondences\": %.1f, \"mean_xy_error_m\": %.4f, \"max_xy_error_m\": %.4f, \"rays_per_cloud\": %zu}\n",
+                n_match, t_match / n_match, 1e3 * n_match / t_match, n_target, t_target / n_target, icp.targetBuilds() - builds0,
+                (t_match + t_target) / n_match, iters / n_match, corr / n_match, sum_err / n_match, worst, clouds[0].size() / 3);
+    return 0;
+}

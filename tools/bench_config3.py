@@ -10,7 +10,44 @@ import numpy as np
 from slam_amd import api, synth
 
 
-def measure(n_clouds=50, cell=0.0, dump_case=None):
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def measure_cpp(clouds, poses, advance=10, passes=2):
+    """The same sequence through the C++ drop-in (include/slam_amd/ccicp.hpp, what ros/scan_registration_node.cpp calls where
+    the reference calls icpTools.cpp:222-298): tests/cpp/ccicp_sequence.cpp compiled with g++ against the shipped library,
+    clouds handed over as files, the target advanced every `advance` clouds.  Returns the program's JSON line as a dict."""
+    import subprocess
+    import tempfile
+    lib = os.path.join(ROOT, "slam_amd", "lib")
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "ccicp_sequence")
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tests", "cpp", "ccicp_sequence.cpp"), "-o", exe,
+                               "-L" + lib, "-l:libslam_mi355x.so", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+        init, truth = [], []
+        for k in range(1, len(clouds)):
+            j = ((k - 1) // advance) * advance if advance > 0 else 0        # the cloud that is the target when k is matched
+            pa, pb = poses[j], poses[k]
+            ca, sa = np.cos(pa[2]), np.sin(pa[2])
+            rel = (ca * (pb[0] - pa[0]) + sa * (pb[1] - pa[1]), -sa * (pb[0] - pa[0]) + ca * (pb[1] - pa[1]), pb[2] - pa[2])
+            yaw = rel[2] + 0.02
+            init.append([rel[0] + 0.1, rel[1] - 0.1, 0.0, 0.0, 0.0, np.sin(yaw / 2), np.cos(yaw / 2)])
+            truth.append(list(rel))
+        for k, c in enumerate(clouds):
+            np.ascontiguousarray(c, np.float32).tofile(os.path.join(d, "cloud%d.f32" % k))
+        np.array(init, np.float64).tofile(os.path.join(d, "init.f64"))
+        np.array(truth, np.float64).tofile(os.path.join(d, "truth.f64"))
+        p = subprocess.run([exe, d, str(len(clouds)), str(advance), str(passes)], capture_output=True, text=True, timeout=600)
+        if p.returncode != 0:
+            raise RuntimeError("ccicp_sequence failed (%d): %s" % (p.returncode, p.stderr[-500:]))
+        out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+        out["poses"] = np.fromfile(os.path.join(d, "poses_out.f64"), np.float64).reshape(-1, 7)
+        out["truth"] = np.array(truth)
+        return out
+
+
+def measure(n_clouds=50, cell=0.0, dump_case=None, advance=10):
     """Runs the sequence twice (the first pass warms buffers and code objects) and returns the summary dict."""
     L = api.lib()
     seg, cc = api.GroundSegmentation(), api.Ccicp()
@@ -117,21 +154,42 @@ def measure(n_clouds=50, cell=0.0, dump_case=None):
             pose, res, z = d_pose.download(), d_res.download()[0], d_z.download()
             t_all += time.perf_counter() - a
             errs.append(np.hypot(pose[4] - rel[0], pose[5] - rel[1])); iters.append(int(res["iters"]))
+            chain_poses.append((pose[4], pose[5], np.arctan2(pose[2], pose[0]), z[0], int(res["iters"]), int(res["n_corr"])))
         icp.close()
         return t_all, errs, iters
 
+    chain_poses = []                                                         # (x, y, yaw, z, iterations, correspondences) per match
     run()                                                                    # warm-up: buffers, code objects
     t_model, t_create, t_front, t_icp, t_h, errs, iters, n_model, n_scene = run()
     run_chain()
+    del chain_poses[:]
     t_chain, errs_c, iters_c = run_chain()
     assert iters_c == iters, "the chain and the stepwise path ran different iteration counts"
     assert np.abs(np.array(errs_c) - np.array(errs)).max() < 1e-9
     n = n_clouds - 1
     total = t_front + t_icp + t_h
+    try:
+        # first with the target fixed (what the Python-driven chain above did): the adapter must hand back the same poses
+        same = measure_cpp(clouds[:min(n_clouds, 6)], poses[:min(n_clouds, 6)], 0, passes=1)
+        want = np.array(chain_poses[:len(same["poses"])])
+        got = same["poses"]
+        yaw = 2.0 * np.arctan2(got[:, 5], got[:, 6])
+        dyaw = np.abs((yaw - want[:, 2] + np.pi) % (2 * np.pi) - np.pi)
+        assert np.abs(got[:, :2] - want[:, :2]).max() < 1e-9 and dyaw.max() < 1e-9 and np.abs(got[:, 2] - want[:, 3]).max() < 1e-9, \
+            "the C++ adapter and the Python-driven chain disagree"
+        cpp = measure_cpp(clouds, poses, advance)
+        cpp.pop("poses"), cpp.pop("truth")
+        cpp["equals_python_chain_on_fixed_target"] = True
+        cpp["what"] = ("the same clouds through the C++ drop-in slam_amd::CCICP (include/slam_amd/ccicp.hpp; tests/cpp/ccicp_sequence.cpp "
+                       "compiled against the shipped library): setSceneCloud + doICPMatch per cloud, the target replaced by the cloud "
+                       "just matched every %d clouds (setTargetCloud, SCAN_TO_SCAN); wall clock per match incl. the cloud's H2D" % advance)
+    except Exception as ex:     # no g++ on the box, ...: the Python-driven chain above still stands
+        cpp = {"error": repr(ex)}
     return {
         "metric": "registered_clouds_per_s", "value": n / t_chain, "unit": "clouds/s", "steps": n, "warmup": n,
         "ms_per_step": t_chain / n * 1e3,
         "ms_per_cloud_chain": round(t_chain / n * 1e3, 3),
+        "cpp_adapter": cpp,
         "chain": "slam_ccicp_scene_dev -> slam_icp_fit_batch_dev -> slam_ccicp_height_pose_dev on one stream: one H2D of the cloud "
                  "(pageable host memory), one read-back of pose / result / height per cloud; identical results to the stepwise path",
         "stepwise_clouds_per_s": n / total,
