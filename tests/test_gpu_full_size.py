@@ -111,3 +111,67 @@ def test_config5_stream_of_10240_scans_matches_oracle():
     num, eocc = np.zeros(size * size), np.full(size * size, -1, np.int8)
     O.grid_finalize(gp, H, M, num, eocc)
     assert np.array_equal(occ, eocc)
+
+
+def test_config5_sliding_window_at_full_length_matches_the_oracle_schedule():
+    """BASELINE config 5 in its own form, at full length: 10 240 scans in 40 chunks through slam_mapper_* against a
+    SLIDING-WINDOW target -- the 5 k-point prior map plus at most 5 k points of the last four registered chunks thinned at
+    0.1 m, rebuilt on the device every four chunks -- with strict_window, so that the schedule is the one the oracle can
+    follow: the target of chunks 4r .. 4r + 3 is built from the oracle's OWN registrations of chunks 4r - 4 .. 4r - 1.
+    Every pose within the north-star tolerance of the oracle's, all 11 M beams' counts and the occupancy bit-exact."""
+    from test_gpu_mapper import thin_points
+    n_scans, chunk, size, res, W, every, target_points, thin = 10240, 256, 2000, 0.05, 4, 4, 5000, 0.1
+    m_ga, m_nga = synth.make_map(5000)
+    batch = synth.make_batch(n_scans, n_loop=n_scans)
+    n_chunks = n_scans // chunk
+    mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=size, grid_size_y=size, resolution=res,
+                    max_scans=chunk, max_points=chunk * 1100, icp=dict(max_iter=30, min_delta=-1.0), window_chunks=W,
+                    rebuild_every=every, keep_prior=1, target_points=target_points, thin_res=thin, merge_every=8, strict_window=1)
+    R, t = np.zeros((n_scans, 4)), np.zeros((n_scans, 2))
+    pending = []
+    for k in range(n_chunks):
+        if len(pending) == mp.n_slots:
+            slot, a = pending.pop(0)
+            R[a:a + chunk], t[a:a + chunk] = mp.wait(slot)
+        pending.append((mp.push(batch.shard(k, n_chunks)), k * chunk))
+    for slot, a in pending:
+        R[a:a + chunk], t[a:a + chunk] = mp.wait(slot)
+    mp.finish()
+    hits, misses = mp.grid.read_counts()
+    occ = mp.grid.read_occupancy()
+    st = mp.stats()
+    mp.close()
+    assert st["chunks"] == n_chunks and st["rebuilds"] == n_chunks // every - 1      # before chunks 4, 8, ..., 36
+
+    # the oracle on the same schedule, with its own registrations in the window
+    Ro, to = np.zeros((n_scans, 4)), np.zeros((n_scans, 2))
+    window, model = [], O.IcpModel(m_ga, m_nga)
+    for k in range(n_chunks):
+        if k > 0 and k % every == 0:
+            ga = np.concatenate([m_ga, thin_points(np.concatenate([w[0] for w in window[-W:]]), thin, size * res, target_points // 2)])
+            nga = np.concatenate([m_nga, thin_points(np.concatenate([w[1] for w in window[-W:]]), thin, size * res, target_points // 2)])
+            model = O.IcpModel(ga, nga)
+        c = batch.shard(k, n_chunks)
+        Rc, tc, _, _, _ = model.fit_batch(c.pts, c.scan_off, c.scan_nga, c.R, c.t, O.icp_params(30, -1.0, 5.0), n_threads=THREADS)
+        Ro[k * chunk:(k + 1) * chunk], to[k * chunk:(k + 1) * chunk] = Rc, tc
+        reg_ga, reg_nga = [], []
+        for s in range(c.n_scans):
+            p = c.pts[c.scan_off[s]:c.scan_off[s + 1]]
+            q = np.stack([(Rc[s, 0] * p[:, 0] + Rc[s, 1] * p[:, 1]) + tc[s, 0], (Rc[s, 2] * p[:, 0] + Rc[s, 3] * p[:, 1]) + tc[s, 1]], 1)
+            reg_ga.append(q[:c.scan_nga[s]])
+            reg_nga.append(q[c.scan_nga[s]:])
+        window.append((np.concatenate(reg_ga), np.concatenate(reg_nga)))
+    assert np.abs(t - to).max() < 1e-4 and ang_diff(yaw(R), yaw(Ro)).max() < 1e-5
+    assert np.abs(t - batch.true_poses[:, :2]).max() < 0.05
+
+    gp = O.grid_params(size, size, res, min_cluster_points=20)
+    ends, origins = [], []
+    for s in range(n_scans):
+        o, e = batch.scan_off[s], batch.scan_off[s + 1]
+        ends.append(O.transform_points(batch.pts[o:e], R[s], t[s]))
+        origins.append(np.tile(t[s].astype(np.float32), (e - o, 1)))
+    H, M, upd = O.grid_raycast(gp, np.concatenate(origins), np.concatenate(ends), n_threads=THREADS)
+    assert np.array_equal(hits, H) and np.array_equal(misses, M)
+    num, eocc = np.zeros(size * size), np.full(size * size, -1, np.int8)
+    O.grid_finalize(gp, H, M, num, eocc)
+    assert np.array_equal(occ, eocc)
