@@ -3,6 +3,9 @@
 // (include/slam_amd/ccicp.hpp) stands where the reference's CCICP stands, and clouds cross as float arrays
 // instead of pcl::PointCloud.  Builds in a catkin workspace against roscpp, sensor_msgs, geometry_msgs
 // (ros/README.md); tests/test_ros_shims.py compiles it against stub message headers.
+#ifndef SLAM_SCAN_REG_DEBUG
+#define SLAM_SCAN_REG_DEBUG 1 // scan_registration.cpp:37 `#define DEBUG 1`
+#endif
 #include <cmath>
 #include <vector>
 
@@ -87,7 +90,8 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input) // :109-181
     }
     icp->setSceneCloud(temp.data(), (int)n, 3); // :139
 
-    { // DEBUG block (:141-148): the segmented scene on mapping/scan_reg/scene
+#if SLAM_SCAN_REG_DEBUG // :141-148 (`#define DEBUG 1`, :37): the segmented scene on mapping/scan_reg/scene.  With the device-resident
+    {                     // adapter this is the one step of a scan that brings clouds back to the host: build with =0 where nobody listens
         std::vector<float> target, scene, target_ground, scene_ground;
         icp->getSegmentedClouds(target, scene, target_ground, scene_ground);
         sensor_msgs::PointCloud2 cloud_msg;
@@ -96,6 +100,7 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input) // :109-181
         cloud_msg.header.stamp = ros::Time::now();
         scenePub.publish(cloud_msg);
     }
+#endif
 
     // scan registration: the result is in the global frame, given the initial pose and targets in the global frame (:156-159)
     const slam_amd::Pose result = icp->doICPMatch(to_pose(poseOut));

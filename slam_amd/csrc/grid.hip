@@ -557,8 +557,14 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
             if (!v) continue;
             tile[ly * kTileStride + lx] = 0u;
             const int s = storage_index(g, tx0 + lx, ty0 + ly);
-            if (v & 0xffffu) atomicAdd(&g.misses[s], (int)(v & 0xffffu));
-            if (v >> 16) atomicAdd(&g.hits[s], (int)(v >> 16));
+            if (ablate & 128) {
+                // measurement only (tools/raycast_interleave.sh): what the write-back would cost with {misses, hits} interleaved
+                // per cell -- ONE 8-byte atomic per touched cell, the planes' memory taken as cells x 8 bytes (wrong counts)
+                atomicAdd(reinterpret_cast<unsigned long long *>(g.hits) + s, ((unsigned long long)(v >> 16) << 32) | (v & 0xffffu));
+            } else {
+                if (v & 0xffffu) atomicAdd(&g.misses[s], (int)(v & 0xffffu));
+                if (v >> 16) atomicAdd(&g.hits[s], (int)(v >> 16));
+            }
             int row = ty0 + ly + g.oy; // the storage row of s (storage_index without its division)
             row -= row >= g.sy ? g.sy : 0;
             d_lo = min(d_lo, row);

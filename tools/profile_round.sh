@@ -24,7 +24,10 @@ for PMC in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc_merge -- $BENCH --raycast merge > $OUT/pmc_merge.json 2> $OUT/pmc_merge.err || echo "pmc merge pass failed"
 done
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_merge -- $BENCH --raycast merge > $OUT/stats_merge.json 2> $OUT/stats_merge.err || echo "stats merge failed"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- python3 bench.py --config 3 --clouds 20 > $OUT/config3.json 2> $OUT/config3.err || echo "config 3 stats failed"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_c3 -- python3 tools/bench_config3.py 20 > $OUT/config3_profiled.json 2> $OUT/config3.err || echo "config 3 stats failed"
+timeout -k 10 600 python3 bench.py --config 3 > $OUT/config3.json 2>> $OUT/config3.err || echo "config 3 failed"
+# the N > 1 path with two ranks on this one GPU (the library's merge over its host-staged communicator, gloo carrying the buffers)
+timeout -k 10 600 python3 bench.py --gpus 2 --backend gloo --one-device --steps 10 --warmup 3 --no-cpu-baseline > $OUT/two_ranks_one_gpu.json 2> $OUT/two_ranks.err || echo "two-rank rehearsal failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_build -- python3 tools/profile_build.py > $OUT/build.txt 2> $OUT/build.err || echo "build stats failed"
 timeout -k 10 600 python3 bench.py --config 5 > $OUT/config5.json 2> $OUT/config5.err || echo "config 5 failed"
 timeout -k 10 600 python3 bench.py --config 4 --no-extras --no-cpu-baseline > $OUT/config4.json 2> $OUT/config4.err || echo "config 4 failed"

@@ -86,7 +86,7 @@ for k, cs in acc.items():
         if mean("SQ_LDS_IDX_ACTIVE") > 0:
             traffic.setdefault(k, {})["lds_bank_conflict_share"] = mean("SQ_LDS_BANK_CONFLICT") / mean("SQ_LDS_IDX_ACTIVE")
 json.dump(traffic, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1, sort_keys=True)
-for name in ("bench.json", "config3.json", "config4.json", "config5.json", "build.txt"):
+for name in ("bench.json", "config3.json", "config4.json", "config5.json", "build.txt", "two_ranks_one_gpu.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, tag + "_" + name))
