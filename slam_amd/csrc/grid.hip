@@ -860,17 +860,86 @@ __global__ void ranges_set_kernel(int *ranges, int mode, int lo, int hi, int sy)
 
 // --------------------------------------------------------------- finalize
 // SURVEY 8(a) G3 on the summed counts, window order out (mls.h:167-175 data[x + size_x*y]).
+__device__ inline void cell_value(int h, int m, double inc, double dec, double minp, double &v, int8_t &o)
+{
+    v = inc * (double)h;
+    o = -1;
+    if (h > 0 && v > minp) o = 100; // mls.cpp:101-105
+    v = v - dec * (double)m;
+    if (m > 0 && v < minp) o = 0; // mls.cpp:137-141
+}
+
 __device__ inline void finalize_cell(const GridView &g, int x, int y, double inc, double dec, double minp, double *num_pts, int8_t *occ)
 {
     const int s = storage_index(g, x, y);
     const int h = g.hits[s] + (g.acc_hits ? g.acc_hits[s] : 0), m = g.misses[s] + (g.acc_misses ? g.acc_misses[s] : 0);
-    double    v = inc * (double)h;
-    int8_t    o = -1;
-    if (h > 0 && v > minp) o = 100; // mls.cpp:101-105
-    v = v - dec * (double)m;
-    if (m > 0 && v < minp) o = 0; // mls.cpp:137-141
+    double    v;
+    int8_t    o;
+    cell_value(h, m, inc, dec, minp, v, o);
     num_pts[x + (size_t)g.sx * y] = v;
     occ[x + (size_t)g.sx * y] = o;
+}
+
+// Four consecutive cells of one storage row per thread, where the row length and the toroidal x origin are multiples of
+// four (any non-rolling grid): 16-byte loads of both count planes, 2 x 16-byte stores of the evidence, one 4-byte store of
+// the occupancy -- the rows kernels stream 17 B per cell and were bound by the requests in flight per thread, not by HBM
+// (one cell per thread: 8.0 us for config 2's 602 rows; four: see DESIGN.md 4.3).  RESET: the counts just folded go back to
+// zero (slam_grid_finalize_reset).
+template <bool RESET>
+__device__ inline void finalize_quad(const GridView &g, int srow, int ix0, int y, double inc, double dec, double minp, double *num_pts,
+                                     int8_t *occ)
+{
+    const size_t s0 = (size_t)srow * g.sx + ix0;
+    int4         h = *reinterpret_cast<const int4 *>(g.hits + s0), m = *reinterpret_cast<const int4 *>(g.misses + s0);
+    const bool   any = (h.x | h.y | h.z | h.w | m.x | m.y | m.z | m.w) != 0;
+    if (g.acc_hits) {
+        const int4 ah = *reinterpret_cast<const int4 *>(g.acc_hits + s0), am = *reinterpret_cast<const int4 *>(g.acc_misses + s0);
+        h.x += ah.x, h.y += ah.y, h.z += ah.z, h.w += ah.w;
+        m.x += am.x, m.y += am.y, m.z += am.z, m.w += am.w;
+    }
+    double v[4];
+    int8_t o[4];
+    cell_value(h.x, m.x, inc, dec, minp, v[0], o[0]);
+    cell_value(h.y, m.y, inc, dec, minp, v[1], o[1]);
+    cell_value(h.z, m.z, inc, dec, minp, v[2], o[2]);
+    cell_value(h.w, m.w, inc, dec, minp, v[3], o[3]);
+    int x0 = ix0 - g.ox; // the window cells stored there (storage_index's inverse): the four do not straddle the seam
+    x0 += x0 < 0 ? g.sx : 0;
+    const size_t w0 = (size_t)x0 + (size_t)g.sx * y;
+    *reinterpret_cast<double2 *>(num_pts + w0) = make_double2(v[0], v[1]);
+    *reinterpret_cast<double2 *>(num_pts + w0 + 2) = make_double2(v[2], v[3]);
+    *reinterpret_cast<unsigned *>(occ + w0) = (unsigned)(unsigned char)o[0] | ((unsigned)(unsigned char)o[1] << 8) |
+                                               ((unsigned)(unsigned char)o[2] << 16) | ((unsigned)(unsigned char)o[3] << 24);
+    if (RESET && any) {
+        *reinterpret_cast<int4 *>(g.hits + s0) = make_int4(0, 0, 0, 0);
+        *reinterpret_cast<int4 *>(g.misses + s0) = make_int4(0, 0, 0, 0);
+    }
+}
+
+// the rows lo..hi of the planes: one cell per thread, or (quads) four
+template <bool RESET>
+__device__ inline void finalize_rows(const GridView &g, int lo, int hi, double inc, double dec, double minp, double *num_pts, int8_t *occ)
+{
+    const bool quads = (g.sx & 3) == 0 && (g.ox & 3) == 0;
+    const int  per_thread = quads ? 4 : 1;
+    const int  per_row = (g.sx + 256 * per_thread - 1) / (256 * per_thread);
+    const long items = (long)(hi - lo + 1) * per_row;
+    for (long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int srow = lo + (int)(it / per_row), ix = ((int)(it % per_row) * 256 + (int)threadIdx.x) * per_thread;
+        if (ix >= g.sx) continue;
+        int y = srow - g.oy; // the window row stored there (storage_index's inverse)
+        y += y < 0 ? g.sy : 0;
+        if (quads) {
+            finalize_quad<RESET>(g, srow, ix, y, inc, dec, minp, num_pts, occ);
+        } else { // here ix counts WINDOW cells of the row (any order covers the row)
+            finalize_cell(g, ix, y, inc, dec, minp, num_pts, occ);
+            if (RESET) {
+                const int s = storage_index(g, ix, y);
+                if (g.hits[s]) g.hits[s] = 0;
+                if (g.misses[s]) g.misses[s] = 0;
+            }
+        }
+    }
 }
 
 // every cell (after the in-order mode, or where the caller wants it)
@@ -889,15 +958,7 @@ __global__ __launch_bounds__(256) void finalize_rows_kernel(GridView g, double i
 {
     const int lo = max(min(ranges[0], ranges[2]), 0), hi = min(max(-ranges[1], -ranges[3]), g.sy - 1);
     if (hi < lo) return;
-    const int  per_row = (g.sx + 255) / 256;
-    const long items = (long)(hi - lo + 1) * per_row;
-    for (long it = blockIdx.x; it < items; it += gridDim.x) {
-        const int srow = lo + (int)(it / per_row), x = (int)(it % per_row) * 256 + threadIdx.x;
-        if (x >= g.sx) continue;
-        int y = srow - g.oy; // the window row stored there (storage_index's inverse)
-        y += y < 0 ? g.sy : 0;
-        finalize_cell(g, x, y, inc, dec, minp, num_pts, occ);
-    }
+    finalize_rows<false>(g, lo, hi, inc, dec, minp, num_pts, occ);
 }
 
 // slam_grid_finalize_reset: finalize_rows_kernel that also zeroes the counts it has just folded (what slam_grid_reset_counts
@@ -917,18 +978,7 @@ __global__ __launch_bounds__(256) void finalize_reset_rows_kernel(GridView g, do
         next[3] = t_nhi;
     }
     if (hi < lo) return;
-    const int  per_row = (g.sx + 255) / 256;
-    const long items = (long)(hi - lo + 1) * per_row;
-    for (long it = blockIdx.x; it < items; it += gridDim.x) {
-        const int srow = lo + (int)(it / per_row), x = (int)(it % per_row) * 256 + threadIdx.x;
-        if (x >= g.sx) continue;
-        int y = srow - g.oy; // the window row stored there (storage_index's inverse)
-        y += y < 0 ? g.sy : 0;
-        finalize_cell(g, x, y, inc, dec, minp, num_pts, occ);
-        const int s = storage_index(g, x, y);
-        if (g.hits[s]) g.hits[s] = 0;
-        if (g.misses[s]) g.misses[s] = 0;
-    }
+    finalize_rows<true>(g, lo, hi, inc, dec, minp, num_pts, occ);
 }
 
 __global__ __launch_bounds__(256) void gather_counts_kernel(GridView g, int32_t *hits_w, int32_t *misses_w)
