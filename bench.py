@@ -285,6 +285,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip model build, single scan, streaming and config-3 legs")
     ap.add_argument("--raycast-seg", type=int, default=0, help="slam_grid_params::raycast_seg_items (0 = library default)")
     ap.add_argument("--raycast-wg", type=int, default=0, help="slam_grid_params::raycast_wg_per_cu (0 = library default)")
+    ap.add_argument("--raycast-max-wg", type=int, default=0, help="slam_grid_params::raycast_max_workgroups (0 = no cap)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the grid update of step k-1 with the registration of step k (one stream: a captured "
                          "hipGraph per step at N=1, call by call otherwise)")
@@ -382,7 +383,7 @@ def main():
     batch = synth.make_batch(S, n_loop=S * world, first=rank * S)
     P = batch.n_points
     icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, lanes_per_point=args.lanes, cell_size=args.cell)
-    grid_kw = dict(rolling=0, min_cluster_points=20, raycast_wg_per_cu=args.raycast_wg, raycast_seg_items=args.raycast_seg or 0,
+    grid_kw = dict(rolling=0, min_cluster_points=20, raycast_wg_per_cu=args.raycast_wg, raycast_max_workgroups=args.raycast_max_wg, raycast_seg_items=args.raycast_seg or 0,
                    raycast_impl={"tiled": api.RAYCAST_TILED, "merge": api.RAYCAST_TILED_MERGE, "global": api.RAYCAST_GLOBAL}[args.raycast])
     grid = api.Grid(GRID, GRID, RES, **grid_kw)
     d_pts = api.DeviceArray.from_host(batch.pts, np.float64)

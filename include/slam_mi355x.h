@@ -227,6 +227,7 @@ typedef struct {
                                    on accumulating in the same LDS tile while the tile has blocks left and writes the tile
                                    back when it leaves it); 0 = library default (16); 8 ... 511 */
     int    raycast_wg_per_cu;   /* tiled raycast: persistent workgroups per CU; 0 = library default (two) */
+    int    raycast_max_workgroups; /* tiled raycast: persistent workgroups in all; 0 = no cap (wg_per_cu x CUs) */
 } slam_grid_params;
 
 void slam_grid_default_params(slam_grid_params *p);

@@ -44,7 +44,7 @@ class GridParams(C.Structure):
     _fields_ = [("max_range", C.c_double), ("occupancy_increment", C.c_double),
                 ("occupancy_decrement", C.c_double), ("min_cluster_points", C.c_int),
                 ("rolling", C.c_int), ("raycast_impl", C.c_int), ("raycast_seg_items", C.c_int),
-                ("raycast_wg_per_cu", C.c_int)]
+                ("raycast_wg_per_cu", C.c_int), ("raycast_max_workgroups", C.c_int)]
 
 
 class MapperParams(C.Structure):

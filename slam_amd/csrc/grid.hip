@@ -1183,6 +1183,13 @@ int reserve_beams(slam_grid *g, size_t n)
 // (tools/raycast_time.py, chunks of 16 blocks: config 2 0.110 ms per call with two against 0.131 with one; config 4's share
 // 0.274 against 0.322).
 int raycast_wg_per_cu(const slam_grid *g, int n_tiles) { return g->wg_per_cu > 0 ? g->wg_per_cu : 2; }
+// ... and how many in all: the whole chip, unless the caller caps it (slam_grid_params::raycast_max_workgroups: a raycast that
+// runs beside registrations holds every CU it has a workgroup on for as long as the launch lasts)
+int raycast_workgroups(const slam_grid *g, int n_tiles)
+{
+    const int all = raycast_wg_per_cu(g, n_tiles) * g->n_cu;
+    return g->prm.raycast_max_workgroups > 0 ? std::min(all, g->prm.raycast_max_workgroups) : all;
+}
 
 int walk_beams(slam_grid *g, int n, hipStream_t st)
 {
@@ -1193,7 +1200,7 @@ int walk_beams(slam_grid *g, int n, hipStream_t st)
         int       *item_off = g->d_tile_fill;
         const dim3 tgrid((n_tiles * 64 + 255) / 256);
         const int  chunk = g->seg_items > 0 ? g->seg_items : kChunkDefault;
-        const dim3 rgrid(raycast_wg_per_cu(g, n_tiles) * g->n_cu); // persistent workgroups (66 KB of LDS each)
+        const dim3 rgrid(raycast_workgroups(g, n_tiles)); // persistent workgroups (75 KB of LDS each)
         g->last_chunks = n_chunks;
         if (n_tiles <= kMaxLdsTiles) {
             // one pass over the block boxes; the raycast workgroups work the prefix of the tile counts out themselves
@@ -1236,6 +1243,7 @@ void slam_grid_default_params(slam_grid_params *p)
     p->raycast_impl = SLAM_RAYCAST_TILED;
     p->raycast_seg_items = 0;
     p->raycast_wg_per_cu = 0;
+    p->raycast_max_workgroups = 0;
 }
 
 int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_params *params,

@@ -278,3 +278,31 @@ def test_config2_grid_full_size_properties(size, res):
     assert np.array_equal(out[0][0], out[2][0]) and np.array_equal(out[0][1], out[2][1])
     assert out[0][2] == out[1][2] == out[2][2] == out[0][0].sum() + out[0][1].sum()
     assert out[0][0].sum() == batch.n_points          # every beam ends inside this grid
+
+
+@pytest.mark.parametrize("seg,wg,cap", [(8, 1, 0), (16, 2, 0), (64, 2, 0), (511, 2, 0), (16, 2, 3), (8, 1, 1), (300, 1, 40)])
+def test_raycast_launch_shapes_are_invisible(seg, wg, cap):
+    """The tiled raycast's work distribution -- blocks a workgroup takes from a tile's list at a time (8 ... 511: with 511 a
+    visit's chunk log holds two chunks, so a tile is written back and revisited after every second), workgroups per CU,
+    workgroups in all (down to ONE, which then walks every tile by itself) -- changes who adds what, never the sums: counts
+    equal the global-atomics form's on 96 scans in a 1500 x 1500 grid, twice over (the second pass starts from used cursors)."""
+    batch = synth.make_batch(96, n_loop=256)
+    Rt = [synth.pose_to_Rt(*p) for p in batch.true_poses]
+    R = np.stack([r.reshape(4) for r, _ in Rt])
+    t = np.stack([tt for _, tt in Rt])
+    d = [api.DeviceArray.from_host(a, dt) for a, dt in ((batch.pts, np.float64), (batch.scan_off, np.int32), (R, np.float64), (t, np.float64))]
+    ref = api.Grid(1500, 1500, 0.05, rolling=0, min_cluster_points=20, raycast_impl=api.RAYCAST_GLOBAL)
+    ref.raycast_scans_dev(d[0], d[1], batch.n_scans, batch.n_points, d[2], d[3])
+    api.synchronize()
+    H, M = ref.read_counts()
+    ref.close()
+    g = api.Grid(1500, 1500, 0.05, rolling=0, min_cluster_points=20, raycast_seg_items=seg, raycast_wg_per_cu=wg, raycast_max_workgroups=cap)
+    for rep in (1, 2):
+        g.raycast_scans_dev(d[0], d[1], batch.n_scans, batch.n_points, d[2], d[3])
+        api.synchronize()
+        h, m = g.read_counts()
+        assert np.array_equal(h, rep * H) and np.array_equal(m, rep * M), (seg, wg, cap, rep)
+    st = g.raycast_stats()
+    assert st["items"] > 0 and st["tile_write_backs"] >= 1
+    assert g.total_updates() == 2 * (int(H.sum()) + int(M.sum()))
+    g.close()
