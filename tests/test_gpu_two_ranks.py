@@ -78,28 +78,29 @@ def union_oracle(res, rolling):
     return H.reshape(-1), M.reshape(-1), occ, (cx, cy)
 
 
-@pytest.mark.parametrize("mode", ["fixed", "rolling"])
-def test_mapper_two_ranks_rehearsal_on_one_gpu(mode, tmp_path):
+@pytest.mark.parametrize("mode,world", [("fixed", 2), ("rolling", 2), ("fixed", 3)])
+def test_mapper_two_ranks_rehearsal_on_one_gpu(mode, world, tmp_path):
     import mp_mapper_rank as W
-    res = run_ranks(mode, tmp_path)
+    res = run_ranks(mode, tmp_path, world)
     for r in res:
         assert str(r["error"]) == "", str(r["error"])
-    a, b = res
+    a, b = res[0], res[-1]
     # every rank ends with the merged map
-    assert np.array_equal(a["hits"], b["hits"]) and np.array_equal(a["misses"], b["misses"]) and np.array_equal(a["occ"], b["occ"])
+    for other in res[1:]:
+        assert np.array_equal(a["hits"], other["hits"]) and np.array_equal(a["misses"], other["misses"]) and np.array_equal(a["occ"], other["occ"])
     # each rank registered its own scans: against the oracle on the same target
     m_ga, m_nga = synth.make_map(10000)
     full = synth.make_batch(W.N_SCANS, n_loop=256)
     model = O.IcpModel(m_ga, m_nga)
     for k, r in enumerate(res):
-        mine = full.shard(k, 2)
+        mine = full.shard(k, world)
         Ro, to, _, _, _ = model.fit_batch(mine.pts, mine.scan_off, mine.scan_nga, mine.R, mine.t, O.icp_params(20, 1e-6, 5.0))
         assert np.abs(r["t"] - to).max() < 1e-4 and np.abs(r["R"] - Ro).max() < 1e-5
     H, M, occ, pose = union_oracle(res, mode == "rolling")
     assert H.sum() > 0
     assert np.array_equal(a["hits"], H) and np.array_equal(a["misses"], M)      # both ranks' updates, each exactly once
     assert np.array_equal(a["occ"], occ)
-    n_chunks = W.N_SCANS // 2 // W.CHUNK
+    n_chunks = W.N_SCANS // world // W.CHUNK
     assert int(a["merges"]) == n_chunks // W.MERGE_EVERY + 1                     # every second chunk, and once more at finish
     if mode == "rolling":
         assert tuple(a["pose"]) == pose and tuple(b["pose"]) == pose
