@@ -279,7 +279,9 @@ int slam_grid_raycast_scans_dev(slam_grid_t *g, const double *d_pts, const int32
 int slam_grid_finalize(slam_grid_t *g, slam_stream_t stream);
 /* slam_grid_finalize followed by slam_grid_reset_counts, in one pass over the rows and one launch: what a batch step
  * ends with (fold this batch's counts into evidence and occupancy, leave the count planes zero for the next batch;
- * the accumulator planes, if any, are not touched).  Same evidence and occupancy as the two calls. */
+ * the accumulator planes, if any, are not touched).  Same evidence and occupancy as the two calls.  It alternates between two
+ * row-range buffers from call to call, so it must not be recorded into a hipGraph that is replayed (slam_graph_*): a captured
+ * step keeps slam_grid_finalize + slam_grid_reset_counts. */
 int slam_grid_finalize_reset(slam_grid_t *g, slam_stream_t stream);
 
 /* One scan with the reference's own ordering and rounding (mls.cpp:73-142):

@@ -298,9 +298,17 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
     *redo_flags = flags + n_scans;
     std::lock_guard<std::mutex> lk(g_spread_mu);
     hipEvent_t &done = g_spread_done[dev & 15];
+    // (a stream that is being captured into a hipGraph may neither wait for an event of uncaptured work nor lend its own to
+    // other streams: a captured spread launch is ordered by its graph alone -- if it ever meets another one, the redo path covers it)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusNone;
+    }
+    const bool ordered = cap == hipStreamCaptureStatusNone;
     if (!done)
         SLAM_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-    else
+    else if (ordered)
         SLAM_HIP(hipStreamWaitEvent(st, done, 0)); // behind the spread launch before this one, on whatever stream it went
     // per scene point, what its last search left for the next (positions beyond the buffer search unseeded)
     const int qcap = std::max(h->spread_points_hint, 1 << 16);
@@ -327,7 +335,7 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
         hipLaunchKernelGGL((icp_fit_spread_kernel<uint16_t, false>), grid, dim3(kSB), kScratchBytes, st, h->mv, fa, gran, flags, first_ticks, qstate, qcap, wide_max);
     }
     SLAM_HIP(hipGetLastError());
-    SLAM_HIP(hipEventRecord(done, st));
+    if (ordered) SLAM_HIP(hipEventRecord(done, st));
     return SLAM_OK;
 }
 
