@@ -278,6 +278,8 @@ def main():
     ap.add_argument("--thin", type=float, default=0.1, help="config 5: pitch of the window's thinning lattice in metres (0 = stride)")
     ap.add_argument("--rebuild-every", type=int, default=4, help="config 5: chunks between rebuilds of the target")
     ap.add_argument("--merge-every", type=int, default=8, help="config 5: chunks between merges over the GPUs + finalize")
+    ap.add_argument("--reg-streams", type=int, default=0, help="config 5: slam_mapper_params::registration_streams (0 = library default)")
+    ap.add_argument("--slots", type=int, default=0, help="config 5: slam_mapper_params::slots (0 = library default)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per scan point (0 = library default)")
     ap.add_argument("--cell", type=float, default=0.0, help="ICP cell pitch in metres (0 = library default)")
     ap.add_argument("--raycast", choices=["tiled", "merge", "global"], default="tiled")
@@ -733,7 +735,7 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, ba
     mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=GRID, grid_size_y=GRID,
                     resolution=RES, max_scans=chunk, max_points=max(c.n_points for c in chunks), icp=dict(max_iter=N_ITERS, min_delta=-1.0),
                     window_chunks=args.window, rebuild_every=args.rebuild_every, keep_prior=1, target_points=5000,
-                    thin_res=args.thin, merge_every=args.merge_every)
+                    thin_res=args.thin, merge_every=args.merge_every, registration_streams=args.reg_streams, slots=args.slots)
     if comm is not None:
         mp.use_comm(comm)
     for s in [mp.push(base) for _ in range(mp.n_slots)]:

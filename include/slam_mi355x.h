@@ -503,6 +503,7 @@ typedef struct {
     int    background_rebuild; /* 1 (default) = the sliding target is rebuilt on a thread of the mapper's own and adopted
                                   by the first push after it is complete (a push waits for it only when the next rebuild
                                   is due or after min(rebuild_every, 4) pushes); 0 or strict_window = inside the push */
+    int    registration_streams; /* 0 = default (two in turn, scans in pairs, for a fixed target; one for a sliding target), 1, 2 */
 } slam_mapper_params;
 
 void slam_mapper_default_params(slam_mapper_params *p);

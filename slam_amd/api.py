@@ -52,7 +52,7 @@ class MapperParams(C.Structure):
                 ("icp", IcpParams), ("indist", C.c_double), ("max_scans", C.c_int), ("max_points", C.c_int),
                 ("window_chunks", C.c_int), ("rebuild_every", C.c_int), ("target_points", C.c_int),
                 ("keep_prior", C.c_int), ("merge_every", C.c_int), ("pipelined", C.c_int), ("strict_window", C.c_int),
-                ("slots", C.c_int), ("thin_res", C.c_double), ("background_rebuild", C.c_int)]
+                ("slots", C.c_int), ("thin_res", C.c_double), ("background_rebuild", C.c_int), ("registration_streams", C.c_int)]
 
 
 class GsegParams(C.Structure):

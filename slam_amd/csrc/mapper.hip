@@ -189,6 +189,7 @@ struct slam_mapper {
     hipStream_t        copy = nullptr, icp_s[2] = {nullptr, nullptr}, grid_s = nullptr; // chunks alternate over the two icp streams
     Slot               slot[kMaxSlots];
     int                n_slots = 5;
+    bool               two_lanes = false;      // chunks alternate over two registration streams
     int                next = 0;
     long               chunks = 0, merges = 0, rebuilds = 0, last_rebuild = -1;
     std::vector<WindowEntry> window;
@@ -507,6 +508,7 @@ void slam_mapper_default_params(slam_mapper_params *p)
     p->thin_res = 0.0;
     p->slots = 0;
     p->background_rebuild = 1;
+    p->registration_streams = 0;
 }
 
 int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int n_ga, const double *m_nga, int n_nga,
@@ -527,7 +529,8 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
         // slowest scan (256-scan chunks: 0.41 -> 0.36 ms).  Below half a scan per CU two chunks fit side by side anyway.
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            params->pipelined && !params->window_chunks && m->prm.icp.pair_scans == 0 && 2 * params->max_scans > cus)
+            params->pipelined && (params->registration_streams == 2 || (!params->window_chunks && params->registration_streams == 0)) &&
+            m->prm.icp.pair_scans == 0 && 2 * params->max_scans > cus)
             m->prm.icp.pair_scans = 2;
         (void)hipGetLastError();
     }
@@ -552,12 +555,11 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
             hip(hipDeviceGetStreamPriorityRange(&least, &greatest));
             const int mid = (least + greatest) / 2;
             hip(hipStreamCreateWithPriority(&m->copy, hipStreamNonBlocking, greatest));
+            m->two_lanes = params->registration_streams == 2 || (params->registration_streams == 0 && !params->window_chunks);
             hip(hipStreamCreateWithPriority(&m->icp_s[0], hipStreamNonBlocking, mid));
             hip(hipStreamCreateWithPriority(&m->grid_s, hipStreamNonBlocking, least));
-            if (params->window_chunks)
-                m->icp_s[1] = m->icp_s[0]; // a sliding target registers its chunks one after the other (slam_mapper_push)
-            else
-                hip(hipStreamCreateWithPriority(&m->icp_s[1], hipStreamNonBlocking, mid));
+            if (m->two_lanes) hip(hipStreamCreateWithPriority(&m->icp_s[1], hipStreamNonBlocking, mid));
+            if (!m->two_lanes) m->icp_s[1] = m->icp_s[0]; // a sliding target registers its chunks one after the other (slam_mapper_push)
         } else {
             hip(hipStreamCreateWithFlags(&m->copy, hipStreamNonBlocking));
             m->icp_s[0] = m->icp_s[1] = m->grid_s = m->copy;
@@ -723,7 +725,7 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     // (and so do the chunks of a sliding target: a chunk registered beside its predecessor meets a window that is a chunk
     // staler, and every further chunk in flight costs more than the overlap gains -- config 5: 0.54 ms per chunk on one
     // stream, 0.51 / 0.53 / 0.56 on two with three / four / five chunks in flight)
-    const int   lane = (m->prm.window_chunks || slam::icp::takes_spread_form(m->target, n_scans)) ? 0 : (int)(m->chunks & 1);
+    const int   lane = (!m->two_lanes || slam::icp::takes_spread_form(m->target, n_scans)) ? 0 : (int)(m->chunks & 1);
     hipStream_t icp_s = m->icp_s[lane];
     MAP_HIP(hipStreamWaitEvent(icp_s, b.copied, 0));
     SLAM_TRY(slam_icp_fit_batch_dev(m->target, b.d_pts, b.d_off, b.d_nga, n_scans, b.d_R, b.d_t, m->prm.indist, nullptr, nullptr,
