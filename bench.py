@@ -708,6 +708,11 @@ def main():
                                             ("value", "ms_per_step", "grid_cell_updates_per_s", "cell_updates_per_step", "kernel_ms", "max_pose_error_m"))
             out["config5"] = side_run(["--config", "5", "--stream-scans", "4096"],
                                       ("value", "ms_per_step", "steps", "grid_cell_updates_per_s", "max_pose_error_m"))
+            # the N > 1 path with two ranks on THIS GPU: bench.py launching its own ranks, the library's merge entry points over
+            # its host-staged communicator (gloo carries the host buffers; RCCL does not put two ranks on one device).  Not a
+            # scaling number -- two ranks share one chip and stage through the host -- but the same code path as --gpus N.
+            out["two_ranks_on_one_gpu"] = side_run(["--gpus", "2", "--backend", "gloo", "--one-device", "--steps", "6", "--warmup", "2",
+                                                    "--no-cpu-baseline"], ("n_gpus", "value", "ms_per_step", "cell_updates_per_step"))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(m_ga, m_nga, batch, GRID, RES)
         print(json.dumps(out), flush=True)
