@@ -519,7 +519,9 @@ int  slam_mapper_chunk_buffers(slam_mapper_t *m, int slot, double **pts, int32_t
                                double **R0, double **t0);
 /* enqueues the chunk in the next slot and returns at once; window_x/y: where a rolling grid is centred for it */
 int  slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_x, double window_y, int *slot);
-/* blocks until the chunk last pushed into `slot` is registered and mapped; its poses to host memory (optional) */
+/* blocks until the chunk last pushed into `slot` is registered and mapped; its poses to host memory (optional).  (The poses
+ * come back through the slot's pinned R0 / t0 buffers, which hold the REGISTERED poses from here until the producer fills
+ * them for the slot's next chunk.) */
 int  slam_mapper_wait(slam_mapper_t *m, int slot, double *R_out, double *t_out);
 /* last merge (if a communicator is installed), finalize, and waits for everything */
 int  slam_mapper_finish(slam_mapper_t *m);

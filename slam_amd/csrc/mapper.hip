@@ -702,12 +702,13 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     const int n_ga = b.h_gab[n_scans], n_nga = n_points - n_ga;
 
     // ---- sliding target: rebuilt before this chunk's registration is enqueued
+    bool       post_at_end = false;
     const bool due = m->prm.window_chunks && m->chunks > 0 && m->chunks - std::max<long>(m->last_rebuild, 0) >= m->prm.rebuild_every;
     if (m->max_lag) {
         // a finished background build becomes the target of this chunk; one still running is waited for only when the
         // pushes since its post are about to reach the window entries it reads, or when the next one is due
         SLAM_TRY(collect_job(m, m->job_in_flight && (due || m->chunks - m->job_chunk >= m->max_lag)));
-        if (due && !m->job_in_flight) SLAM_TRY(post_job(m));
+        post_at_end = due && !m->job_in_flight; // posted behind this chunk's copy (below): the rebuild's kernels share the copy stream
     } else if (due) {
         SLAM_TRY(rebuild_target(m));
     }
@@ -720,6 +721,10 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     MAP_HIP(hipMemcpyAsync(b.d_R, b.h_R, 32 * (size_t)n_scans, hipMemcpyHostToDevice, m->copy));
     MAP_HIP(hipMemcpyAsync(b.d_t, b.h_t, 16 * (size_t)n_scans, hipMemcpyHostToDevice, m->copy));
     MAP_HIP(hipEventRecord(b.copied, m->copy));
+    // The background rebuild is posted HERE, behind this chunk's copy: its seventeen short launches run on the copy stream and
+    // each waits for a CU behind the registration's workgroups; posted before the copy (round 2), the copy -- and with it this
+    // chunk's registration -- sat behind the rebuild's first stage (a 0.5 ms hole in the registration stream per rebuild).
+    if (post_at_end) SLAM_TRY(post_job(m));
     // ---- register
     // chunks alternate over the two registration streams; the spread form (a handful of scans) takes one call at a time
     // (and so do the chunks of a sliding target: a chunk registered beside its predecessor meets a window that is a chunk
@@ -743,6 +748,11 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
         w.chunk = m->chunks;
         MAP_HIP(hipEventRecord(w.ready, icp_s));
     }
+    // the registered poses go back to the slot's pinned pose buffers on THIS stream (12 KB): slam_mapper_wait then needs no
+    // stream of its own -- round 2 read them back on the copy stream and synchronised it, which during a background rebuild
+    // (whose launches share that stream) held the producer for the whole rebuild: a 0.4 ms hole in the registrations per rebuild
+    MAP_HIP(hipMemcpyAsync(b.h_R, b.d_R, 32 * (size_t)n_scans, hipMemcpyDeviceToHost, icp_s));
+    MAP_HIP(hipMemcpyAsync(b.h_t, b.d_t, 16 * (size_t)n_scans, hipMemcpyDeviceToHost, icp_s));
     MAP_HIP(hipEventRecord(b.registered, icp_s));
     // ---- the previous chunk's merge, now that this chunk's registration is in the queue ahead of the wait
     SLAM_TRY(finish_merge(m));
@@ -774,11 +784,10 @@ int slam_mapper_wait(slam_mapper_t *m, int slot, double *R_out, double *t_out)
     SLAM_REQUIRE(m && slot >= 0 && slot < m->n_slots, SLAM_E_INVALID, "slam_mapper_wait: bad arguments");
     Slot &b = m->slot[slot];
     if (!b.busy) return SLAM_OK;
-    MAP_HIP(hipEventSynchronize(b.registered));
-    if (R_out) MAP_HIP(hipMemcpyAsync(R_out, b.d_R, 32 * (size_t)b.n_scans, hipMemcpyDeviceToHost, m->copy));
-    if (t_out) MAP_HIP(hipMemcpyAsync(t_out, b.d_t, 16 * (size_t)b.n_scans, hipMemcpyDeviceToHost, m->copy));
+    MAP_HIP(hipEventSynchronize(b.registered)); // the poses are in the slot's pinned buffers (slam_mapper_push)
+    if (R_out) memcpy(R_out, b.h_R, 32 * (size_t)b.n_scans);
+    if (t_out) memcpy(t_out, b.h_t, 16 * (size_t)b.n_scans);
     MAP_HIP(hipEventSynchronize(b.mapped)); // the slot's device buffers are free again
-    if (R_out || t_out) MAP_HIP(hipStreamSynchronize(m->copy));
     b.busy = false;
     return SLAM_OK;
 }

@@ -28,3 +28,12 @@ print("everything else between %.1f and %.1f us:" % ((a[0] - t0) / 1e3, (b[1] - 
 for e in ev:
     if e[1] > a[0] and e[0] < b[1] and "icp_fit" not in e[2]:
         print("   %-28s start %8.1f end %8.1f dur %6.1f queue %s" % (e[2], (e[0] - t0) / 1e3, (e[1] - t0) / 1e3, (e[1] - e[0]) / 1e3, e[3]))
+print("compact view (I = registration, R = raycast, c = copyBuffer, f = fill, w = window_points, . = a rebuild kernel) from %.1f us:" % 0.0)
+line = []
+for e in ev:
+    if e[0] < t0 or e[0] > t0 + 6000e3:
+        continue
+    n = e[2]
+    tag = "I" if "icp_fit" in n else ("R" if "raycast" in n else ("c" if "copyBuffer" in n else ("f" if "fillBuffer" in n else ("w" if "window_points" in n else ("b" if "beams" in n or "tile_items" in n else ".")))))
+    line.append("%s%.0f-%.0f" % (tag, (e[0] - t0) / 1e3, (e[1] - t0) / 1e3))
+print(" ".join(line))
