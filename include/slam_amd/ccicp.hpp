@@ -247,6 +247,7 @@ public:
         return n_scene_;
     }
     int lastIterations() const { return last_iters_; }
+    int stepwiseMatches() const { return stepwise_matches_; } // matches redone through the stepwise entry points (lattice beyond the chain's)
     int targetBuilds() const { return target_builds_; } // how often the target's index was built (it is kept across matches)
 
     RegistrationType type;
@@ -419,6 +420,7 @@ private:
     // 2 M voxels: d_counts[3] said that this cloud's lattice does not fit)
     Pose match_stepwise(const Pose &initPose, double yaw0, double pitch0, double roll0)
     {
+        ++stepwise_matches_;
         raw_n_ = scene_n_in_, raw_stride_ = scene_stride_;
         std::swap(raw_, scene_raw_);
         reserve(labels_, (size_t)raw_n_ + 16);
@@ -479,7 +481,7 @@ private:
     slam_stream_t stream_ = nullptr;
     Cloud         raw_, scene_raw_, labels_, obs_, flags_, seg_target_, seg_scene_, ground_target_, ground_scene_, scene_ground_;
     int           raw_n_ = 0, raw_stride_ = 3, obs_n_ = 0, seg_target_n_ = 0, seg_scene_n_ = 0, ground_target_n_ = 0,
-        ground_scene_n_ = 0, num_corr_ = 0, last_iters_ = 0, scene_n_in_ = 0, scene_stride_ = 3, target_in_box_ = 0, target_builds_ = 0;
+        ground_scene_n_ = 0, num_corr_ = 0, last_iters_ = 0, scene_n_in_ = 0, scene_stride_ = 3, target_in_box_ = 0, target_builds_ = 0, stepwise_matches_ = 0;
     int     n_model_[2] = {0, 0}, n_scene_[2] = {0, 0};
     bool    target_dirty_ = true, scene_ready_ = false, scene_known_ = false, seg_scene_valid_ = false, ground_scene_valid_ = false;
     float   ext_[4] = {0, 0, 0, 0};       // x_lo, x_hi, y_lo, y_hi of the target's finite points

@@ -41,13 +41,13 @@ int main(int argc, char **argv)
     icp.setSceneCloud(scene.data(), (int)scene.size() / 3, 3);                 // :139
     const slam_amd::Pose r = icp.doICPMatch(pose);                             // :159
 
-    const double v[16] = {r.x, r.y, r.z, r.qx, r.qy, r.qz, r.qw, (double)icp.getNumberCorrespondences(),
+    const double v[17] = {r.x, r.y, r.z, r.qx, r.qy, r.qz, r.qw, (double)icp.getNumberCorrespondences(),
                           (double)icp.targetSize(), (double)icp.sceneSize(), (double)icp.groundTargetSize(),
                           (double)icp.groundSceneSize(), (double)icp.modelCounts()[0], (double)icp.modelCounts()[1],
-                          (double)icp.sceneCounts()[0], (double)icp.sceneCounts()[1]};
+                          (double)icp.sceneCounts()[0], (double)icp.sceneCounts()[1], (double)icp.stepwiseMatches()};
     FILE *f = std::fopen(out.c_str(), "wb");
     if (!f) return 2;
-    std::fwrite(v, 8, 16, f);
+    std::fwrite(v, 8, 17, f);
     std::fclose(f);
     // getSegmentedClouds (icpTools.cpp:644-650, scan_registration.cpp:142): four clouds of the sizes reported above
     std::vector<float> c_target, c_scene, c_gt, c_gs;

@@ -91,15 +91,22 @@ def _quat_rpy(roll, pitch, yaw):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rtype", [0, 1])
-def test_ccicp_facade_matches_oracle_chain(tmp_path, rtype):
+@pytest.mark.parametrize("rtype,tall", [(0, False), (1, False), (0, True)])
+def test_ccicp_facade_matches_oracle_chain(tmp_path, rtype, tall):
     """CCICP::doICPMatch(initPose) end to end (icpTools.cpp:222-298): two 131 k-ray clouds in, pose out,
-    against the same chain made of oracle pieces."""
+    against the same chain made of oracle pieces.  tall: a few returns 70 m above the sensor make the scene's voxel lattice
+    larger than the device-resident chain's accumulator (2 M voxels): the adapter redoes that match through the stepwise
+    entry points -- the same numbers must come out."""
     exe = compile_cpp(str(tmp_path), "ccicp_test")
     d = str(tmp_path)
     ka, kb = 3, 4
     A, pa = synth.make_cloud3d(ka, n_loop=50)
     B, pb = synth.make_cloud3d(kb, n_loop=50)
+    if tall:
+        # clusters (a polar bin keeps its points only from six on) far out and high up (overhead returns): 265 x 245 x 37 voxels of 0.5 x 0.5 x 2 m
+        rs = np.random.RandomState(2)
+        extra = [c + rs.uniform(-0.1, 0.1, (10, 3)) for c in ([66.0, 61.0, 30.0], [-66.0, -61.0, 28.0], [66.0, -61.0, 25.0], [-66.0, 61.0, 31.0], [3.0, 4.0, 72.0])]
+        B = np.ascontiguousarray(np.concatenate([B] + extra).astype(np.float32))
     ca, sa = np.cos(pa[2]), np.sin(pa[2])
     rel = np.array([ca * (pb[0] - pa[0]) + sa * (pb[1] - pa[1]), -sa * (pb[0] - pa[0]) + ca * (pb[1] - pa[1])])
     rel_th = pb[2] - pa[2]
@@ -129,6 +136,7 @@ def test_ccicp_facade_matches_oracle_chain(tmp_path, rtype):
     s_ga, s_nga = O.ccicp_split(seg_scene, None)
     gnd_scene, n_gvox = O.voxel_downsample(np.concatenate([B[lab_b == O.GSEG_GROUND], np.zeros((int((lab_b == O.GSEG_GROUND).sum()), 1), np.float32)], 1), (0.5, 0.5, 5.0))
     assert list(got[8:16]) == [len(seg_target), n_vox, len(gnd_a), n_gvox, len(m_ga), len(m_nga), len(s_ga), len(s_nga)]
+    assert int(got[16]) == (1 if tall else 0)        # the tall scene went through the stepwise entry points, the others through the chain
     scene_xyz = np.fromfile(out + ".scene", np.float32).reshape(-1, 3)      # getSegmentedClouds: the voxel-filtered scene
     assert len(scene_xyz) == n_vox and np.abs(scene_xyz - seg_scene[:, :3]).max() < 1e-4
     assert len(s_ga) + len(s_nga) > 300 and len(m_ga) + len(m_nga) > 5000
