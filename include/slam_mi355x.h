@@ -271,6 +271,10 @@ int slam_grid_raycast_dev(slam_grid_t *g, const float *d_origin_xy, const float 
 int slam_grid_raycast_scans_dev(slam_grid_t *g, const double *d_pts, const int32_t *d_scan_off,
                                 int n_scans, int n_points, const double *d_R, const double *d_t,
                                 slam_stream_t stream);
+/* Reserves the raycast's scratch (beams, block boxes, work list) for calls of up to max_beams beams.  A raycast call
+ * that finds its scratch too small grows it -- which frees the old block, and a free waits for the whole device: a
+ * caller that streams batches of varying size (slam_mapper_* does this itself from max_points) reserves once instead. */
+int slam_grid_reserve(slam_grid_t *g, int max_beams);
 
 /* Folds the counts gathered since the last finalize into the per-cell evidence
  * value (Cluster::num_pts) and the occupancy byte by SURVEY 8(a) G3:

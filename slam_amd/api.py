@@ -89,7 +89,7 @@ EXPORTS = [
     "slam_grid_default_params", "slam_grid_create", "slam_grid_destroy", "slam_grid_clear", "slam_grid_reset_counts",
     "slam_grid_set_min_cluster_points", "slam_grid_set_max_range", "slam_grid_set_pose",
     "slam_grid_get_pose", "slam_grid_add_endpoints", "slam_grid_add_endpoints_dev",
-    "slam_grid_raycast", "slam_grid_raycast_dev", "slam_grid_raycast_scans_dev",
+    "slam_grid_raycast", "slam_grid_raycast_dev", "slam_grid_raycast_scans_dev", "slam_grid_reserve",
     "slam_grid_finalize", "slam_grid_finalize_reset", "slam_grid_add_scan_inorder", "slam_grid_add_scan_inorder_dev", "slam_grid_read_counts",
     "slam_grid_read_occupancy", "slam_grid_read_num_pts", "slam_grid_total_updates",
     "slam_grid_info", "slam_grid_window_cell", "slam_grid_counts_dev", "slam_grid_mark_rows", "slam_grid_raycast_stats", "slam_grid_dirty_rows", "slam_grid_dirty_rows_dev",
@@ -201,6 +201,7 @@ def lib():
     L.slam_grid_raycast.argtypes = [_vp, _vp, _vp, C.c_int]
     L.slam_grid_raycast_dev.argtypes = [_vp, _vp, _vp, C.c_int, _vp]
     L.slam_grid_raycast_scans_dev.argtypes = [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]
+    L.slam_grid_reserve.argtypes = [_vp, C.c_int]
     L.slam_grid_finalize.argtypes = [_vp, _vp]
     L.slam_grid_finalize_reset.argtypes = [_vp, _vp]
     L.slam_grid_add_scan_inorder.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int]
@@ -653,6 +654,9 @@ class Grid:
     def raycast_scans_dev(self, d_pts, d_off, n_scans, n_points, d_R, d_t, stream=None):
         check(lib().slam_grid_raycast_scans_dev(self.h, d_pts.ptr, d_off.ptr, int(n_scans),
                                                 int(n_points), d_R.ptr, d_t.ptr, _sp(stream)))
+
+    def reserve(self, max_beams):
+        check(lib().slam_grid_reserve(self.h, int(max_beams)))
 
     def finalize(self, stream=None):
         check(lib().slam_grid_finalize(self.h, _sp(stream)))

@@ -27,6 +27,10 @@ void  pool_trim(); // hipFree of everything cached
 // One pinned host buffer per host thread (grown on demand, never freed), for a call's staging and read-back;
 // valid until the same thread asks again.
 void *pinned_scratch(size_t bytes);
+// Pinned blocks that outlive the call (an index build's plan travels back while the caller goes on): taken from and
+// returned to a free list, never given back to the runtime.  At most 16 KB each.
+void *pinned_block_get(size_t bytes);
+void  pinned_block_put(void *p);
 // The stream the index build and the mapper's target rebuild run on: one per device, created on first use at the
 // highest priority level and never destroyed.  A level of its own, because HIP deals the streams of one level over a
 // few hardware queues shared in creation order: on the default stream the build's dozen short kernels and three host

@@ -1140,10 +1140,11 @@ namespace {
 int reserve(void **p, size_t *cap, size_t bytes)
 {
     if (bytes <= *cap) return SLAM_OK;
-    if (*p) (void)hipFree(*p);
+    if (*p) (void)hipFree(*p); // (waits for the device: callers with varying sizes reserve up front, slam_grid_reserve)
+    const size_t grown = *cap + *cap / 4;
     *p = nullptr;
     *cap = 0;
-    size_t want = std::max(bytes, (size_t)4096);
+    size_t want = std::max(std::max(bytes, grown), (size_t)4096);
     SLAM_HIP(hipMalloc(p, want));
     *cap = want;
     return SLAM_OK;
@@ -1538,6 +1539,12 @@ int slam_grid_raycast(slam_grid_t *g, const float *origin_xy, const float *end_x
     SLAM_TRY(slam_grid_raycast_dev(g, d_o, d_e, n, nullptr));
     SLAM_HIP(hipStreamSynchronize(nullptr));
     return SLAM_OK;
+}
+
+int slam_grid_reserve(slam_grid_t *g, int max_beams)
+{
+    SLAM_REQUIRE(g && max_beams >= 0, SLAM_E_INVALID, "slam_grid_reserve: bad arguments");
+    return max_beams ? reserve_beams(g, (size_t)max_beams) : SLAM_OK;
 }
 
 int slam_grid_raycast_scans_dev(slam_grid_t *g, const double *d_pts, const int32_t *d_scan_off, int n_scans,

@@ -1225,17 +1225,10 @@ void slam_icp_default_params(slam_icp_params *p)
 
 namespace {
 
-// Icp::Icp, icp.cpp:26-70; the model arrays are host memory unless on_device
-int icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga, const slam_icp_params *params, bool on_device,
-               slam_icp_t **out)
+// the handle of Icp::Icp (icp.cpp:26-70) before its index exists
+int icp_new(const slam_icp_params *params, bool on_device, slam_icp **out)
 {
-    SLAM_REQUIRE(out, SLAM_E_INVALID, "slam_icp_create: null out pointer");
     *out = nullptr;
-    SLAM_REQUIRE(n_ga >= 0 && n_nga >= 0 && (m_ga || n_ga == 0) && (m_nga || n_nga == 0),
-                 SLAM_E_INVALID, "slam_icp_create: bad model arrays");
-    // icp.cpp:38-43 "LIBICP works only with at least 5 model points"
-    SLAM_REQUIRE(n_ga + n_nga >= 5, SLAM_E_TOO_FEW_MODEL_POINTS,
-                 "LIBICP works only with at least 5 model points (got %d)", n_ga + n_nga);
     SLAM_TRY(require_device());
     slam_icp *h = new (std::nothrow) slam_icp();
     SLAM_REQUIRE(h, SLAM_E_NOMEM, "slam_icp_create: out of host memory");
@@ -1272,7 +1265,28 @@ int icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga, con
         set_error("slam_icp_create_dev: the point-to-line mode takes its model from host arrays");
         rc = SLAM_E_UNSUPPORTED;
     }
-    if (rc == SLAM_OK) rc = build_index(h, m_ga, n_ga, m_nga, n_nga, on_device);
+    if (rc != SLAM_OK) {
+        slam_icp_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return SLAM_OK;
+}
+
+// Icp::Icp, icp.cpp:26-70; the model arrays are host memory unless on_device
+int icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga, const slam_icp_params *params, bool on_device,
+               slam_icp_t **out)
+{
+    SLAM_REQUIRE(out, SLAM_E_INVALID, "slam_icp_create: null out pointer");
+    *out = nullptr;
+    SLAM_REQUIRE(n_ga >= 0 && n_nga >= 0 && (m_ga || n_ga == 0) && (m_nga || n_nga == 0),
+                 SLAM_E_INVALID, "slam_icp_create: bad model arrays");
+    // icp.cpp:38-43 "LIBICP works only with at least 5 model points"
+    SLAM_REQUIRE(n_ga + n_nga >= 5, SLAM_E_TOO_FEW_MODEL_POINTS,
+                 "LIBICP works only with at least 5 model points (got %d)", n_ga + n_nga);
+    slam_icp *h = nullptr;
+    SLAM_TRY(icp_new(params, on_device, &h));
+    int rc = build_index(h, m_ga, n_ga, m_nga, n_nga, on_device);
     if (rc == SLAM_OK && h->prm.mode == SLAM_ICP_P2L) rc = compute_normals(h, m_ga, n_ga, m_nga, n_nga);
     if (rc != SLAM_OK) {
         slam_icp_destroy(h);
@@ -1283,6 +1297,37 @@ int icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga, con
 }
 
 } // namespace
+
+namespace slam {
+namespace icp {
+
+int create_begin(const double *d_ga, int cap_ga, const double *d_nga, int cap_nga, const int *d_cnt, const slam_icp_params *params,
+                 hipStream_t st, slam_icp **out)
+{
+    SLAM_REQUIRE(out && cap_ga >= 0 && cap_nga >= 0 && (d_ga || cap_ga == 0) && (d_nga || cap_nga == 0), SLAM_E_INVALID,
+                 "create_begin: bad model arrays");
+    slam_icp *h = nullptr;
+    SLAM_TRY(icp_new(params, true, &h));
+    const int rc = build_index_begin(h, d_ga, cap_ga, d_nga, cap_nga, d_cnt, true, st);
+    if (rc != SLAM_OK) {
+        slam_icp_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return SLAM_OK;
+}
+
+bool create_ready(slam_icp *h) { return build_index_ready(h); }
+
+int create_finish(slam_icp *h)
+{
+    const int rc = build_index_finish(h);
+    if (rc != SLAM_OK) slam_icp_destroy(h);
+    return rc;
+}
+
+} // namespace icp
+} // namespace slam
 
 extern "C" {
 

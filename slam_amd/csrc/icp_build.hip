@@ -25,7 +25,7 @@ using namespace slam::icp;
 
 namespace {
 
-inline unsigned align16(unsigned v) { return (v + 15u) & ~15u; }
+__host__ __device__ inline unsigned align16(unsigned v) { return (v + 15u) & ~15u; }
 
 struct BBox {
     float  lo[2] = {FLT_MAX, FLT_MAX}, hi[2] = {-FLT_MAX, -FLT_MAX};
@@ -33,11 +33,25 @@ struct BBox {
     size_t nfin = 0;
 };
 
-// ------------------------------------------------------------------ planning (host; shared by both builds)
+// ------------------------------------------------------------------ planning
+// One set of expressions for the host build and for the device build's plan kernels (which run them on the device, so that
+// the build needs the host only once, at its end): no FMA contraction, IEEE division and square root on both sides.
 
-// Lattice, blob layout and the LDS decision from the model's extent.
-int plan_index(slam_icp *h, int n_ga, int n_nga, BBox bb, unsigned *lds_total_out, float *maxabs_out)
+// Lattice, blob layout and the LDS decision from the model's extent and counts.
+struct IndexPlan {
+    Lattice  lat;
+    int      n_cls[2], base[2];
+    double   cx, cy;
+    unsigned off_pts, off_start[2], off_oidx, blob_bytes;
+    int      in_lds, start32;
+    unsigned lds_bytes;
+    float    maxabs;
+    int      ncells;
+};
+
+__host__ __device__ inline IndexPlan plan_core(int n_ga, int n_nga, BBox bb, double cell_size, int force_global, unsigned lds_total)
 {
+#pragma clang fp contract(off)
     if (bb.nfin == 0) {
         bb.lo[0] = bb.lo[1] = 0.f;
         bb.hi[0] = bb.hi[1] = 1.f;
@@ -45,74 +59,121 @@ int plan_index(slam_icp *h, int n_ga, int n_nga, BBox bb, unsigned *lds_total_ou
     }
     const float *lo = bb.lo, *hi = bb.hi;
     const int    n_all = n_ga + n_nga;
-    const int    max_cls = std::max(n_ga, n_nga);
-
-    int lds_cap = 0;
-    int dev = 0;
-    SLAM_HIP(hipGetDevice(&dev));
-    SLAM_HIP(hipDeviceGetAttribute(&lds_cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
-    const unsigned lds_total = std::min<unsigned>((unsigned)lds_cap, kLdsTotal);
+    const int    max_cls = n_ga > n_nga ? n_ga : n_nga;
     const unsigned scratch = kScratchBytes;
 
     // LDS budget for the two start arrays (u16 entries) after points + original indices
     const long fixed16 = (long)scratch + align16(8u * n_all) + align16(2u * n_all) + 64;
     long       cells_lds = ((long)lds_total - fixed16) / (2 * 2) - 1;
-    bool       lds = !h->prm.force_global && max_cls <= 65535 && cells_lds >= 256;
+    bool       lds = !force_global && max_cls <= 65535 && cells_lds >= 256;
 
-    const float w = std::max(hi[0] - lo[0], 1e-3f), ht = std::max(hi[1] - lo[1], 1e-3f);
-    const float maxabs = std::max(std::max(std::fabs(lo[0]), std::fabs(hi[0])),
-                                  std::max(std::fabs(lo[1]), std::fabs(hi[1])));
-    long budget = lds ? cells_lds : std::min<long>(std::max<long>(4L * n_all, 1024), 1L << 22);
+    const float w = hi[0] - lo[0] > 1e-3f ? hi[0] - lo[0] : 1e-3f, ht = hi[1] - lo[1] > 1e-3f ? hi[1] - lo[1] : 1e-3f;
+    const float ax = fabsf(lo[0]) > fabsf(hi[0]) ? fabsf(lo[0]) : fabsf(hi[0]), ay = fabsf(lo[1]) > fabsf(hi[1]) ? fabsf(lo[1]) : fabsf(hi[1]);
+    const float maxabs = ax > ay ? ax : ay;
+    long        hbm = 4L * n_all > 1024 ? 4L * n_all : 1024;
+    if (hbm > (1L << 22)) hbm = 1L << 22;
+    const long budget = lds ? cells_lds : hbm;
     // target about two cells per point on wall-like maps; never more than the budget
-    long want = std::min<long>(budget, std::max<long>(64, 2L * n_all));
-    double hcell = h->prm.cell_size > 0 ? h->prm.cell_size : std::sqrt((double)w * ht / (double)want);
-    hcell = std::max(hcell, (double)maxabs * 1.52587890625e-05 /* 2^-16 */);
-    hcell = std::max(hcell, 1e-4);
+    long want = 2L * n_all > 64 ? 2L * n_all : 64;
+    if (want > budget) want = budget;
+    double hcell = cell_size > 0 ? cell_size : sqrt((double)w * ht / (double)want);
+    if (hcell < (double)maxabs * 1.52587890625e-05 /* 2^-16 */) hcell = (double)maxabs * 1.52587890625e-05;
+    if (hcell < 1e-4) hcell = 1e-4;
     int nx, ny;
     for (;;) {
-        nx = (int)std::floor(w / hcell) + 1;
-        ny = (int)std::floor(ht / hcell) + 1;
+        nx = (int)floor(w / hcell) + 1;
+        ny = (int)floor(ht / hcell) + 1;
         if ((long)nx * ny <= budget) break;
         hcell *= 1.05;
     }
 
-    ModelView &mv = h->mv;
-    memset(&mv, 0, sizeof mv);
-    mv.lat.nx = nx;
-    mv.lat.ny = ny;
-    mv.lat.x0 = lo[0];
-    mv.lat.y0 = lo[1];
-    mv.lat.h = (float)hcell;
-    mv.lat.inv_h = 1.0f / mv.lat.h;
+    IndexPlan ip;
+    ip.lat.nx = nx;
+    ip.lat.ny = ny;
+    ip.lat.x0 = lo[0];
+    ip.lat.y0 = lo[1];
+    ip.lat.h = (float)hcell;
+    ip.lat.inv_h = 1.0f / ip.lat.h;
     // the cell map floor(fl(fl(x-x0)*inv_h)) is monotone and off by at most ~3*2^-24*nx cells per evaluation,
     // i.e. ~6*2^-24*maxabs metres for a model point and a query together; 2^-19*maxabs covers that 5x
     // (and stays below h/8 by the choice of h above)
-    mv.lat.margin = std::max(mv.lat.h * 0.0009765625f, maxabs * 1.9073486328125e-06f);
-    mv.n_cls[0] = n_ga;
-    mv.n_cls[1] = n_nga;
-    mv.base[0] = 0;
-    mv.base[1] = n_ga;
-    mv.cx = bb.sum[0] / (double)bb.nfin;
-    mv.cy = bb.sum[1] / (double)bb.nfin;
+    const float m_h = ip.lat.h * 0.0009765625f, m_a = maxabs * 1.9073486328125e-06f;
+    ip.lat.margin = m_h > m_a ? m_h : m_a;
+    ip.n_cls[0] = n_ga;
+    ip.n_cls[1] = n_nga;
+    ip.base[0] = 0;
+    ip.base[1] = n_ga;
+    ip.cx = bb.sum[0] / (double)bb.nfin;
+    ip.cy = bb.sum[1] / (double)bb.nfin;
 
-    h->start32 = !lds; // the HBM-resident index always uses 32-bit positions
-    const unsigned esz = h->start32 ? 4u : 2u;
+    ip.start32 = !lds; // the HBM-resident index always uses 32-bit positions
+    const unsigned esz = ip.start32 ? 4u : 2u;
     const int      ncells = nx * ny;
     unsigned       o = 0;
-    mv.off_pts = o;
+    ip.off_pts = o;
     o = align16(o + 8u * (unsigned)n_all);
-    mv.off_start[0] = o;
+    ip.off_start[0] = o;
     o = align16(o + esz * (unsigned)(ncells + 1));
-    mv.off_start[1] = o;
+    ip.off_start[1] = o;
     o = align16(o + esz * (unsigned)(ncells + 1));
-    mv.off_oidx = o;
+    ip.off_oidx = o;
     o = align16(o + esz * (unsigned)n_all);
-    mv.blob_bytes = o;
-    if (lds && scratch + o > lds_total) lds = false, h->start32 = false; // keeps u16 entries, read from HBM
-    h->in_lds = lds;
-    h->lds_bytes = lds ? scratch + o : scratch;
+    ip.blob_bytes = o;
+    if (lds && scratch + o > lds_total) lds = false, ip.start32 = 0; // keeps u16 entries, read from HBM
+    ip.in_lds = lds;
+    ip.lds_bytes = lds ? scratch + o : scratch;
+    ip.maxabs = maxabs;
+    ip.ncells = ncells;
+    return ip;
+}
+
+// cells the index can have at most for a model of up to n_all points (what a build reserves before it knows the extent)
+inline long cells_bound(int n_all, unsigned lds_total)
+{
+    const long lds = ((long)lds_total - (long)kScratchBytes - 64) / 4;
+    long       hbm = std::max<long>(4L * n_all, 1024);
+    hbm = std::min<long>(hbm, 1L << 22);
+    return std::max(lds, hbm) + 1;
+}
+
+unsigned device_lds_total()
+{
+    int lds_cap = 0, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lds_cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return std::min<unsigned>((unsigned)lds_cap, kLdsTotal);
+}
+
+void adopt_index_plan(slam_icp *h, const IndexPlan &ip)
+{
+    ModelView &mv = h->mv;
+    memset(&mv, 0, sizeof mv);
+    mv.lat = ip.lat;
+    for (int c = 0; c < 2; ++c) {
+        mv.n_cls[c] = ip.n_cls[c];
+        mv.base[c] = ip.base[c];
+        mv.off_start[c] = ip.off_start[c];
+    }
+    mv.cx = ip.cx;
+    mv.cy = ip.cy;
+    mv.off_pts = ip.off_pts;
+    mv.off_oidx = ip.off_oidx;
+    mv.blob_bytes = ip.blob_bytes;
+    h->start32 = ip.start32 != 0;
+    h->in_lds = ip.in_lds != 0;
+    h->lds_bytes = ip.lds_bytes;
+}
+
+int plan_index(slam_icp *h, int n_ga, int n_nga, const BBox &bb, unsigned *lds_total_out, float *maxabs_out)
+{
+    const unsigned lds_total = device_lds_total();
+    SLAM_REQUIRE(lds_total, SLAM_E_HIP, "the device does not report its LDS size");
+    const IndexPlan ip = plan_core(n_ga, n_nga, bb, h->prm.cell_size, h->prm.force_global, lds_total);
+    adopt_index_plan(h, ip);
     *lds_total_out = lds_total;
-    *maxabs_out = maxabs;
+    *maxabs_out = ip.maxabs;
     return SLAM_OK;
 }
 
@@ -121,22 +182,30 @@ struct ListCand {
     double frac, hs, pad_m, x0, y0;
     long   nx, ny;
 };
+constexpr int kPitchSteps = 49;               // 0.25 * 1.12^k <= 64
+constexpr int kMaxCand = 2 * kPitchSteps;
+
+// candidate (frac, hs) over the extent bb; false when it is not tried
+__host__ __device__ inline bool list_candidate(const BBox &bb, float margin_abs, double frac, double hs, ListCand &c)
+{
+#pragma clang fp contract(off)
+    c.frac = frac;
+    c.hs = hs;
+    c.pad_m = hs * frac; // halo in metres
+    if (c.pad_m < 8.0 * margin_abs) return false;
+    c.x0 = (double)bb.lo[0] - c.pad_m;
+    c.y0 = (double)bb.lo[1] - c.pad_m;
+    c.nx = (long)floor(((double)bb.hi[0] + c.pad_m - c.x0) / hs) + 1;
+    c.ny = (long)floor(((double)bb.hi[1] + c.pad_m - c.y0) / hs) + 1;
+    return c.nx * c.ny <= 60000;
+}
 
 void list_candidates(const BBox &bb, float margin_abs, std::vector<ListCand> &out)
 {
     for (double frac : {0.25, 0.125}) {
         for (double hs = 0.25; hs <= 64.0; hs *= 1.12) {
             ListCand c;
-            c.frac = frac;
-            c.hs = hs;
-            c.pad_m = hs * frac; // halo in metres
-            if (c.pad_m < 8.0 * margin_abs) continue;
-            c.x0 = (double)bb.lo[0] - c.pad_m;
-            c.y0 = (double)bb.lo[1] - c.pad_m;
-            c.nx = (long)std::floor(((double)bb.hi[0] + c.pad_m - c.x0) / hs) + 1;
-            c.ny = (long)std::floor(((double)bb.hi[1] + c.pad_m - c.y0) / hs) + 1;
-            if (c.nx * c.ny > 60000) continue;
-            out.push_back(c);
+            if (list_candidate(bb, margin_abs, frac, hs, c)) out.push_back(c);
         }
     }
 }
@@ -156,7 +225,7 @@ __host__ __device__ inline void halo_cells(const ListGeom &g, double px, double 
     by = fby < g.ny - 1 ? fby : g.ny - 1;
 }
 
-inline ListGeom geom_of(const ListCand &c)
+__host__ __device__ inline ListGeom geom_of(const ListCand &c)
 {
     ListGeom g;
     g.pad_m = c.pad_m;
@@ -168,43 +237,83 @@ inline ListGeom geom_of(const ListCand &c)
     return g;
 }
 
-// Whether candidate c with n_ent[] entries per class is the one to build; fills the list side of h->mv if so.
-bool accept_list(slam_icp *h, const ListCand &c, const size_t n_ent[2], double budget, float maxabs, float margin_abs)
+// The list side of the index for one candidate lattice
+struct ListPlan {
+    unsigned           loff_pts, loff_start[2], loff_axis[2], lblob_bytes;
+    int                lbase[2];
+    Lattice            llat;
+    float              lpad, lkeps, cert2;
+    int                ncells;
+    unsigned long long n_ent[2];
+};
+
+// Whether candidate c with n_ent[] entries per class is the one to build; lp is its layout if so.
+__host__ __device__ inline bool accept_list_core(const ListCand &c, const unsigned long long n_ent[2], double budget, float maxabs,
+                                                 float margin_abs, ListPlan &lp)
 {
+#pragma clang fp contract(off)
     if (n_ent[0] > 65535 || n_ent[1] > 65535) return false;
     const int    ncells = (int)(c.nx * c.ny);
     const size_t bytes = align16(8u * (unsigned)(n_ent[0] + n_ent[1])) + 2 * (size_t)align16(2u * (unsigned)(ncells + 1)) +
                          2 * (size_t)align16(4u * (unsigned)(ncells / 16 + 1));
     if ((double)bytes > budget) return false;
-    ModelView &mv = h->mv;
-    unsigned   o = 0;
-    mv.loff_pts = o;
+    unsigned o = 0;
+    lp.loff_pts = o;
     o = align16(o + 8u * (unsigned)(n_ent[0] + n_ent[1]));
     for (int k = 0; k < 2; ++k) {
-        mv.loff_start[k] = o;
+        lp.loff_start[k] = o;
         o = align16(o + 2u * (unsigned)(ncells + 1));
     }
     for (int k = 0; k < 2; ++k) {
-        mv.loff_axis[k] = o;
+        lp.loff_axis[k] = o;
         o = align16(o + 4u * (unsigned)(ncells / 16 + 1));
     }
-    mv.lblob_bytes = o;
-    mv.lbase[0] = 0;
-    mv.lbase[1] = (int)n_ent[0];
-    mv.llat.nx = (int)c.nx;
-    mv.llat.ny = (int)c.ny;
-    mv.llat.x0 = (float)c.x0;
-    mv.llat.y0 = (float)c.y0;
-    mv.llat.h = (float)c.hs;
-    mv.llat.inv_h = 1.0f / mv.llat.h;
-    mv.llat.margin = std::max(mv.llat.h * 0.0009765625f, margin_abs);
-    mv.lpad = (float)c.frac;
-    mv.lkeps = 8.0f * 2.0f * maxabs * 1.1920929e-07f; // 8 ulp of |x| + |y| <= 2 maxabs (query within the lattice)
+    lp.lblob_bytes = o;
+    lp.lbase[0] = 0;
+    lp.lbase[1] = (int)n_ent[0];
+    lp.llat.nx = (int)c.nx;
+    lp.llat.ny = (int)c.ny;
+    lp.llat.x0 = (float)c.x0;
+    lp.llat.y0 = (float)c.y0;
+    lp.llat.h = (float)c.hs;
+    lp.llat.inv_h = 1.0f / lp.llat.h;
+    const float m_h = lp.llat.h * 0.0009765625f;
+    lp.llat.margin = m_h > margin_abs ? m_h : margin_abs;
+    lp.lpad = (float)c.frac;
+    lp.lkeps = 8.0f * 2.0f * maxabs * 1.1920929e-07f; // 8 ulp of |x| + |y| <= 2 maxabs (query within the lattice)
     // a point within `cert` of a query lies within cert + (cell-map rounding) of the query's nominal cell
-    const double cert = c.pad_m - 4.0 * (double)mv.llat.margin - 2.0 * std::fabs((double)mv.llat.x0 - c.x0) -
-                        2.0 * std::fabs((double)mv.llat.y0 - c.y0);
+    const double cert = c.pad_m - 4.0 * (double)lp.llat.margin - 2.0 * fabs((double)lp.llat.x0 - c.x0) -
+                        2.0 * fabs((double)lp.llat.y0 - c.y0);
     if (cert <= 0) return false;
-    mv.cert2 = (float)(cert * cert * 0.999);
+    lp.cert2 = (float)(cert * cert * 0.999);
+    lp.ncells = ncells;
+    lp.n_ent[0] = n_ent[0];
+    lp.n_ent[1] = n_ent[1];
+    return true;
+}
+
+void adopt_list_plan(slam_icp *h, const ListPlan &lp)
+{
+    ModelView &mv = h->mv;
+    mv.loff_pts = lp.loff_pts;
+    for (int k = 0; k < 2; ++k) {
+        mv.loff_start[k] = lp.loff_start[k];
+        mv.loff_axis[k] = lp.loff_axis[k];
+        mv.lbase[k] = lp.lbase[k];
+    }
+    mv.lblob_bytes = lp.lblob_bytes;
+    mv.llat = lp.llat;
+    mv.lpad = lp.lpad;
+    mv.lkeps = lp.lkeps;
+    mv.cert2 = lp.cert2;
+}
+
+bool accept_list(slam_icp *h, const ListCand &c, const size_t n_ent[2], double budget, float maxabs, float margin_abs)
+{
+    const unsigned long long n[2] = {(unsigned long long)n_ent[0], (unsigned long long)n_ent[1]};
+    ListPlan                 lp;
+    if (!accept_list_core(c, n, budget, maxabs, margin_abs, lp)) return false;
+    adopt_list_plan(h, lp);
     return true;
 }
 
@@ -406,21 +515,89 @@ int build_index_host(slam_icp *h, const double *m_ga, int n_ga, const double *m_
 }
 
 // ------------------------------------------------------------------ device build
+// The whole build is enqueued on one stream without a host wait in between: extent -> plan kernel (the lattice, the blob
+// layout, the list candidates, all by the expressions above) -> cell index -> candidates' entry counts -> list plan kernel
+// (the first candidate that fits) -> lists; every kernel reads the plan from device memory and is launched over what the
+// model can be at most (`cap` points per class: the mapper's thinned window knows its counts only on the device).  The
+// host reads the plan back ONCE, when it needs the handle (build_index_finish).
+
+struct DevPlan {
+    int                cnt[2];           // points per class
+    BBox               bb;               // extent, sum and count of the finite points (fixed order)
+    IndexPlan          ip;
+    float              margin_abs;
+    double             budget;           // bytes the lists may take
+    int                nc;               // list candidates
+    int                pick;             // the candidate built, -1: none
+    ListGeom           geom[kMaxCand];
+    double             frac[kMaxCand];
+    unsigned long long n_ent[kMaxCand][2]; // entries per class of every candidate (zeroed; atomics)
+    ListPlan           lp;
+    unsigned           most;             // points in the fullest cell of the index (zeroed; atomicMax)
+};
+
+struct BuildWs {               // what the host knows when it enqueues the build
+    const double  *m[2];       // model classes, f64 xy (device)
+    const int     *d_cnt;      // points per class on the device, or null: host_cnt
+    int            host_cnt[2];
+    int            cap[2];     // points per class at most
+    DevPlan       *plan;
+    double        *rows;       // [n_rows][8] extent partials
+    int            n_rows;
+    float2        *xyf;        // [cap_all] the f32 model (icp.cpp:54,60), class order
+    int           *cell_of;    // [cap_all]
+    int           *tmp;        // [cap_all] original indices bucketed by cell, unordered inside a cell
+    unsigned      *cellcnt;    // [2][ncells + 1] counts, then exclusive prefix | [2][ncells] cursors (zeroed)
+    unsigned      *tiles;      // scan tile totals
+    unsigned      *lcnt;       // the same two arrays for the list lattice (zeroed)
+    int           *ent;        // point of every list entry, bucketed by list cell
+    unsigned char *blob, *lblob;
+    double         cell_size;
+    int            force_global, want_lists;
+    unsigned       lds_total;
+};
 
 struct BuildArgs {
-    const double *m[2];   // model classes, f64 xy (device)
+    const double *m[2];
     int           cnt[2], base[2], n_all;
     Lattice       lat;
     int           ncells;
-    float2       *xyf;     // [n_all] the f32 model (icp.cpp:54,60), class order
-    int          *cell_of; // [n_all]
+    float2       *xyf;
+    int          *cell_of;
     unsigned     *start;   // [2][ncells + 1] counts, then exclusive prefix
     unsigned     *cursor;  // [2][ncells]
-    int          *tmp;     // [n_all] original indices bucketed by cell, unordered inside a cell
+    int          *tmp;
     unsigned char *blob;
     unsigned      off_pts, off_start[2], off_oidx;
     int           esz;     // bytes per start / oidx entry in the blob: 2 or 4
 };
+
+__device__ inline BuildArgs build_args(const BuildWs &w)
+{
+    const DevPlan &p = *w.plan;
+    BuildArgs      a;
+    a.m[0] = w.m[0];
+    a.m[1] = w.m[1];
+    a.cnt[0] = p.cnt[0];
+    a.cnt[1] = p.cnt[1];
+    a.base[0] = 0;
+    a.base[1] = p.cnt[0];
+    a.n_all = p.cnt[0] + p.cnt[1];
+    a.lat = p.ip.lat;
+    a.ncells = p.ip.ncells;
+    a.xyf = w.xyf;
+    a.cell_of = w.cell_of;
+    a.start = w.cellcnt;
+    a.cursor = w.cellcnt + 2 * (size_t)(a.ncells + 1);
+    a.tmp = w.tmp;
+    a.blob = w.blob;
+    a.off_pts = p.ip.off_pts;
+    a.off_start[0] = p.ip.off_start[0];
+    a.off_start[1] = p.ip.off_start[1];
+    a.off_oidx = p.ip.off_oidx;
+    a.esz = p.ip.start32 ? 4 : 2;
+    return a;
+}
 
 __device__ inline void store_entry(unsigned char *base, int esz, size_t i, unsigned v)
 {
@@ -430,17 +607,19 @@ __device__ inline void store_entry(unsigned char *base, int esz, size_t i, unsig
         reinterpret_cast<unsigned *>(base)[i] = v;
 }
 
+__device__ inline int ws_count(const BuildWs &w, int c) { return w.d_cnt ? w.d_cnt[c] : w.host_cnt[c]; }
+
 // extent, sum and count of the finite points of a device-resident model: one row of partials per workgroup
-// (fixed order: the host adds the rows in index order)
-__global__ __launch_bounds__(256) void idx_bbox_kernel(const double *m_ga, int n_ga, const double *m_nga, int n_nga,
-                                                       double *rows /* [blocks][8]: lo x,y hi x,y sum x,y n pad */)
+// (fixed order: the plan kernel adds the rows in index order)
+__global__ __launch_bounds__(256) void idx_bbox_kernel(BuildWs w)
 {
     __shared__ double s[4][8];
+    const int n_ga = min(max(ws_count(w, 0), 0), w.cap[0]), n_nga = min(max(ws_count(w, 1), 0), w.cap[1]);
     const int i = blockIdx.x * 256 + threadIdx.x, n_all = n_ga + n_nga;
     float     lx = FLT_MAX, ly = FLT_MAX, hx = -FLT_MAX, hy = -FLT_MAX;
     double    sx = 0, sy = 0, nf = 0;
     if (i < n_all) {
-        const double *p = i < n_ga ? m_ga + 2 * (size_t)i : m_nga + 2 * (size_t)(i - n_ga);
+        const double *p = i < n_ga ? w.m[0] + 2 * (size_t)i : w.m[1] + 2 * (size_t)(i - n_ga);
         const float   x = (float)p[0], y = (float)p[1];
         if ((x - x <= 0.0f) && (y - y <= 0.0f)) {
             lx = hx = x;
@@ -466,7 +645,7 @@ __global__ __launch_bounds__(256) void idx_bbox_kernel(const double *m_ga, int n
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double *r = rows + 8 * (size_t)blockIdx.x;
+        double *r = w.rows + 8 * (size_t)blockIdx.x;
         r[0] = fmin(fmin(s[0][0], s[1][0]), fmin(s[2][0], s[3][0]));
         r[1] = fmin(fmin(s[0][1], s[1][1]), fmin(s[2][1], s[3][1]));
         r[2] = fmax(fmax(s[0][2], s[1][2]), fmax(s[2][2], s[3][2]));
@@ -478,10 +657,105 @@ __global__ __launch_bounds__(256) void idx_bbox_kernel(const double *m_ga, int n
     }
 }
 
-// icp.cpp:54,60: the f32 copy of the model; cell of every point; points per cell
-__global__ __launch_bounds__(256) void idx_count_kernel(BuildArgs a)
+// One wavefront: the rows of idx_bbox_kernel added in index order, plan_core, the list candidates.
+constexpr int kPlanRows = 1024;
+__global__ __launch_bounds__(64) void plan_kernel(BuildWs w)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __shared__ double s_sum[kPlanRows][3];
+    __shared__ double s_hs[kPitchSteps];
+    __shared__ int    s_ok[2 * 64];
+    const int         lane = threadIdx.x;
+    DevPlan          &p = *w.plan;
+    const int         n_ga = min(max(ws_count(w, 0), 0), w.cap[0]), n_nga = min(max(ws_count(w, 1), 0), w.cap[1]);
+    const int         rows_used = (n_ga + n_nga + 255) / 256;
+    BBox              bb;
+    float             lx = FLT_MAX, ly = FLT_MAX, hx = -FLT_MAX, hy = -FLT_MAX;
+    double            sx = 0, sy = 0, nf = 0; // lane 0's
+    for (int r0 = 0; r0 < rows_used; r0 += kPlanRows) {
+        const int n = min(kPlanRows, rows_used - r0);
+        for (int r = lane; r < n; r += 64) {
+            const double *row = w.rows + 8 * (size_t)(r0 + r);
+            s_sum[r][0] = row[4], s_sum[r][1] = row[5], s_sum[r][2] = row[6];
+            if (row[6] > 0) {
+                lx = fminf(lx, (float)row[0]);
+                ly = fminf(ly, (float)row[1]);
+                hx = fmaxf(hx, (float)row[2]);
+                hy = fmaxf(hy, (float)row[3]);
+            }
+        }
+        __syncthreads();
+        if (lane == 0)
+            for (int r = 0; r < n; ++r)
+                if (s_sum[r][2] > 0) sx += s_sum[r][0], sy += s_sum[r][1], nf += s_sum[r][2];
+        __syncthreads();
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        lx = fminf(lx, __shfl_xor(lx, o));
+        ly = fminf(ly, __shfl_xor(ly, o));
+        hx = fmaxf(hx, __shfl_xor(hx, o));
+        hy = fmaxf(hy, __shfl_xor(hy, o));
+    }
+    sx = __shfl(sx, 0), sy = __shfl(sy, 0), nf = __shfl(nf, 0);
+    bb.lo[0] = lx, bb.lo[1] = ly, bb.hi[0] = hx, bb.hi[1] = hy;
+    bb.sum[0] = sx, bb.sum[1] = sy;
+    bb.nfin = (size_t)nf;
+    const IndexPlan ip = plan_core(n_ga, n_nga, bb, w.cell_size, w.force_global, w.lds_total); // (every lane: uniform)
+    const size_t    nfin = bb.nfin;
+    if (bb.nfin == 0) {
+        bb.lo[0] = bb.lo[1] = 0.f;
+        bb.hi[0] = bb.hi[1] = 1.f;
+    }
+    const double budget = (double)w.lds_total - (double)kScratchBytes - 64.0;
+    const float  margin_abs = ip.maxabs * 1.9073486328125e-06f; // 2^-19 * maxabs, as for the cell lattice
+    // candidates: a model whose points alone overflow the budget has no lists
+    const bool lists = w.want_lists && 8.0 * (double)nfin <= budget && nfin <= 2 * 65535;
+    if (lane == 0) {
+        double hs = 0.25;
+        for (int k = 0; k < kPitchSteps; ++k) {
+            s_hs[k] = hs <= 64.0 ? hs : 0.0;
+            hs *= 1.12;
+        }
+    }
+    __syncthreads();
+    int nc = 0;
+    if (lists) {
+        ListCand c[2];
+        bool     ok[2];
+        for (int t = 0; t < 2; ++t) { // candidate t * 64 + lane = (frac index, pitch step) in the host's order
+            const int k = t * 64 + lane, fi = k / kPitchSteps, step = k % kPitchSteps;
+            ok[t] = k < kMaxCand && s_hs[step] > 0.0 && list_candidate(bb, margin_abs, fi ? 0.125 : 0.25, s_hs[step], c[t]);
+            s_ok[k] = ok[t] ? 1 : 0;
+        }
+        __syncthreads();
+        for (int t = 0; t < 2; ++t) {
+            const int k = t * 64 + lane;
+            int       pos = 0;
+            for (int j = 0; j < k; ++j) pos += s_ok[j];
+            if (ok[t]) {
+                p.geom[pos] = geom_of(c[t]);
+                p.frac[pos] = c[t].frac;
+            }
+        }
+        for (int j = 0; j < 2 * 64; ++j) nc += s_ok[j];
+    }
+    if (lane == 0) {
+        p.cnt[0] = n_ga;
+        p.cnt[1] = n_nga;
+        p.bb = bb;
+        p.bb.nfin = nfin;
+        p.ip = ip;
+        p.margin_abs = margin_abs;
+        p.budget = budget;
+        p.nc = nc;
+        p.pick = -1;
+    }
+}
+
+// icp.cpp:54,60: the f32 copy of the model; cell of every point; points per cell
+__global__ __launch_bounds__(256) void idx_count_kernel(BuildWs w)
+{
+    const BuildArgs a = build_args(w);
+    const int       i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n_all) return;
     const int     c = i >= a.cnt[0] ? 1 : 0;
     const double *p = a.m[c] + 2 * (size_t)(i - a.base[c]);
@@ -506,6 +780,34 @@ struct ScanArgs {
     int            n, n_tiles, esz;
 };
 
+// LISTS = 0: the cell index; 1: the list lattice (false: nothing to scan)
+template <int LISTS>
+__device__ inline bool scan_args(const BuildWs &w, ScanArgs &a)
+{
+    const DevPlan &p = *w.plan;
+    if (LISTS) {
+        if (p.pick < 0) return false;
+        a.n = p.lp.ncells;
+        a.v[0] = w.lcnt;
+        a.v[1] = w.lcnt + (a.n + 1);
+        a.out[0] = w.lblob + p.lp.loff_start[0];
+        a.out[1] = w.lblob + p.lp.loff_start[1];
+        a.esz = 2;
+        a.most = nullptr;
+    } else {
+        a.n = p.ip.ncells;
+        a.v[0] = w.cellcnt;
+        a.v[1] = w.cellcnt + (a.n + 1);
+        a.out[0] = w.blob + p.ip.off_start[0];
+        a.out[1] = w.blob + p.ip.off_start[1];
+        a.esz = p.ip.start32 ? 4 : 2;
+        a.most = &w.plan->most;
+    }
+    a.tiles = w.tiles;
+    a.n_tiles = a.n / kScanTile + 1; // covers position n itself
+    return true;
+}
+
 __device__ inline unsigned block_sum_1024(unsigned x, unsigned *s_wave)
 {
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
@@ -517,12 +819,15 @@ __device__ inline unsigned block_sum_1024(unsigned x, unsigned *s_wave)
     return t;
 }
 
-// grid (n_tiles, 2)
-__global__ __launch_bounds__(1024) void scan_tiles_kernel(ScanArgs a)
+// grid (tiles at most, 2)
+template <int LISTS>
+__global__ __launch_bounds__(1024) void scan_tiles_kernel(BuildWs w)
 {
     __shared__ unsigned s_wave[16];
-    const int           c = blockIdx.y, k0 = blockIdx.x * kScanTile + (int)threadIdx.x * kScanPer;
-    unsigned            sum = 0, most = 0;
+    ScanArgs            a;
+    if (!scan_args<LISTS>(w, a) || (int)blockIdx.x >= a.n_tiles) return;
+    const int c = blockIdx.y, k0 = blockIdx.x * kScanTile + (int)threadIdx.x * kScanPer;
+    unsigned  sum = 0, most = 0;
 #pragma unroll
     for (int j = 0; j < kScanPer; ++j) {
         const unsigned x = k0 + j < a.n ? a.v[c][k0 + j] : 0u;
@@ -537,11 +842,14 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(ScanArgs a)
     }
 }
 
-__global__ __launch_bounds__(1024) void scan_apply_kernel(ScanArgs a)
+template <int LISTS>
+__global__ __launch_bounds__(1024) void scan_apply_kernel(BuildWs w)
 {
     __shared__ unsigned s_wave[16];
-    const int           c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned            before = 0;
+    ScanArgs            a;
+    if (!scan_args<LISTS>(w, a) || (int)blockIdx.x >= a.n_tiles) return;
+    const int c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned  before = 0;
     for (int t = tid; t < tile; t += 1024) before += a.tiles[c * a.n_tiles + t];
     before = block_sum_1024(before, s_wave);
     const int k0 = tile * kScanTile + tid * kScanPer;
@@ -559,7 +867,7 @@ __global__ __launch_bounds__(1024) void scan_apply_kernel(ScanArgs a)
     if (lane == 63) s_wave[wave] = incl;
     __syncthreads();
     unsigned run = before + incl - sum;
-    for (int w = 0; w < wave; ++w) run += s_wave[w];
+    for (int k = 0; k < wave; ++k) run += s_wave[k];
 #pragma unroll
     for (int j = 0; j < kScanPer; ++j) {
         if (k0 + j <= a.n) { // position n receives the total
@@ -570,29 +878,19 @@ __global__ __launch_bounds__(1024) void scan_apply_kernel(ScanArgs a)
     }
 }
 
-int launch_scan(unsigned *v0, unsigned *v1, int n, unsigned char *out0, unsigned char *out1, int esz, unsigned *tiles,
-                hipStream_t st, unsigned *most = nullptr)
+inline int scan_tiles_for(long n) { return (int)(n / kScanTile + 1); }
+
+template <int LISTS>
+void launch_scan(const BuildWs &w, int tiles_max, hipStream_t st)
 {
-    ScanArgs a;
-    a.most = most;
-    a.v[0] = v0;
-    a.v[1] = v1;
-    a.out[0] = out0;
-    a.out[1] = out1;
-    a.tiles = tiles;
-    a.n = n;
-    a.n_tiles = n / kScanTile + 1; // covers position n itself
-    a.esz = esz;
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(a.n_tiles, 2), dim3(1024), 0, st, a);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3(a.n_tiles, 2), dim3(1024), 0, st, a);
-    return SLAM_OK;
+    hipLaunchKernelGGL((scan_tiles_kernel<LISTS>), dim3(tiles_max, 2), dim3(1024), 0, st, w);
+    hipLaunchKernelGGL((scan_apply_kernel<LISTS>), dim3(tiles_max, 2), dim3(1024), 0, st, w);
 }
 
-inline size_t scan_tile_words(int n) { return 2 * (size_t)(n / kScanTile + 1); }
-
-__global__ __launch_bounds__(256) void idx_fill_kernel(BuildArgs a)
+__global__ __launch_bounds__(256) void idx_fill_kernel(BuildWs w)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const BuildArgs a = build_args(w);
+    const int       i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n_all) return;
     const int      c = i >= a.cnt[0] ? 1 : 0;
     const int      cell = a.cell_of[i];
@@ -601,9 +899,10 @@ __global__ __launch_bounds__(256) void idx_fill_kernel(BuildArgs a)
 }
 
 // a stable counting sort keeps the original order inside a cell: position = rank of the original index
-__global__ __launch_bounds__(256) void idx_rank_kernel(BuildArgs a)
+__global__ __launch_bounds__(256) void idx_rank_kernel(BuildWs w)
 {
-    const int s = blockIdx.x * 256 + threadIdx.x;
+    const BuildArgs a = build_args(w);
+    const int       s = blockIdx.x * 256 + threadIdx.x;
     if (s >= a.n_all) return;
     const int       c = s >= a.cnt[0] ? 1 : 0;
     const int       j = a.tmp[s];
@@ -618,18 +917,19 @@ __global__ __launch_bounds__(256) void idx_rank_kernel(BuildArgs a)
 }
 
 // entries per class of every candidate list lattice (blockIdx.y = candidate)
-__global__ __launch_bounds__(256) void list_cand_kernel(const float2 *xyf, int n_all, int n_ga, const ListGeom *cands,
-                                                        unsigned long long *n_ent /* [cands][2] */)
+__global__ __launch_bounds__(256) void list_cand_kernel(BuildWs w)
 {
     __shared__ unsigned long long s[4][2];
-    const ListGeom     g = cands[blockIdx.y];
-    const int          i = blockIdx.x * 256 + threadIdx.x;
+    DevPlan                      &p = *w.plan;
+    if ((int)blockIdx.y >= p.nc) return;
+    const ListGeom     g = p.geom[blockIdx.y];
+    const int          i = blockIdx.x * 256 + threadIdx.x, n_ga = p.cnt[0], n_all = p.cnt[0] + p.cnt[1];
     unsigned long long c0 = 0, c1 = 0;
     if (i < n_all) {
-        const float2 p = xyf[i];
-        if ((p.x - p.x <= 0.0f) && (p.y - p.y <= 0.0f)) {
+        const float2 q = w.xyf[i];
+        if ((q.x - q.x <= 0.0f) && (q.y - q.y <= 0.0f)) {
             long ax, bx, ay, by;
-            halo_cells(g, (double)p.x, (double)p.y, ax, bx, ay, by);
+            halo_cells(g, (double)q.x, (double)q.y, ax, bx, ay, by);
             const unsigned long long k = (unsigned long long)((bx - ax + 1) * (by - ay + 1));
             if (i < n_ga)
                 c0 = k;
@@ -646,8 +946,41 @@ __global__ __launch_bounds__(256) void list_cand_kernel(const float2 *xyf, int n
     __syncthreads();
     if (threadIdx.x < 2) {
         const unsigned long long v = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
-        if (v) atomicAdd(&n_ent[2 * (size_t)blockIdx.y + threadIdx.x], v);
+        if (v) atomicAdd(&p.n_ent[blockIdx.y][threadIdx.x], v);
     }
+}
+
+// One wavefront: the first candidate, in the host's order, whose lists fit
+__global__ __launch_bounds__(64) void list_plan_kernel(BuildWs w)
+{
+    DevPlan  &p = *w.plan;
+    const int lane = threadIdx.x;
+    int       pick = -1;
+    ListPlan  lp;
+    for (int k0 = 0; k0 < p.nc && pick < 0; k0 += 64) {
+        const int k = k0 + lane;
+        bool      ok = false;
+        if (k < p.nc) {
+            const ListGeom &g = p.geom[k];
+            ListCand        c;
+            c.frac = p.frac[k];
+            c.hs = g.hs;
+            c.pad_m = g.pad_m;
+            c.x0 = g.x0;
+            c.y0 = g.y0;
+            c.nx = g.nx;
+            c.ny = g.ny;
+            const unsigned long long n_ent[2] = {p.n_ent[k][0], p.n_ent[k][1]};
+            ok = accept_list_core(c, n_ent, p.budget, p.ip.maxabs, p.margin_abs, lp);
+        }
+        const unsigned long long m = __ballot(ok);
+        if (m) {
+            const int first = __ffsll((long long)m) - 1;
+            pick = k0 + first;
+            if (lane == first) p.lp = lp;
+        }
+    }
+    if (lane == 0) p.pick = pick;
 }
 
 struct ListArgs {
@@ -663,9 +996,37 @@ struct ListArgs {
     unsigned      loff_pts, loff_start[2], loff_axis[2];
 };
 
-template <int FILL>
-__global__ __launch_bounds__(256) void list_scatter_kernel(ListArgs a)
+__device__ inline bool list_args(const BuildWs &w, ListArgs &a)
 {
+    const DevPlan &p = *w.plan;
+    if (p.pick < 0) return false;
+    a.xyf = w.xyf;
+    a.cnt[0] = p.cnt[0];
+    a.cnt[1] = p.cnt[1];
+    a.base[0] = 0;
+    a.base[1] = p.cnt[0];
+    a.n_all = p.cnt[0] + p.cnt[1];
+    a.g = p.geom[p.pick];
+    a.ncells = p.lp.ncells;
+    a.start = w.lcnt;
+    a.cursor = w.lcnt + 2 * (size_t)(a.ncells + 1);
+    a.ent = w.ent;
+    a.lbase[0] = p.lp.lbase[0];
+    a.lbase[1] = p.lp.lbase[1];
+    a.lblob = w.lblob;
+    a.loff_pts = p.lp.loff_pts;
+    for (int k = 0; k < 2; ++k) {
+        a.loff_start[k] = p.lp.loff_start[k];
+        a.loff_axis[k] = p.lp.loff_axis[k];
+    }
+    return true;
+}
+
+template <int FILL>
+__global__ __launch_bounds__(256) void list_scatter_kernel(BuildWs w)
+{
+    ListArgs a;
+    if (!list_args(w, a)) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n_all) return;
     const float2 p = a.xyf[i];
@@ -694,8 +1055,10 @@ constexpr int kSortWaves = 4;   // wavefronts per workgroup, each taking (cell, 
 constexpr int kSmallCell = 128; // lists up to this long: one wavefront, quadratic counting; longer: a workgroup that sorts
 constexpr int kBigCell = 4096;  // entries a workgroup sorts in LDS (longer lists: quadratic through the cache, correct and slow)
 
-__global__ __launch_bounds__(64 * kSortWaves) void list_sort_kernel(ListArgs a)
+__global__ __launch_bounds__(64 * kSortWaves) void list_sort_kernel(BuildWs w)
 {
+    ListArgs a;
+    if (!list_args(w, a)) return;
     __shared__ float s_xs[kSortWaves][kListStage], s_ys[kSortWaves][kListStage], s_ks[kSortWaves][kListStage];
     __shared__ int   s_js[kSortWaves][kListStage];
     const int        lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -815,15 +1178,21 @@ __device__ inline void bitonic_sort_lds(float *key, int *val, int N /* power of 
         }
 }
 
-__global__ __launch_bounds__(256) void list_sort_big_kernel(ListArgs a)
+// grid (workgroups, 2): a workgroup takes the cells blockIdx.x, blockIdx.x + gridDim.x, ... of class blockIdx.y
+__global__ __launch_bounds__(256) void list_sort_big_kernel(BuildWs w)
 {
     __shared__ float s_key[kBigCell];
     __shared__ int   s_val[kBigCell];
     __shared__ unsigned s_red[4];
-    const int       c = blockIdx.y, cell = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float s_ext[4][4];
+    ListArgs a;
+    if (!list_args(w, a)) return;
+    const int       c = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned *st = a.start + (size_t)c * (a.ncells + 1);
+    for (int cell = blockIdx.x; cell < a.ncells; cell += gridDim.x) {
     const int       lo = (int)st[cell], n = (int)st[cell + 1] - lo;
-    if (n <= kSmallCell) return;
+    if (n <= kSmallCell) continue; // (uniform over the workgroup)
+    __syncthreads(); // the cell before is through with the shared arrays
     const int    *ent = a.ent + a.lbase[c] + lo;
     const float2 *xy = a.xyf + a.base[c];
     float2       *out = reinterpret_cast<float2 *>(a.lblob + a.loff_pts) + a.lbase[c] + lo;
@@ -834,7 +1203,6 @@ __global__ __launch_bounds__(256) void list_sort_big_kernel(ListArgs a)
         mnx = fminf(mnx, p.x), mxx = fmaxf(mxx, p.x);
         mny = fminf(mny, p.y), mxy = fmaxf(mxy, p.y);
     }
-    __shared__ float s_ext[4][4];
     for (int o = 32; o > 0; o >>= 1) {
         mnx = fminf(mnx, __shfl_xor(mnx, o)), mxx = fmaxf(mxx, __shfl_xor(mxx, o));
         mny = fminf(mny, __shfl_xor(mny, o)), mxy = fmaxf(mxy, __shfl_xor(mxy, o));
@@ -928,6 +1296,7 @@ __global__ __launch_bounds__(256) void list_sort_big_kernel(ListArgs a)
             out[rank] = P;
         }
     }
+    } // cell
 }
 
 double ms_since(std::chrono::steady_clock::time_point t0)
@@ -935,236 +1304,139 @@ double ms_since(std::chrono::steady_clock::time_point t0)
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
-struct Workspace { // pool blocks of one build, returned when it ends
-    std::vector<void *> blocks;
-    hipStream_t         st = nullptr; // the stream the build's kernels run on
-    void *get(size_t bytes)
-    {
-        void *p = pool_alloc(bytes);
-        if (p) blocks.push_back(p);
-        return p;
-    }
-    ~Workspace()
-    {
-        // on EVERY way out, error returns included: kernels already enqueued may still write these blocks, and the pool
-        // hands a freed block to the next caller (another thread's rebuild) without synchronising
-        if (!blocks.empty()) {
-            (void)hipStreamSynchronize(st);
-            (void)hipGetLastError();
-        }
-        for (void *p : blocks) pool_free(p);
-    }
+constexpr int kSortBigGrid = 512; // workgroups per class of list_sort_big_kernel (cells with long lists are few)
+
+} // namespace
+
+// A build that has been enqueued and not yet adopted: its workspace (still in use by the device), the plan's pinned copy
+// and the event behind it
+struct slam_icp_pending {
+    std::vector<void *> blocks;   // pool blocks of the build
+    DevPlan            *h_plan = nullptr; // pinned
+    hipEvent_t          done = nullptr;
+    hipStream_t         st = nullptr;
+    bool                recorded = false;  // `done` has been recorded behind the build
+    size_t              blob_cap = 0, lblob_cap = 0;
+    std::chrono::steady_clock::time_point t_begin;
 };
 
-struct EventGuard { // an event of one build, destroyed on every way out
-    hipEvent_t ev = nullptr;
-    ~EventGuard()
-    {
-        if (ev) (void)hipEventDestroy(ev);
-    }
-};
+namespace {
 
-constexpr int kCandFirst = 24; // candidate pitches counted with the cell index; the rest only if none of them fits
-
-int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, int n_nga, bool on_device)
+void *ws_get(slam_icp_pending *pb, size_t bytes)
 {
-    const auto   t_begin = std::chrono::steady_clock::now();
-    const int    n_all = n_ga + n_nga;
-    const int    cnt[2] = {n_ga, n_nga};
-    hipStream_t  st = build_stream();
-    Workspace    ws;
-    ws.st = st;
-    const int    pblocks = (n_all + 255) / 256;
-    // (device arrays: complete when the call is made -- the build does not order itself behind the default stream: that
-    // stream shares a hardware queue with whatever the application runs, and an event on it can sit behind a whole
-    // registration launch)
+    void *p = pool_alloc(bytes);
+    if (p) pb->blocks.push_back(p);
+    return p;
+}
 
-    // ---- the model in HBM (f64, as the caller holds it) and its extent
-    BBox          bb;
-    const double *d_m[2] = {m_ga, m_nga};
-    if (!on_device) {
-        const double *src[2] = {m_ga, m_nga};
-        bb = host_bbox(src, cnt);
-        double *d_in = static_cast<double *>(ws.get(16 * (size_t)std::max(n_all, 1)));
-        if (!d_in) return SLAM_E_NOMEM;
-        if (n_ga) SLAM_HIP(hipMemcpyAsync(d_in, m_ga, 16 * (size_t)n_ga, hipMemcpyHostToDevice, st));
-        if (n_nga) SLAM_HIP(hipMemcpyAsync(d_in + 2 * (size_t)n_ga, m_nga, 16 * (size_t)n_nga, hipMemcpyHostToDevice, st));
-        d_m[0] = d_in;
-        d_m[1] = d_in + 2 * (size_t)n_ga;
-    } else {
-        double *rows = static_cast<double *>(ws.get(64 * (size_t)pblocks));
-        double *hr = static_cast<double *>(pinned_scratch(64 * (size_t)pblocks));
-        if (!rows || !hr) return SLAM_E_NOMEM;
-        hipLaunchKernelGGL(idx_bbox_kernel, dim3(pblocks), dim3(256), 0, st, m_ga, n_ga, m_nga, n_nga, rows);
-        SLAM_HIP(hipMemcpyAsync(hr, rows, 64 * (size_t)pblocks, hipMemcpyDeviceToHost, st));
-        SLAM_HIP(hipStreamSynchronize(st));
-        for (int b = 0; b < pblocks; ++b) {
-            const double *r = hr + 8 * (size_t)b;
-            if (r[6] <= 0) continue;
-            bb.lo[0] = std::min(bb.lo[0], (float)r[0]);
-            bb.lo[1] = std::min(bb.lo[1], (float)r[1]);
-            bb.hi[0] = std::max(bb.hi[0], (float)r[2]);
-            bb.hi[1] = std::max(bb.hi[1], (float)r[3]);
-            bb.sum[0] += r[4];
-            bb.sum[1] += r[5];
-            bb.nfin += (size_t)r[6];
-        }
+// gives the workspace back; wait = the device may still be using it
+void drop_pending(slam_icp *h, bool wait)
+{
+    slam_icp_pending *pb = h->pending;
+    if (!pb) return;
+    if (wait) {
+        if (pb->recorded)
+            (void)hipEventSynchronize(pb->done);
+        else
+            (void)hipStreamSynchronize(pb->st); // a begin that failed half-way: whatever it enqueued
+        (void)hipGetLastError();
     }
-    const size_t nfin = bb.nfin;
-    unsigned     lds_total = 0;
-    float        maxabs = 0;
-    SLAM_TRY(plan_index(h, n_ga, n_nga, bb, &lds_total, &maxabs));
-    if (bb.nfin == 0) {
-        bb.lo[0] = bb.lo[1] = 0.f;
-        bb.hi[0] = bb.hi[1] = 1.f;
-    }
-    ModelView &mv = h->mv;
-    const int  ncells = mv.lat.nx * mv.lat.ny;
+    for (void *p : pb->blocks) pool_free(p);
+    if (pb->h_plan) pinned_block_put(pb->h_plan);
+    if (pb->done) (void)hipEventDestroy(pb->done);
+    delete pb;
+    h->pending = nullptr;
+}
 
-    // ---- list candidates (host arithmetic only); a model whose points alone overflow the budget has no lists
+int build_begin_device(slam_icp *h, const double *m_ga, int cap_ga, const double *m_nga, int cap_nga, const int *d_cnt,
+                       bool on_device, hipStream_t st)
+{
+    const unsigned lds_total = device_lds_total();
+    SLAM_REQUIRE(lds_total, SLAM_E_HIP, "the device does not report its LDS size");
+    slam_icp_pending *pb = new (std::nothrow) slam_icp_pending();
+    SLAM_REQUIRE(pb, SLAM_E_NOMEM, "out of host memory");
+    h->pending = pb;
+    pb->st = st;
+    pb->t_begin = std::chrono::steady_clock::now();
+    const int  cap_all = cap_ga + cap_nga;
+    const int  pblocks = std::max(1, (cap_all + 255) / 256);
+    const bool want_lists = h->sweep == 2 || h->two_phase;
     h->have_lists = false;
-    const double budget = (double)lds_total - (double)kScratchBytes - 64.0;
-    const float  margin_abs = maxabs * 1.9073486328125e-06f; // 2^-19 * maxabs, as for the cell lattice
-    std::vector<ListCand> cands;
-    std::vector<ListGeom> geoms;
-    if ((h->sweep == 2 || h->two_phase) && 8.0 * (double)nfin <= budget && nfin <= 2 * 65535) {
-        list_candidates(bb, margin_abs, cands);
-        geoms.resize(cands.size());
-        for (size_t k = 0; k < cands.size(); ++k) geoms[k] = geom_of(cands[k]);
-    }
-    const int nc = (int)cands.size();
-    h->build_ms[0] = ms_since(t_begin);
 
-    // ---- one workspace block, counters first (one memset): cell counts + cursors, candidate entry counts,
-    // list counts + cursors (sized for the largest candidate lattice)
-    const auto   t_index = std::chrono::steady_clock::now();
-    const size_t cnt_words = 2 * (size_t)(ncells + 1) + 2 * (size_t)ncells + 8;
-    size_t       lcells_max = 0;
-    for (const ListCand &c : cands) lcells_max = std::max(lcells_max, (size_t)(c.nx * c.ny));
-    const size_t lcnt_words = nc ? 2 * (lcells_max + 1) + 2 * lcells_max + 8 : 0;
-    const size_t zero_bytes = ((4 * cnt_words + 15) & ~(size_t)15) + 16 * (size_t)std::max(nc, 1) + 4 * lcnt_words + 16;
-    unsigned char *zero = static_cast<unsigned char *>(ws.get(zero_bytes));
-    h->d_blob = pool_alloc(mv.blob_bytes);
-    if (!zero || !h->d_blob) return SLAM_E_NOMEM;
-    mv.blob = static_cast<const unsigned char *>(h->d_blob);
-    BuildArgs a;
-    a.m[0] = d_m[0];
-    a.m[1] = d_m[1];
-    a.cnt[0] = n_ga;
-    a.cnt[1] = n_nga;
-    a.base[0] = 0;
-    a.base[1] = n_ga;
-    a.n_all = n_all;
-    a.lat = mv.lat;
-    a.ncells = ncells;
-    a.xyf = static_cast<float2 *>(ws.get(8 * (size_t)n_all));
-    a.cell_of = static_cast<int *>(ws.get(4 * (size_t)n_all));
-    a.tmp = static_cast<int *>(ws.get(4 * (size_t)n_all));
-    if (!a.xyf || !a.cell_of || !a.tmp) return SLAM_E_NOMEM;
-    unsigned *d_tiles = static_cast<unsigned *>(ws.get(4 * std::max(scan_tile_words(ncells), scan_tile_words((int)lcells_max))));
-    if (!d_tiles) return SLAM_E_NOMEM;
-    a.start = reinterpret_cast<unsigned *>(zero);
-    a.cursor = a.start + 2 * (size_t)(ncells + 1);
-    unsigned long long *d_ent = reinterpret_cast<unsigned long long *>(zero + ((4 * cnt_words + 15) & ~(size_t)15));
-    unsigned           *d_lcnt = reinterpret_cast<unsigned *>(d_ent + 2 * (size_t)std::max(nc, 1));
-    unsigned           *d_most = reinterpret_cast<unsigned *>(zero + zero_bytes - 16); // points in the fullest cell
-    a.blob = static_cast<unsigned char *>(h->d_blob);
-    a.off_pts = mv.off_pts;
-    a.off_start[0] = mv.off_start[0];
-    a.off_start[1] = mv.off_start[1];
-    a.off_oidx = mv.off_oidx;
-    a.esz = h->start32 ? 4 : 2;
+    BuildWs w;
+    memset(&w, 0, sizeof w);
+    w.d_cnt = d_cnt;
+    w.host_cnt[0] = cap_ga;
+    w.host_cnt[1] = cap_nga;
+    w.cap[0] = cap_ga;
+    w.cap[1] = cap_nga;
+    w.cell_size = h->prm.cell_size;
+    w.force_global = h->prm.force_global;
+    w.want_lists = want_lists ? 1 : 0;
+    w.lds_total = lds_total;
+    w.m[0] = m_ga;
+    w.m[1] = m_nga;
+    if (!on_device) { // host arrays (exact counts): one block in HBM
+        double *d_in = static_cast<double *>(ws_get(pb, 16 * (size_t)std::max(cap_all, 1)));
+        if (!d_in) return SLAM_E_NOMEM;
+        if (cap_ga) SLAM_HIP(hipMemcpyAsync(d_in, m_ga, 16 * (size_t)cap_ga, hipMemcpyHostToDevice, st));
+        if (cap_nga) SLAM_HIP(hipMemcpyAsync(d_in + 2 * (size_t)cap_ga, m_nga, 16 * (size_t)cap_nga, hipMemcpyHostToDevice, st));
+        w.m[0] = d_in;
+        w.m[1] = d_in + 2 * (size_t)cap_ga;
+    }
+    // ---- what the build can need at most
+    const long   cb = cells_bound(cap_all, lds_total);
+    const long   lcb = want_lists ? 60000 : 0;
+    const size_t cnt_words = 2 * (size_t)(cb + 1) + 2 * (size_t)cb + 8;
+    const size_t lcnt_words = want_lists ? 2 * (size_t)(lcb + 1) + 2 * (size_t)lcb + 8 : 0;
+    const size_t plan_bytes = (sizeof(DevPlan) + 255) & ~(size_t)255;
+    const size_t zero_bytes = plan_bytes + 4 * cnt_words + 4 * lcnt_words;
+    pb->blob_cap = (size_t)align16(8u * (unsigned)cap_all) + 2 * (size_t)align16(4u * (unsigned)(cb + 1)) + align16(4u * (unsigned)cap_all) + 64;
+    pb->lblob_cap = want_lists ? (size_t)lds_total : 0;
+    unsigned char *zero = static_cast<unsigned char *>(ws_get(pb, zero_bytes));
+    w.rows = static_cast<double *>(ws_get(pb, 64 * (size_t)pblocks));
+    w.n_rows = pblocks;
+    w.xyf = static_cast<float2 *>(ws_get(pb, 8 * (size_t)std::max(cap_all, 1)));
+    w.cell_of = static_cast<int *>(ws_get(pb, 4 * (size_t)std::max(cap_all, 1)));
+    w.tmp = static_cast<int *>(ws_get(pb, 4 * (size_t)std::max(cap_all, 1)));
+    const int tiles_idx = scan_tiles_for(cb), tiles_lst = scan_tiles_for(lcb);
+    w.tiles = static_cast<unsigned *>(ws_get(pb, 4 * 2 * (size_t)std::max(tiles_idx, tiles_lst)));
+    w.ent = want_lists ? static_cast<int *>(ws_get(pb, 4 * 2 * (size_t)65536)) : nullptr;
+    h->d_blob = pool_alloc(pb->blob_cap);
+    h->d_lblob = want_lists ? pool_alloc(pb->lblob_cap) : nullptr;
+    pb->h_plan = static_cast<DevPlan *>(pinned_block_get(sizeof(DevPlan)));
+    if (!zero || !w.rows || !w.xyf || !w.cell_of || !w.tmp || !w.tiles || (want_lists && (!w.ent || !h->d_lblob)) || !h->d_blob || !pb->h_plan)
+        return SLAM_E_NOMEM;
+    w.plan = reinterpret_cast<DevPlan *>(zero);
+    w.cellcnt = reinterpret_cast<unsigned *>(zero + plan_bytes);
+    w.lcnt = w.cellcnt + cnt_words;
+    w.blob = static_cast<unsigned char *>(h->d_blob);
+    w.lblob = static_cast<unsigned char *>(h->d_lblob);
+    SLAM_HIP(hipEventCreateWithFlags(&pb->done, hipEventDisableTiming));
+
     SLAM_HIP(hipMemsetAsync(zero, 0, zero_bytes, st));
-    SLAM_HIP(hipMemsetAsync(h->d_blob, 0, mv.blob_bytes, st)); // the padding between the arrays is part of the blob
-    hipLaunchKernelGGL(idx_count_kernel, dim3(pblocks), dim3(256), 0, st, a);
-    // the first candidates' entry counts travel back while the cell index is finished
-    ListGeom           *d_geom = nullptr;
-    unsigned long long *h_ent = nullptr;
-    EventGuard          ent_done;
-    hipEvent_t         &ev_ent = ent_done.ev;
-    const int           nc_first = std::min(nc, kCandFirst);
-    if (nc) {
-        d_geom = static_cast<ListGeom *>(ws.get(sizeof(ListGeom) * (size_t)nc));
-        h_ent = static_cast<unsigned long long *>(pinned_scratch(16 * (size_t)nc));
-        if (!d_geom || !h_ent) return SLAM_E_NOMEM;
-        SLAM_HIP(hipMemcpyAsync(d_geom, geoms.data(), sizeof(ListGeom) * (size_t)nc, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(list_cand_kernel, dim3(pblocks, nc_first), dim3(256), 0, st, a.xyf, n_all, n_ga, d_geom, d_ent);
-        SLAM_HIP(hipMemcpyAsync(h_ent, d_ent, 16 * (size_t)nc_first, hipMemcpyDeviceToHost, st));
-        SLAM_HIP(hipEventCreateWithFlags(&ev_ent, hipEventDisableTiming));
-        SLAM_HIP(hipEventRecord(ev_ent, st));
+    SLAM_HIP(hipMemsetAsync(h->d_blob, 0, pb->blob_cap, st)); // the padding between the arrays is part of the blob
+    if (want_lists) SLAM_HIP(hipMemsetAsync(h->d_lblob, 0, pb->lblob_cap, st));
+    hipLaunchKernelGGL(idx_bbox_kernel, dim3(pblocks), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(64), 0, st, w);
+    hipLaunchKernelGGL(idx_count_kernel, dim3(pblocks), dim3(256), 0, st, w);
+    if (want_lists) hipLaunchKernelGGL(list_cand_kernel, dim3(pblocks, kMaxCand), dim3(256), 0, st, w);
+    launch_scan<0>(w, tiles_idx, st);
+    hipLaunchKernelGGL(idx_fill_kernel, dim3(pblocks), dim3(256), 0, st, w);
+    hipLaunchKernelGGL(idx_rank_kernel, dim3(pblocks), dim3(256), 0, st, w);
+    if (want_lists) {
+        hipLaunchKernelGGL(list_plan_kernel, dim3(1), dim3(64), 0, st, w);
+        hipLaunchKernelGGL((list_scatter_kernel<0>), dim3(pblocks), dim3(256), 0, st, w);
+        launch_scan<1>(w, tiles_lst, st);
+        hipLaunchKernelGGL((list_scatter_kernel<1>), dim3(pblocks), dim3(256), 0, st, w);
+        hipLaunchKernelGGL(list_sort_kernel, dim3(1024), dim3(64 * kSortWaves), 0, st, w);
+        hipLaunchKernelGGL(list_sort_big_kernel, dim3(kSortBigGrid, 2), dim3(256), 0, st, w);
     }
-    SLAM_TRY(launch_scan(a.start, a.start + (ncells + 1), ncells, a.blob + a.off_start[0], a.blob + a.off_start[1], a.esz, d_tiles, st, d_most));
-    hipLaunchKernelGGL(idx_fill_kernel, dim3(pblocks), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(idx_rank_kernel, dim3(pblocks), dim3(256), 0, st, a);
     SLAM_HIP(hipGetLastError());
-    h->build_ms[1] = ms_since(t_index);
-
-    // ---- halo lists
-    if (nc) {
-        const auto t_plan = std::chrono::steady_clock::now();
-        SLAM_HIP(hipEventSynchronize(ev_ent)); // the build's one read-back
-        int    pick = -1;
-        size_t n_ent[2] = {0, 0};
-        auto   choose = [&](int k0, int k1) {
-            for (int k = k0; k < k1 && pick < 0; ++k) {
-                n_ent[0] = (size_t)h_ent[2 * (size_t)k];
-                n_ent[1] = (size_t)h_ent[2 * (size_t)k + 1];
-                if (accept_list(h, cands[k], n_ent, budget, maxabs, margin_abs)) pick = k;
-            }
-        };
-        choose(0, nc_first);
-        if (pick < 0 && nc > nc_first) { // rare: a second round for the coarser pitches
-            hipLaunchKernelGGL(list_cand_kernel, dim3(pblocks, nc - nc_first), dim3(256), 0, st, a.xyf, n_all, n_ga,
-                               d_geom + nc_first, d_ent + 2 * (size_t)nc_first);
-            SLAM_HIP(hipMemcpyAsync(h_ent + 2 * (size_t)nc_first, d_ent + 2 * (size_t)nc_first, 16 * (size_t)(nc - nc_first),
-                                    hipMemcpyDeviceToHost, st));
-            SLAM_HIP(hipStreamSynchronize(st));
-            choose(nc_first, nc);
-        }
-        h->build_ms[2] = ms_since(t_plan);
-        if (pick >= 0) {
-            const auto t_lists = std::chrono::steady_clock::now();
-            ListArgs   l;
-            l.xyf = a.xyf;
-            l.cnt[0] = n_ga;
-            l.cnt[1] = n_nga;
-            l.base[0] = 0;
-            l.base[1] = n_ga;
-            l.n_all = n_all;
-            l.g = geoms[pick];
-            l.ncells = l.g.nx * l.g.ny;
-            l.start = d_lcnt;
-            l.cursor = l.start + 2 * (size_t)(l.ncells + 1);
-            l.ent = static_cast<int *>(ws.get(4 * std::max<size_t>(n_ent[0] + n_ent[1], 1)));
-            h->d_lblob = pool_alloc(mv.lblob_bytes);
-            if (!l.ent || !h->d_lblob) return SLAM_E_NOMEM;
-            mv.lblob = static_cast<const unsigned char *>(h->d_lblob);
-            l.lbase[0] = mv.lbase[0];
-            l.lbase[1] = mv.lbase[1];
-            l.lblob = static_cast<unsigned char *>(h->d_lblob);
-            l.loff_pts = mv.loff_pts;
-            for (int k = 0; k < 2; ++k) {
-                l.loff_start[k] = mv.loff_start[k];
-                l.loff_axis[k] = mv.loff_axis[k];
-            }
-            SLAM_HIP(hipMemsetAsync(h->d_lblob, 0, mv.lblob_bytes, st));
-            hipLaunchKernelGGL((list_scatter_kernel<0>), dim3(pblocks), dim3(256), 0, st, l);
-            SLAM_TRY(launch_scan(l.start, l.start + (l.ncells + 1), l.ncells, l.lblob + l.loff_start[0], l.lblob + l.loff_start[1], 2, d_tiles, st));
-            hipLaunchKernelGGL((list_scatter_kernel<1>), dim3(pblocks), dim3(256), 0, st, l);
-            hipLaunchKernelGGL(list_sort_kernel, dim3(std::min((2 * l.ncells + kSortWaves - 1) / kSortWaves, 1024)), dim3(64 * kSortWaves), 0, st, l);
-            hipLaunchKernelGGL(list_sort_big_kernel, dim3(l.ncells, 2), dim3(256), 0, st, l);
-            SLAM_HIP(hipGetLastError());
-            list_done(h);
-            h->build_ms[3] = ms_since(t_lists);
-        }
-    }
-    // the workspace goes back to the pool when this returns: the device must be done with it
-    unsigned char *h_tail = static_cast<unsigned char *>(pinned_scratch(16 * (size_t)std::max(nc, 1) + 64));
-    unsigned      *h_most = h_tail ? reinterpret_cast<unsigned *>(h_tail + 16 * (size_t)std::max(nc, 1)) : nullptr;
-    if (h_most) SLAM_HIP(hipMemcpyAsync(h_most, d_most, 4, hipMemcpyDeviceToHost, st));
-    SLAM_HIP(hipStreamSynchronize(st));
-    if (h_most) h->max_cell_points = (int)*h_most;
-    h->built_on_device = true;
+    SLAM_HIP(hipMemcpyAsync(pb->h_plan, w.plan, sizeof(DevPlan), hipMemcpyDeviceToHost, st));
+    SLAM_HIP(hipEventRecord(pb->done, st));
+    pb->recorded = true;
+    h->build_ms[0] = ms_since(pb->t_begin);
     return SLAM_OK;
 }
 
@@ -1173,14 +1445,79 @@ int build_index_device(slam_icp *h, const double *m_ga, int n_ga, const double *
 namespace slam {
 namespace icp {
 
+int build_index_begin(slam_icp *h, const double *m_ga, int cap_ga, const double *m_nga, int cap_nga, const int *d_cnt, bool on_device,
+                      hipStream_t st)
+{
+    const int rc = build_begin_device(h, m_ga, cap_ga, m_nga, cap_nga, d_cnt, on_device, st);
+    if (rc != SLAM_OK) { // nothing of a failed begin stays behind (the kernels already enqueued write into blocks the device is done with first)
+        drop_pending(h, true);
+        release_index(h);
+    }
+    return rc;
+}
+
+bool build_index_ready(slam_icp *h)
+{
+    if (!h->pending) return true;
+    const hipError_t e = hipEventQuery(h->pending->done);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e == hipSuccess;
+}
+
+int build_index_finish(slam_icp *h)
+{
+    slam_icp_pending *pb = h->pending;
+    if (!pb) return SLAM_OK;
+    const auto t_wait = std::chrono::steady_clock::now();
+    const hipError_t e = hipEventSynchronize(pb->done); // the build's one wait
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        drop_pending(h, false);
+        release_index(h);
+        return hip_fail(e, "hipEventSynchronize(index build)", __FILE__, __LINE__);
+    }
+    h->build_ms[1] = ms_since(t_wait);
+    const DevPlan &p = *pb->h_plan;
+    int            rc = SLAM_OK;
+    if (p.cnt[0] + p.cnt[1] < 5) { // icp.cpp:38-43 (counts that only the device knew)
+        set_error("LIBICP works only with at least 5 model points (got %d)", p.cnt[0] + p.cnt[1]);
+        rc = SLAM_E_TOO_FEW_MODEL_POINTS;
+    } else if ((size_t)p.ip.blob_bytes > pb->blob_cap || (p.pick >= 0 && (size_t)p.lp.lblob_bytes > pb->lblob_cap)) {
+        set_error("index build: the plan outgrew its reservation (%u of %zu bytes)", p.ip.blob_bytes, pb->blob_cap);
+        rc = SLAM_E_HIP;
+    }
+    if (rc == SLAM_OK) {
+        adopt_index_plan(h, p.ip);
+        h->mv.blob = static_cast<const unsigned char *>(h->d_blob);
+        if (p.pick >= 0) {
+            adopt_list_plan(h, p.lp);
+            h->mv.lblob = static_cast<const unsigned char *>(h->d_lblob);
+            list_done(h);
+        } else if (h->d_lblob) {
+            pool_free(h->d_lblob);
+            h->d_lblob = nullptr;
+        }
+        h->max_cell_points = (int)p.most;
+        h->built_on_device = true;
+    }
+    drop_pending(h, false);
+    if (rc != SLAM_OK) release_index(h);
+    return rc;
+}
+
 int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, int n_nga, bool on_device)
 {
     if (h->prm.build_on_host && !on_device) return build_index_host(h, m_ga, n_ga, m_nga, n_nga);
-    return build_index_device(h, m_ga, n_ga, m_nga, n_nga, on_device);
+    // (device arrays: complete when the call is made -- the build does not order itself behind the default stream: that
+    // stream shares a hardware queue with whatever the application runs, and an event on it can sit behind a whole
+    // registration launch)
+    SLAM_TRY(build_index_begin(h, m_ga, n_ga, m_nga, n_nga, nullptr, on_device, build_stream()));
+    return build_index_finish(h);
 }
 
 void release_index(slam_icp *h)
 {
+    drop_pending(h, true);
     if (h->d_blob) pool_free(h->d_blob);
     if (h->d_lblob) pool_free(h->d_lblob);
     h->d_blob = h->d_lblob = nullptr;

@@ -140,6 +140,8 @@ __host__ __device__ inline int lattice_coord(float v, float v0, float inv_h, int
 } // namespace icp
 } // namespace slam
 
+struct slam_icp_pending; // icp_build.hip: an index build that is enqueued and not yet adopted
+
 struct slam_icp {
     slam_icp_params prm;
     int             sub_step = 10; // icp.cpp:27
@@ -175,7 +177,8 @@ struct slam_icp {
     int             n_cu = 256;          // CUs of the device the handle was made on
     int             max_cell_points = 0; // points in the fullest cell of the index (either class)
     bool            built_on_device = false;
-    double          build_ms[4] = {0, 0, 0, 0}; // host pass + upload, cell index kernels, list plan (sync), list kernels
+    double          build_ms[4] = {0, 0, 0, 0}; // enqueueing the build, its one wait (the other two: unused since the plan moved to the device)
+    slam_icp_pending *pending = nullptr;        // between build_index_begin and build_index_finish
 };
 
 namespace slam {
@@ -183,6 +186,14 @@ namespace icp {
 // icp_build.hip: Icp::Icp's model copy + index (icp.cpp:26-70, kdtree.cpp:72-106 stand-in).  m_* are host
 // arrays unless on_device; fills h->mv, h->d_blob, h->d_lblob, ...
 int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, int n_nga, bool on_device);
+// The same in two halves, for callers that keep the device busy meanwhile (the mapper's sliding target): begin enqueues the
+// whole build on `st` and returns; the model may hold fewer points than cap_* -- d_cnt (int[2] in device memory, complete
+// in stream order; null: exactly cap_*) says how many.  The handle is usable after finish (the build's one host wait;
+// SLAM_E_TOO_FEW_MODEL_POINTS when d_cnt named fewer than 5); ready = finish would not block.
+int  build_index_begin(slam_icp *h, const double *m_ga, int cap_ga, const double *m_nga, int cap_nga, const int *d_cnt, bool on_device,
+                       hipStream_t st);
+bool build_index_ready(slam_icp *h);
+int  build_index_finish(slam_icp *h);
 void release_index(slam_icp *h);
 void destroy_unsynchronised(slam_icp *h); // slam_icp_destroy without its device synchronisation
 } // namespace icp

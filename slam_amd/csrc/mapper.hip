@@ -13,25 +13,33 @@
 //                 -> every merge_every chunks: dirty-row merge over the ranks (hook installed by
 //                 slam_mapper_use_comm, slam_mi355x_rccl.h), fold into the accumulator, finalize -> event mapped
 // so that the copy of chunk k+1, the registration of chunk k and the map update of chunk k-1 overlap.
-// Every rebuild_every chunks the target is rebuilt on the device (slam_icp_create_dev, icp_build.hip) from the
-// prior map (optional) plus the decimated points of the last window_chunks chunks whose registration has
-// finished: the newest chunk is not waited for, so the target lags by one chunk instead of stalling the pipeline
-// (the north-star's "sliding-window local map ... accepting staleness").  The rebuild's three host waits (the thinned
-// count, the list plan, the fullest cell) each queue behind ICP workgroups that hold every CU for 0.4 ms: they run on
-// a thread of the mapper's own (background_rebuild), the producer's thread keeps pushing against the old target and
-// adopts the new one at the first push after it is complete.
+// Every rebuild_every chunks the target is rebuilt on the device (icp_build.hip) from the prior map (optional) plus the
+// thinned points of the last window_chunks chunks (the north-star's "sliding-window local map ... accepting staleness").
+// The whole rebuild -- thinning, extent, plan, cell index, halo lists -- is ENQUEUED on a stream of its own with the counts
+// it produces left on the device (build_index_begin): no host wait and no thread.  The producer keeps pushing against the
+// old target and adopts the new one at the first push that finds the build's plan back in pinned memory (strict_window: it
+// waits for it).
 #include <algorithm>
 #include <chrono>
-#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <new>
-#include <thread>
 #include <vector>
 
 #include "icp_model.hpp"
 
-namespace slam { namespace icp { bool takes_spread_form(const slam_icp *h, int n_scans); } } // icp.hip
+namespace slam {
+namespace icp { // icp.hip
+bool takes_spread_form(const slam_icp *h, int n_scans);
+// slam_icp_create_dev in two halves (build_index_begin / _finish): begin enqueues the index build of a model of up to cap_*
+// points per class (d_cnt: int[2] on the device, in stream order; null = exactly cap_*) on st and returns a handle that may
+// only be passed to create_ready / create_finish / slam_icp_destroy; finish makes it usable (its one host wait) or destroys it.
+int  create_begin(const double *d_ga, int cap_ga, const double *d_nga, int cap_nga, const int *d_cnt, const slam_icp_params *params,
+                  hipStream_t st, slam_icp **out);
+bool create_ready(slam_icp *h);
+int  create_finish(slam_icp *h);
+} // namespace icp
+} // namespace slam
 
 using namespace slam;
 
@@ -105,10 +113,12 @@ __global__ __launch_bounds__(256) void thin_min_kernel(Segs s, ThinGeom g, unsig
     if (c >= 0) atomicMin(&lat[c], (unsigned)i);
 }
 
-// PASS 0: winners per block; PASS 1: the winners, every stride-th, written in rank order
+// PASS 0: winners per block; PASS 1: the winners, every stride-th, written in rank order -- the stride from the total the
+// scan left on the device (more cells than the target may hold: every stride-th), the class's count (prior + kept) with it
 template <int PASS>
 __global__ __launch_bounds__(256) void thin_pick_kernel(Segs s, ThinGeom g, const unsigned *lat, unsigned *block_count,
-                                                        const unsigned *block_off, int stride, double2 *out)
+                                                        const unsigned *block_off, const unsigned *total, int cap, int prior,
+                                                        int *count_out, double2 *out)
 {
     __shared__ unsigned s_w[4];
     const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -126,10 +136,14 @@ __global__ __launch_bounds__(256) void thin_pick_kernel(Segs s, ThinGeom g, cons
         if (threadIdx.x == 0) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
         return;
     }
+    const unsigned kept = *total, stride = max(1u, (kept + (unsigned)cap - 1u) / (unsigned)max(cap, 1));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = prior + (int)((kept + stride - 1u) / stride);
     unsigned k = block_off[blockIdx.x] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
     for (int w = 0; w < wave; ++w) k += s_w[w];
-    if (win && k % (unsigned)stride == 0) out[k / (unsigned)stride] = q;
+    if (win && k % stride == 0) out[k / stride] = q;
 }
+
+__global__ void set_counts_kernel(int *cnt, int a, int b) { cnt[0] = a, cnt[1] = b; }
 
 // exclusive prefix of the block counts (a few thousand), total behind the last; one workgroup
 __global__ __launch_bounds__(1024) void thin_scan_kernel(const unsigned *cnt, int n, unsigned *off, unsigned *total)
@@ -187,6 +201,7 @@ struct slam_mapper {
     hipEvent_t         target_used[2] = {nullptr, nullptr}, retired_used[2] = {nullptr, nullptr}; // behind the last launch on each
                                                                                                   // registration stream that read the handle
     hipStream_t        copy = nullptr, icp_s[2] = {nullptr, nullptr}, grid_s = nullptr; // chunks alternate over the two icp streams
+    hipStream_t        build_s = nullptr;      // the sliding target's rebuilds
     Slot               slot[kMaxSlots];
     int                n_slots = 5;
     bool               two_lanes = false;      // chunks alternate over two registration streams
@@ -194,30 +209,23 @@ struct slam_mapper {
     long               chunks = 0, merges = 0, rebuilds = 0, last_rebuild = -1;
     std::vector<WindowEntry> window;
     std::vector<double> prior_ga, prior_nga; // host copies of the model given at create
-    double            *d_model_ga = nullptr, *d_model_nga = nullptr;
-    size_t             cap_model = 0;
+    double            *d_model_ga = nullptr, *d_model_nga = nullptr; // [prior | window part] per class
+    size_t             cap_model = 0;          // points reserved (both classes)
     unsigned          *d_thin = nullptr;      // [2][nx*ny] lowest window rank per lattice cell and class
     unsigned          *d_thin_blk = nullptr;  // [2][blocks + blocks + 1] winners per block, their prefix, the total
     size_t             cap_thin_blk = 0;
-    double2           *d_thin_out[2] = {nullptr, nullptr};
-    size_t             cap_thin_out = 0;
     slam_mapper_merge_fn merge_begin = nullptr, merge_finish = nullptr;
     void              *merge_ctx = nullptr;
     bool               merge_pending = false;
     int                last_rows[2] = {0, -1};
-    double             rebuild_ms = 0;
-    // background rebuild (prm.background_rebuild, not with strict_window): one job at a time
+    double             rebuild_ms = 0;         // host time spent enqueueing rebuilds and waiting for their plans
     int                device = 0;
-    int                max_lag = 0;            // pushes a job may stay in flight: the window ring holds that many entries more
-    std::thread        worker;
-    std::mutex         mu;
-    std::condition_variable cv;
-    bool               job_posted = false, job_done = false, quit = false, job_in_flight = false;
-    long               job_chunk = 0;          // m->chunks when the job was posted
-    std::vector<WindowEntry> job_use;          // the window entries the job reads (by value)
-    slam_icp_t        *job_fresh = nullptr;
-    int                job_rc = SLAM_OK;
-    char               job_err[256] = "";
+    int                max_lag = 0;            // pushes a build may stay un-adopted (0: every rebuild is waited for at once)
+    slam_icp_t        *building = nullptr;     // the target whose build is enqueued and not yet adopted
+    long               building_chunk = 0;     // m->chunks when it was begun
+    int               *d_cnt = nullptr;        // points per class of the model being built (the thinning leaves them here)
+    size_t             model_prior[2] = {0, 0}; // prior points resident at the head of d_model_ga / d_model_nga
+    hipEvent_t         window_read = nullptr;  // behind the last rebuild's reads of the window ring
 };
 
 namespace {
@@ -241,8 +249,9 @@ int stride_for(const slam_mapper *m, int n)
     return std::max(1, (n + per_chunk - 1) / per_chunk);
 }
 
-// one class of the window thinned into out[]; *n_out = points written
-int thin_class(slam_mapper *m, const std::vector<const WindowEntry *> &use, int cls, int cap, double2 *out, int *n_out, hipStream_t st)
+// one class of the window thinned into out[] (room for cap points); the class's count (prior + kept) goes to *count_out
+int thin_class(slam_mapper *m, const std::vector<const WindowEntry *> &use, int cls, int cap, int prior, int *count_out, double2 *out,
+               hipStream_t st)
 {
     Segs s;
     memset(&s, 0, sizeof s);
@@ -254,8 +263,7 @@ int thin_class(slam_mapper *m, const std::vector<const WindowEntry *> &use, int 
         s.total += n;
         ++s.count;
     }
-    *n_out = 0;
-    if (!s.total) return SLAM_OK;
+    if (!s.total) return SLAM_OK; // (the count stays the prior's: set_counts_kernel)
     ThinGeom g;
     int      gx = 0, gy = 0;
     double   res = 0;
@@ -269,96 +277,31 @@ int thin_class(slam_mapper *m, const std::vector<const WindowEntry *> &use, int 
     const int    blocks = (s.total + 255) / 256;
     if (!m->d_thin) MAP_HIP(hipMalloc((void **)&m->d_thin, 4 * cells));
     if ((size_t)(2 * blocks + 1) > m->cap_thin_blk) {
-        if (m->d_thin_blk) (void)hipFree(m->d_thin_blk);
+        if (m->d_thin_blk) {
+            MAP_HIP(hipStreamSynchronize(st)); // (grows once or twice in a mapper's life)
+            (void)hipFree(m->d_thin_blk);
+        }
         m->cap_thin_blk = (size_t)(2 * blocks + 1) * 2;
         MAP_HIP(hipMalloc((void **)&m->d_thin_blk, 4 * m->cap_thin_blk));
     }
     unsigned *cnt = m->d_thin_blk, *off = cnt + blocks, *total = off + blocks;
     MAP_HIP(hipMemsetAsync(m->d_thin, 0xff, 4 * cells, st));
     hipLaunchKernelGGL(thin_min_kernel, dim3(blocks), dim3(256), 0, st, s, g, m->d_thin);
-    hipLaunchKernelGGL((thin_pick_kernel<0>), dim3(blocks), dim3(256), 0, st, s, g, m->d_thin, cnt, off, 1, out);
+    hipLaunchKernelGGL((thin_pick_kernel<0>), dim3(blocks), dim3(256), 0, st, s, g, m->d_thin, cnt, off, total, cap, prior, count_out, out);
     hipLaunchKernelGGL(thin_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, blocks, off, total);
-    unsigned *h_total = static_cast<unsigned *>(pinned_scratch(64));
-    SLAM_REQUIRE(h_total, SLAM_E_NOMEM, "no pinned memory");
-    MAP_HIP(hipMemcpyAsync(h_total, total, 4, hipMemcpyDeviceToHost, st));
-    MAP_HIP(hipStreamSynchronize(st));
-    const int kept = (int)*h_total;
-    const int stride = std::max(1, (kept + cap - 1) / std::max(cap, 1)); // more cells than the target may hold: every stride-th
-    hipLaunchKernelGGL((thin_pick_kernel<1>), dim3(blocks), dim3(256), 0, st, s, g, m->d_thin, cnt, off, stride, out);
+    hipLaunchKernelGGL((thin_pick_kernel<1>), dim3(blocks), dim3(256), 0, st, s, g, m->d_thin, cnt, off, total, cap, prior, count_out, out);
     MAP_HIP(hipGetLastError());
-    *n_out = (kept + stride - 1) / stride;
     return SLAM_OK;
 }
 
-// everything in the window whose registration has finished (the newest may still be running: skipped), newest W
-int collect_window(slam_mapper *m, std::vector<WindowEntry> &use)
+// the window as the next target sees it: the newest window_chunks chunks, oldest first
+void collect_window(slam_mapper *m, std::vector<const WindowEntry *> &use)
 {
     use.clear();
-    for (const WindowEntry &w : m->window) {
-        if (w.chunk < 0) continue;
-        if (m->prm.strict_window) MAP_HIP(hipEventSynchronize(w.ready)); // reproducible: wait for the newest too
-        if (hipEventQuery(w.ready) == hipSuccess) use.push_back(w);
-    }
-    (void)hipGetLastError();
-    std::sort(use.begin(), use.end(), [](const WindowEntry &a, const WindowEntry &b) { return a.chunk < b.chunk; });
+    for (const WindowEntry &w : m->window)
+        if (w.chunk >= 0) use.push_back(&w);
+    std::sort(use.begin(), use.end(), [](const WindowEntry *a, const WindowEntry *b) { return a->chunk < b->chunk; });
     if ((int)use.size() > m->prm.window_chunks) use.erase(use.begin(), use.end() - m->prm.window_chunks); // the newest W
-    return SLAM_OK;
-}
-
-// The target for `use`: prior map (optional) + the window, thinned.  Runs on the caller's thread or on the mapper's
-// worker; touches only the rebuild's own buffers (d_model_*, d_thin*) and, read-only, the window entries in `use`.
-// *fresh stays null when there is nothing to build from.
-int build_target(slam_mapper *m, const std::vector<WindowEntry> &entries, slam_icp_t **fresh)
-{
-    *fresh = nullptr;
-    std::vector<const WindowEntry *> use;
-    for (const WindowEntry &w : entries) use.push_back(&w);
-    if (use.empty()) return SLAM_OK; // nothing registered yet: keep the current target
-    const size_t p_ga = m->prm.keep_prior ? m->prior_ga.size() / 2 : 0, p_nga = m->prm.keep_prior ? m->prior_nga.size() / 2 : 0;
-    hipStream_t  st = build_stream(); // the stream slam_icp_create_dev builds on; everything read here is complete by now
-    const bool   thin = m->prm.thin_res > 0;
-    size_t       w_ga = 0, w_nga = 0;
-    for (const WindowEntry *w : use) w_ga += (size_t)w->n_ga, w_nga += (size_t)w->n_nga;
-    if (thin) { // one point per lattice cell and class over the whole window
-        const int cap = std::max(64, m->prm.target_points / 2);
-        if ((size_t)cap > m->cap_thin_out) {
-            for (double2 *&p : m->d_thin_out)
-                if (p) (void)hipFree(p), p = nullptr;
-            m->cap_thin_out = (size_t)cap;
-            for (double2 *&p : m->d_thin_out) MAP_HIP(hipMalloc((void **)&p, 16 * m->cap_thin_out));
-        }
-        int n0 = 0, n1 = 0;
-        SLAM_TRY(thin_class(m, use, 0, cap, m->d_thin_out[0], &n0, st));
-        SLAM_TRY(thin_class(m, use, 1, cap, m->d_thin_out[1], &n1, st));
-        w_ga = (size_t)n0;
-        w_nga = (size_t)n1;
-    }
-    const size_t n_ga = p_ga + w_ga, n_nga = p_nga + w_nga;
-    if (n_ga + n_nga < 5) return SLAM_OK;
-    if (n_ga + n_nga > m->cap_model) {
-        if (m->d_model_ga) pool_free(m->d_model_ga);
-        m->cap_model = (n_ga + n_nga) * 2;
-        m->d_model_ga = static_cast<double *>(pool_alloc(16 * m->cap_model));
-        if (!m->d_model_ga) return SLAM_E_NOMEM;
-    }
-    m->d_model_nga = m->d_model_ga + 2 * n_ga;
-    if (p_ga) MAP_HIP(hipMemcpyAsync(m->d_model_ga, m->prior_ga.data(), 16 * p_ga, hipMemcpyHostToDevice, st));
-    if (p_nga) MAP_HIP(hipMemcpyAsync(m->d_model_nga, m->prior_nga.data(), 16 * p_nga, hipMemcpyHostToDevice, st));
-    if (thin) {
-        if (w_ga) MAP_HIP(hipMemcpyAsync(m->d_model_ga + 2 * p_ga, m->d_thin_out[0], 16 * w_ga, hipMemcpyDeviceToDevice, st));
-        if (w_nga) MAP_HIP(hipMemcpyAsync(m->d_model_nga + 2 * p_nga, m->d_thin_out[1], 16 * w_nga, hipMemcpyDeviceToDevice, st));
-    } else {
-        size_t o_ga = p_ga, o_nga = p_nga;
-        for (const WindowEntry *w : use) {
-            if (w->n_ga) MAP_HIP(hipMemcpyAsync(m->d_model_ga + 2 * o_ga, w->ga, 16 * (size_t)w->n_ga, hipMemcpyDeviceToDevice, st));
-            if (w->n_nga) MAP_HIP(hipMemcpyAsync(m->d_model_nga + 2 * o_nga, w->nga, 16 * (size_t)w->n_nga, hipMemcpyDeviceToDevice, st));
-            o_ga += (size_t)w->n_ga;
-            o_nga += (size_t)w->n_nga;
-        }
-    }
-    // (slam_icp_create_dev returns with the index complete: every read of the window above has finished by then)
-    SLAM_TRY(slam_icp_create_dev(m->d_model_ga, (int)n_ga, m->d_model_nga, (int)n_nga, &m->prm.icp, fresh));
-    return SLAM_OK;
 }
 
 // the producer's thread: the new target replaces the current one; the one before last is destroyed
@@ -373,99 +316,79 @@ void adopt_target(slam_mapper *m, slam_icp_t *fresh)
     ++m->rebuilds;
 }
 
-int rebuild_target(slam_mapper *m)
+// Enqueues on st the target for the window as it is now: prior map (optional) + the window, thinned, and the build of its
+// index.  Everything it reads is waited for in stream order (the window entries: behind their events); the host waits for nothing.
+int begin_rebuild(slam_mapper *m, hipStream_t st)
 {
-    std::vector<WindowEntry> use;
-    SLAM_TRY(collect_window(m, use));
-    if (use.empty()) return SLAM_OK;
-    const auto  t0 = std::chrono::steady_clock::now();
-    slam_icp_t *fresh = nullptr;
-    SLAM_TRY(build_target(m, use, &fresh));
-    adopt_target(m, fresh);
-    m->last_rebuild = m->chunks;
+    std::vector<const WindowEntry *> use;
+    collect_window(m, use);
+    if (use.empty()) return SLAM_OK; // nothing registered yet: keep the current target
+    const auto   t0 = std::chrono::steady_clock::now();
+    const size_t p_ga = m->prm.keep_prior ? m->prior_ga.size() / 2 : 0, p_nga = m->prm.keep_prior ? m->prior_nga.size() / 2 : 0;
+    const bool   thin = m->prm.thin_res > 0;
+    size_t       w_ga = 0, w_nga = 0; // room for the window's part of each class
+    for (const WindowEntry *w : use) w_ga += (size_t)w->n_ga, w_nga += (size_t)w->n_nga;
+    if (thin) w_ga = w_nga = (size_t)std::max(64, m->prm.target_points / 2); // one point per lattice cell and class, at most this many
+    const size_t cap_ga = p_ga + w_ga, cap_nga = p_nga + w_nga;
+    if (!thin && cap_ga + cap_nga < 5) return SLAM_OK;
+    for (const WindowEntry *w : use) MAP_HIP(hipStreamWaitEvent(st, w->ready, 0));
+    if (cap_ga + cap_nga > m->cap_model || !m->d_model_ga) {
+        if (m->d_model_ga) {
+            MAP_HIP(hipStreamSynchronize(st)); // an earlier build may still read the old block (grows once or twice)
+            pool_free(m->d_model_ga);
+        }
+        m->cap_model = (cap_ga + cap_nga) * 2;
+        m->d_model_ga = static_cast<double *>(pool_alloc(16 * m->cap_model));
+        if (!m->d_model_ga) return SLAM_E_NOMEM;
+        m->model_prior[0] = m->model_prior[1] = (size_t)-1;
+    }
+    if (!m->d_cnt) MAP_HIP(hipMalloc((void **)&m->d_cnt, 2 * sizeof(int)));
+    // class GA at the head of the block, class NGA behind GA's reservation; the prior's points go in when the layout changes
+    double *d_ga = m->d_model_ga, *d_nga = m->d_model_ga + 2 * cap_ga;
+    if (m->model_prior[0] != p_ga || m->model_prior[1] != p_nga || m->d_model_nga != d_nga) {
+        if (p_ga) MAP_HIP(hipMemcpyAsync(d_ga, m->prior_ga.data(), 16 * p_ga, hipMemcpyHostToDevice, st));
+        if (p_nga) MAP_HIP(hipMemcpyAsync(d_nga, m->prior_nga.data(), 16 * p_nga, hipMemcpyHostToDevice, st));
+        m->model_prior[0] = p_ga;
+        m->model_prior[1] = p_nga;
+        m->d_model_nga = d_nga;
+    }
+    const int *d_cnt = nullptr;
+    if (thin) {
+        hipLaunchKernelGGL(set_counts_kernel, dim3(1), dim3(1), 0, st, m->d_cnt, (int)p_ga, (int)p_nga);
+        SLAM_TRY(thin_class(m, use, 0, (int)w_ga, (int)p_ga, m->d_cnt + 0, reinterpret_cast<double2 *>(d_ga + 2 * p_ga), st));
+        SLAM_TRY(thin_class(m, use, 1, (int)w_nga, (int)p_nga, m->d_cnt + 1, reinterpret_cast<double2 *>(d_nga + 2 * p_nga), st));
+        d_cnt = m->d_cnt;
+    } else {
+        size_t o_ga = p_ga, o_nga = p_nga;
+        for (const WindowEntry *w : use) {
+            if (w->n_ga) MAP_HIP(hipMemcpyAsync(d_ga + 2 * o_ga, w->ga, 16 * (size_t)w->n_ga, hipMemcpyDeviceToDevice, st));
+            if (w->n_nga) MAP_HIP(hipMemcpyAsync(d_nga + 2 * o_nga, w->nga, 16 * (size_t)w->n_nga, hipMemcpyDeviceToDevice, st));
+            o_ga += (size_t)w->n_ga;
+            o_nga += (size_t)w->n_nga;
+        }
+    }
+    MAP_HIP(hipEventRecord(m->window_read, st)); // (the ring's entries are free to be rewritten behind this)
+    SLAM_TRY(slam::icp::create_begin(d_ga, (int)cap_ga, d_nga, (int)cap_nga, d_cnt, &m->prm.icp, st, &m->building));
+    m->building_chunk = m->chunks;
     m->rebuild_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SLAM_OK;
 }
 
-// ---- the same on the mapper's own thread
-void worker_main(slam_mapper *m)
+// The build in flight becomes the target: when its plan is back, or -- block -- after waiting for it.  A window that came
+// to fewer than five points (icp.cpp:38-43) leaves the current target in place.
+int adopt_build(slam_mapper *m, bool block)
 {
-    (void)hipSetDevice(m->device);
-    build_stream_for_this_thread(m->copy); // the rebuild's kernels and read-backs go between the chunk copies
-    std::unique_lock<std::mutex> lk(m->mu);
-    for (;;) {
-        m->cv.wait(lk, [&] { return m->job_posted || m->quit; });
-        if (m->quit) return;
-        m->job_posted = false;
-        lk.unlock();
-        const auto  t0 = std::chrono::steady_clock::now();
-        slam_icp_t *fresh = nullptr;
-        const int   rc = build_target(m, m->job_use, &fresh);
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        lk.lock();
-        m->job_fresh = fresh;
-        m->job_rc = rc;
-        if (rc != SLAM_OK) snprintf(m->job_err, sizeof m->job_err, "%s", slam_last_error());
-        m->rebuild_ms += ms;
-        m->job_done = true;
-        m->cv.notify_all();
-    }
-}
-
-// adopts a finished job; block = wait for the one in flight
-int collect_job(slam_mapper *m, bool block)
-{
-    if (!m->job_in_flight) return SLAM_OK;
-    slam_icp_t *fresh = nullptr;
-    int         rc = SLAM_OK;
-    {
-        std::unique_lock<std::mutex> lk(m->mu);
-        if (block) m->cv.wait(lk, [&] { return m->job_done; });
-        if (!m->job_done) return SLAM_OK;
-        m->job_done = false;
-        fresh = m->job_fresh;
-        m->job_fresh = nullptr;
-        rc = m->job_rc;
-    }
-    m->job_in_flight = false;
-    if (rc != SLAM_OK) { // the old target stays; the push that finds this out is refused before it has consumed anything
-        set_error("slam_mapper: the background rebuild of the sliding target failed (the previous target stays in use): %s", m->job_err);
-        return rc;
-    }
+    if (!m->building) return SLAM_OK;
+    if (!block && !slam::icp::create_ready(m->building)) return SLAM_OK;
+    const auto  t0 = std::chrono::steady_clock::now();
+    slam_icp_t *fresh = m->building;
+    m->building = nullptr;
+    const int rc = slam::icp::create_finish(fresh); // (destroys the handle when it fails)
+    m->rebuild_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rc == SLAM_E_TOO_FEW_MODEL_POINTS) return SLAM_OK;
+    SLAM_TRY(rc);
     adopt_target(m, fresh);
     return SLAM_OK;
-}
-
-int post_job(slam_mapper *m)
-{
-    std::vector<WindowEntry> use;
-    SLAM_TRY(collect_window(m, use));
-    m->last_rebuild = m->chunks; // the cadence counts from the post
-    if (use.empty()) return SLAM_OK;
-    {
-        std::lock_guard<std::mutex> lk(m->mu);
-        m->job_use.swap(use);
-        m->job_posted = true;
-        m->job_done = false;
-    }
-    m->job_chunk = m->chunks;
-    m->job_in_flight = true;
-    m->cv.notify_all();
-    return SLAM_OK;
-}
-
-void stop_worker(slam_mapper *m)
-{
-    if (!m->worker.joinable()) return;
-    {
-        std::unique_lock<std::mutex> lk(m->mu);
-        if (m->job_in_flight) m->cv.wait(lk, [&] { return m->job_done; });
-        m->quit = true;
-    }
-    m->cv.notify_all();
-    m->worker.join();
-    if (m->job_fresh) slam_icp_destroy(m->job_fresh), m->job_fresh = nullptr;
-    m->job_in_flight = false;
 }
 
 int finish_merge(slam_mapper *m)
@@ -535,6 +458,8 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
         (void)hipGetLastError();
     }
     int rc = slam_grid_create(params->grid_size_x, params->grid_size_y, params->resolution, &m->prm.grid, &m->grid);
+    // (chunks differ in size: a raycast that had to grow its scratch would free the old block, and a free waits for the device)
+    if (rc == SLAM_OK) rc = slam_grid_reserve(m->grid, params->max_points);
     if (rc == SLAM_OK) rc = slam_icp_create(m_ga, n_ga, m_nga, n_nga, &m->prm.icp, &m->target); // the prior map: the first target
     auto hip = [&](hipError_t e) {
         if (rc == SLAM_OK && e != hipSuccess) rc = hip_fail(e, "slam_mapper_create", __FILE__, __LINE__);
@@ -560,9 +485,19 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
             hip(hipStreamCreateWithPriority(&m->grid_s, hipStreamNonBlocking, least));
             if (m->two_lanes) hip(hipStreamCreateWithPriority(&m->icp_s[1], hipStreamNonBlocking, mid));
             if (!m->two_lanes) m->icp_s[1] = m->icp_s[0]; // a sliding target registers its chunks one after the other (slam_mapper_push)
+            if (params->window_chunks) {
+                const char *e = getenv("X_BUILD_STREAM");
+                const int   which = e ? atoi(e) : 2;
+                if (which == 0) hip(hipStreamCreateWithPriority(&m->build_s, hipStreamNonBlocking, mid));
+                if (which == 1) hip(hipStreamCreateWithPriority(&m->build_s, hipStreamNonBlocking, greatest));
+                if (which == 2) hip(hipStreamCreateWithPriority(&m->build_s, hipStreamNonBlocking, least));
+                if (which == 3) m->build_s = m->copy;
+                if (which == 4) m->build_s = m->icp_s[0];
+                if (which == 5) m->build_s = m->grid_s;
+            }
         } else {
             hip(hipStreamCreateWithFlags(&m->copy, hipStreamNonBlocking));
-            m->icp_s[0] = m->icp_s[1] = m->grid_s = m->copy;
+            m->icp_s[0] = m->icp_s[1] = m->grid_s = m->build_s = m->copy;
         }
         for (int k = 0; k < 2; ++k) {
             hip(hipEventCreateWithFlags(&m->target_used[k], hipEventDisableTiming));
@@ -589,6 +524,9 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
             hip(hipEventCreateWithFlags(&b.mapped, hipEventDisableTiming));
         }
         hip(hipGetDevice(&m->device));
+        hip(hipEventCreateWithFlags(&m->window_read, hipEventDisableTiming));
+        hip(hipEventRecord(m->window_read, m->icp_s[0]));
+        if (!m->build_s) m->build_s = m->icp_s[0];
         // the window keeps one entry more than it uses: the newest is still being written when a rebuild looks -- and as
         // many more as pushes may pass while a background rebuild reads its entries (it is waited for after max_lag)
         const bool bg = params->window_chunks && params->background_rebuild && !params->strict_window;
@@ -606,7 +544,6 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
         slam_mapper_destroy(m);
         return rc;
     }
-    if (m->max_lag) m->worker = std::thread(worker_main, m);
     *out = m;
     return SLAM_OK;
 }
@@ -614,8 +551,8 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
 void slam_mapper_destroy(slam_mapper_t *m)
 {
     if (!m) return;
-    stop_worker(m);
     (void)hipDeviceSynchronize();
+    if (m->building) slam_icp_destroy(m->building);
     for (Slot &b : m->slot) {
         for (void *p : {(void *)b.d_pts, (void *)b.d_off, (void *)b.d_nga, (void *)b.d_gab, (void *)b.d_R, (void *)b.d_t})
             if (p) (void)hipFree(p);
@@ -630,8 +567,9 @@ void slam_mapper_destroy(slam_mapper_t *m)
         if (w.ready) (void)hipEventDestroy(w.ready);
     }
     if (m->d_model_ga) pool_free(m->d_model_ga);
-    for (void *p : {(void *)m->d_thin, (void *)m->d_thin_blk, (void *)m->d_thin_out[0], (void *)m->d_thin_out[1]})
+    for (void *p : {(void *)m->d_thin, (void *)m->d_thin_blk, (void *)m->d_cnt})
         if (p) (void)hipFree(p);
+    if (m->window_read) (void)hipEventDestroy(m->window_read);
     if (m->target) slam_icp_destroy(m->target);
     if (m->retired) slam_icp_destroy(m->retired);
     if (m->grid) slam_grid_destroy(m->grid);
@@ -644,6 +582,7 @@ void slam_mapper_destroy(slam_mapper_t *m)
     if (!one && m->icp_s[0]) (void)hipStreamDestroy(m->icp_s[0]);
     if (!one && m->icp_s[1] && m->icp_s[1] != m->icp_s[0]) (void)hipStreamDestroy(m->icp_s[1]);
     if (!one && m->grid_s) (void)hipStreamDestroy(m->grid_s);
+    if (m->build_s && m->build_s != m->copy && m->build_s != m->icp_s[0] && m->build_s != m->grid_s) (void)hipStreamDestroy(m->build_s);
     delete m;
 }
 
@@ -702,15 +641,14 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     const int n_ga = b.h_gab[n_scans], n_nga = n_points - n_ga;
 
     // ---- sliding target: rebuilt before this chunk's registration is enqueued
-    bool       post_at_end = false;
+    // (enqueued on the rebuild's own stream; a build still un-adopted is waited for only when the next one is due or after
+    // max_lag pushes)
     const bool due = m->prm.window_chunks && m->chunks > 0 && m->chunks - std::max<long>(m->last_rebuild, 0) >= m->prm.rebuild_every;
-    if (m->max_lag) {
-        // a finished background build becomes the target of this chunk; one still running is waited for only when the
-        // pushes since its post are about to reach the window entries it reads, or when the next one is due
-        SLAM_TRY(collect_job(m, m->job_in_flight && (due || m->chunks - m->job_chunk >= m->max_lag)));
-        post_at_end = due && !m->job_in_flight; // posted behind this chunk's copy (below): the rebuild's kernels share the copy stream
-    } else if (due) {
-        SLAM_TRY(rebuild_target(m));
+    if (m->building) SLAM_TRY(adopt_build(m, due || m->chunks - m->building_chunk >= std::max(m->max_lag, 1)));
+    if (due) {
+        SLAM_TRY(begin_rebuild(m, m->build_s));
+        m->last_rebuild = m->chunks;
+        if (!m->max_lag) SLAM_TRY(adopt_build(m, true)); // strict_window / background_rebuild = 0: this chunk meets the new target
     }
 
     // ---- copy
@@ -721,10 +659,6 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     MAP_HIP(hipMemcpyAsync(b.d_R, b.h_R, 32 * (size_t)n_scans, hipMemcpyHostToDevice, m->copy));
     MAP_HIP(hipMemcpyAsync(b.d_t, b.h_t, 16 * (size_t)n_scans, hipMemcpyHostToDevice, m->copy));
     MAP_HIP(hipEventRecord(b.copied, m->copy));
-    // The background rebuild is posted HERE, behind this chunk's copy: its seventeen short launches run on the copy stream and
-    // each waits for a CU behind the registration's workgroups; posted before the copy (round 2), the copy -- and with it this
-    // chunk's registration -- sat behind the rebuild's first stage (a 0.5 ms hole in the registration stream per rebuild).
-    if (post_at_end) SLAM_TRY(post_job(m));
     // ---- register
     // chunks alternate over the two registration streams; the spread form (a handful of scans) takes one call at a time
     // (and so do the chunks of a sliding target: a chunk registered beside its predecessor meets a window that is a chunk
@@ -739,6 +673,7 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     if (m->prm.window_chunks) {
         WindowEntry &w = m->window[(size_t)(m->chunks % (long)m->window.size())];
         const int    sg = stride_for(m, n_ga), sn = stride_for(m, n_nga);
+        if (icp_s != m->build_s) MAP_HIP(hipStreamWaitEvent(icp_s, m->window_read, 0)); // a rebuild may still be reading the entry
         hipLaunchKernelGGL(window_points_kernel, dim3((n_points + 255) / 256), dim3(256), 0, icp_s,
                            reinterpret_cast<const double2 *>(b.d_pts), b.d_off, b.d_nga, b.d_gab, n_scans, n_points, b.d_R, b.d_t, sg, sn,
                            w.ga, w.nga);
@@ -795,7 +730,7 @@ int slam_mapper_wait(slam_mapper_t *m, int slot, double *R_out, double *t_out)
 int slam_mapper_finish(slam_mapper_t *m)
 {
     SLAM_REQUIRE(m, SLAM_E_INVALID, "null handle");
-    SLAM_TRY(collect_job(m, true));
+    SLAM_TRY(adopt_build(m, true));
     SLAM_TRY(finish_merge(m));
     if (m->merge_begin) { // whatever was added since the last merge
         int lo = 0, hi = -1;
@@ -832,10 +767,7 @@ int slam_mapper_stats(slam_mapper_t *m, long *chunks, long *merges, long *rebuil
     if (chunks) *chunks = m->chunks;
     if (merges) *merges = m->merges;
     if (rebuilds) *rebuilds = m->rebuilds;
-    if (rebuild_ms) {
-        std::lock_guard<std::mutex> lk(m->mu); // the worker adds to it
-        *rebuild_ms = m->rebuild_ms;
-    }
+    if (rebuild_ms) *rebuild_ms = m->rebuild_ms;
     if (last_merge_rows) last_merge_rows[0] = m->last_rows[0], last_merge_rows[1] = m->last_rows[1];
     return SLAM_OK;
 }

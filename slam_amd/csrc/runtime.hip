@@ -183,6 +183,39 @@ void *pinned_scratch(size_t bytes)
     return p;
 }
 
+namespace {
+constexpr size_t      kPinnedBlock = 16384;
+std::mutex            g_pinned_mu;
+std::vector<void *>  *g_pinned_free = nullptr; // never destroyed (see the pool)
+} // namespace
+
+void *pinned_block_get(size_t bytes)
+{
+    if (bytes > kPinnedBlock) return nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mu);
+        if (g_pinned_free && !g_pinned_free->empty()) {
+            void *p = g_pinned_free->back();
+            g_pinned_free->pop_back();
+            return p;
+        }
+    }
+    void *p = nullptr;
+    if (hipHostMalloc(&p, kPinnedBlock, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+
+void pinned_block_put(void *p)
+{
+    if (!p) return;
+    std::lock_guard<std::mutex> lk(g_pinned_mu);
+    if (!g_pinned_free) g_pinned_free = new std::vector<void *>();
+    g_pinned_free->push_back(p);
+}
+
 } // namespace slam
 
 using namespace slam;
