@@ -193,9 +193,9 @@ int slam_icp_get_normals(slam_icp_t *icp, double *normals_xy);
 /* what the index looks like (for DESIGN.md / bench reporting) */
 int slam_icp_index_info(slam_icp_t *icp, int *nx, int *ny, double *cell, int *in_lds,
                         size_t *lds_bytes, int *lanes_per_point);
-/* How the index was built: on_device = 1 for the device kernels; ms[0..3] = host wall time of the model
- * upload and extent, the cell-index kernels' enqueue, the list plan (the build's one read-back) and the list
- * kernels' enqueue. */
+/* How the index was built: on_device = 1 for the device kernels; ms[0] = host wall time of enqueueing the
+ * build (upload, extent, plan, cell index, lists: about twenty launches), ms[1] = its one wait, for the plan the
+ * device worked out (lattice, blob layout, the list lattice that fits); ms[2..3] = 0. */
 int slam_icp_build_info(slam_icp_t *icp, int *on_device, double ms[4]);
 /* The index as it lies in HBM: which = 0 the cell index, 1 the halo lists (0 bytes when the model has
  * none).  bytes (optional) receives the size; buf (optional, cap bytes) the content.  Synchronous. */
@@ -494,19 +494,21 @@ typedef struct {
     int    merge_every;        /* chunks between merges over the GPUs + finalize; 0 = only at slam_mapper_finish */
     int    pipelined;          /* 1 = copy, registration (two in turn for a fixed target) and grid update on streams of their
                                   own; 0 = one stage after the other on one stream (same results) */
-    int    strict_window;      /* 1 = a rebuild waits for the newest registered chunk (reproducible targets; the
-                                  pipeline stalls for one registration); 0 = it takes what has finished */
+    int    strict_window;      /* 1 = the push a rebuild is due at waits for it: the chunk meets the target built from every
+                                  chunk before it (reproducible; the pipeline drains once per rebuild); 0 = the build is
+                                  enqueued (same window) and adopted by a later push, see background_rebuild */
     int    slots;              /* chunks in flight (device + pinned buffers each): 2..8; 0 = default: 5 with a fixed target -- the
                                   host enqueues chunk k while two registrations run on the two registration streams and
                                   the chunks before them are mapped and read back (256-scan chunks: two 0.54 ms per chunk,
-                                  three 0.43, four 0.38, five 0.37) -- and 3 with a sliding target, whose chunks register
-                                  one after the other (every chunk in flight is a chunk the window lags behind) */
+                                  three 0.43, four 0.38, five 0.37) -- and 4 with a sliding target, whose chunks register
+                                  one after the other (config 5: three 0.460 ms per chunk, four 0.448, five 0.447, six 0.459) */
     double thin_res;           /* > 0: the window is thinned to one point per cell of this pitch (metres) and class over
                                   the grid's extent, the oldest measurement of a cell kept (where pcl::VoxelGrid keeps a
                                   centroid, icpTools.cpp:620-633); 0: every stride-th point of a chunk instead */
-    int    background_rebuild; /* 1 (default) = the sliding target is rebuilt on a thread of the mapper's own and adopted
-                                  by the first push after it is complete (a push waits for it only when the next rebuild
-                                  is due or after min(rebuild_every, 4) pushes); 0 or strict_window = inside the push */
+    int    background_rebuild; /* 1 (default) = the sliding target's rebuild is enqueued on a stream of its own (no host wait:
+                                  the index build plans itself on the device) and adopted by the first push that finds it
+                                  complete (a push waits for it only when the next rebuild is due or after
+                                  min(rebuild_every, 4) pushes); 0 or strict_window = the push waits for it at once */
     int    registration_streams; /* 0 = default (two in turn, scans in pairs, for a fixed target; one for a sliding target), 1, 2 */
 } slam_mapper_params;
 

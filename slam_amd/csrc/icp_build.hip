@@ -658,7 +658,7 @@ __global__ __launch_bounds__(256) void idx_bbox_kernel(BuildWs w)
 }
 
 // One wavefront: the rows of idx_bbox_kernel added in index order, plan_core, the list candidates.
-constexpr int kPlanRows = 1024;
+constexpr int kPlanRows = 256;
 __global__ __launch_bounds__(64) void plan_kernel(BuildWs w)
 {
     __shared__ double s_sum[kPlanRows][3];
@@ -826,11 +826,12 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(BuildWs w)
     __shared__ unsigned s_wave[16];
     ScanArgs            a;
     if (!scan_args<LISTS>(w, a) || (int)blockIdx.x >= a.n_tiles) return;
-    const int c = blockIdx.y, k0 = blockIdx.x * kScanTile + (int)threadIdx.x * kScanPer;
-    unsigned  sum = 0, most = 0;
+    const int       c = blockIdx.y, k0 = blockIdx.x * kScanTile + (int)threadIdx.x * kScanPer;
+    const unsigned *v = c ? a.v[1] : a.v[0]; // (a select, not an index into the local struct: that would put the struct into LDS)
+    unsigned        sum = 0, most = 0;
 #pragma unroll
     for (int j = 0; j < kScanPer; ++j) {
-        const unsigned x = k0 + j < a.n ? a.v[c][k0 + j] : 0u;
+        const unsigned x = k0 + j < a.n ? v[k0 + j] : 0u;
         sum += x;
         most = max(most, x);
     }
@@ -848,15 +849,17 @@ __global__ __launch_bounds__(1024) void scan_apply_kernel(BuildWs w)
     __shared__ unsigned s_wave[16];
     ScanArgs            a;
     if (!scan_args<LISTS>(w, a) || (int)blockIdx.x >= a.n_tiles) return;
-    const int c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned  before = 0;
+    const int      c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned      *v = c ? a.v[1] : a.v[0];
+    unsigned char *out = c ? a.out[1] : a.out[0];
+    unsigned       before = 0;
     for (int t = tid; t < tile; t += 1024) before += a.tiles[c * a.n_tiles + t];
     before = block_sum_1024(before, s_wave);
     const int k0 = tile * kScanTile + tid * kScanPer;
     unsigned  x[kScanPer], sum = 0;
 #pragma unroll
     for (int j = 0; j < kScanPer; ++j) {
-        x[j] = k0 + j < a.n ? a.v[c][k0 + j] : 0u;
+        x[j] = k0 + j < a.n ? v[k0 + j] : 0u;
         sum += x[j];
     }
     unsigned incl = sum;
@@ -871,8 +874,8 @@ __global__ __launch_bounds__(1024) void scan_apply_kernel(BuildWs w)
 #pragma unroll
     for (int j = 0; j < kScanPer; ++j) {
         if (k0 + j <= a.n) { // position n receives the total
-            a.v[c][k0 + j] = run;
-            store_entry(a.out[c], a.esz, (size_t)(k0 + j), run);
+            v[k0 + j] = run;
+            store_entry(out, a.esz, (size_t)(k0 + j), run);
         }
         run += x[j];
     }

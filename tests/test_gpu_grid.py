@@ -306,3 +306,32 @@ def test_raycast_launch_shapes_are_invisible(seg, wg, cap):
     assert st["items"] > 0 and st["tile_write_backs"] >= 1
     assert g.total_updates() == 2 * (int(H.sum()) + int(M.sum()))
     g.close()
+
+
+def test_reserve_then_batches_of_growing_size():
+    """slam_grid_reserve: the raycast's scratch sized once for the largest batch -- batches of growing size enqueued back to
+    back on one stream (each would otherwise free and re-allocate the scratch under the one before it, with a device-wide
+    wait) leave the counts the global-atomics form leaves; a batch beyond the reservation still grows it (correct, slower)."""
+    batch = synth.make_batch(64, n_loop=256)
+    Rt = [synth.pose_to_Rt(*p) for p in batch.true_poses]
+    R = np.stack([r.reshape(4) for r, _ in Rt])
+    t = np.stack([tt for _, tt in Rt])
+    d = [api.DeviceArray.from_host(a, dt) for a, dt in ((batch.pts, np.float64), (batch.scan_off, np.int32), (R, np.float64), (t, np.float64))]
+    sizes = [5, 17, 33, 64]
+
+    def run(g, stream=None):
+        for n in sizes:
+            g.raycast_scans_dev(d[0], d[1], n, int(batch.scan_off[n]), d[2], d[3], stream)
+        api.synchronize()
+        return g.read_counts()
+
+    ref = api.Grid(1500, 1500, 0.05, rolling=0, min_cluster_points=20, raycast_impl=api.RAYCAST_GLOBAL)
+    H, M = run(ref)
+    ref.close()
+    for reserve in (batch.n_points, int(batch.scan_off[17]), 0):      # all of it, less than the largest batch, none
+        g = api.Grid(1500, 1500, 0.05, rolling=0, min_cluster_points=20)
+        g.reserve(reserve)
+        st = api.Stream()
+        h, m = run(g, st)
+        assert np.array_equal(h, H) and np.array_equal(m, M), reserve
+        g.close()
