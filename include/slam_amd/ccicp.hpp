@@ -289,7 +289,8 @@ private:
         slam_free(c.p);
         c.p = nullptr;
         c.cap = 0;
-        if (slam_malloc(&c.p, bytes) == SLAM_OK) c.cap = bytes;
+        const size_t want = bytes + bytes / 4; // clouds of a sequence differ by a few per cent: grow rarely
+        if (slam_malloc(&c.p, want) == SLAM_OK) c.cap = want;
     }
     void upload(Cloud &dst, const float *xyz, int n, int stride)
     {

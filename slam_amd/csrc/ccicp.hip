@@ -559,11 +559,14 @@ struct DevBuf {
     int reserve(size_t bytes)
     {
         if (bytes <= cap) return SLAM_OK;
+        // a quarter more than asked: clouds of a sequence differ by a few per cent, and every growth is a free (which waits
+        // for the device) and an allocation
+        const size_t want = bytes + bytes / 4;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        SLAM_HIP(hipMalloc(&p, bytes));
-        cap = bytes;
+        SLAM_HIP(hipMalloc(&p, want));
+        cap = want;
         return SLAM_OK;
     }
     ~DevBuf()

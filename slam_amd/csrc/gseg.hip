@@ -389,11 +389,12 @@ struct slam_gseg {
 static int gseg_reserve(slam_gseg *h, size_t n)
 {
     if (n <= h->cap_points) return SLAM_OK;
+    const size_t want = n + n / 4; // (clouds of a sequence differ by a few per cent: grow rarely)
     if (h->d_bin_of) (void)hipFree(h->d_bin_of);
     h->d_bin_of = nullptr;
     h->cap_points = 0;
-    SLAM_HIP(hipMalloc((void **)&h->d_bin_of, sizeof(int) * n));
-    h->cap_points = n;
+    SLAM_HIP(hipMalloc((void **)&h->d_bin_of, sizeof(int) * want));
+    h->cap_points = want;
     return SLAM_OK;
 }
 
@@ -495,8 +496,9 @@ int slam_gseg_segment(slam_gseg_t *h, const float *xyz, int n, int stride, uint8
         if (h->d_stage) (void)hipFree(h->d_stage);
         h->d_stage = nullptr;
         h->cap_stage = 0;
-        SLAM_HIP(hipMalloc(&h->d_stage, bytes + (size_t)n));
-        h->cap_stage = bytes + (size_t)n;
+        const size_t want = bytes + (size_t)n + (bytes + (size_t)n) / 4;
+        SLAM_HIP(hipMalloc(&h->d_stage, want));
+        h->cap_stage = want;
     }
     float   *d_xyz = static_cast<float *>(h->d_stage);
     uint8_t *d_lab = reinterpret_cast<uint8_t *>(h->d_stage) + bytes;
