@@ -438,14 +438,17 @@ def main():
     # (start, end) events around the registration launches of the timed region, on the stream of each
     live = [(api.Event(), api.Event()) for _ in range(min(args.steps, 64))]
 
+    d_R0, d_t0 = d_pose0.view(0, batch.R.shape), d_pose0.view(batch.R.size, batch.t.shape)
+
     def enqueue_icp(k, a, e=None, handle=None, timed=False):
         s_ = k % NB
         a.wait_event(grid_done[s_])                    # the grid update NB steps ago has read these poses
-        pose[s_].copy_from(d_pose0, a)
         if timed and k < len(live):
             live[k][0].record(a)
         if e: e[0].record(a)
-        (handle or icp).fit_batch_dev(d_pts, d_off, d_nga, S, pR[s_], pt[s_], 5.0, res[s_], None, a)
+        # the batch's initial poses are read where they lie, the registered poses written to this step's buffer
+        # (slam_icp_fit_batch_from_dev: no copy of the initial poses into the in/out arrays, no launch gap behind it)
+        (handle or icp).fit_batch_from_dev(d_pts, d_off, d_nga, S, d_R0, d_t0, pR[s_], pt[s_], 5.0, res[s_], None, a)
         if e: e[1].record(a)
         if timed and k < len(live):
             live[k][1].record(a)
@@ -503,8 +506,7 @@ def main():
         try:
             graph = api.Graph(sa)
             with graph:      # the warm-up ran the same calls: every scratch buffer exists
-                pose[0].copy_from(d_pose0, sa)
-                icp.fit_batch_dev(d_pts, d_off, d_nga, S, pR[0], pt[0], 5.0, d_res, None, sa)
+                icp.fit_batch_from_dev(d_pts, d_off, d_nga, S, d_R0, d_t0, pR[0], pt[0], 5.0, d_res, None, sa)
                 grid.raycast_scans_dev(d_pts, d_off, S, P, pR[0], pt[0], sa)
                 grid.finalize(sa)            # (a captured graph replays fixed kernel arguments: finalize_reset alternates
                 grid.reset_counts(sa)        # between two range buffers from call to call, so the graph keeps the two-call form)

@@ -175,6 +175,15 @@ int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *
                            const int32_t *d_scan_nga, int n_scans, double *d_R, double *d_t,
                            double indist, slam_icp_result *d_result, double *d_trace,
                            slam_stream_t stream);
+/* The same with the initial poses read from d_R0 / d_t0 and the registered poses written to d_R / d_t (the two may
+ * be the same arrays: that is slam_icp_fit_batch_dev).  Icp::fit takes R, t in/out because its caller keeps one pose
+ * (icp.cpp:80-114); a stream of batches whose initial poses come from elsewhere (an odometry buffer, the batch before)
+ * saves the copy into the output arrays and the launch gap behind it.  A scan with fewer than 5 points gets its
+ * initial pose. */
+int slam_icp_fit_batch_from_dev(slam_icp_t *icp, const double *d_pts, const int32_t *d_scan_off,
+                                const int32_t *d_scan_nga, int n_scans, const double *d_R0, const double *d_t0,
+                                double *d_R, double *d_t, double indist, slam_icp_result *d_result,
+                                double *d_trace, slam_stream_t stream);
 
 /* KDTree::n_nearest(qv, 1, result), kdtree.cpp:378-391, for n float queries
  * against one class (0 = GA, 1 = NGA): squared float distance and ORIGINAL

@@ -83,7 +83,7 @@ EXPORTS = [
     "slam_icp_default_params", "slam_icp_create", "slam_icp_create_dev", "slam_icp_destroy",
     "slam_icp_build_info", "slam_icp_index_blob",
     "slam_icp_set_max_iterations", "slam_icp_set_min_delta", "slam_icp_set_subsampling_step",
-    "slam_icp_fit", "slam_icp_fit_batch_dev", "slam_icp_nearest_dev", "slam_icp_get_edge_weight",
+    "slam_icp_fit", "slam_icp_fit_batch_dev", "slam_icp_fit_batch_from_dev", "slam_icp_nearest_dev", "slam_icp_get_edge_weight",
     "slam_icp_get_normals",
     "slam_icp_index_info", "slam_icp_list_info",
     "slam_grid_default_params", "slam_grid_create", "slam_grid_destroy", "slam_grid_clear", "slam_grid_reset_counts",
@@ -180,6 +180,8 @@ def lib():
                                C.POINTER(IcpResult)]
     L.slam_icp_fit_batch_dev.argtypes = [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, C.c_double, _vp,
                                          _vp, _vp]
+    L.slam_icp_fit_batch_from_dev.argtypes = [_vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, C.c_double, _vp,
+                                              _vp, _vp]
     L.slam_icp_nearest_dev.argtypes = [_vp, C.c_int, _vp, C.c_int, _vp, _vp, _vp]
     L.slam_icp_get_edge_weight.argtypes = [_vp, _vp]
     L.slam_icp_get_normals.argtypes = [_vp, _vp]
@@ -530,6 +532,14 @@ class Icp:
                       d_trace=None, stream=None):
         check(lib().slam_icp_fit_batch_dev(
             self.h, d_pts.ptr, d_off.ptr, d_nga.ptr, int(n_scans), d_R.ptr, d_t.ptr, float(indist),
+            d_result.ptr if d_result is not None else None,
+            d_trace.ptr if d_trace is not None else None, _sp(stream)))
+
+    def fit_batch_from_dev(self, d_pts, d_off, d_nga, n_scans, d_R0, d_t0, d_R, d_t, indist=5.0, d_result=None,
+                           d_trace=None, stream=None):
+        """Initial poses read from d_R0 / d_t0, registered poses written to d_R / d_t."""
+        check(lib().slam_icp_fit_batch_from_dev(
+            self.h, d_pts.ptr, d_off.ptr, d_nga.ptr, int(n_scans), d_R0.ptr, d_t0.ptr, d_R.ptr, d_t.ptr, float(indist),
             d_result.ptr if d_result is not None else None,
             d_trace.ptr if d_trace is not None else None, _sp(stream)))
 

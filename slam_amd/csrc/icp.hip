@@ -693,12 +693,12 @@ __device__ inline void store_fit(const FitArgs &fa, int s, const FitState &fs, i
 __device__ inline FitState load_fit(const FitArgs &fa, int s, int iter_begin)
 {
     FitState fs;
-    fs.r00 = uniform(fa.R[4 * s + 0]);
-    fs.r01 = uniform(fa.R[4 * s + 1]);
-    fs.r10 = uniform(fa.R[4 * s + 2]);
-    fs.r11 = uniform(fa.R[4 * s + 3]);
-    fs.t0 = uniform(fa.t[2 * s + 0]);
-    fs.t1 = uniform(fa.t[2 * s + 1]);
+    fs.r00 = uniform(fa.R0[4 * s + 0]);
+    fs.r01 = uniform(fa.R0[4 * s + 1]);
+    fs.r10 = uniform(fa.R0[4 * s + 2]);
+    fs.r11 = uniform(fa.R0[4 * s + 3]);
+    fs.t0 = uniform(fa.t0[2 * s + 0]);
+    fs.t1 = uniform(fa.t0[2 * s + 1]);
     fs.delta = 0.0;
     fs.iters = iter_begin;
     fs.n_corr = 0;
@@ -1155,6 +1155,8 @@ int launch_fit(slam_icp *h, const FitArgs &fa_in, int n_scans, hipStream_t st)
         if (h->phase_events) SLAM_HIP(hipEventRecord(h->ev[1], st));
         h->sweep = 2;
         fa.phase = 2;
+        fa.R0 = fa.R; // the second launch carries on from what the first left
+        fa.t0 = fa.t;
         if (rc == SLAM_OK) rc = launch_fit_m<SLAM_ICP_P2P>(h, fa, n_scans, st);
         if (h->phase_events) {
             SLAM_HIP(hipEventRecord(h->ev[2], st));
@@ -1398,7 +1400,15 @@ int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *
                            double indist, slam_icp_result *d_result, double *d_trace,
                            slam_stream_t stream)
 {
-    SLAM_REQUIRE(icp && d_scan_off && d_scan_nga && d_R && d_t && n_scans >= 0, SLAM_E_INVALID,
+    return slam_icp_fit_batch_from_dev(icp, d_pts, d_scan_off, d_scan_nga, n_scans, d_R, d_t, d_R, d_t, indist, d_result, d_trace, stream);
+}
+
+int slam_icp_fit_batch_from_dev(slam_icp_t *icp, const double *d_pts, const int32_t *d_scan_off,
+                                const int32_t *d_scan_nga, int n_scans, const double *d_R0, const double *d_t0,
+                                double *d_R, double *d_t, double indist, slam_icp_result *d_result, double *d_trace,
+                                slam_stream_t stream)
+{
+    SLAM_REQUIRE(icp && d_scan_off && d_scan_nga && d_R0 && d_t0 && d_R && d_t && n_scans >= 0, SLAM_E_INVALID,
                  "slam_icp_fit_batch_dev: bad arguments");
     SLAM_TRY(require_device());
     FitArgs fa;
@@ -1407,6 +1417,8 @@ int slam_icp_fit_batch_dev(slam_icp_t *icp, const double *d_pts, const int32_t *
     fa.scan_nga = d_scan_nga;
     fa.R = d_R;
     fa.t = d_t;
+    fa.R0 = d_R0;
+    fa.t0 = d_t0;
     fa.result = d_result;
     fa.trace = d_trace;
     fa.max_iter = icp->prm.max_iter;

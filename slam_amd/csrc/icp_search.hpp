@@ -791,8 +791,9 @@ struct FitArgs {
     const double2 *pts;
     const int     *scan_off;
     const int     *scan_nga;
-    double        *R;
+    double        *R;        // the poses found, 4 + 2 doubles per scan
     double        *t;
+    const double  *R0, *t0;  // the poses the fits start from (R, t themselves for a fit in place)
     slam_icp_result *result;
     double        *trace;
     int            max_iter;

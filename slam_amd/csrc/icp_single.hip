@@ -220,7 +220,20 @@ __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitAr
     const int off = fa.scan_off[s];
     const int n = fa.scan_off[s + 1] - off;
     const int nga = fa.scan_nga[s];
-    if (n < 5 || fa.max_iter <= 0) return; // icp.cpp:100-103: R, t untouched
+    if (n < 5 || fa.max_iter <= 0) { // icp.cpp:100-103: R, t untouched -- the pose the fit was given
+        if (blockIdx.x == 0 && threadIdx.x < 6 && fa.R0 != fa.R) {
+            if (threadIdx.x < 4)
+                fa.R[4 * s + threadIdx.x] = fa.R0[4 * s + threadIdx.x];
+            else
+                fa.t[2 * s + threadIdx.x - 4] = fa.t0[2 * s + threadIdx.x - 4];
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && fa.result) {
+            fa.result[s].iters = 0;
+            fa.result[s].n_corr = 0;
+            fa.result[s].delta = 0.0;
+        }
+        return;
+    }
     const bool wide = n <= wide_max; // 64 lanes per query up to here, 16 beyond
     if (part >= active_parts(n, wide ? 64 : 16, parts)) return;
     const unsigned char *base = mv.blob;
@@ -233,12 +246,12 @@ __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitAr
     }
     const IndexPtrs<StartT> ix = make_ptrs<StartT>(base, mv);
     FitState                fs;
-    fs.r00 = uniform(fa.R[4 * s + 0]);
-    fs.r01 = uniform(fa.R[4 * s + 1]);
-    fs.r10 = uniform(fa.R[4 * s + 2]);
-    fs.r11 = uniform(fa.R[4 * s + 3]);
-    fs.t0 = uniform(fa.t[2 * s + 0]);
-    fs.t1 = uniform(fa.t[2 * s + 1]);
+    fs.r00 = uniform(fa.R0[4 * s + 0]);
+    fs.r01 = uniform(fa.R0[4 * s + 1]);
+    fs.r10 = uniform(fa.R0[4 * s + 2]);
+    fs.r11 = uniform(fa.R0[4 * s + 3]);
+    fs.t0 = uniform(fa.t0[2 * s + 0]);
+    fs.t1 = uniform(fa.t0[2 * s + 1]);
     fs.delta = 0.0;
     fs.iters = 0;
     fs.n_corr = 0;

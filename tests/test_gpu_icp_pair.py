@@ -118,3 +118,42 @@ def test_default_pairs_from_two_scans_per_cu(world):
         icp.close()
     assert np.array_equal(out[0][2]["n_corr"], out[1][2]["n_corr"])
     assert np.abs(out[0][1] - out[1][1]).max() < 1e-8 and np.abs(out[0][0] - out[1][0]).max() < 1e-8
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["fused", "pairs", "spread", "two launches", "ring only"])
+def test_fit_from_separate_initial_poses_equals_the_fit_in_place(form):
+    """slam_icp_fit_batch_from_dev: initial poses read from one pair of arrays, registered poses written to another -- the
+    same bits as slam_icp_fit_batch_dev leaves in place, in every launch form; the initial poses are not written; a scan
+    of fewer than five points comes back with its initial pose (icp.cpp:100-103)."""
+    from slam_amd import api
+    m_ga, m_nga = synth.make_map(10000)
+    n_scans = {"spread": 3}.get(form, 12)
+    batch = synth.make_batch(n_scans, n_loop=64)
+    off = batch.scan_off.copy()
+    # the last scan shrinks to four points
+    pts = batch.pts[:off[-2] + 4].copy()
+    off[-1] = off[-2] + 4
+    nga = batch.scan_nga.copy()
+    nga[-1] = min(nga[-1], 2)
+    kw = {"fused": dict(pair_scans=-1), "pairs": dict(pair_scans=2), "spread": {}, "two launches": dict(split_launch=1),
+          "ring only": dict(lanes_per_point=4)}[form]
+    icp = api.Icp(m_ga, m_nga, max_iter=12, min_delta=-1.0, **kw)
+    d_pts = api.DeviceArray.from_host(pts, np.float64)
+    d_off = api.DeviceArray.from_host(off, np.int32)
+    d_nga = api.DeviceArray.from_host(nga, np.int32)
+    d_R0, d_t0 = api.DeviceArray.from_host(batch.R, np.float64), api.DeviceArray.from_host(batch.t, np.float64)
+    d_Ra, d_ta = api.DeviceArray.from_host(batch.R, np.float64), api.DeviceArray.from_host(batch.t, np.float64)
+    d_Rb, d_tb = api.DeviceArray(batch.R.shape, np.float64), api.DeviceArray(batch.t.shape, np.float64)
+    d_Rb.zero(); d_tb.zero()
+    ra, rb = api.DeviceArray((n_scans,), api.RESULT_DTYPE), api.DeviceArray((n_scans,), api.RESULT_DTYPE)
+    icp.fit_batch_dev(d_pts, d_off, d_nga, n_scans, d_Ra, d_ta, 5.0, ra)
+    icp.fit_batch_from_dev(d_pts, d_off, d_nga, n_scans, d_R0, d_t0, d_Rb, d_tb, 5.0, rb)
+    api.synchronize()
+    Ra, ta, Rb, tb = d_Ra.download(), d_ta.download(), d_Rb.download(), d_tb.download()
+    assert np.array_equal(Ra, Rb) and np.array_equal(ta, tb)
+    assert np.array_equal(ra.download()["iters"], rb.download()["iters"]) and (rb.download()["iters"][:-1] == 12).all()
+    assert np.array_equal(d_R0.download(), batch.R) and np.array_equal(d_t0.download(), batch.t)
+    assert np.array_equal(Rb[-1], batch.R[-1]) and np.array_equal(tb[-1], batch.t[-1]) and rb.download()["iters"][-1] == 0
+    assert np.abs(tb[:-1] - batch.true_poses[:-1, :2]).max() < 0.3
+    icp.close()
