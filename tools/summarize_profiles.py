@@ -36,9 +36,9 @@ def kname(k):
     return name
 
 
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))
+stats = sorted(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
 if stats:
-    rows = list(csv.DictReader(open(stats[0])))
+    rows = list(csv.DictReader(open(stats[-1])))     # (gpurun merges into gpurun_out/: the newest run's file)
     with open(os.path.join(dst, tag + "_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
@@ -92,9 +92,9 @@ for name in ("bench.json", "config3.json", "config4.json", "config5.json", "buil
         shutil.copy(p, os.path.join(dst, tag + "_" + name))
 # the side runs: kernel stats of the merged raycast, config 3 and the index build; counters of the merged raycast
 for sub, out in (("stats_merge", "raycast_merge_kernel_stats.csv"), ("stats_c3", "config3_kernel_stats.csv"), ("stats_build", "build_kernel_stats.csv")):
-    st = glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv"))
+    st = sorted(glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv")), key=os.path.getmtime)
     if st:
-        rows = list(csv.DictReader(open(st[0])))
+        rows = list(csv.DictReader(open(st[-1])))
         with open(os.path.join(dst, tag + "_" + out), "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
