@@ -21,7 +21,10 @@
 // waits for it).
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <new>
 #include <vector>
 
@@ -228,6 +231,36 @@ struct slam_mapper {
 };
 
 namespace {
+
+// Host-side trace of the mapper's calls (measurement build only, SLAM_MAPPER_TRACE=<file>): a label and a monotonic time per
+// mark, written out by slam_mapper_finish; tools/xtrace_periods.py turns it into per-chunk periods.  This is what showed the
+// producer standing still inside slam_grid_raycast_scans_dev whenever a chunk was the largest so far.
+#ifdef SLAM_MEASURE
+std::vector<std::pair<const char *, double>> g_trace;
+inline void xt(const char *label)
+{
+    static const bool on = getenv("SLAM_MAPPER_TRACE") != nullptr;
+    if (!on) return;
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    g_trace.push_back({label, ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3});
+}
+void xt_dump()
+{
+    const char *path = getenv("SLAM_MAPPER_TRACE");
+    if (!path || g_trace.empty()) return;
+    if (FILE *f = fopen(path, "w")) {
+        for (size_t i = 0; i < g_trace.size(); ++i)
+            fprintf(f, "%-18s %12.1f  +%.1f\n", g_trace[i].first, g_trace[i].second - g_trace[0].second,
+                    i ? g_trace[i].second - g_trace[i - 1].second : 0.0);
+        fclose(f);
+    }
+    g_trace.clear();
+}
+#else
+inline void xt(const char *) {}
+inline void xt_dump() {}
+#endif
 
 #define MAP_HIP(expr) SLAM_HIP(expr)
 
@@ -637,10 +670,13 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     // ---- sliding target: rebuilt before this chunk's registration is enqueued
     // (enqueued on the rebuild's own stream; a build still un-adopted is waited for only when the next one is due or after
     // max_lag pushes)
+    xt("push");
     const bool due = m->prm.window_chunks && m->chunks > 0 && m->chunks - std::max<long>(m->last_rebuild, 0) >= m->prm.rebuild_every;
     if (m->building) SLAM_TRY(adopt_build(m, due || m->chunks - m->building_chunk >= std::max(m->max_lag, 1)));
+    xt("adopted");
     if (due) {
         SLAM_TRY(begin_rebuild(m, m->build_s));
+        xt("begun");
         m->last_rebuild = m->chunks;
         if (!m->max_lag) SLAM_TRY(adopt_build(m, true)); // strict_window / background_rebuild = 0: this chunk meets the new target
     }
@@ -653,6 +689,7 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     MAP_HIP(hipMemcpyAsync(b.d_R, b.h_R, 32 * (size_t)n_scans, hipMemcpyHostToDevice, m->copy));
     MAP_HIP(hipMemcpyAsync(b.d_t, b.h_t, 16 * (size_t)n_scans, hipMemcpyHostToDevice, m->copy));
     MAP_HIP(hipEventRecord(b.copied, m->copy));
+    xt("copied");
     // ---- register
     // chunks alternate over the two registration streams; the spread form (a handful of scans) takes one call at a time
     // (and so do the chunks of a sliding target: a chunk registered beside its predecessor meets a window that is a chunk
@@ -683,6 +720,7 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     MAP_HIP(hipMemcpyAsync(b.h_R, b.d_R, 32 * (size_t)n_scans, hipMemcpyDeviceToHost, icp_s));
     MAP_HIP(hipMemcpyAsync(b.h_t, b.d_t, 16 * (size_t)n_scans, hipMemcpyDeviceToHost, icp_s));
     MAP_HIP(hipEventRecord(b.registered, icp_s));
+    xt("fit enqueued");
     // ---- the previous chunk's merge, now that this chunk's registration is in the queue ahead of the wait
     SLAM_TRY(finish_merge(m));
     // ---- map
@@ -701,6 +739,7 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
         }
     }
     MAP_HIP(hipEventRecord(b.mapped, m->grid_s));
+    xt("grid enqueued");
     b.busy = true;
     b.n_scans = n_scans;
     m->next = (s + 1) % m->n_slots;
@@ -713,10 +752,13 @@ int slam_mapper_wait(slam_mapper_t *m, int slot, double *R_out, double *t_out)
     SLAM_REQUIRE(m && slot >= 0 && slot < m->n_slots, SLAM_E_INVALID, "slam_mapper_wait: bad arguments");
     Slot &b = m->slot[slot];
     if (!b.busy) return SLAM_OK;
-    MAP_HIP(hipEventSynchronize(b.registered)); // the poses are in the slot's pinned buffers (slam_mapper_push)
+    xt("wait");
+    MAP_HIP(hipEventSynchronize(b.registered));
+    xt("wait: registered"); // the poses are in the slot's pinned buffers (slam_mapper_push)
     if (R_out) memcpy(R_out, b.h_R, 32 * (size_t)b.n_scans);
     if (t_out) memcpy(t_out, b.h_t, 16 * (size_t)b.n_scans);
     MAP_HIP(hipEventSynchronize(b.mapped)); // the slot's device buffers are free again
+    xt("wait: mapped");
     b.busy = false;
     return SLAM_OK;
 }
@@ -724,6 +766,7 @@ int slam_mapper_wait(slam_mapper_t *m, int slot, double *R_out, double *t_out)
 int slam_mapper_finish(slam_mapper_t *m)
 {
     SLAM_REQUIRE(m, SLAM_E_INVALID, "null handle");
+    xt_dump();
     SLAM_TRY(adopt_build(m, true));
     SLAM_TRY(finish_merge(m));
     if (m->merge_begin) { // whatever was added since the last merge

@@ -1,4 +1,6 @@
-"""Per-chunk host periods from the mapper's X_TRACE dump (gpurun_out/xtrace.txt; a measurement build only)."""
+"""Per-chunk host periods of a slam_mapper_t from its call trace (measurement build only: python -m slam_amd.build --measure,
+then SLAM_AMD_MEASURE=1 SLAM_MAPPER_TRACE=gpurun_out/xtrace.txt python bench.py --config 5): where the producer's time goes
+between two pushes, rebuild pushes apart from the others.    python tools/xtrace_periods.py [gpurun_out/xtrace.txt]"""
 import sys
 L = [l.split() for l in open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/xtrace.txt")]
 ev = [(" ".join(x[:-2]), float(x[-2])) for x in L]
