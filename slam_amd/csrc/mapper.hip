@@ -227,7 +227,6 @@ struct slam_mapper {
     long               building_chunk = 0;     // m->chunks when it was begun
     int               *d_cnt = nullptr;        // points per class of the model being built (the thinning leaves them here)
     size_t             model_prior[2] = {0, 0}; // prior points resident at the head of d_model_ga / d_model_nga
-    hipEvent_t         window_read = nullptr;  // behind the last rebuild's reads of the window ring
 };
 
 namespace {
@@ -399,7 +398,6 @@ int begin_rebuild(slam_mapper *m, hipStream_t st)
             o_nga += (size_t)w->n_nga;
         }
     }
-    MAP_HIP(hipEventRecord(m->window_read, st)); // (the ring's entries are free to be rewritten behind this)
     SLAM_TRY(slam::icp::create_begin(d_ga, (int)cap_ga, d_nga, (int)cap_nga, d_cnt, &m->prm.icp, st, &m->building));
     m->building_chunk = m->chunks;
     m->rebuild_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -551,8 +549,6 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
             hip(hipEventCreateWithFlags(&b.mapped, hipEventDisableTiming));
         }
         hip(hipGetDevice(&m->device));
-        hip(hipEventCreateWithFlags(&m->window_read, hipEventDisableTiming));
-        hip(hipEventRecord(m->window_read, m->icp_s[0]));
         if (!m->build_s) m->build_s = m->icp_s[0];
         // the window keeps one entry more than it uses: the newest is still being written when a rebuild looks -- and as
         // many more as pushes may pass while a background rebuild reads its entries (it is waited for after max_lag)
@@ -596,7 +592,7 @@ void slam_mapper_destroy(slam_mapper_t *m)
     if (m->d_model_ga) pool_free(m->d_model_ga);
     for (void *p : {(void *)m->d_thin, (void *)m->d_thin_blk, (void *)m->d_cnt})
         if (p) (void)hipFree(p);
-    if (m->window_read) (void)hipEventDestroy(m->window_read);
+
     if (m->target) slam_icp_destroy(m->target);
     if (m->retired) slam_icp_destroy(m->retired);
     if (m->grid) slam_grid_destroy(m->grid);
@@ -704,7 +700,8 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     if (m->prm.window_chunks) {
         WindowEntry &w = m->window[(size_t)(m->chunks % (long)m->window.size())];
         const int    sg = stride_for(m, n_ga), sn = stride_for(m, n_nga);
-        if (icp_s != m->build_s) MAP_HIP(hipStreamWaitEvent(icp_s, m->window_read, 0)); // a rebuild may still be reading the entry
+        // (no wait for a rebuild in flight: it reads the entries of the window_chunks chunks before the push it was begun at,
+        // the ring holds 1 + max_lag entries more than that, and a build is adopted -- complete -- before max_lag pushes have passed)
         hipLaunchKernelGGL(window_points_kernel, dim3((n_points + 255) / 256), dim3(256), 0, icp_s,
                            reinterpret_cast<const double2 *>(b.d_pts), b.d_off, b.d_nga, b.d_gab, n_scans, n_points, b.d_R, b.d_t, sg, sn,
                            w.ga, w.nga);
