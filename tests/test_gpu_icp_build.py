@@ -114,3 +114,39 @@ def test_create_is_fast_and_pooled(capsys):
     with capsys.disabled():
         for k, (best, info) in out.items():
             print("\n  slam_icp_create %s: %.3f ms (enqueueing the build %.3f, its one wait %.3f)" % (k, best * 1e3, info[0], info[1]))
+
+
+def test_builds_from_two_threads_at_once():
+    """Two host threads creating handles at the same time (the reference runs two CCICP objects in one process,
+    scan_registration.cpp:57 and graphSlamTools.cpp:14): the builds share the library's build stream, its buffer pool and
+    its pinned plan blocks; every handle still holds the bytes of the host build of its own model."""
+    import threading
+    rs = np.random.RandomState(5)
+    m_ga, m_nga = synth.make_map()
+    models = [(m_ga, m_nga), (rs.randn(3000, 2) * 4.0, rs.rand(9000, 2) * [50.0, 20.0])]
+    want = []
+    for ga, nga in models:
+        host = api.Icp(ga, nga, build_on_host=1)
+        want.append((host.index_info(), host.index_blob(0), host.index_blob(1)))
+        host.close()
+    errors = []
+
+    def work(k):
+        try:
+            ga, nga = models[k]
+            for _ in range(25):
+                dev = api.Icp(ga, nga)
+                ok = dev.index_info() == want[k][0] and np.array_equal(dev.index_blob(0), want[k][1]) and np.array_equal(dev.index_blob(1), want[k][2])
+                dev.close()
+                if not ok:
+                    errors.append("thread %d: a build differs from the host build of its model" % k)
+                    return
+        except Exception as e:      # noqa: BLE001 (reported below)
+            errors.append("thread %d: %r" % (k, e))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
