@@ -31,16 +31,12 @@ void *pinned_scratch(size_t bytes);
 // returned to a free list, never given back to the runtime.  At most 16 KB each.
 void *pinned_block_get(size_t bytes);
 void  pinned_block_put(void *p);
-// The stream the index build and the mapper's target rebuild run on: one per device, created on first use at the
+// The stream slam_icp_create[_dev] builds its index on: one per device, created on first use at the
 // highest priority level and never destroyed.  A level of its own, because HIP deals the streams of one level over a
-// few hardware queues shared in creation order: on the default stream the build's dozen short kernels and three host
-// waits queued behind whatever registration shared that queue (0.4 ms each).  Null on failure (callers fall back to
+// few hardware queues shared in creation order: on the default stream the build's twenty short kernels and its host
+// wait queued behind whatever registration shared that queue (0.4 ms).  Null on failure (callers fall back to
 // the default stream).
 hipStream_t build_stream();
-// ... unless the calling thread has named a stream of its own for its builds (the mapper's rebuild thread: the mapper's
-// copy stream, where only short operations live -- which hardware queue a further stream would land on is the runtime's
-// choice, and one rebuild in five landed behind the registrations)
-void build_stream_for_this_thread(hipStream_t s);
 
 } // namespace slam
 

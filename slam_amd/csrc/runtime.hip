@@ -137,12 +137,8 @@ void pool_trim()
     for (const PoolBlock &b : drop) (void)hipFree(b.p);
 }
 
-static thread_local hipStream_t t_build_override = nullptr;
-void build_stream_for_this_thread(hipStream_t s) { t_build_override = s; }
-
 hipStream_t build_stream()
 {
-    if (t_build_override) return t_build_override;
     static std::mutex  mu;
     static hipStream_t streams[64] = {};
     int                dev = 0;
