@@ -324,7 +324,7 @@ class DeviceArray:
         check(lib().slam_memcpy_d2d(self.ptr, other.ptr, self.nbytes, _sp(stream)))
 
     def zero(self, stream=None):
-        check(lib().slam_memset(self.ptr, 0, self.nbytes, stream))
+        check(lib().slam_memset(self.ptr, 0, self.nbytes, _sp(stream)))
 
     def view(self, first, shape):
         """`shape` elements of this block from element `first` on: shares the memory, does not own it."""
