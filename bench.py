@@ -43,7 +43,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def cpu_baseline(m_ga, m_nga, batch, grid_size, res):
+def cpu_baseline(m_ga, m_nga, batch, grid_size, res, p2l=False):
     """Times the CPU oracle (a port of the reference path; tests pin it) on this
     host: ICP over a bounded sample of the same scans with OpenMP over scans,
     plus the Bresenham update of those scans.  Test infrastructure used as a
@@ -54,8 +54,8 @@ def cpu_baseline(m_ga, m_nga, batch, grid_size, res):
     threads = max(1, min(cores, 64))
     n_s = min(batch.n_scans, 128)
     sub = batch.shard(0, max(1, batch.n_scans // n_s)) if n_s < batch.n_scans else batch
-    model = O.IcpModel(m_ga, m_nga)
-    p = O.icp_params(N_ITERS, -1.0, 5.0, O.NN_KDTREE)
+    model = O.IcpModel(m_ga, m_nga, normals_k=10 if p2l else 0)
+    p = O.icp_params(N_ITERS, -1.0, 5.0, O.NN_KDTREE, O.MODE_P2L if p2l else O.MODE_P2P)
     # repeated until about 20 core-seconds have gone into it, so that thread start-up and the clock do not matter
     reps, t_icp = 0, 0.0
     while t_icp * threads < 20.0 and reps < 200:
@@ -91,6 +91,7 @@ def cpu_baseline(m_ga, m_nga, batch, grid_size, res):
     return {
         "value": sub.n_points / (t_icp + t_grid_best), "unit": "points/s", "cores": threads,
         "kind": "port",
+        "solver": "point-to-line (oracle fit_step_p2l: icpPointToPlane.cpp:37-107)" if p2l else "point-to-point (icpPointToPoint.cpp:33-172)",
         "sample": "%d x (%d of the %d scans x %d ICP iterations; kd-tree NN, OpenMP over scans, %d threads) "
                   "+ Bresenham of the same scans into the %dx%d grid (the faster of OpenMP over beams with "
                   "atomic increments and one thread)"
@@ -103,11 +104,12 @@ def cpu_baseline(m_ga, m_nga, batch, grid_size, res):
     }
 
 
-def pmc_profile():
-    """The committed PMC summary of this same command (profiles/rNN_traffic.json, written by
-    tools/summarize_profiles.py from separate rocprofv3 --pmc passes): (file name, dict) or (None, {})."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+def pmc_profile(p2l=False):
+    """The committed PMC summary of this same command (profiles/rNN_traffic.json, rNN_p2l_traffic.json for --mode p2l;
+    written by tools/summarize_profiles.py from separate rocprofv3 --pmc passes): (file name, dict) or (None, {})."""
+    import re
+    pat = re.compile(r"^r\d+_p2l_traffic\.json$" if p2l else r"^r\d+_traffic\.json$")
+    files = sorted(os.path.join(ROOT, "profiles", f) for f in os.listdir(os.path.join(ROOT, "profiles")) if pat.match(f))
     if not files:
         return None, {}
     try:
@@ -280,6 +282,9 @@ def main():
     ap.add_argument("--merge-every", type=int, default=8, help="config 5: chunks between merges over the GPUs + finalize")
     ap.add_argument("--reg-streams", type=int, default=0, help="config 5: slam_mapper_params::registration_streams (0 = library default)")
     ap.add_argument("--slots", type=int, default=0, help="config 5: slam_mapper_params::slots (0 = library default)")
+    ap.add_argument("--mode", choices=["p2p", "p2l"], default="p2p",
+                    help="the ICP step: p2p = what the reference compiles and calls (icpPointToPoint.cpp:33-172); p2l = the solver "
+                         "north_star names, point-to-line error + 3x3 normal equations (icpPointToPlane.cpp:37-107, stale upstream)")
     ap.add_argument("--lanes", type=int, default=0, help="lanes per scan point (0 = library default)")
     ap.add_argument("--cell", type=float, default=0.0, help="ICP cell pitch in metres (0 = library default)")
     ap.add_argument("--raycast", choices=["tiled", "merge", "global"], default="tiled")
@@ -387,7 +392,9 @@ def main():
     # ---- synthetic inputs of BASELINE config 2 (per rank: its own 256 scans of the loop)
     batch = synth.make_batch(S, n_loop=S * world, first=rank * S)
     P = batch.n_points
-    icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, lanes_per_point=args.lanes, cell_size=args.cell)
+    p2l = args.mode == "p2l"
+    mode_kw = dict(mode=api.ICP_P2L, normals_k=10) if p2l else {}
+    icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, lanes_per_point=args.lanes, cell_size=args.cell, **mode_kw)
     grid_kw = dict(rolling=0, min_cluster_points=20, raycast_wg_per_cu=args.raycast_wg, raycast_max_workgroups=args.raycast_max_wg, raycast_seg_items=args.raycast_seg or 0,
                    raycast_impl={"tiled": api.RAYCAST_TILED, "merge": api.RAYCAST_TILED_MERGE, "global": api.RAYCAST_GLOBAL}[args.raycast])
     grid = api.Grid(GRID, GRID, RES, **grid_kw)
@@ -422,7 +429,7 @@ def main():
     n_cu = api.device_info()[1]
     icp_one = icp                                       # library defaults: what the one-stream forms use
     if launch == "pipeline" and S < 2 * n_cu and args.lanes == 0:
-        icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, cell_size=args.cell, pair_scans=2)
+        icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, cell_size=args.cell, pair_scans=2, **mode_kw)
     # three priority levels: never the same hardware queue (see mapper.hip)
     SA, sb = [api.Stream(), api.Stream(priority=-1)], api.Stream(priority=1)
     SB = [sb] + [api.Stream(priority=1) for _ in grids[1:]]      # one grid stream per grid
@@ -630,7 +637,7 @@ def main():
         kr = kernels["raycast_tiled_kernel (+ beams, work list)"]
         kr["vs_global_atomic_ceiling"] = kr["GBps"] / ATOMIC_CEILING_GBS
         dom = max(kernels, key=lambda n: kernels[n]["ms"])
-        prof_file, prof = pmc_profile()
+        prof_file, prof = pmc_profile(p2l)
         pk = prof.get(dom.split(" ")[0], {})
         busy, lanes = pk.get("valu_busy_frac"), pk.get("valu_active_lane_share")
         held = min(n_cu, (S + 1) // 2 if paired else S) if dom == icp_name else n_cu
@@ -664,6 +671,8 @@ def main():
             "ms_per_step": step_ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 pose / f32 distance / int32 counts",
             "data": "synthetic",
+            "icp_step": "point-to-line, 3x3 normal equations per iteration (icpPointToPlane.cpp:37-107; SLAM_ICP_P2L)" if p2l else
+                        "point-to-point, 2x2 closed form (icpPointToPoint.cpp:33-172; SLAM_ICP_P2P: what the reference compiles)",
             "launch": {"pipeline": "consecutive steps on %d streams: registrations (two scans per workgroup) alternate on two, the grid "
                                    "update of the step before runs on %s" % (2 + len(SB), "the third" if len(SB) == 1 else
                                                                             "two more in turn, each step into a zeroed grid buffer of its own (two buffers)"),
@@ -712,6 +721,10 @@ def main():
             # short runs of the other GPU configs of BASELINE.json, each in a process of its own (this one stays idle):
             # one GPU's share of config 4 (1024 scans into 4000 x 4000, pipelined steps) and config 5 (the streaming mapper
             # with its sliding-window target, PCIe inclusive)
+            # the solver north_star names (point-to-line, 3x3 normal equations) on the same workload, same pipelined step, the CPU
+            # oracle's point-to-line step timed beside it
+            out["p2l"] = side_run(["--mode", "p2l", "--steps", "30", "--warmup", "5", "--no-extras"],
+                                  ("value", "ms_per_step", "icp_step", "grid_cell_updates_per_s", "kernel_ms", "roofline", "one_stream", "max_pose_error_m", "cpu_baseline"))
             out["config4_share"] = side_run(["--config", "4", "--steps", "12", "--warmup", "3", "--no-extras", "--no-cpu-baseline"],
                                             ("value", "ms_per_step", "grid_cell_updates_per_s", "cell_updates_per_step", "kernel_ms", "max_pose_error_m"))
             out["config5"] = side_run(["--config", "5", "--stream-scans", "4096"],
@@ -722,7 +735,7 @@ def main():
             out["two_ranks_on_one_gpu"] = side_run(["--gpus", "2", "--backend", "gloo", "--one-device", "--steps", "6", "--warmup", "2",
                                                     "--no-cpu-baseline"], ("n_gpus", "value", "ms_per_step", "cell_updates_per_step"))
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(m_ga, m_nga, batch, GRID, RES)
+            out["cpu_baseline"] = cpu_baseline(m_ga, m_nga, batch, GRID, RES, p2l)
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()

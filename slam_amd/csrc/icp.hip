@@ -251,14 +251,15 @@ struct Team {
 // would wait for a few lanes): its offset goes to the wavefront's region of a queue in LDS (fixed regions:
 // the order does not depend on timing, so sums stay bitwise reproducible) that all wavefronts drain
 // together afterwards (drain_queue).
+template <int MODE>
 __device__ inline void list_pass(const ListPtrs &lp, const ModelView &mv, const FitArgs &fa, const Pose &T, int n, int nga,
                                  int p0, const double2 P, double acc[kNumAcc], unsigned *wave_cnt, unsigned short *queue,
                                  int &fell_back, int tid)
 {
     const int  lane = tid & 63, wave = tid >> 6;
     const int  p = p0 + tid;
-    const int  cls = p < nga ? 0 : 1;
-    const bool valid = p < n && mv.n_cls[cls] > 3; // icpPointToPoint.cpp:59,93
+    const int  cls = MODE == SLAM_ICP_P2L ? 1 : (p < nga ? 0 : 1);                  // a point-to-line model is one class
+    const bool valid = p < n && (MODE == SLAM_ICP_P2L || mv.n_cls[cls] > 3); // icpPointToPoint.cpp:59,93
     bool       done = true;
     if (valid) {
         float  qx, qy;
@@ -266,7 +267,11 @@ __device__ inline void list_pass(const ListPtrs &lp, const ModelView &mv, const 
         float2 m;
         transform_query(T, P, qx, qy);
         done = list_search(b, m, lp, mv, cls, qx, qy);
-        if (done && (double)b.d < fa.indist) add_p2p_xy(mv, m, qx, qy, acc); // :76
+        if (MODE == SLAM_ICP_P2L) { // icpPointToPlane.cpp:55-77: every template point, no gate
+            if (done) add_p2l(m, mv.lnormals[mv.lbase[1] + b.pos], qx, qy, acc);
+        } else if (done && (double)b.d < fa.indist) {
+            add_p2p_xy(mv, m, qx, qy, acc); // :76
+        }
         fell_back += done ? 0 : 1;
     }
     const unsigned long long need = __ballot(!done);
@@ -278,7 +283,7 @@ __device__ inline void list_pass(const ListPtrs &lp, const ModelView &mv, const 
 // points past the pass (block_search, then the ring search if that does not decide), then the queued
 // ones (ring search).  Entry e of the queue lives in the region of the wavefront whose inclusive count
 // prefix first exceeds e.
-template <typename StartT, bool LISTS, int TB>
+template <typename StartT, bool LISTS, int TB, int MODE>
 __device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ListPtrs &lp, const ModelView &mv, const FitArgs &fa,
                                    const Pose &T, int off, int n, int nga, int p0, double acc[kNumAcc], int tail,
                                    const unsigned *wave_cnt, const unsigned short *queue, int tid)
@@ -309,20 +314,32 @@ __device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ListPtrs &
         if (e < total) {
             const bool is_tail = e < tail;
             const int  p = p0 + (is_tail ? TB + e : (int)queue[min(w, kW - 1) * 64 + (e - tail - excl)]);
-            const int  cls = p < nga ? 0 : 1;
-            if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
-                float qx, qy;
+            const int  cls = MODE == SLAM_ICP_P2L ? 1 : (p < nga ? 0 : 1);
+            if (MODE == SLAM_ICP_P2L || mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
+                const double gate = MODE == SLAM_ICP_P2L ? (double)INFINITY : fa.indist; // icpPointToPlane.cpp has no gate
+                float        qx, qy;
                 transform_query(T, fa.pts[off + p], qx, qy);
                 Best   b;
                 float2 m;
                 bool   have_m = false;
                 if (LISTS) {
                     have_m = list_scan_coop(b, m, lp, mv, cls, qx, qy, lane % kCoop);
-                    if (!have_m) b = nn_search<kCoop, StartT>(ix, mv, cls, qx, qy, lane % kCoop, fa.indist);
+                    if (!have_m) b = nn_search<kCoop, StartT>(ix, mv, cls, qx, qy, lane % kCoop, gate);
                 } else {
-                    b = nn_search<kCoop, StartT>(ix, mv, cls, qx, qy, lane % kCoop, fa.indist);
+                    b = nn_search<kCoop, StartT>(ix, mv, cls, qx, qy, lane % kCoop, gate);
                 }
-                if (lane % kCoop == 0 && b.pos >= 0 && (double)b.d < fa.indist) { // :76
+                if (MODE == SLAM_ICP_P2L) {
+                    if (lane % kCoop == 0 && b.pos >= 0) {
+                        double2 nrm;
+                        if (have_m) {
+                            nrm = mv.lnormals[mv.lbase[1] + b.pos];
+                        } else {
+                            m = ix.pts[mv.base[1] + b.pos];
+                            nrm = reinterpret_cast<const double2 *>(mv.normals)[b.oidx];
+                        }
+                        add_p2l(m, nrm, qx, qy, acc);
+                    }
+                } else if (lane % kCoop == 0 && b.pos >= 0 && (double)b.d < fa.indist) { // :76
                     if (!have_m) m = ix.pts[mv.base[cls] + b.pos];
                     add_p2p_xy(mv, m, qx, qy, acc);
                 }
@@ -357,30 +374,18 @@ __device__ inline void accumulate_point(const IndexPtrs<StartT> &ix, const Model
             far += (sub == 0 && !(b.pos >= 0 && b.d < mv.cert2)) ? 1 : 0; // beyond what the halo lists certify
         }
     } else {
-        // icpPointToPlane.cpp:55-77: single class, no inlier gate
-        const Best b0 = nn_search<GG, StartT>(ix, mv, 0, qx, qy, sub, INFINITY);
-        const Best b1 = nn_search<GG, StartT>(ix, mv, 1, qx, qy, sub, INFINITY);
-        const bool use1 = b0.pos < 0 || (b1.pos >= 0 && b1.d < b0.d);
-        const Best b = use1 ? b1 : b0;
-        if (sub == 0 && b.pos >= 0) {
-            const int    cls = use1 ? 1 : 0;
-            const float2 m = ix.pts[mv.base[cls] + b.pos];
-            const int    all = (cls ? mv.n_cls[0] : 0) + (int)b.oidx;
-            const double nx = mv.normals[2 * all], ny = mv.normals[2 * all + 1];
-            const double dx = (double)m.x, dy = (double)m.y;
-            const double sx = (double)qx, sy = (double)qy;
-            const double a0 = ny * sx - nx * sy, a1 = nx, a2 = ny;
-            const double bb = nx * dx + ny * dy - nx * sx - ny * sy;
-            acc[0] += a0 * a0;
-            acc[1] += a0 * a1;
-            acc[2] += a0 * a2;
-            acc[3] += a1 * a1;
-            acc[4] += a1 * a2;
-            acc[5] += a2 * a2;
-            acc[6] += a0 * bb;
-            acc[7] += a1 * bb;
-            acc[8] += a2 * bb;
+        // icpPointToPlane.cpp:55-77: single class (all model points are class 1 of the index, oidx = all-index), no inlier gate
+        Best b;
+        if (SEEDED) {
+            float e_out;
+            b = nn_search_seeded<GG, StartT>(ix, mv, 1, qx, qy, sub, (double)INFINITY, *seed, 0.0f, 0.0f, e_out);
+            *seed = b.pos;
+        } else {
+            b = nn_search<GG, StartT>(ix, mv, 1, qx, qy, sub, (double)INFINITY);
         }
+        if (sub == 0 && b.pos >= 0)
+            add_p2l(ix.pts[mv.base[1] + b.pos], reinterpret_cast<const double2 *>(mv.normals)[b.oidx], qx, qy, acc);
+        far += (sub == 0 && !(b.pos >= 0 && b.d < mv.cert2)) ? 1 : 0; // beyond what the halo lists certify
     }
 }
 
@@ -478,13 +483,13 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
             int pass = 0;
             for (int p0 = 0; p0 < n; ++pass) {
                 int rem = n - p0;
-                if (SWEEP && MODE == SLAM_ICP_P2P) {
+                if (SWEEP) {
                     // a pass of kBlock points, then the cooperative rounds: the queries the pass left
                     // undecided and, when fewer than kCoopPerBlock points remain after it, those too
                     int tail = 0;
                     if (rem > kCoopPerBlock) {
                         const double2 P = pass == 0 ? Pc0 : (p0 + tid < n ? fa.pts[off + p0 + tid] : Pc0);
-                        list_pass(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back, tid);
+                        list_pass<MODE>(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back, tid);
                         tail = rem - kBlock;
                         tail = tail > 0 && tail <= kCoopPerBlock ? tail : 0;
                     } else { // a scan shorter than one cooperative round
@@ -494,7 +499,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                     }
                     tm.sync();
                     if (SLAM_STAMPS(fa)) c_mid = __builtin_amdgcn_s_memtime();
-                    drain_queue<StartT, SWEEP == 2, TB>(ix, lp, mv, fa, T, off, n, nga, p0, acc, tail, wave_cnt, queue, tid);
+                    drain_queue<StartT, SWEEP == 2, TB, MODE>(ix, lp, mv, fa, T, off, n, nga, p0, acc, tail, wave_cnt, queue, tid);
                     p0 += kBlock + tail;
                     if (p0 < n) tm.sync(); // the queue is reused by the next pass
                 } else if (G > 0) {
@@ -503,7 +508,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                         const int p = p0 + tid / (G > 0 ? G : 1);
                         P = fa.pts[off + min(p, n - 1)];
                     }
-                    if (kSeedRing && MODE == SLAM_ICP_P2P && pass < kHoist) {
+                    if (kSeedRing && pass < kHoist) {
                         // (the per-pass state is selected by value: a pointer into the three would put them on the stack)
                         int   sd = pass == 0 ? sd0 : (pass == 1 ? sd1 : sd2);
                         float em = pass == 0 ? em0 : (pass == 1 ? em1 : em2);
@@ -569,24 +574,8 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                 if (MODE == SLAM_ICP_P2P) {
                     d_out = p2p_step(S, mv, o, nc_out);
                 } else {
-                    nc_out = n;
-                    double A[9] = {S[0], S[1], S[2], S[1], S[3], S[4], S[2], S[4], S[5]};
-                    double b[3] = {S[6], S[7], S[8]};
-                    if (solve3(A, b)) { // icpPointToPlane.cpp:85
-                        const double w = b[0], nn = sqrt(1.0 + w * w); // :88-95 U*V^T
-                        const double R_[4] = {1.0 / nn, -w / nn, w / nn, 1.0 / nn};
-                        const double t_[2] = {b[1], b[2]};
-                        o[0] = R_[0] * r00 + R_[1] * r10; // :166-167 R = R_*R ; t = R_*t + t_
-                        o[1] = R_[0] * r01 + R_[1] * r11;
-                        o[2] = R_[2] * r00 + R_[3] * r10;
-                        o[3] = R_[2] * r01 + R_[3] * r11;
-                        o[4] = (R_[0] * t0 + R_[1] * t1) + t_[0];
-                        o[5] = (R_[2] * t0 + R_[3] * t1) + t_[1];
-                        const double a0 = R_[0] - 1.0, a3 = R_[3] - 1.0;
-                        const double nr2 = a0 * a0 + R_[1] * R_[1] + R_[2] * R_[2] + a3 * a3;
-                        const double nt2 = t_[0] * t_[0] + t_[1] * t_[1];
-                        d_out = sqrt(nr2 > nt2 ? nr2 : nt2); // :170
-                    } // else: falls out of the if at :85 and returns 0, pose unchanged
+                    nc_out = n; // every template point has a correspondence (icpPointToPlane.cpp:55-77)
+                    d_out = p2l_step(S, o);
                 }
                 if (lane == 0) {
 #pragma unroll
@@ -897,6 +886,20 @@ __global__ __launch_bounds__(256) void icp_normals_kernel(const float2 *all, int
     normals[2 * i + 1] = cos(th);
 }
 
+// Point-to-line with halo lists: the normal of every list ENTRY, so that a list sweep's neighbour has its normal one load
+// away (an entry is a copy of a model point: the exact search finds it at distance zero; among exact duplicates the lowest
+// original index, which is also the one a search for a query there returns).  Runs once per map.
+template <typename StartT>
+__global__ __launch_bounds__(256) void icp_list_normals_kernel(ModelView mv, int n_ent, double2 *out)
+{
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_ent) return;
+    const IndexPtrs<StartT> ix = make_ptrs<StartT>(mv.blob, mv);
+    const float2            p = reinterpret_cast<const float2 *>(mv.lblob + mv.loff_pts)[e];
+    const Best              b = nn_search<1, StartT>(ix, mv, 1, p.x, p.y, 0, (double)INFINITY);
+    out[e] = b.pos >= 0 ? reinterpret_cast<const double2 *>(mv.normals)[b.oidx] : make_double2(0.0, 0.0);
+}
+
 // IcpPointToPoint::getEdgeWeight, icpPointToPoint.cpp:233-316 (with dy = ax - bx
 // of :262), over the correspondences of the last executed fitStep, i.e. those
 // found from `pose` = R,t as they stood when that step began.  One workgroup.
@@ -1028,6 +1031,22 @@ int compute_normals(slam_icp *h, const double *m_ga, int n_ga, const double *m_n
     (void)hipFree(d_all);
     SLAM_HIP(e);
     h->mv.normals = h->d_normals;
+    h->mv.lnormals = nullptr;
+    if (h->have_lists) { // a normal per halo-list entry (the entries end where the first start array begins)
+        const int n_ent = (int)((h->mv.loff_start[0] - h->mv.loff_pts) / 8u);
+        if (n_ent > 0) {
+            SLAM_HIP(hipMalloc((void **)&h->d_lnormals, sizeof(double2) * (size_t)n_ent));
+            double2   *out = reinterpret_cast<double2 *>(h->d_lnormals);
+            const dim3 lgrid((n_ent + 255) / 256);
+            if (h->start32)
+                hipLaunchKernelGGL((icp_list_normals_kernel<uint32_t>), lgrid, dim3(256), 0, nullptr, h->mv, n_ent, out);
+            else
+                hipLaunchKernelGGL((icp_list_normals_kernel<uint16_t>), lgrid, dim3(256), 0, nullptr, h->mv, n_ent, out);
+            SLAM_HIP(hipGetLastError());
+            SLAM_HIP(hipDeviceSynchronize());
+            h->mv.lnormals = out;
+        }
+    }
     return SLAM_OK;
 }
 
@@ -1091,6 +1110,43 @@ int launch_fit_m(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
     return SLAM_E_INVALID;
 }
 
+// lanes per scene point in the ring form of a pair: one is a measurement of the point-to-point kernel;
+// point-to-line pairs come with two
+template <typename StartT, int MODE>
+auto pair_kernel(int lanes) -> void (*)(ModelView, FitArgs, int)
+{
+    if constexpr (MODE == SLAM_ICP_P2P) {
+        if (lanes == 1) return icp_fit_pair_kernel<StartT, MODE, 1>;
+    }
+    return icp_fit_pair_kernel<StartT, MODE, 2>;
+}
+
+// The default schedule of a batch, either solver: first iterations by the ring search (index in LDS), the rest by the
+// list sweeps (halo lists in LDS), one launch -- every workgroup swaps its LDS contents when its own scan gets there.
+template <int MODE>
+int launch_fit_fused(slam_icp *h, FitArgs &fa, int n_scans, hipStream_t st)
+{
+    fa.switch_iter = h->switch_iter;
+    // two scans per workgroup where the batch leaves CUs to spare for it (slam_icp_params::pair_scans)
+    const size_t pair_lds = std::max(h->lds_bytes, h->list_lds_bytes) - kScratchBytes + 2 * TeamDims<kBlock / 2>::kScratch;
+    // Library default: from two scans per CU on.  Measured on config 2's scans (tools/pair_time.py): 256 scans on 256 CUs
+    // 0.39 ms alone against 0.61 in pairs (half the CUs idle); 512 scans 0.72 against 0.61; 1024 scans 1.31 against 1.16.
+    const int pair = h->pair > 0 ? h->pair : (h->pair == 0 && n_scans >= 2 * h->n_cu ? 2 : 0);
+    if (pair && pair_lds + 64 <= kLdsTotal && n_scans >= 2) { // (+ the kernel's one static word, with its alignment)
+        auto kern = h->start32 ? pair_kernel<uint32_t, MODE>(pair) : pair_kernel<uint16_t, MODE>(pair);
+        SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds));
+        hipLaunchKernelGGL(kern, dim3((n_scans + 1) / 2), dim3(kBlock), pair_lds, st, h->mv, fa, n_scans);
+        SLAM_HIP(hipGetLastError());
+        return SLAM_OK;
+    }
+    auto         kern = h->start32 ? icp_fit_fused_kernel<uint32_t, MODE> : icp_fit_fused_kernel<uint16_t, MODE>;
+    const size_t lds = std::max(h->lds_bytes, h->list_lds_bytes);
+    SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(n_scans), dim3(kBlock), lds, st, h->mv, fa);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
 int launch_fit(slam_icp *h, const FitArgs &fa_in, int n_scans, hipStream_t st)
 {
     if (n_scans <= 0) return SLAM_OK;
@@ -1101,32 +1157,13 @@ int launch_fit(slam_icp *h, const FitArgs &fa_in, int n_scans, hipStream_t st)
     fa.far_div = h->far_div;
     if (h->prm.mode == SLAM_ICP_P2L) {
         SLAM_REQUIRE(h->d_normals, SLAM_E_INVALID, "point-to-line mode needs model normals");
+        // the same schedule as point-to-point (the nine sums differ, nothing else); a model whose index or lists do not fit
+        // LDS runs the ring search for every iteration
+        if (h->two_phase && h->have_lists && h->in_lds && h->d_lnormals) return launch_fit_fused<SLAM_ICP_P2L>(h, fa, n_scans, st);
         return launch_fit_m<SLAM_ICP_P2L>(h, fa, n_scans, st);
     }
-    if (h->two_phase && h->have_lists && h->in_lds && !h->phase_events && !h->split_launch) {
-        // first iterations by the ring search (index in LDS), the rest by the list sweeps (halo lists in LDS),
-        // one launch: every workgroup swaps its LDS contents when its own scan gets there
-        fa.switch_iter = h->switch_iter;
-        // two scans per workgroup where the batch leaves CUs to spare for it (slam_icp_params::pair_scans)
-        const size_t pair_lds = std::max(h->lds_bytes, h->list_lds_bytes) - kScratchBytes + 2 * TeamDims<kBlock / 2>::kScratch;
-        // Library default: from two scans per CU on.  Measured on config 2's scans (tools/pair_time.py): 256 scans on 256 CUs
-        // 0.39 ms alone against 0.61 in pairs (half the CUs idle); 512 scans 0.72 against 0.61; 1024 scans 1.31 against 1.16.
-        const int pair = h->pair > 0 ? h->pair : (h->pair == 0 && n_scans >= 2 * h->n_cu ? 2 : 0);
-        if (pair && pair_lds + 64 <= kLdsTotal && n_scans >= 2) { // (+ the kernel's one static word, with its alignment)
-            auto kern = h->start32 ? (pair == 1 ? icp_fit_pair_kernel<uint32_t, SLAM_ICP_P2P, 1> : icp_fit_pair_kernel<uint32_t, SLAM_ICP_P2P, 2>)
-                                   : (pair == 1 ? icp_fit_pair_kernel<uint16_t, SLAM_ICP_P2P, 1> : icp_fit_pair_kernel<uint16_t, SLAM_ICP_P2P, 2>);
-            SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pair_lds));
-            hipLaunchKernelGGL(kern, dim3((n_scans + 1) / 2), dim3(kBlock), pair_lds, st, h->mv, fa, n_scans);
-            SLAM_HIP(hipGetLastError());
-            return SLAM_OK;
-        }
-        auto         kern = h->start32 ? icp_fit_fused_kernel<uint32_t, SLAM_ICP_P2P> : icp_fit_fused_kernel<uint16_t, SLAM_ICP_P2P>;
-        const size_t lds = std::max(h->lds_bytes, h->list_lds_bytes);
-        SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3(n_scans), dim3(kBlock), lds, st, h->mv, fa);
-        SLAM_HIP(hipGetLastError());
-        return SLAM_OK;
-    }
+    if (h->two_phase && h->have_lists && h->in_lds && !h->phase_events && !h->split_launch)
+        return launch_fit_fused<SLAM_ICP_P2P>(h, fa, n_scans, st);
     if (h->two_phase && h->have_lists) {
         // the same schedule as two launches (SLAM_ICP_SPLIT=1, or while the phases are being timed): the second
         // launch starts when the slowest scan of the first has handed over
@@ -1180,6 +1217,7 @@ void destroy_unsynchronised(slam_icp *icp)
     for (auto &e : icp->ev)
         if (e) (void)hipEventDestroy(e);
     if (icp->d_normals) (void)hipFree(icp->d_normals);
+    if (icp->d_lnormals) (void)hipFree(icp->d_lnormals);
     for (DevBuf *b : {&icp->w_pts, &icp->w_stamps, &icp->w_ew, &icp->w_state, &icp->w_single}) b->release();
     delete icp;
 }
@@ -1196,7 +1234,7 @@ bool takes_spread_form(const slam_icp *h, int n_scans)
 {
     const int spread_max = h->prm.spread_scans > 0 ? std::min(h->prm.spread_scans, h->n_cu)
                                                    : (h->prm.spread_scans < 0 ? 0 : h->n_cu / kSpreadMinParts);
-    return n_scans >= 1 && n_scans <= spread_max && h->prm.mode == SLAM_ICP_P2P && h->prm.lanes_per_point == 0;
+    return n_scans >= 1 && n_scans <= spread_max && h->prm.lanes_per_point == 0;
 }
 
 } // namespace icp
@@ -1238,11 +1276,11 @@ int icp_new(const slam_icp_params *params, bool on_device, slam_icp **out)
         h->prm = *params;
     else
         slam_icp_default_params(&h->prm);
-    // 0 = library default (ring search with 2 lanes per point, then list sweeps; point-to-line: ring search only);
+    // 0 = library default (ring search with 2 lanes per point, then list sweeps);
     // N > 0 = ring search with N lanes per point; -1 = ring search, lanes chosen per pass
     h->sweep = h->prm.lanes_per_point == -2 ? 2 : 0;
     h->G = h->prm.lanes_per_point > 0 ? h->prm.lanes_per_point : (h->prm.lanes_per_point == -1 ? 0 : 2);
-    h->two_phase = h->prm.lanes_per_point == 0 && h->prm.mode == SLAM_ICP_P2P;
+    h->two_phase = h->prm.lanes_per_point == 0; // either solver (the point-to-line lists carry a normal per entry)
     if (h->prm.first_iterations > 0) h->switch_iter = h->prm.first_iterations;
     if (h->prm.far_div > 0) h->far_div = h->prm.far_div;
     h->split_launch = h->prm.split_launch != 0;
@@ -1288,8 +1326,18 @@ int icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga, con
                  "LIBICP works only with at least 5 model points (got %d)", n_ga + n_nga);
     slam_icp *h = nullptr;
     SLAM_TRY(icp_new(params, on_device, &h));
-    int rc = build_index(h, m_ga, n_ga, m_nga, n_nga, on_device);
-    if (rc == SLAM_OK && h->prm.mode == SLAM_ICP_P2L) rc = compute_normals(h, m_ga, n_ga, m_nga, n_nga);
+    int rc;
+    if (h->prm.mode == SLAM_ICP_P2L) {
+        // icpPointToPlane.cpp:55-77 knows no classes: ONE index over all model points, GA then NGA (the order of its
+        // M_normal), held as class 1, so that a query is searched once and a neighbour's original index is its all-index
+        std::vector<double> all(2 * (size_t)(n_ga + n_nga));
+        if (n_ga) memcpy(all.data(), m_ga, 16 * (size_t)n_ga);
+        if (n_nga) memcpy(all.data() + 2 * (size_t)n_ga, m_nga, 16 * (size_t)n_nga);
+        rc = build_index(h, nullptr, 0, all.data(), n_ga + n_nga, false);
+        if (rc == SLAM_OK) rc = compute_normals(h, m_ga, n_ga, m_nga, n_nga);
+    } else {
+        rc = build_index(h, m_ga, n_ga, m_nga, n_nga, on_device);
+    }
     if (rc != SLAM_OK) {
         slam_icp_destroy(h);
         return rc;

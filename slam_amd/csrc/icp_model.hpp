@@ -56,7 +56,10 @@ struct ModelView {
     int      base[2];       // first point of each class in pts
     Lattice  lat;
     double   cx, cy;        // shift origin for the running sums (model centroid)
-    const double *normals;  // P2L: double2 per ORIGINAL all-index (GA then NGA), or null
+    const double *normals;  // P2L: double2 per ORIGINAL all-index (GA then NGA), or null.  A point-to-line model is ONE class
+                            // (icpPointToPlane.cpp:55-77 has no classes): every point lives in class 1 of the index, in the
+                            // order GA then NGA, so that a neighbour's `oidx` is its all-index
+    const double2 *lnormals; // P2L with halo lists: the normal of every list ENTRY (parallel to the lists' pts; stays in HBM/L2)
     // Halo lists (list-sweep mode): per class and cell of a second, coarser lattice, every point within the
     // cell dilated by `pad` cells, ordered along the axis of larger extent.  A query whose best distance
     // over its own cell's list is below cert2 has seen every point that close: no neighbour cells.
@@ -156,6 +159,7 @@ struct slam_icp {
     size_t          lds_bytes = 0;
     void           *d_blob = nullptr;
     double         *d_normals = nullptr;
+    double         *d_lnormals = nullptr; // normals per halo-list entry (P2L)
     slam::icp::DevBuf          w_pts, w_stamps, w_ew, w_state, w_single; // w_pts: slam_icp_fit's block (points + header)
     int             spread_points_hint = 0; // points of the batch when the caller knows them (slam_icp_fit), else 0
     size_t          step_pose_off = 0;   // where in w_pts the pose of the last executed step lies

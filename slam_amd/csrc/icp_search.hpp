@@ -671,51 +671,77 @@ __device__ inline void p2p_rotation(const double H[4], double R_[4])
     }
 }
 
-// matrix.cpp:420-508 Gauss-Jordan with full pivoting, 3x3, one rhs (oracle: o_solve3)
+// matrix.cpp:420-508 Gauss-Jordan with full pivoting, 3x3, one rhs (oracle: o_solve3).  The pivot's row and column are
+// run-time values; every array index below is a compile-time one (rows and columns are picked by selects), so A and b
+// stay in registers -- indexed by irow / icol they went to scratch memory, 80 bytes per lane of every kernel that solves.
+// The operations and their order are the reference's, result bit for bit.
+__device__ inline double pick3(double v0, double v1, double v2, int i) { return i == 0 ? v0 : (i == 1 ? v1 : v2); }
+
 __device__ inline bool solve3(double A[9], double b[3])
 {
-    int indxc[3], indxr[3], ipiv[3] = {0, 0, 0};
+    int ipiv0 = 0, ipiv1 = 0, ipiv2 = 0;
     int irow = 0, icol = 0;
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         double big = 0.0;
-        for (int j = 0; j < 3; j++)
-            if (ipiv[j] != 1)
-                for (int k = 0; k < 3; k++)
-                    if (ipiv[k] == 0 && fabs(A[3 * j + k]) >= big) {
-                        big = fabs(A[3 * j + k]);
-                        irow = j;
-                        icol = k;
-                    }
-        ++ipiv[icol];
-        if (irow != icol) {
-            for (int l = 0; l < 3; l++) {
-                const double tmp = A[3 * irow + l];
-                A[3 * irow + l] = A[3 * icol + l];
-                A[3 * icol + l] = tmp;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int pj = j == 0 ? ipiv0 : (j == 1 ? ipiv1 : ipiv2);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const int  pk = k == 0 ? ipiv0 : (k == 1 ? ipiv1 : ipiv2);
+                const bool c = (pj != 1) & (pk == 0) & (fabs(A[3 * j + k]) >= big);
+                big = c ? fabs(A[3 * j + k]) : big;
+                irow = c ? j : irow;
+                icol = c ? k : icol;
             }
-            const double tmp = b[irow];
-            b[irow] = b[icol];
-            b[icol] = tmp;
         }
-        indxr[i] = irow;
-        indxc[i] = icol;
-        if (fabs(A[3 * icol + icol]) < 1e-20) return false;
-        const double pivinv = 1.0 / A[3 * icol + icol];
-        A[3 * icol + icol] = 1.0;
-        for (int l = 0; l < 3; l++) A[3 * icol + l] *= pivinv;
-        b[icol] *= pivinv;
-        for (int ll = 0; ll < 3; ll++)
-            if (ll != icol) {
-                const double dum = A[3 * ll + icol];
-                A[3 * ll + icol] = 0.0;
-                for (int l = 0; l < 3; l++) A[3 * ll + l] -= A[3 * icol + l] * dum;
-                b[ll] -= b[icol] * dum;
+        ipiv0 += icol == 0 ? 1 : 0;
+        ipiv1 += icol == 1 ? 1 : 0;
+        ipiv2 += icol == 2 ? 1 : 0;
+        // rows irow and icol change places (the same row: nothing moves)
+        double ri[3], rc[3];
+#pragma unroll
+        for (int l = 0; l < 3; l++) {
+            ri[l] = pick3(A[l], A[3 + l], A[6 + l], irow);
+            rc[l] = pick3(A[l], A[3 + l], A[6 + l], icol);
+        }
+        const double bi = pick3(b[0], b[1], b[2], irow), bcv = pick3(b[0], b[1], b[2], icol);
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+            for (int l = 0; l < 3; l++) {
+                double v = A[3 * r + l];
+                v = r == irow ? rc[l] : v;
+                v = r == icol ? ri[l] : v;
+                A[3 * r + l] = v;
             }
+            double w = b[r];
+            w = r == irow ? bcv : w;
+            w = r == icol ? bi : w;
+            b[r] = w;
+        }
+        // (row icol now holds ri, b[icol] holds bi)
+        const double piv = pick3(ri[0], ri[1], ri[2], icol);
+        if (fabs(piv) < 1e-20) return false;
+        const double pivinv = 1.0 / piv;
+        double       prow[3];
+#pragma unroll
+        for (int l = 0; l < 3; l++) prow[l] = (l == icol ? 1.0 : ri[l]) * pivinv;
+        const double bp = bi * pivinv;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const bool   is_piv = r == icol;
+            const double dum = pick3(A[3 * r], A[3 * r + 1], A[3 * r + 2], icol);
+#pragma unroll
+            for (int l = 0; l < 3; l++) {
+                const double cur = l == icol ? 0.0 : A[3 * r + l];
+                A[3 * r + l] = is_piv ? prow[l] : cur - prow[l] * dum;
+            }
+            b[r] = is_piv ? bp : b[r] - bp * dum;
+        }
     }
-    (void)indxr;
-    (void)indxc; // column unscrambling only affects the inverse, not the solution vector
-    return true;
+    return true; // (column unscrambling only affects the inverse, not the solution vector)
 }
 
 // One point-to-point step from the nine sums S = {n, sum(p_m - c), sum(p_t - c), sum (p_t - c)(p_m - c)^T}
@@ -785,6 +811,53 @@ __device__ inline void add_p2p_xy(const ModelView &mv, const float2 m, float qx,
     acc[6] += bx * ay;
     acc[7] += by * ax;
     acc[8] += by * ay;
+}
+
+// icpPointToPlane.cpp:61-82: one correspondence of the point-to-line step -- model point d = m, its normal n, template
+// point s = the float query widened -- into the nine sums of A^T A | A^T b, A row = [n_y s_x - n_x s_y, n_x, n_y],
+// b = n . (d - s).  No inlier gate, no classes (:55-77).
+__device__ inline void add_p2l(const float2 m, const double2 nrm, float qx, float qy, double acc[kNumAcc])
+{
+    const double nx = nrm.x, ny = nrm.y;
+    const double dx = (double)m.x, dy = (double)m.y;
+    const double sx = (double)qx, sy = (double)qy;
+    const double a0 = ny * sx - nx * sy, a1 = nx, a2 = ny;
+    const double bb = nx * dx + ny * dy - nx * sx - ny * sy;
+    acc[0] += a0 * a0;
+    acc[1] += a0 * a1;
+    acc[2] += a0 * a2;
+    acc[3] += a1 * a1;
+    acc[4] += a1 * a2;
+    acc[5] += a2 * a2;
+    acc[6] += a0 * bb;
+    acc[7] += a1 * bb;
+    acc[8] += a2 * bb;
+}
+
+// One point-to-line step from the nine sums S = {A^T A upper triangle, A^T b}: icpPointToPlane.cpp:80-107.  The 3x3
+// system goes through the reference's Gauss-Jordan (matrix.cpp:420-508); R_ = I + [[0,-w],[w,0]] re-orthonormalised by
+// svd -> U*V^T (:88-95) has the closed form [[1,-w],[w,1]] / sqrt(1 + w^2) (oracle: o_orthonormal_from_omega, pinned
+// against the compiled matrix.cpp).  pose is updated in place when the system could be solved; returns the step's delta
+// (0 with the pose unchanged when it could not: the reference falls out of the if at :85).
+__device__ inline double p2l_step(const double S[kNumAcc], double pose[6])
+{
+    double A[9] = {S[0], S[1], S[2], S[1], S[3], S[4], S[2], S[4], S[5]};
+    double b[3] = {S[6], S[7], S[8]};
+    if (!solve3(A, b)) return 0.0; // :85
+    const double w = b[0], nn = sqrt(1.0 + w * w);
+    const double R_[4] = {1.0 / nn, -w / nn, w / nn, 1.0 / nn};
+    const double t_[2] = {b[1], b[2]};
+    const double r00 = pose[0], r01 = pose[1], r10 = pose[2], r11 = pose[3], t0 = pose[4], t1 = pose[5];
+    pose[0] = R_[0] * r00 + R_[1] * r10; // :101-102 R = R_*R ; t = R_*t + t_
+    pose[1] = R_[0] * r01 + R_[1] * r11;
+    pose[2] = R_[2] * r00 + R_[3] * r10;
+    pose[3] = R_[2] * r01 + R_[3] * r11;
+    pose[4] = (R_[0] * t0 + R_[1] * t1) + t_[0];
+    pose[5] = (R_[2] * t0 + R_[3] * t1) + t_[1];
+    const double a0 = R_[0] - 1.0, a3 = R_[3] - 1.0;
+    const double nr2 = a0 * a0 + R_[1] * R_[1] + R_[2] * R_[2] + a3 * a3;
+    const double nt2 = t_[0] * t_[0] + t_[1] * t_[1];
+    return sqrt(nr2 > nt2 ? nr2 : nt2); // :103
 }
 
 struct FitArgs {

@@ -61,7 +61,7 @@ __host__ __device__ inline int active_parts(int n, int G, int parts)
 }
 
 // The iterations of one scan as seen by one of its workgroups.  Returns false when an exchange timed out.
-template <int G, typename StartT>
+template <int G, typename StartT, int MODE>
 __device__ inline bool spread_iterations(const ModelView &mv, const FitArgs &fa, const IndexPtrs<StartT> &ix,
                                          unsigned char *smem, unsigned long long *gran /* [2][parts][18] of this scan */,
                                          int *abort_word, unsigned long long first_ticks, float2 *qstate, int qcap, int parts, int s,
@@ -90,8 +90,8 @@ __device__ inline bool spread_iterations(const ModelView &mv, const FitArgs &fa,
         for (int p0 = part * kPerPass; p0 < n; p0 += n_act * kPerPass) {
             const int p = p0 + tid / G, lig = tid % G;
             if (p < n) {
-                const int cls = p < nga ? 0 : 1;
-                if (mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
+                const int cls = MODE == SLAM_ICP_P2L ? 1 : (p < nga ? 0 : 1); // a point-to-line model is one class
+                if (MODE == SLAM_ICP_P2L || mv.n_cls[cls] > 3) { // icpPointToPoint.cpp:59,93
                     float         qx, qy;
                     const double2 P = fa.pts[off + p];
                     transform_query(T, P, qx, qy);
@@ -105,9 +105,15 @@ __device__ inline bool spread_iterations(const ModelView &mv, const FitArgs &fa,
                     }
                     const float move = move_r * (fabsf((float)P.x) + fabsf((float)P.y) + 1.0e-3f) + move_t;
                     float       empty = 0.0f;
-                    const Best  b = nn_search_rows<G, StartT>(ix, mv, cls, qx, qy, lig, fa.indist, seed, move, empty);
+                    const double gate = MODE == SLAM_ICP_P2L ? (double)INFINITY : fa.indist; // icpPointToPlane.cpp:55-77: no gate
+                    const Best   b = nn_search_rows<G, StartT>(ix, mv, cls, qx, qy, lig, gate, seed, move, empty);
                     if (lig == 0) {
-                        if (b.pos >= 0 && (double)b.d < fa.indist) add_p2p<StartT>(ix, mv, cls, b, qx, qy, acc); // :76
+                        if (MODE == SLAM_ICP_P2L) {
+                            if (b.pos >= 0)
+                                add_p2l(ix.pts[mv.base[1] + b.pos], reinterpret_cast<const double2 *>(mv.normals)[b.oidx], qx, qy, acc);
+                        } else if (b.pos >= 0 && (double)b.d < fa.indist) {
+                            add_p2p<StartT>(ix, mv, cls, b, qx, qy, acc); // :76
+                        }
                         if (stateful) qstate[off + p] = make_float2(empty, __int_as_float(b.pos));
                     }
                 }
@@ -167,8 +173,8 @@ __device__ inline bool spread_iterations(const ModelView &mv, const FitArgs &fa,
                                         __builtin_amdgcn_readlane(__double2loint(v8), 8 * k));
             S[8] = v9;
             double o[6] = {r00, r01, r10, r11, t0, t1};
-            int    nc_out = 0;
-            const double d_out = p2p_step(S, mv, o, nc_out);
+            int    nc_out = n; // point-to-line: every template point has a correspondence
+            const double d_out = MODE == SLAM_ICP_P2L ? p2l_step(S, o) : p2p_step(S, mv, o, nc_out);
             if (lane == 0) {
 #pragma unroll
                 for (int k = 0; k < 6; ++k) bc[k] = o[k];
@@ -211,7 +217,7 @@ __device__ inline bool spread_iterations(const ModelView &mv, const FitArgs &fa,
 }
 
 // grid (parts, n_scans); a workgroup whose scan does not need it exits at once
-template <typename StartT, bool LDS>
+template <typename StartT, bool LDS, int MODE>
 __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitArgs fa, unsigned long long *gran, int *flags /* [2][n_scans] abort | redo */,
                                                                 unsigned long long first_ticks, float2 *qstate, int qcap, int wide_max)
 {
@@ -257,8 +263,8 @@ __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitAr
     fs.n_corr = 0;
     fs.hand_over = false;
     unsigned long long *g = gran + (size_t)s * 2 * parts * kGranPerWg;
-    const bool          ok = wide ? spread_iterations<64, StartT>(mv, fa, ix, smem, g, flags + s, first_ticks, qstate, qcap, parts, s, off, n, nga, fs)
-                                  : spread_iterations<16, StartT>(mv, fa, ix, smem, g, flags + s, first_ticks, qstate, qcap, parts, s, off, n, nga, fs);
+    const bool          ok = wide ? spread_iterations<64, StartT, MODE>(mv, fa, ix, smem, g, flags + s, first_ticks, qstate, qcap, parts, s, off, n, nga, fs)
+                                  : spread_iterations<16, StartT, MODE>(mv, fa, ix, smem, g, flags + s, first_ticks, qstate, qcap, parts, s, off, n, nga, fs);
     if (part == 0 && threadIdx.x == 0) {
         // workgroup 0 decides: if IT saw every exchange through, the pose is complete whatever the others did afterwards
         if (!ok) flags[gridDim.y + s] = 1; // redo: the one-workgroup form takes this scan, from the pose left untouched here
@@ -338,14 +344,17 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
 #ifdef SLAM_MEASURE
     if (const char *e = getenv("SLAM_SPREAD_WIDE_MAX")) wide_max = atoi(e);
 #endif
+    const bool p2l = h->prm.mode == SLAM_ICP_P2L; // the nine sums and the solve differ, nothing else
     if (h->in_lds) {
-        auto kern = icp_fit_spread_kernel<uint16_t, true>;
+        auto kern = p2l ? icp_fit_spread_kernel<uint16_t, true, SLAM_ICP_P2L> : icp_fit_spread_kernel<uint16_t, true, SLAM_ICP_P2P>;
         SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         hipLaunchKernelGGL(kern, grid, dim3(kSB), h->lds_bytes, st, h->mv, fa, gran, flags, first_ticks, qstate, qcap, wide_max);
     } else if (h->start32) {
-        hipLaunchKernelGGL((icp_fit_spread_kernel<uint32_t, false>), grid, dim3(kSB), kScratchBytes, st, h->mv, fa, gran, flags, first_ticks, qstate, qcap, wide_max);
+        auto kern = p2l ? icp_fit_spread_kernel<uint32_t, false, SLAM_ICP_P2L> : icp_fit_spread_kernel<uint32_t, false, SLAM_ICP_P2P>;
+        hipLaunchKernelGGL(kern, grid, dim3(kSB), kScratchBytes, st, h->mv, fa, gran, flags, first_ticks, qstate, qcap, wide_max);
     } else {
-        hipLaunchKernelGGL((icp_fit_spread_kernel<uint16_t, false>), grid, dim3(kSB), kScratchBytes, st, h->mv, fa, gran, flags, first_ticks, qstate, qcap, wide_max);
+        auto kern = p2l ? icp_fit_spread_kernel<uint16_t, false, SLAM_ICP_P2L> : icp_fit_spread_kernel<uint16_t, false, SLAM_ICP_P2P>;
+        hipLaunchKernelGGL(kern, grid, dim3(kSB), kScratchBytes, st, h->mv, fa, gran, flags, first_ticks, qstate, qcap, wide_max);
     }
     SLAM_HIP(hipGetLastError());
     if (ordered) SLAM_HIP(hipEventRecord(done, st));

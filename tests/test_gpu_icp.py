@@ -288,27 +288,66 @@ def test_config4_share_1024_scans_properties(world):
     icp.close()
 
 
-def test_point_to_line_mode_matches_own_oracle():
-    """north-star 3x3 normal-equation step (icpPointToPlane.cpp:37-107, not compiled
-    upstream): normals and poses against the build's own scalar oracle."""
+P2L_FORMS = {
+    # what slam_icp_fit_batch_dev dispatches to (icp.hip launch_fit): (scans, parameters)
+    "spread": (6, dict()),                                            # few scans: many workgroups per scan
+    "fused": (40, dict(spread_scans=-1)),                             # ring search, then list sweeps, one scan per workgroup
+    "pairs": (41, dict(spread_scans=-1, pair_scans=2)),               # the same with two scans per workgroup (odd batch)
+    "ring-only": (20, dict(spread_scans=-1, lanes_per_point=2)),      # round 1's form: the ring search for every iteration
+    "index-in-hbm": (20, dict(spread_scans=-1, force_global=1)),      # a model too large for LDS takes this
+}
+
+
+@pytest.mark.parametrize("form", sorted(P2L_FORMS))
+def test_point_to_line_mode_matches_own_oracle(form):
+    """north-star 3x3 normal-equation step (icpPointToPlane.cpp:37-107, not compiled upstream): normals and poses of
+    every launch form against the build's own scalar oracle, delta of every step."""
+    n_scans, kw = P2L_FORMS[form]
     m_ga, m_nga = synth.make_map(5000)
     model = O.IcpModel(m_ga, m_nga, normals_k=10)
-    icp = api.Icp(m_ga, m_nga, mode=api.ICP_P2L, normals_k=10, max_iter=15, min_delta=-1.0)
+    icp = api.Icp(m_ga, m_nga, mode=api.ICP_P2L, normals_k=10, max_iter=15, min_delta=-1.0, **kw)
+    info = icp.index_info()
+    assert info["two_forms"] == (form not in ("ring-only",)) and info["in_lds"] == (form != "index-in-hbm")
     n_gpu, n_cpu = icp.normals(), model.normals()
     # a normal and its negative are the same line: compare up to sign
     dots = np.abs((n_gpu * n_cpu).sum(1))
     assert dots.min() > 1 - 1e-9
-    batch = synth.make_batch(6, n_loop=256)
+    batch = synth.make_batch(n_scans, n_loop=256)
     R, t, res, trace = icp.fit_batch(batch, trace=True)
     for s in range(batch.n_scans):
         t_ga, t_nga = batch.scan(s)
         Ro, to, tr, steps = model.fit(t_ga, t_nga, batch.R[s], batch.t[s],
                                       O.icp_params(15, -1.0, 5.0, O.NN_KDTREE, O.MODE_P2L))
         assert steps == res["iters"][s] == 15
+        assert res["n_corr"][s] == len(t_ga) + len(t_nga)          # every template point (icpPointToPlane.cpp:55-77)
         assert np.abs(t[s] - to).max() < POS_TOL
         assert ang_diff(yaw(R[s]), yaw(Ro)).max() < ANG_TOL
-        assert np.abs(trace[s, :, 6] - tr[:, 6]).max() < 1e-7
+        if np.abs(trace[s, :, 6] - tr[:, 6]).max() >= 1e-7:
+            # an exact float distance tie somewhere in the scan (scan 14 of this batch has one in its first step: two model
+            # points at 0.009734867 m^2 of one query): the kd-tree takes the one it visits last (kdtree.cpp:612-618), the
+            # GPU and the brute-force arbiter (kdtree.cpp:360-375) the lowest index -- the arbiter decides
+            _, _, tr, _ = model.fit(t_ga, t_nga, batch.R[s], batch.t[s], O.icp_params(15, -1.0, 5.0, O.NN_BRUTE, O.MODE_P2L))
+        assert np.abs(trace[s, :, 6] - tr[:, 6]).max() < 1e-7, s
     assert np.abs(t - batch.true_poses[:, :2]).max() < 0.03
+    icp.close()
+
+
+def test_point_to_line_host_fit_and_early_exit():
+    """Icp::fit's shape (icp.h:65) in point-to-line mode: one scan through slam_icp_fit (the spread form), stopping on
+    min_delta after the same number of steps as the oracle; a template of fewer than 5 points leaves R, t untouched."""
+    m_ga, m_nga = synth.make_map(5000)
+    model = O.IcpModel(m_ga, m_nga, normals_k=10)
+    icp = api.Icp(m_ga, m_nga, mode=api.ICP_P2L, normals_k=10, max_iter=40, min_delta=1e-6)
+    batch = synth.make_batch(3, n_loop=256)
+    for s in range(3):
+        t_ga, t_nga = batch.scan(s)
+        R, t, res = icp.fit(t_ga, t_nga, batch.R[s], batch.t[s], 5.0)
+        Ro, to, tr, steps = model.fit(t_ga, t_nga, batch.R[s], batch.t[s], O.icp_params(40, 1e-6, 5.0, O.NN_KDTREE, O.MODE_P2L))
+        assert res.iters == steps and steps < 40
+        assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL
+    t_ga, t_nga = batch.scan(0)
+    with pytest.raises(api.SlamError):
+        icp.fit(t_ga[:2], t_nga[:2], batch.R[0], batch.t[0], 5.0)
     icp.close()
 
 
