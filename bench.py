@@ -43,6 +43,25 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+_JSON_FD = None
+
+
+def quiet_stdout():
+    """From here on file descriptor 1 is stderr: gloo, RCCL and the HIP runtime print banners on stdout from C++ ("[Gloo] Rank 0
+    is connected to ...", the RCCL version line), and stdout must carry ONE JSON line.  emit() writes to the saved descriptor."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    os.write(_JSON_FD if _JSON_FD is not None else 1, line)
+
+
 def cpu_baseline(m_ga, m_nga, batch, grid_size, res, p2l=False):
     """Times the CPU oracle (a port of the reference path; tests pin it) on this
     host: ICP over a bounded sample of the same scans with OpenMP over scans,
@@ -309,6 +328,20 @@ def main():
     ap.add_argument("--one-device", action="store_true", help="all ranks use GPU 0 (rehearsal with --backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearse the N>1 code path (communicator + row merge) with one rank")
+    ap.add_argument("--no-merge", action="store_true",
+                    help="N>1 without the exchange step: every rank runs the N=1 step on its own shard and nothing is summed -- the "
+                         "scaling of independent ranks, to set beside the default N>1 run (its difference is the cost of the merge)")
+    ap.add_argument("--merge-order", choices=["early", "late"], default="late",
+                    help="N>1 pipelined: late (default) = a step's raycast, merge_begin and merge_finish are enqueued together two "
+                         "registrations later; early = raycast and merge_begin with the step's own registration (they wait for it on the "
+                         "device), merge_finish two registrations later.  With ONE rank (--force-dist, 100 steps, three runs each): "
+                         "late 0.363-0.367 ms per step, early 0.373-0.375, no merge 0.343-0.345 -- an early raycast takes CUs from the "
+                         "registration that has just started; whether hiding the ranks' exchange behind it pays with 8 ranks is for "
+                         "the first multi-GPU lease to say")
+    ap.add_argument("--reg-cu-cap", type=int, default=0, metavar="K",
+                    help="registration streams leave K CUs of every XCD alone (hipExtStreamCreateWithCUMask), so that the short kernels of "
+                         "the other streams -- RCCL's all-reduce, the grid update -- find a CU while 0.6 ms registration workgroups hold "
+                         "the rest (0 = ordinary streams)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="print the launch `python bench.py --gpus N` would make of its N ranks (one JSON line) and exit")
     args = ap.parse_args()
@@ -319,6 +352,7 @@ def main():
         # `python bench.py --gpus N` by itself: this process becomes the launcher of N ranks and touches no GPU
         raise SystemExit(self_launch(args, sys.argv[1:]))
 
+    quiet_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -331,7 +365,7 @@ def main():
         out = run_config3(args.clouds)
         out.update({"n_gpus": 1, "higher_is_better": True, "data": "synthetic", "vs_baseline": None,
                     "dtype": "f64 pose / f32 distance", "device": api.device_info()[0]})
-        print(json.dumps(out), flush=True)
+        emit(out)
         return
 
     torch = dist = None
@@ -344,6 +378,7 @@ def main():
     from slam_amd import api, synth
     api.set_device(local_rank)
     multi = world > 1 or args.force_dist
+    merging = multi and not args.no_merge
     comm = None
     if multi:
         if world == 1:
@@ -354,25 +389,16 @@ def main():
         # control plane (rendezvous, barriers, the maximum over the ranks' clocks) over gloo; the data plane -- the
         # planes' rows -- goes through the library's own RCCL communicator, whose id rank 0 hands out here
         dist.init_process_group("gloo")
-        if args.backend == "gloo":
+        if merging and args.backend == "gloo":
             # rehearsal (several ranks on ONE GPU, where RCCL cannot run): the library's own merge entry points over its
             # host-staged communicator (slam_comm_create_host), gloo carrying the host buffers
             def gloo_allreduce(a, op):
                 dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM if op == api.COMM_SUM else dist.ReduceOp.MIN)
             comm = api.Comm.host(rank, world, gloo_allreduce)
-        if args.backend == "nccl":
+        if merging and args.backend == "nccl":
             ids = [api.Comm.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            # RCCL prints its version banner on stdout when a communicator is made: keep stdout for the ONE JSON line
-            sys.stdout.flush()
-            keep = os.dup(1)
-            os.dup2(2, 1)
-            try:
-                comm = api.Comm(ids[0], rank, world)
-            finally:
-                sys.stdout.flush()
-                os.dup2(keep, 1)
-                os.close(keep)
+            comm = api.Comm(ids[0], rank, world)     # (RCCL's version banner goes where quiet_stdout() sent descriptor 1)
 
     m_ga, m_nga = synth.make_map(MAP_POINTS)
 
@@ -431,7 +457,7 @@ def main():
     if launch == "pipeline" and S < 2 * n_cu and args.lanes == 0:
         icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, cell_size=args.cell, pair_scans=2, **mode_kw)
     # three priority levels: never the same hardware queue (see mapper.hip)
-    SA, sb = [api.Stream(), api.Stream(priority=-1)], api.Stream(priority=1)
+    SA, sb = [api.Stream(reserve_cus_per_xcd=args.reg_cu_cap), api.Stream(priority=-1, reserve_cus_per_xcd=args.reg_cu_cap)], api.Stream(priority=1)
     SB = [sb] + [api.Stream(priority=1) for _ in grids[1:]]      # one grid stream per grid
     sa = SA[0]
     NB = 4
@@ -461,27 +487,49 @@ def main():
             live[k][1].record(a)
         icp_done[s_].record(a)
 
-    def enqueue_grid(k, b, e=None, g=None):
+    def enqueue_grid_update(k, b, e=None, g=None):
+        """raycast of step k behind its registration [N>1: + the ranks' row ranges start travelling]; no host wait"""
         s_ = k % NB
         g = g or grid
         b.wait_event(icp_done[s_])
-        # (every step starts from zero counts: the step before ended with slam_grid_finalize_reset)
+        # (every step starts from zero counts: the step before on this grid ended with slam_grid_finalize_reset)
         g.raycast_scans_dev(d_pts, d_off, S, P, pR[s_], pt[s_], b)
         if e: e[2].record(b)
-        if multi:
+        if merging:
             comm.merge_begin(g, b)
-            merge_rows_seen.append(comm.merge_finish(g, b))         # waits for the united range, then the row all-reduce
+
+    def enqueue_grid_fold(k, b, e=None, g=None):
+        """[N>1: the host's one wait of a step -- the united row range of step k -- then the all-reduce of those rows,] finalize"""
+        s_ = k % NB
+        g = g or grid
+        if merging:
+            merge_rows_seen.append(comm.merge_finish(g, b))
         if e: e[3].record(b)
         g.finalize_reset(b)          # evidence + occupancy of this batch, count planes zero again: one launch
         if e: e[4].record(b)
         grid_done[s_].record(b)
 
+    def enqueue_grid(k, b, e=None, g=None):
+        enqueue_grid_update(k, b, e, g)
+        enqueue_grid_fold(k, b, e, g)
+
     def run_steps(n, events=None, pipelined=True, handle=None, timed=False):
         if n <= 0:
             return
         E = (lambda k: events[k]) if events else (lambda k: None)
-        if pipelined:
-            # the host stays two registrations ahead of the grid update it enqueues (with N>1 that call waits for a row range)
+        if pipelined and merging and len(grids) == 2 and args.merge_order == "early":
+            # N>1: a step's raycast and the start of its merge are enqueued WITH its registration (they wait for it on the
+            # device); the host's wait for the united row range of step k-2 comes two registrations later, just before the
+            # raycast of step k goes behind it on the same grid -- by then that range is normally back (merge.merge_wait_ms)
+            for k in range(n):
+                enqueue_icp(k, SA[k % 2], E(k), handle, timed)
+                if k >= 2:
+                    enqueue_grid_fold(k - 2, SB[k % 2], E(k - 2), grids[k % 2])
+                enqueue_grid_update(k, SB[k % 2], E(k), grids[k % 2])
+            for k in range(max(n - 2, 0), n):
+                enqueue_grid_fold(k, SB[k % 2], E(k), grids[k % 2])
+        elif pipelined:
+            # the host stays two registrations ahead of the grid update it enqueues
             for k in range(n):
                 enqueue_icp(k, SA[k % 2], E(k), handle, timed)
                 if k >= 2:
@@ -508,6 +556,8 @@ def main():
     sync()
     barrier()
     sync()
+    if comm is not None:
+        comm.stats_reset()           # the merge statistics of the JSON line are those of the timed steps
     graph = None
     if launch == "graph":
         try:
@@ -536,6 +586,7 @@ def main():
     barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    merge_stats = comm.stats() if comm is not None else None
     if upd_per_step is None:      # no warm-up to count them in: the timed steps' own updates, before anything else runs
         upd_per_step = sum(g_.total_updates() for g_ in grids) // max(args.steps, 1)
     live_ms = [a_.elapsed_ms(b_) for a_, b_ in live] if (graph is None and args.steps > 0) else []
@@ -563,6 +614,7 @@ def main():
         cnt = torch.tensor([P, upd_per_step], dtype=torch.int64)
         dist.all_reduce(cnt)
         total_pts, total_upd = int(cnt[0].item()), int(cnt[1].item())
+    if merging:
         # one more update, merged but not yet folded away (a step ends with finalize_reset, which zeroes the counts): the
         # merged planes hold every rank's updates of a step, once
         grid.raycast_scans_dev(d_pts, d_off, S, P, d_R, d_t, sb)
@@ -574,7 +626,7 @@ def main():
         assert merged == total_upd, "merged planes hold %d updates, the ranks made %d" % (merged, total_upd)
         grid.finalize_reset(sb)
         sync()
-    else:
+    if not multi:
         total_pts, total_upd = P, upd_per_step
 
     # per-kernel device time from the HIP events recorded on the launch stream
@@ -590,7 +642,7 @@ def main():
 
     # the storage rows one step's finalize (and count reset) covers: the rows the step's raycast touched -- with N>1 the
     # rows any rank touched (the merge's united range); read back from the device-tracked range, outside the timed region
-    if multi and merge_rows_seen:
+    if merging and merge_rows_seen:
         rows_lo, rows_hi = merge_rows_seen[-1]
     else:
         grid.raycast_scans_dev(d_pts, d_off, S, P, d_R, d_t, sa)
@@ -682,11 +734,13 @@ def main():
                                    "finalize%s" % ("2" if (S, GRID) == (256, 2000) else ("4" if (S, GRID) == (1024, 4000) else "2 (resized)"),
                                                    S, P, N_ITERS, M, GRID, GRID, RES,
                                                    ", all-reduce of the touched rows of the int32 planes (%s)" %
-                                                   ("slam_grid_merge_begin/_finish over RCCL" if args.backend == "nccl" else "slam_grid_merge_begin/_finish over the host-staged communicator, gloo rehearsal") if multi else ""),
+                                                   ("slam_grid_merge_begin/_finish over RCCL" if args.backend == "nccl" else "slam_grid_merge_begin/_finish over the host-staged communicator, gloo rehearsal") if merging
+                                                   else (", NO merge (--no-merge: independent ranks)" if multi else "")),
                        "scans_per_gpu": S, "icp_iters": N_ITERS, "grid": [GRID, GRID], "grid_buffers": len(grids), "resolution": RES,
                        "map_points": M, "icp_index": info, "raycast": args.raycast,
                        "raycast_worklist": grid.raycast_stats(),
-                       "merge_rows": list(merge_rows_seen[-1]) if multi and merge_rows_seen else None},
+                       "merge_rows": list(merge_rows_seen[-1]) if merging and merge_rows_seen else None,
+                       "reg_cu_cap_per_xcd": args.reg_cu_cap},
             "grid_cell_updates_per_s": total_upd * args.steps / elapsed,
             "cell_updates_per_step": total_upd,
             "point_iterations_per_s": total_pts * N_ITERS * args.steps / elapsed,
@@ -701,6 +755,25 @@ def main():
             "max_pose_error_m": pose_err,
             "device": api.device_info()[0],
         }
+        if multi:
+            # what a scaling curve is read with: how many ranks the transport itself counts, what the exchange step moved and
+            # what it cost -- per timed step, on rank 0 (the ranks move the same rows: the all-reduce is over their union)
+            ms_ = merge_stats or {}
+            n_m = max(ms_.get("merges", 0), 1)
+            out["rccl_ranks"] = ms_.get("n_ranks") if merging else None
+            out["merge"] = None if not merging else {
+                "transport": "rccl" if ms_.get("transport") == 0 else "host-staged (gloo rehearsal)",
+                "rccl_version": ms_.get("rccl_version"), "ranks": ms_.get("n_ranks"),
+                "merges_in_timed_region": ms_.get("merges"),
+                "rows_per_merge": ms_.get("rows", 0) / n_m, "bytes_per_merge_per_rank": ms_.get("bytes", 0) / n_m,
+                "merge_wait_ms": ms_.get("wait_ms", 0.0) / n_m,
+                "allreduce_ms": (ms_.get("allreduce_ms", 0.0) / ms_["timed"]) if ms_.get("timed") else None,
+                "allreduce_GBps_per_rank": (ms_.get("bytes", 0) / n_m) / (ms_["allreduce_ms"] / ms_["timed"] * 1e-3) / 1e9
+                if ms_.get("timed") and ms_.get("allreduce_ms") else None,
+                "what": "merge_wait_ms = host time inside slam_grid_merge_finish waiting for the united row range (per merge); "
+                        "allreduce_ms = HIP events around the grouped row all-reduces on the grid stream (includes the time their "
+                        "kernels waited for a CU beside the registration workgroups); both from slam_comm_get_stats"}
+            out["no_merge"] = bool(args.no_merge)
         if world == 1 and not args.no_extras:
             # the model build reported separately; metric (1) with the transfers in; the reference's own
             # usage (one scan per match); config 3's match
@@ -736,7 +809,7 @@ def main():
                                                     "--no-cpu-baseline"], ("n_gpus", "value", "ms_per_step", "cell_updates_per_step"))
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(m_ga, m_nga, batch, GRID, RES, p2l)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if multi:
         dist.barrier()
         if comm is not None:
@@ -798,7 +871,7 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, ba
         elapsed = float(tt.item())
     if rank == 0:
         pts = sum(c.n_points for c in chunks) * world
-        print(json.dumps({
+        emit({
             "metric": "registered_scan_points_per_s", "value": pts / elapsed, "unit": "points/s", "n_gpus": world,
             "steps": n_chunks, "warmup": n_warm, "ms_per_step": elapsed / n_chunks * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 pose / f32 distance / int32 counts", "data": "synthetic",
@@ -810,7 +883,7 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, ba
                                       else "the fixed 5 k-point prior map",
                                       GRID, GRID, RES, args.merge_every),
                        "pcie_inclusive": True, "mapper": st, "target_index": mp.target_index_info()},
-            "grid_cell_updates_per_s": upd * world / elapsed, "max_pose_error_m": worst, "device": api.device_info()[0]}), flush=True)
+            "grid_cell_updates_per_s": upd * world / elapsed, "max_pose_error_m": worst, "device": api.device_info()[0]})
     mp.close()
     if dist is not None:
         dist.barrier()

@@ -70,6 +70,10 @@ int slam_stream_create(slam_stream_t *stream);
 /* priority > 0: the device's highest stream priority, < 0: its lowest, 0: the middle.  When workgroups of several
  * streams wait for CUs, those of the higher priority are placed first. */
 int slam_stream_create_with_priority(slam_stream_t *stream, int priority);
+/* A stream whose kernels leave `reserve_per_xcd` CUs of every XCD alone (hipExtStreamCreateWithCUMask): for work that
+ * would otherwise hold every CU for its whole duration -- the registration batches, 0.6 ms per workgroup -- while short
+ * kernels of other streams (an RCCL all-reduce, the grid update) wait for a CU to come free.  0 = an ordinary stream. */
+int slam_stream_create_reserving_cus(slam_stream_t *stream, int reserve_per_xcd);
 int slam_stream_destroy(slam_stream_t stream);
 int slam_stream_synchronize(slam_stream_t stream);
 int slam_device_synchronize(void);

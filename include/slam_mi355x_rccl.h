@@ -40,6 +40,21 @@ typedef int (*slam_host_allreduce_fn)(void *ctx, int32_t *buf, size_t count, int
 int  slam_comm_create_host(int rank, int n_ranks, slam_host_allreduce_fn allreduce, void *ctx, slam_comm_t **out);
 void slam_comm_destroy(slam_comm_t *comm);
 int  slam_comm_info(slam_comm_t *comm, int *rank, int *n_ranks);
+/* What the merges over this communicator cost since it was made (or since the last slam_comm_stats_reset): what a
+ * multi-GPU run reports so that its scaling can be read (bench.py N > 1: `merge` in the JSON line). */
+typedef struct slam_comm_stats {
+    int       rank, n_ranks;   /* as the transport itself counts them (ncclCommUserRank / ncclCommCount) */
+    int       transport;       /* 0 = RCCL, 1 = host-staged */
+    int       rccl_version;    /* ncclGetVersion, e.g. 22203; 0 for the host-staged transport */
+    long long merges;          /* slam_grid_merge_finish calls that merged */
+    long long rows;            /* storage rows they summed, in total */
+    long long bytes;           /* payload of those all-reduces per rank: 2 planes x 4 B x the cells of those rows */
+    double    wait_ms;         /* host time spent inside slam_grid_merge_finish waiting for the united row range */
+    double    allreduce_ms;    /* device time of the row all-reduces of the last `timed` merges (HIP events around them on */
+    long long timed;           /* their stream: includes the time their kernels waited for a CU) */
+} slam_comm_stats;
+int  slam_comm_get_stats(slam_comm_t *comm, slam_comm_stats *out); /* waits for the timed all-reduces to complete */
+int  slam_comm_stats_reset(slam_comm_t *comm);
 
 /* ncclAllReduce(planes, planes, 2*size_x*size_y, ncclInt32, ncclSum) on `stream` */
 int  slam_grid_allreduce(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream);
@@ -53,7 +68,9 @@ int  slam_grid_allreduce_rows(slam_grid_t *grid, slam_comm_t *comm, int row_lo, 
  *           *row_lo / *row_hi (optional) receive the range (row_hi < row_lo: nothing to merge).
  * Storage rows mean the same world cells on every rank only while the ranks' windows sit on the same cells: the same
  * all-reduce carries every rank's window position (in cells, MLS::setPose mls.cpp:419-431) and finish fails with
- * SLAM_E_INVALID, merging nothing, when rolling grids were moved apart. */
+ * SLAM_E_INVALID, merging nothing, when rolling grids were moved apart.
+ * Up to four merges may be in flight on one communicator (a pipelined caller begins the merge of the next batch, into
+ * another grid, before it finishes this one's); they finish in the order they were begun, every rank the same. */
 int  slam_grid_merge_begin(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream);
 int  slam_grid_merge_finish(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream, int *row_lo, int *row_hi);
 /* the streaming mapper's periodic merge (slam_mapper_params::merge_every) over this communicator */

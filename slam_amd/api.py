@@ -77,7 +77,7 @@ EXPORTS = [
     "slam_memcpy_d2d", "slam_host_alloc", "slam_host_free", "slam_memcpy_h2d_async",
     "slam_memcpy_d2h_async", "slam_stream_wait_event", "slam_graph_begin_capture", "slam_graph_end_capture",
     "slam_graph_launch", "slam_graph_destroy",
-    "slam_stream_create", "slam_stream_create_with_priority", "slam_stream_destroy", "slam_stream_synchronize",
+    "slam_stream_create", "slam_stream_create_with_priority", "slam_stream_create_reserving_cus", "slam_stream_destroy", "slam_stream_synchronize",
     "slam_device_synchronize", "slam_event_create", "slam_event_destroy", "slam_event_record",
     "slam_event_synchronize", "slam_event_elapsed_ms",
     "slam_icp_default_params", "slam_icp_create", "slam_icp_create_dev", "slam_icp_destroy",
@@ -160,6 +160,7 @@ def lib():
     L.slam_graph_destroy.argtypes = [_vp]
     L.slam_stream_create.argtypes = [C.POINTER(_vp)]
     L.slam_stream_create_with_priority.argtypes = [C.POINTER(_vp), C.c_int]
+    L.slam_stream_create_reserving_cus.argtypes = [C.POINTER(_vp), C.c_int]
     L.slam_stream_destroy.argtypes = [_vp]
     L.slam_stream_synchronize.argtypes = [_vp]
     L.slam_event_create.argtypes = [C.POINTER(_vp)]
@@ -376,9 +377,13 @@ class PinnedArray:
 
 
 class Stream:
-    def __init__(self, priority=None):
+    def __init__(self, priority=None, reserve_cus_per_xcd=0):
+        """reserve_cus_per_xcd > 0: a stream whose kernels leave that many CUs of every XCD alone
+        (slam_stream_create_reserving_cus; such a stream has no priority of its own)."""
         p = _vp()
-        if priority is None:
+        if reserve_cus_per_xcd:
+            check(lib().slam_stream_create_reserving_cus(C.byref(p), int(reserve_cus_per_xcd)))
+        elif priority is None:
             check(lib().slam_stream_create(C.byref(p)))
         else:
             check(lib().slam_stream_create_with_priority(C.byref(p), int(priority)))
@@ -983,7 +988,7 @@ class Ccicp:
 # ------------------------------------------------------------------ RCCL merge
 _rccl = None
 RCCL_EXPORTS = ["slam_comm_unique_id", "slam_comm_create", "slam_comm_create_host", "slam_comm_adopt", "slam_comm_destroy",
-                "slam_comm_info", "slam_grid_allreduce", "slam_grid_allreduce_rows", "slam_grid_merge_begin",
+                "slam_comm_info", "slam_comm_get_stats", "slam_comm_stats_reset", "slam_grid_allreduce", "slam_grid_allreduce_rows", "slam_grid_merge_begin",
                 "slam_grid_merge_finish", "slam_mapper_use_comm"]
 
 
@@ -1007,6 +1012,8 @@ def rccl_lib():
     R.slam_comm_destroy.argtypes = [_vp]
     R.slam_comm_destroy.restype = None
     R.slam_comm_info.argtypes = [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    R.slam_comm_get_stats.argtypes = [_vp, C.POINTER(CommStats)]
+    R.slam_comm_stats_reset.argtypes = [_vp]
     R.slam_grid_allreduce.argtypes = [_vp, _vp, _vp]
     R.slam_grid_allreduce_rows.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp]
     R.slam_grid_merge_begin.argtypes = [_vp, _vp, _vp]
@@ -1014,6 +1021,12 @@ def rccl_lib():
     R.slam_mapper_use_comm.argtypes = [_vp, _vp]
     _rccl = R
     return R
+
+
+class CommStats(C.Structure):
+    _fields_ = [("rank", C.c_int), ("n_ranks", C.c_int), ("transport", C.c_int), ("rccl_version", C.c_int),
+                ("merges", C.c_longlong), ("rows", C.c_longlong), ("bytes", C.c_longlong), ("wait_ms", C.c_double),
+                ("allreduce_ms", C.c_double), ("timed", C.c_longlong)]
 
 
 class Comm:
@@ -1057,6 +1070,15 @@ class Comm:
         r, n = C.c_int(), C.c_int()
         check(rccl_lib().slam_comm_info(self.h, C.byref(r), C.byref(n)))
         return r.value, n.value
+
+    def stats(self):
+        """slam_comm_get_stats as a dict (waits for the timed all-reduces)."""
+        st = CommStats()
+        check(rccl_lib().slam_comm_get_stats(self.h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in CommStats._fields_}
+
+    def stats_reset(self):
+        check(rccl_lib().slam_comm_stats_reset(self.h))
 
     def allreduce_grid(self, grid, stream=None):
         check(rccl_lib().slam_grid_allreduce(grid.h, self.h, _sp(stream)))

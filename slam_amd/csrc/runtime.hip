@@ -366,6 +366,26 @@ int slam_stream_create_with_priority(slam_stream_t *stream, int priority)
     return SLAM_OK;
 }
 
+int slam_stream_create_reserving_cus(slam_stream_t *stream, int reserve_per_xcd)
+{
+    SLAM_REQUIRE(stream && reserve_per_xcd >= 0, SLAM_E_INVALID, "slam_stream_create_reserving_cus: bad arguments");
+    SLAM_TRY(require_device());
+    int dev = 0, n_cu = 0;
+    SLAM_HIP(hipGetDevice(&dev));
+    SLAM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    constexpr int kXcd = 8; // MI355X: bit i of a CU mask is a CU of XCD i % 8 (measured: tools/exp/cumask.hip)
+    SLAM_REQUIRE(n_cu > 0 && n_cu % kXcd == 0 && reserve_per_xcd < n_cu / kXcd, SLAM_E_INVALID,
+                 "slam_stream_create_reserving_cus: cannot keep %d CUs per XCD free on a device of %d CUs", reserve_per_xcd, n_cu);
+    if (reserve_per_xcd == 0) return slam_stream_create(stream);
+    const int             words = (n_cu + 31) / 32, off = kXcd * reserve_per_xcd;
+    std::vector<uint32_t> mask((size_t)words, 0u);
+    for (int i = off; i < n_cu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    hipStream_t s;
+    SLAM_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)words, mask.data()));
+    *stream = (slam_stream_t)s;
+    return SLAM_OK;
+}
+
 int slam_stream_destroy(slam_stream_t stream)
 {
     if (!stream) return SLAM_OK;

@@ -38,3 +38,37 @@ def test_bench_line_contract_and_arithmetic():
     for name, kk in d["kernels"].items():
         assert kk.get("GBps", 0.0) <= 8000.0, (name, kk)
     assert d["max_pose_error_m"] < 0.05
+
+
+def _bench(*argv):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(argv), cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), "stdout must be ONE JSON line: %r" % (lines[:3],)
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_force_dist_runs_the_n_gt_1_pipeline_over_a_real_rccl_communicator():
+    """The N > 1 code path -- RCCL communicator made from an ncclUniqueId, slam_grid_merge_begin / _finish in every pipelined
+    step -- with the one rank a one-GPU box has, and the fields a scaling curve is read with."""
+    d = _bench("--force-dist", "--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline")
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["no_merge"] is False
+    m = d["merge"]
+    assert m["transport"] == "rccl" and m["rccl_version"] > 20000 and m["ranks"] == 1
+    assert m["merges_in_timed_region"] == 4
+    lo, hi = d["config"]["merge_rows"]
+    assert 0 <= lo <= hi < 2000 and abs(m["rows_per_merge"] - (hi - lo + 1)) < 8       # the room's rows, step after step
+    assert m["bytes_per_merge_per_rank"] == m["rows_per_merge"] * 2000 * 8            # [hits | misses] int32 of those rows
+    assert m["merge_wait_ms"] >= 0.0 and m["allreduce_ms"] > 0.0
+    assert d["max_pose_error_m"] < 0.05
+
+
+@pytest.mark.gpu
+def test_bench_no_merge_and_reserved_cus():
+    """--no-merge: the same ranks with the exchange step left out (what the merge costs is the difference to the default
+    run); --reg-cu-cap: registration streams that leave CUs of every XCD to the other streams' kernels."""
+    d = _bench("--force-dist", "--no-merge", "--reg-cu-cap", "1", "--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline")
+    assert d["no_merge"] is True and d["merge"] is None and d["rccl_ranks"] is None
+    assert d["config"]["reg_cu_cap_per_xcd"] == 1 and "NO merge" in d["config"]["workload"]
+    assert d["max_pose_error_m"] < 0.05 and d["value"] > 1e8
