@@ -199,6 +199,95 @@ def stream_rate(api, synth, m_ga, m_nga, batch, grid_size, n_chunks=48, **kw):
     return dt, R, t, st
 
 
+def endpoint_inputs(api, synth, batch, R, t):
+    """The two inputs of the endpoint leg, as float32 xyz rows: (name, obstacle set, ground set).
+    config 2: every registered scan point as an obstacle endpoint in the map frame ((float)(R p + t), icpPointToPoint.cpp:69-70's
+    rounding); config 3: one 64-ring cloud split by the ground segmentation into its drv (obstacle below the robot's height)
+    and ground sets, as MLS::addToOccupancy does it (mls.cpp:61-67)."""
+    ends = []
+    for s in range(batch.n_scans):
+        p = batch.pts[batch.scan_off[s]:batch.scan_off[s + 1]]
+        Rs, ts = R[s].reshape(4), t[s]
+        ends.append(np.stack([(Rs[0] * p[:, 0] + Rs[1] * p[:, 1]) + ts[0], (Rs[2] * p[:, 0] + Rs[3] * p[:, 1]) + ts[1]], 1).astype(np.float32))
+    ends = np.concatenate(ends)
+    ends = np.concatenate([ends, np.zeros((len(ends), 1), np.float32)], 1)
+    xyz = synth.make_cloud3d(3, n_loop=50)[0]
+    seg = api.GroundSegmentation()
+    lab = seg.segment(xyz)
+    seg.close()
+    return [("config 2: the %d registered endpoints of the batch as obstacle points" % len(ends), ends, np.zeros((0, 3), np.float32)),
+            ("config 3: one 64-ring cloud, segmented: %d drv (obstacle) + %d ground points" %
+             (int((lab == api.GSEG_OBSTACLE).sum()), int((lab == api.GSEG_GROUND).sum())),
+             np.ascontiguousarray(xyz[lab == api.GSEG_OBSTACLE]), np.ascontiguousarray(xyz[lab == api.GSEG_GROUND]))]
+
+
+def endpoint_leg(api, synth, batch, R, t, grid_size, res, with_cpu):
+    """The grid update the reference actually performs -- MLS::addToOccupancy's endpoint binning (mls.cpp:73-142: one counter
+    per accepted point, no free-space traversal) -- through slam_grid_add_endpoints_dev + slam_grid_finalize_reset.
+    SURVEY 8(d): 16 B per cell update (8 B point xy + 8 B counter read-modify-write) against the ~1.3 TB/s ceiling of global
+    atomics.  The CPU oracle's loop (ogrid_add_endpoints, one thread: the reference's execution model) is timed beside it."""
+    out, reps = [], 40
+    st = api.Stream()
+    for name, obs, gnd in endpoint_inputs(api, synth, batch, R, t):
+        g = api.Grid(grid_size, grid_size, res, rolling=0, min_cluster_points=20)
+        d_obs = api.DeviceArray.from_host(obs if len(obs) else np.zeros((1, 3), np.float32))
+        d_gnd = api.DeviceArray.from_host(gnd if len(gnd) else np.zeros((1, 3), np.float32))
+
+        def add():
+            api.check(api.lib().slam_grid_add_endpoints_dev(g.h, d_obs.ptr, len(obs), d_gnd.ptr, len(gnd), 3, st.ptr))
+        for _ in range(3):
+            add()
+            g.finalize_reset(st)
+        st.synchronize()
+        u0 = g.total_updates()
+        add()
+        st.synchronize()
+        upd = g.total_updates() - u0
+        g.finalize_reset(st)
+        # replayed from hipGraphs: launched call by call from Python the host's enqueue rate (15-25 us per call) is what an
+        # event pair would measure, not these microsecond kernels
+        st.synchronize()
+        g_k, g_pair = api.Graph(st), api.Graph(st)
+        with g_k:
+            for _ in range(reps):                # the kernel alone, back to back (counts accumulate; one fold after)
+                add()
+        with g_pair:
+            for _ in range(reps):                # the update as a mapper issues it: endpoints, then finalize + count reset
+                add()                            # (captured, slam_grid_finalize_reset is its two-call form: grid.hip)
+                g.finalize_reset(st)
+        e = [api.Event() for _ in range(4)]
+        e[0].record(st)
+        g_k.launch()
+        e[1].record(st)
+        g.finalize_reset(st)
+        e[2].record(st)
+        g_pair.launch()
+        e[3].record(st)
+        st.synchronize()
+        ms_k = e[0].elapsed_ms(e[1]) / reps
+        ms_pair = e[2].elapsed_ms(e[3]) / reps
+        leg = {"input": name, "grid": [grid_size, grid_size], "cell_updates_per_call": int(upd),
+               "endpoints_kernel_ms": ms_k, "endpoints_plus_finalize_reset_ms": ms_pair,
+               "cell_updates_per_s": upd / (ms_pair * 1e-3), "cell_updates_per_s_kernel_alone": upd / (ms_k * 1e-3),
+               "alg_bytes": 16 * int(upd), "GBps": 16 * upd / (ms_k * 1e-3) / 1e9,
+               "vs_global_atomic_ceiling": 16 * upd / (ms_k * 1e-3) / 1e9 / 1300.0}
+        if with_cpu:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib as O
+            gp = O.grid_params(grid_size, grid_size, res, min_cluster_points=20)
+            hits, misses = np.zeros(grid_size * grid_size, np.int32), np.zeros(grid_size * grid_size, np.int32)
+            O.grid_add_endpoints(gp, obs, gnd, hits, misses)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                O.grid_add_endpoints(gp, obs, gnd, hits, misses)
+            leg["cpu_oracle_cell_updates_per_s_1thread"] = 5 * upd / (time.perf_counter() - t0)
+        out.append(leg)
+        g.close()
+    return {"what": "MLS::addToOccupancy's endpoint update (mls.cpp:73-142) via slam_grid_add_endpoints_dev + slam_grid_finalize_reset; "
+                    "alg_bytes = 16 B per accepted point (SURVEY 8(d)), GBps over the endpoints kernel's own time, ceiling = 1.3 TB/s of "
+                    "global atomics (MI355X_MICROARCH.md)", "legs": out}
+
+
 def run_config3(n_clouds):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_config3
@@ -785,6 +874,10 @@ def main():
                                      "path": "slam_mapper_push/_wait: pinned host chunk -> H2D | ICP | raycast on three "
                                              "streams -> poses D2H; 48 chunks, three in flight, filling and draining included"}
             out["single_scan"] = single_scan_times(api, synth, m_ga, m_nga)
+            try:
+                out["endpoint"] = endpoint_leg(api, synth, batch, d_R.download().reshape(-1, 4), t_fin, GRID, RES, not args.no_cpu_baseline)
+            except Exception as ex:   # the headline line must not depend on the extra leg
+                out["endpoint"] = {"error": repr(ex)}
             try:
                 c3 = run_config3(args.clouds)
                 out["config3"] = {k: c3[k] for k in ("workload", "ms_per_cloud_chain", "cpp_adapter", "ms_per_cloud", "clouds_per_s", "stepwise_clouds_per_s",

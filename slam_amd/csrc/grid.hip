@@ -122,25 +122,69 @@ __device__ inline void block_add_updates(unsigned long long *slots, unsigned n)
 }
 
 // ------------------------------------------------------------- endpoints
+// MLS::addToOccupancy's two loops (mls.cpp:73-106 obstacle points, :110-142 ground points) as counts: one workgroup takes
+// kEndpointsPerBlock consecutive points, lanes take consecutive points (coalesced, and runs of equal cells stay inside a
+// wavefront).  The rows it touched and the number of points it accepted leave the workgroup ONCE: the range words and the
+// update counter are single addresses, and same-address atomics retire one at a time (11 ns each) -- with one pair per
+// wavefront, the thousands of wavefronts that start together right after a reset (range empty: every one of them widens
+// it) cost 70 us on config 2's 276 k endpoints, four times the kernel's own work (round 4, bench.py's endpoint leg).
+constexpr int kEndpointsPerBlock = 1024;
+
 __global__ __launch_bounds__(256) void endpoints_kernel(GridView g, const float *obs, int n_obs,
                                                         const float *gnd, int n_gnd, int stride)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    unsigned  did = 0;
-    int       row = -1;
-    if (i < n_obs + n_gnd) {
-        const bool   is_obs = i < n_obs;
-        const float *p = is_obs ? obs + (size_t)i * stride : gnd + (size_t)(i - n_obs) * stride;
-        int cx, cy;
-        if (point_cell(g, p[0], p[1], &cx, &cy)) {
-            const int s = storage_index(g, cx, cy);
-            atomicAdd(is_obs ? &g.hits[s] : &g.misses[s], 1); // mls.cpp:99 / :135 as counts
-            did = 1;
-            row = s / g.sx;
+    __shared__ int      s_lo[4], s_nhi[4];
+    __shared__ unsigned s_cnt[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int       lo = 0x7fffffff, nhi = 0x7fffffff; // lowest row, minus the highest
+    unsigned  cnt = 0;
+#pragma unroll
+    for (int k = 0; k < kEndpointsPerBlock / 256; ++k) {
+        const int i = blockIdx.x * kEndpointsPerBlock + k * 256 + (int)threadIdx.x;
+        bool      did = false;
+        int       key = -1;
+        if (i < n_obs + n_gnd) {
+            const bool   is_obs = i < n_obs;
+            const float *p = is_obs ? obs + (size_t)i * stride : gnd + (size_t)(i - n_obs) * stride;
+            int cx, cy;
+            if (point_cell(g, p[0], p[1], &cx, &cy)) {
+                const int s = storage_index(g, cx, cy), row = s / g.sx;
+                did = true;
+                key = (is_obs ? 0 : g.sx * g.sy) + s; // word of [hits | misses] this point counts in
+                lo = min(lo, row);
+                nhi = min(nhi, -row);
+                ++cnt;
+            }
+        }
+        // Consecutive points of a scan or of a lidar ring fall into the same cell in runs (beams 0.25 degrees apart are
+        // centimetres apart at the wall): the first lane of a run adds the run's length, one atomic per run instead of one
+        // per point (mls.cpp:99 / :135 as counts: integer sums, any grouping gives the same planes).
+        const int                prev = __shfl_up(key, 1);
+        const bool               head = did && (lane == 0 || prev != key);
+        const unsigned long long heads = __ballot(head || !did); // a dropped point ends a run too
+        if (head) {
+            const unsigned long long after = lane == 63 ? 0ull : heads >> (lane + 1);
+            const int                len = after ? __builtin_ctzll(after) + 1 : 64 - lane;
+            atomicAdd(&g.hits[key], len);
         }
     }
-    mark_dirty_rows(g.dirty, row, row);
-    block_add_updates(g.updates, did);
+    for (int off = 32; off > 0; off >>= 1) {
+        lo = min(lo, __shfl_xor(lo, off));
+        nhi = min(nhi, __shfl_xor(nhi, off));
+        cnt += (unsigned)__shfl_xor((int)cnt, off);
+    }
+    if (lane == 0) s_lo[wave] = lo, s_nhi[wave] = nhi, s_cnt[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        lo = min(min(s_lo[0], s_lo[1]), min(s_lo[2], s_lo[3]));
+        nhi = min(min(s_nhi[0], s_nhi[1]), min(s_nhi[2], s_nhi[3]));
+        cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (lo != 0x7fffffff) { // look first: a stale look only costs a superfluous atomic (mark_dirty_rows)
+            if (lo < __hip_atomic_load(&g.dirty[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&g.dirty[0], lo);
+            if (nhi < __hip_atomic_load(&g.dirty[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&g.dirty[1], nhi);
+        }
+        if (cnt) atomicAdd(&g.updates[(blockIdx.x * 7u + blockIdx.y * 7919u) & (kUpdateSlots - 1)], (unsigned long long)cnt);
+    }
 }
 
 // --------------------------------------------------------------- raycast
@@ -1481,7 +1525,7 @@ int slam_grid_add_endpoints_dev(slam_grid_t *g, const float *d_obs, int n_obs, c
                  "slam_grid_add_endpoints_dev: bad arguments");
     const int n = n_obs + n_gnd;
     if (n == 0) return SLAM_OK;
-    hipLaunchKernelGGL(endpoints_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), g->gv, d_obs,
+    hipLaunchKernelGGL(endpoints_kernel, dim3((n + kEndpointsPerBlock - 1) / kEndpointsPerBlock), dim3(256), 0, as_stream(stream), g->gv, d_obs,
                        n_obs, d_gnd, n_gnd, stride);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
@@ -1583,7 +1627,18 @@ int slam_grid_finalize(slam_grid_t *g, slam_stream_t stream)
 int slam_grid_finalize_reset(slam_grid_t *g, slam_stream_t stream)
 {
     SLAM_REQUIRE(g, SLAM_E_INVALID, "null handle");
-    if (g->state_from_inorder) { // the in-order mode keeps its evidence in planes of its own: the two steps as they are
+    // A stream that is being captured into a hipGraph records this call's kernel arguments once: the switch between the two
+    // range buffers below happens on the HOST, per call, and a replay would read the same stale buffer every time (rows never
+    // reset or never folded, silently).  Captured, the call is the two-step form, whose arguments do not change from call to call.
+    bool capturing = false;
+    if (stream) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(as_stream(stream), &cap) == hipSuccess)
+            capturing = cap != hipStreamCaptureStatusNone;
+        else
+            (void)hipGetLastError();
+    }
+    if (g->state_from_inorder || capturing) { // (the in-order mode keeps its evidence in planes of its own: the two steps as they are)
         SLAM_TRY(slam_grid_finalize(g, stream));
         return slam_grid_reset_counts(g, stream);
     }

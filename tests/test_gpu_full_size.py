@@ -217,3 +217,63 @@ def test_config5_sliding_window_at_full_length_matches_the_oracle_schedule():
     num, eocc = np.zeros(size * size), np.full(size * size, -1, np.int8)
     O.grid_finalize(gp, H, M, num, eocc)
     assert np.array_equal(occ, eocc)
+
+
+def test_endpoint_update_at_full_size_matches_oracle():
+    """The grid update the reference actually performs -- MLS::addToOccupancy's endpoint loops (mls.cpp:73-142) -- on the
+    BASELINE inputs at 2000 x 2000 @ 0.05 m: (a) config 2: every registered endpoint of the 256 scans as an obstacle point,
+    one call; (b) config 3: ten 64-ring clouds, each split into its drv and ground sets by the ground segmentation, added
+    scan by scan -- counts, evidence doubles and occupancy bit for bit, in the counting mode (counts summed, folded once) and
+    in the in-order mode (the reference's sequential += 1.0 / -= 0.3 on the double, thresholds as it goes)."""
+    size, res = 2000, 0.05
+    gp = O.grid_params(size, size, res, min_cluster_points=20)
+    # (a)
+    m_ga, m_nga = synth.make_map()
+    batch = synth.make_batch(256)
+    icp = api.Icp(m_ga, m_nga, max_iter=30, min_delta=-1.0)
+    R, t, res_, _ = icp.fit_batch(batch, indist=5.0)
+    icp.close()
+    ends = np.concatenate([O.transform_points(batch.pts[batch.scan_off[s]:batch.scan_off[s + 1]], R[s], t[s]) for s in range(256)])
+    assert len(ends) == batch.n_points
+    H, M = np.zeros(size * size, np.int32), np.zeros(size * size, np.int32)
+    O.grid_add_endpoints(gp, ends, np.zeros((0, 2), np.float32), H, M)
+    g = api.Grid(size, size, res, rolling=0, min_cluster_points=20)
+    g.add_endpoints(ends, np.zeros((0, 2), np.float32))
+    g.finalize()
+    api.synchronize()
+    hits, misses = g.read_counts()
+    assert np.array_equal(hits, H) and np.array_equal(misses, M) and int(H.sum()) == batch.n_points and M.sum() == 0
+    assert g.total_updates() == batch.n_points
+    num, occ = np.zeros(size * size), np.full(size * size, -1, np.int8)
+    O.grid_finalize(gp, H, M, num, occ)
+    assert np.array_equal(g.read_occupancy(), occ) and np.array_equal(g.read_num_pts(), num)
+    assert (occ == 100).sum() > 1000          # walls seen twenty times and more
+    g.close()
+    # (b)
+    g = api.Grid(size, size, res, rolling=0, min_cluster_points=20)
+    g_in = api.Grid(size, size, res, rolling=0, min_cluster_points=20)
+    H[:], M[:] = 0, 0
+    num_in, drv_in, occ_in = np.zeros(size * size), np.full(size * size, -1, np.int8), np.full(size * size, -1, np.int8)
+    total = 0
+    for k in range(10):
+        xyz = synth.make_cloud3d(5 * k, n_loop=50)[0]
+        lab = O.gseg_segment(xyz)[0]
+        obs, gnd = np.ascontiguousarray(xyz[lab == O.GSEG_OBSTACLE]), np.ascontiguousarray(xyz[lab == O.GSEG_GROUND])
+        assert len(obs) > 10000 and len(gnd) > 10000
+        g.add_endpoints(obs, gnd)
+        g_in.add_scan_inorder(obs, gnd)
+        O.grid_add_endpoints(gp, obs, gnd, H, M)
+        O.grid_add_scan_inorder(gp, obs, gnd, num_in, drv_in, occ_in)
+        total += len(obs) + len(gnd)
+    g.finalize()
+    api.synchronize()
+    hits, misses = g.read_counts()
+    assert np.array_equal(hits, H) and np.array_equal(misses, M)
+    assert g.total_updates() == int(H.sum()) + int(M.sum()) <= total
+    num, occ = np.zeros(size * size), np.full(size * size, -1, np.int8)
+    O.grid_finalize(gp, H, M, num, occ)
+    assert np.array_equal(g.read_occupancy(), occ) and np.array_equal(g.read_num_pts(), num)
+    assert np.array_equal(g_in.read_occupancy(), occ_in) and np.array_equal(g_in.read_num_pts(), num_in)   # bit-exact doubles
+    assert (occ_in == 100).sum() > 0 and (occ_in == 0).sum() > 0
+    g.close()
+    g_in.close()

@@ -335,3 +335,43 @@ def test_reserve_then_batches_of_growing_size():
         h, m = run(g, st)
         assert np.array_equal(h, H) and np.array_equal(m, M), reserve
         g.close()
+
+
+def test_finalize_reset_inside_a_replayed_graph():
+    """slam_grid_finalize_reset alternates between two device range buffers on the HOST, call by call; recorded into a hipGraph
+    its kernel arguments would be frozen and every replay would read the same stale range (rows never folded or never reset,
+    silently).  Captured, the call takes its two-step form: a replayed [endpoints, finalize_reset] must leave exactly what the
+    same calls leave when issued one by one."""
+    rs = np.random.RandomState(5)
+    obs = (rs.randn(30000, 3) * [6, 4, 1]).astype(np.float32)
+    gnd = (rs.randn(50000, 3) * [9, 9, 1]).astype(np.float32)
+    d_obs, d_gnd = api.DeviceArray.from_host(obs), api.DeviceArray.from_host(gnd)
+    L = api.lib()
+    st = api.Stream()
+    grids = [api.Grid(500, 500, 0.1, rolling=0, min_cluster_points=3) for _ in range(2)]
+
+    def step(g):
+        api.check(L.slam_grid_add_endpoints_dev(g.h, d_obs.ptr, len(obs), d_gnd.ptr, len(gnd), 3, st.ptr))
+        g.finalize_reset(st)
+    for g in grids:                       # the same uncaptured history on both
+        step(g)
+    st.synchronize()
+    graph = api.Graph(st)
+    with graph:
+        step(grids[0])
+    for r in range(3):
+        graph.launch()
+        step(grids[1])
+        st.synchronize()
+        h0, m0 = grids[0].read_counts()
+        assert not h0.any() and not m0.any(), r                       # folded and reset by every replay
+        assert np.array_equal(grids[0].read_occupancy(), grids[1].read_occupancy()), r
+        assert np.array_equal(grids[0].read_num_pts(), grids[1].read_num_pts()), r
+    step(grids[0])                        # ... and the handle goes on uncaptured afterwards
+    step(grids[1])
+    st.synchronize()
+    assert np.array_equal(grids[0].read_occupancy(), grids[1].read_occupancy())
+    assert (grids[0].read_occupancy() == 100).sum() > 0
+    assert grids[0].total_updates() == grids[1].total_updates()
+    for g in grids:
+        g.close()
