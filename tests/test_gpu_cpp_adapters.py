@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
+from ccicp_chain import oracle_scan_match, quat_rpy as _quat_rpy
+from mls_chain import oracle_local_map
 from slam_amd import build, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -83,13 +85,6 @@ def test_ccicp_adapter_compiles_against_the_cabi(tmp_path):
     assert os.path.exists(compile_cpp(str(tmp_path), "ccicp_test"))
 
 
-def _quat_rpy(roll, pitch, yaw):
-    cy, sy, cp, sp, cr, sr = (np.cos(yaw / 2), np.sin(yaw / 2), np.cos(pitch / 2), np.sin(pitch / 2),
-                              np.cos(roll / 2), np.sin(roll / 2))
-    return [sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy,
-            cr * cp * cy + sr * sp * sy]
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("rtype,tall", [(0, False), (1, False), (0, True)])
 def test_ccicp_facade_matches_oracle_chain(tmp_path, rtype, tall):
@@ -120,37 +115,17 @@ def test_ccicp_facade_matches_oracle_chain(tmp_path, rtype, tall):
     subprocess.check_call([exe, d, out, str(rtype)])
     got = np.fromfile(out, np.float64)
 
-    # the same chain from oracle pieces
-    fa = O.classify_ga(out_a)
-    kept = np.flatnonzero(fa != 255)
-    bx = np.floor((out_a[:, 0].astype(np.float64) + 300.0) / 0.5).astype(np.int64)
-    by = np.floor((out_a[:, 1].astype(np.float64) + 300.0) / 0.5).astype(np.int64)
-    order = kept[np.argsort((bx * 1200 + by)[kept], kind="stable")]
-    seg_target = np.concatenate([out_a[order], (fa[order] == 1).astype(np.float32)[:, None]], 1)
-    m_ga, m_nga = O.ccicp_split(seg_target, O.ccicp_crop(seg_target, init[0], init[1]))
-    lab_b, *_ = O.gseg_segment(B)
-    out_b = B[lab_b >= O.GSEG_OBSTACLE]
-    fb = O.classify_ga(out_b)
-    kb_ = fb != 255
-    seg_scene, n_vox = O.voxel_downsample(np.concatenate([out_b[kb_], fb[kb_, None].astype(np.float32)], 1))
-    s_ga, s_nga = O.ccicp_split(seg_scene, None)
-    gnd_scene, n_gvox = O.voxel_downsample(np.concatenate([B[lab_b == O.GSEG_GROUND], np.zeros((int((lab_b == O.GSEG_GROUND).sum()), 1), np.float32)], 1), (0.5, 0.5, 5.0))
-    assert list(got[8:16]) == [len(seg_target), n_vox, len(gnd_a), n_gvox, len(m_ga), len(m_nga), len(s_ga), len(s_nga)]
+    # the same chain from oracle pieces (tests/ccicp_chain.py)
+    e = oracle_scan_match(out_a, gnd_a, B, init)
+    assert list(got[8:16]) == e["sizes"]
     assert int(got[16]) == (1 if tall else 0)        # the tall scene went through the stepwise entry points, the others through the chain
     scene_xyz = np.fromfile(out + ".scene", np.float32).reshape(-1, 3)      # getSegmentedClouds: the voxel-filtered scene
-    assert len(scene_xyz) == n_vox and np.abs(scene_xyz - seg_scene[:, :3]).max() < 1e-4
-    assert len(s_ga) + len(s_nga) > 300 and len(m_ga) + len(m_nga) > 5000
-
-    yaw0 = rel_th + 0.03
-    R0, t0 = synth.pose_to_Rt(init[0], init[1], yaw0)
-    # the voxel centroids differ in the last float bit between oracle and device: fit the oracle on the oracle's
-    model = O.IcpModel(m_ga, m_nga)
-    R, t, trace, steps = model.fit(s_ga, s_nga, R0, t0, O.icp_params(20, 1e-6, 5.0))
-    yaw = np.arctan2(R[1, 0], R[0, 0])
-    assert abs(got[0] - t[0]) < 1e-4 and abs(got[1] - t[1]) < 1e-4
-    q = _quat_rpy(0.0, 0.0, yaw)
-    assert np.abs(got[3:7] - q).max() < 1e-5
-    assert abs(got[7] - trace[-1, 7]) <= 2                                  # correspondences of the last step
+    assert len(scene_xyz) == e["sizes"][1] and np.abs(scene_xyz - e["seg_scene"][:, :3]).max() < 1e-4
+    assert e["sizes"][6] + e["sizes"][7] > 300 and e["sizes"][4] + e["sizes"][5] > 5000
+    yaw = e["yaw"]
+    assert abs(got[0] - e["t"][0]) < 1e-4 and abs(got[1] - e["t"][1]) < 1e-4
+    assert np.abs(got[3:7] - e["q"]).max() < 1e-5
+    assert abs(got[7] - e["n_corr"]) <= 2                                  # correspondences of the last step
     z, nc, _ = O.ccicp_height(gnd_a, [got[0], got[1], init[2]] + list(got[3:7]))
     assert abs(got[2] - z) < 1e-6            # (near the sensor the ring pattern leaves no ground within 3 m: z may stay)
     # and the match is sane: B's pose in A's frame, to the 0.5 m voxel centroids the scene is reduced to
@@ -180,42 +155,8 @@ def test_mls_one_cloud_form_matches_oracle(tmp_path):
     cloud_out = np.frombuffer(raw[64 + 40000:], np.float32).reshape(-1, 3)
 
     res, size = 0.2, 200
-    gp = O.grid_params(size, size, res, min_cluster_points=20, rolling=1)
-    num, drv, eocc = np.zeros(size * size), np.full(size * size, -1, np.int8), np.full(size * size, -1, np.int8)
-    cx = cy = 0.0
-    gc = np.zeros((0, 3), np.float32)
-    n_drv = n_gnd = 0
-    for k in range(3):
-        px, py = poses[k][0], poses[k][1]
-        dx, dy = int(np.round((px - cx) / res)), int(np.round((py - cy) / res))     # mls.cpp:419-424
-        if dx or dy:
-            from test_gpu_stream import roll
-            num = roll(num.reshape(size, size), dx, dy).reshape(-1)
-            drv = roll(drv.reshape(size, size), dx, dy, -1).reshape(-1)
-            eocc = roll(eocc.reshape(size, size), dx, dy, -1).reshape(-1)
-            cx += dx * res
-            cy += dy * res
-            gc = gc + np.array([-(dx * res), -(dy * res), 0], np.float32)             # :433-454
-            crop = np.float32(size * res / 2)
-            gc = gc[(gc[:, 0] >= -crop) & (gc[:, 0] <= crop) & (gc[:, 1] >= -crop) & (gc[:, 1] <= crop)]
-        yaw = 0.02 * k
-        c, s = np.cos(yaw), np.sin(yaw)
-        # tf's matrix from the quaternion the program was given (not from the angle): the same doubles
-        q = poses[k][3:]
-        dd = sum(v * v for v in q); s2 = 2.0 / dd
-        xs, ys, zs = q[0] * s2, q[1] * s2, q[2] * s2
-        wx, wy, wz, xx, xy, xz, yy, yz, zz = q[3] * xs, q[3] * ys, q[3] * zs, q[0] * xs, q[0] * ys, q[0] * zs, q[1] * ys, q[1] * zs, q[2] * zs
-        Rm = np.array([[1 - (yy + zz), xy - wz, xz + wy], [xy + wz, 1 - (xx + zz), yz - wx], [xz - wy, yz + wx, 1 - (xx + yy)]])
-        P = clouds[k].astype(np.float64)
-        T = np.stack([Rm[0, 0] * P[:, 0] + Rm[0, 1] * P[:, 1] + Rm[0, 2] * P[:, 2] + (cx - px),
-                      Rm[1, 0] * P[:, 0] + Rm[1, 1] * P[:, 1] + Rm[1, 2] * P[:, 2] + (cy - py),
-                      Rm[2, 0] * P[:, 0] + Rm[2, 1] * P[:, 1] + Rm[2, 2] * P[:, 2] + 0.0], 1).astype(np.float32)
-        lab, *_ = O.gseg_segment(T)
-        o, g = T[lab == O.GSEG_OBSTACLE], T[lab == O.GSEG_GROUND]
-        O.grid_add_scan_inorder(gp, np.concatenate([o, np.zeros((len(o), 1), np.float32)], 1),
-                                np.concatenate([g, np.zeros((len(g), 1), np.float32)], 1), num, drv, eocc)
-        gc = np.concatenate([gc, o])
-        n_drv, n_gnd = len(o), len(g)
+    snaps = oracle_local_map(clouds, poses, size, res)                  # tests/mls_chain.py: mls.cpp:34-150 from oracle pieces
+    cx, cy, eocc, n_drv, n_gnd, gc = snaps[-1]
     assert (head[0], head[1]) == (cx, cy)
     assert (int(head[2]), int(head[3])) == (n_drv, n_gnd)
     assert np.array_equal(occ, eocc)

@@ -1,23 +1,148 @@
 """The two ROS node shims (ros/scan_registration_node.cpp, ros/local_mapper_node.cpp: scan_registration.cpp:57-199,
-local_mapper.cpp:29-130 over the library) compile against stub message headers with the real messages' type and field
-names and link against the C-ABI library.  Compile-only: there is no ROS in this image."""
+local_mapper.cpp:29-130 over the library).  There is no ROS in this image, so:
+  * (CPU) both sources compile -Werror against stand-in headers with the real messages' type and field names
+    (tests/cpp/ros_stub/) and link against the C-ABI library; the harnesses that RUN them compile too;
+  * (GPU) each node's own main() runs inside a harness process on an in-process roscpp stand-in
+    (tests/cpp/ros_stub/ros/ros.h: subscriptions with queue size 1, spin / spinOnce / Rate, recorded publications) that
+    plays the other nodes of nasa_mapping.launch: messages in on the reference's topics, the published PoseStamped /
+    OccupancyGrid compared with the adapter-level oracle chains (tests/ccicp_chain.py, tests/mls_chain.py), the
+    `orientation.w == 9999` sentinel, the < 20 000-point drop and the pose-newer-than-cloud gate included."""
 import os
 import subprocess
 
+import numpy as np
 import pytest
 
-from slam_amd import build
+import oracle_lib as O
+from ccicp_chain import oracle_scan_match, quat_rpy
+from mls_chain import oracle_local_map
+from slam_amd import build, synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("node", ["scan_registration_node", "local_mapper_node"])
-def test_ros_shim_compiles_and_links(tmp_path, node):
+def _compile(src, exe, extra_inc=()):
     build.build()
     lib = os.path.join(ROOT, "slam_amd", "lib")
-    exe = str(tmp_path / node)
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter",
-                           "-I", os.path.join(ROOT, "tests", "cpp", "ros_stub"), "-I", os.path.join(ROOT, "include"),
-                           "-I", os.path.join(ROOT, "ros"), os.path.join(ROOT, "ros", node + ".cpp"), "-o", exe,
-                           "-L" + lib, "-l:libslam_mi355x.so", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    inc = [os.path.join(ROOT, "tests", "cpp", "ros_stub"), os.path.join(ROOT, "include"), os.path.join(ROOT, "ros")] + list(extra_inc)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-Wno-unused-function"] +
+                          [a for i in inc for a in ("-I", i)] + [src, "-o", exe, "-L" + lib, "-l:libslam_mi355x.so",
+                                                                 "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+@pytest.mark.parametrize("node", ["scan_registration_node", "local_mapper_node"])
+def test_ros_shim_compiles_and_links(tmp_path, node):
+    exe = _compile(os.path.join(ROOT, "ros", node + ".cpp"), str(tmp_path / node))
     assert os.path.exists(exe)
+    # with nobody on the other side (no harness hook) the node's main() returns at once -- and must not need a GPU to do so
+    # before its first message: only local_mapper's constructor (a grid on the device) does, so run scan_registration's only
+    if node == "scan_registration_node":
+        subprocess.check_call([exe], timeout=60)
+
+
+@pytest.mark.parametrize("node", ["scan_registration", "local_mapper"])
+def test_ros_harness_compiles(tmp_path, node):
+    exe = _compile(os.path.join(ROOT, "tests", "cpp", "ros_%s_harness.cpp" % node), str(tmp_path / node),
+                   [os.path.join(ROOT, "tests", "cpp")])
+    assert os.path.exists(exe)
+
+
+@pytest.mark.gpu
+def test_scan_registration_node_runs_and_publishes_the_oracle_pose(tmp_path):
+    """scan_registration.cpp:109-199 as a running node: ekf pose, graph_slam's two target clouds and Velodyne scans arrive
+    on the reference's topics; mapping/scan_reg/pose carries the pose the oracle chain finds, stamped with the scan's stamp
+    in frame /global; a scan before the targets, a scan of fewer than 20 000 points and a scan without anything to match
+    (doICPMatch's orientation.w == 9999) publish nothing."""
+    exe = _compile(os.path.join(ROOT, "tests", "cpp", "ros_scan_registration_harness.cpp"), str(tmp_path / "h"),
+                   [os.path.join(ROOT, "tests", "cpp")])
+    d = str(tmp_path)
+    A, pa = synth.make_cloud3d(3, n_loop=50)
+    B, pb = synth.make_cloud3d(4, n_loop=50)
+    ca, sa = np.cos(pa[2]), np.sin(pa[2])
+    rel = np.array([ca * (pb[0] - pa[0]) + sa * (pb[1] - pa[1]), -sa * (pb[0] - pa[0]) + ca * (pb[1] - pa[1])])
+    rel_th = pb[2] - pa[2]
+    init = [rel[0] + 0.15, rel[1] - 0.1, 0.05] + quat_rpy(0.0, 0.0, rel_th + 0.03)
+    lab_a, *_ = O.gseg_segment(A)
+    out_a, gnd_a = A[lab_a >= O.GSEG_OBSTACLE], A[lab_a == O.GSEG_GROUND]
+    for name, a in (("target.f32", out_a), ("scene.f32", B), ("target_ground.f32", gnd_a), ("init.f64", np.array(init))):
+        np.ascontiguousarray(a).tofile(os.path.join(d, name))
+    out = os.path.join(d, "out.bin")
+    p = subprocess.run([exe, d, out], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    got = np.fromfile(out, np.float64)
+    log = open(out + ".log").read().splitlines()
+    n_pose, n_scene, n_warn, n_err = (int(v) for v in got[:4])
+    poses = got[4:4 + 10 * n_pose].reshape(n_pose, 10)
+    scenes = got[4 + 10 * n_pose:].reshape(n_scene, 2)
+
+    def at(event):
+        line = [l for l in log if l.startswith(event + " |")][0]
+        return int(line.split("so far: ")[1].split(",")[0]), int(line.split("warnings ")[1].split(",")[0]), int(line.split("errors ")[1])
+    # the order of events: nothing before the targets, nothing for the small scan (one warning), one pose for the scan,
+    # none for the ground-only scan (one error), one more for the repeated scan
+    assert at("targets") == (0, 0, 0)                # the scan that came before the targets was ignored silently (:114-115)
+    assert at("scan") == (0, 1, 0)                   # the 5000-point scan: dropped with "Input Cloud is to small" (:122-125)
+    assert at("ground-only scan") == (1, 1, 0)
+    assert at("pose + scan again") == (1, 1, 1)      # orientation.w == 9999 -> "ICP could not complete registration" (:161-165)
+    assert at("end") == (2, 1, 1)
+    assert (n_pose, n_warn, n_err) == (2, 1, 1)
+    assert any("to small" in l and "5000" in l for l in log) and any("could not complete registration" in l for l in log)
+
+    # what the node hands the matcher: the scan turned by the pose's roll and pitch (none here) and lifted by its z (:128-138)
+    scene = np.stack([B[:, 0], B[:, 1], (B[:, 2].astype(np.float64) + init[2]).astype(np.float32)], 1)
+    e = oracle_scan_match(out_a, gnd_a, scene, init)
+    for row, (sec, nsec) in zip(poses, ((13, 250), (15, 500))):
+        assert abs(row[0] - e["t"][0]) < 1e-4 and abs(row[1] - e["t"][1]) < 1e-4
+        assert np.abs(row[3:7] - e["q"]).max() < 1e-5
+        z, nc, _ = O.ccicp_height(gnd_a, [row[0], row[1], init[2]] + list(row[3:7]))
+        assert abs(row[2] - z) < 1e-6
+        assert (int(row[7]), int(row[8])) == (sec, nsec) and row[9] == 1.0          # the scan's stamp, frame /global (:170-172)
+    assert np.array_equal(poses[0, :7], poses[1, :7])                               # the same inputs, the same answer
+    assert abs(poses[0, 0] - rel[0]) < 0.3 and abs(poses[0, 1] - rel[1]) < 0.3      # and a sane one
+    # the debug cloud of the segmented scene (:141-148) went out for every scan that reached the matcher, in frame /local
+    assert n_scene == 3 and (scenes[:, 1] == 1.0).all()
+    assert int(scenes[0, 0]) == int(scenes[2, 0]) == e["sizes"][1] and scenes[1, 0] == 0
+
+
+@pytest.mark.gpu
+def test_local_mapper_node_runs_and_publishes_the_oracle_grid(tmp_path):
+    """local_mapper.cpp:95-126 as a running node: 50 Hz poll, a cloud is mapped once a pose at least as new has arrived
+    (:102), and /mapping/local_drivability carries nav_msgs/OccupancyGrid with the bytes the oracle's MLS::addToMap sequence
+    leaves -- after every cloud -- with local_mapper's geometry (200 x 200 @ 0.2 m, origin -20, -20; mls.h:167-175)."""
+    exe = _compile(os.path.join(ROOT, "tests", "cpp", "ros_local_mapper_harness.cpp"), str(tmp_path / "h"),
+                   [os.path.join(ROOT, "tests", "cpp")])
+    d = str(tmp_path)
+    clouds, poses = [], []
+    for k in range(3):
+        xyz, _ = synth.make_cloud3d(k, n_loop=50)
+        clouds.append(xyz)
+        poses.append([0.13 * k, -0.21 * k, 0.0] + quat_rpy(0.0, 0.0, 0.02 * k))
+        xyz.tofile(os.path.join(d, "cloud%d.f32" % k))
+    np.array(poses).tofile(os.path.join(d, "poses.f64"))
+    out = os.path.join(d, "out.bin")
+    p = subprocess.run([exe, d, out, "3"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    got = np.fromfile(out, np.float64)
+    log = open(out + ".log").read().splitlines()
+    n_grid, n_cloud = int(got[0]), int(got[1])
+    assert n_grid == n_cloud == 3
+    grids = got[2:2 + 7 * n_grid].reshape(n_grid, 7)
+    cl = got[2 + 7 * n_grid:].reshape(n_cloud, 2)
+    occ = np.fromfile(out + ".occ", np.int8).reshape(n_grid, 40000)
+
+    def at(event):
+        return int([l for l in log if l.startswith(event + " |")][0].split("so far: ")[1])
+    assert at("cloud 0 with its pose") == 0 and at("round after cloud 0") == 1      # mapped in the round it arrived with its pose
+    assert at("round after cloud 1") == 1                                          # cloud 1 waited: the newest pose was older than it (:102)
+    assert at("quiet round") == 1 and at("cloud 2 with its pose") == 2            # ... and was mapped when its pose came
+    assert at("end") == 3
+
+    snaps = oracle_local_map(clouds, poses, 200, 0.2)
+    for k in range(3):
+        res, w, h, ox, oy, frame_ok, n_data = grids[k]
+        assert (float(np.float32(0.2)), 200, 200, 1.0, 40000) == (res, w, h, frame_ok, n_data)
+        assert (ox, oy) == (-20.0, -20.0)                                           # mls.h:170-171: -resolution * size / 2
+        assert np.array_equal(occ[k], snaps[k][2]), k
+        assert cl[k, 0] > 0 and cl[k, 1] == 1.0                                     # the filtered obstacle cloud, frame /local_oriented
+    assert (occ[2] == 100).sum() > 0 and (occ[2] == 0).sum() > 0
