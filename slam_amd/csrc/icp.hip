@@ -1352,12 +1352,13 @@ namespace slam {
 namespace icp {
 
 int create_begin(const double *d_ga, int cap_ga, const double *d_nga, int cap_nga, const int *d_cnt, const slam_icp_params *params,
-                 hipStream_t st, slam_icp **out)
+                 hipStream_t st, slam_icp **out, bool beside)
 {
     SLAM_REQUIRE(out && cap_ga >= 0 && cap_nga >= 0 && (d_ga || cap_ga == 0) && (d_nga || cap_nga == 0), SLAM_E_INVALID,
                  "create_begin: bad model arrays");
     slam_icp *h = nullptr;
     SLAM_TRY(icp_new(params, true, &h));
+    h->build_beside = beside;
     const int rc = build_index_begin(h, d_ga, cap_ga, d_nga, cap_nga, d_cnt, true, st);
     if (rc != SLAM_OK) {
         slam_icp_destroy(h);

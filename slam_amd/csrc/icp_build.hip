@@ -658,8 +658,8 @@ __global__ __launch_bounds__(256) void idx_bbox_kernel(BuildWs w)
 }
 
 // One wavefront: the rows of idx_bbox_kernel added in index order, plan_core, the list candidates.
-constexpr int kPlanRows = 256;
-__global__ __launch_bounds__(64) void plan_kernel(BuildWs w)
+constexpr int kPlanRows = 64; // rows staged per round (1.5 KB of LDS: the kernel sits beside a registration workgroup)
+__global__ __launch_bounds__(64, 8) void plan_kernel(BuildWs w) // (8 wavefronts per SIMD: at most 64 registers, see kScanThreads)
 {
     __shared__ double s_sum[kPlanRows][3];
     __shared__ double s_hs[kPitchSteps];
@@ -767,10 +767,12 @@ __global__ __launch_bounds__(256) void idx_count_kernel(BuildWs w)
 }
 
 // Exclusive prefix of the per-cell counts of both classes, in place (v[n] = total), also stored as `esz`-byte
-// entries in the blob's start arrays.  Two launches over tiles of 8192 values: the tiles' totals, then every
+// entries in the blob's start arrays.  Two launches over tiles of 2048 values: the tiles' totals, then every
 // tile adds the totals before it (a few dozen values) and scans itself -- a single workgroup walking 80 k cells
-// took 100 us, one CU's share of the bandwidth.
-constexpr int kScanPer = 8, kScanTile = 1024 * kScanPer;
+// took 100 us, one CU's share of the bandwidth.  Workgroups of four wavefronts (round 4; sixteen before): one wavefront
+// per SIMD and 40 registers fit into what a registration workgroup leaves of a CU, so a rebuild of the mapper's sliding
+// target runs beside the registrations instead of waiting for CUs at the launch boundaries.
+constexpr int kScanThreads = 256, kScanPer = 8, kScanTile = kScanThreads * kScanPer;
 
 struct ScanArgs {
     unsigned      *v[2];    // counts of class 0 / 1, n + 1 values each
@@ -808,22 +810,22 @@ __device__ inline bool scan_args(const BuildWs &w, ScanArgs &a)
     return true;
 }
 
-__device__ inline unsigned block_sum_1024(unsigned x, unsigned *s_wave)
+__device__ inline unsigned block_sum_scan(unsigned x, unsigned *s_wave)
 {
     for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
     if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = x;
     __syncthreads();
     unsigned t = 0;
-    for (int w = 0; w < 16; ++w) t += s_wave[w];
+    for (int w = 0; w < kScanThreads / 64; ++w) t += s_wave[w];
     __syncthreads();
     return t;
 }
 
 // grid (tiles at most, 2)
 template <int LISTS>
-__global__ __launch_bounds__(1024) void scan_tiles_kernel(BuildWs w)
+__global__ __launch_bounds__(kScanThreads) void scan_tiles_kernel(BuildWs w)
 {
-    __shared__ unsigned s_wave[16];
+    __shared__ unsigned s_wave[kScanThreads / 64];
     ScanArgs            a;
     if (!scan_args<LISTS>(w, a) || (int)blockIdx.x >= a.n_tiles) return;
     const int       c = blockIdx.y, k0 = blockIdx.x * kScanTile + (int)threadIdx.x * kScanPer;
@@ -835,7 +837,7 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(BuildWs w)
         sum += x;
         most = max(most, x);
     }
-    const unsigned t = block_sum_1024(sum, s_wave);
+    const unsigned t = block_sum_scan(sum, s_wave);
     if (threadIdx.x == 0) a.tiles[c * a.n_tiles + blockIdx.x] = t;
     if (a.most) {
         for (int o = 32; o > 0; o >>= 1) most = max(most, (unsigned)__shfl_xor((int)most, o));
@@ -844,17 +846,17 @@ __global__ __launch_bounds__(1024) void scan_tiles_kernel(BuildWs w)
 }
 
 template <int LISTS>
-__global__ __launch_bounds__(1024) void scan_apply_kernel(BuildWs w)
+__global__ __launch_bounds__(kScanThreads) void scan_apply_kernel(BuildWs w)
 {
-    __shared__ unsigned s_wave[16];
+    __shared__ unsigned s_wave[kScanThreads / 64];
     ScanArgs            a;
     if (!scan_args<LISTS>(w, a) || (int)blockIdx.x >= a.n_tiles) return;
     const int      c = blockIdx.y, tile = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     unsigned      *v = c ? a.v[1] : a.v[0];
     unsigned char *out = c ? a.out[1] : a.out[0];
     unsigned       before = 0;
-    for (int t = tid; t < tile; t += 1024) before += a.tiles[c * a.n_tiles + t];
-    before = block_sum_1024(before, s_wave);
+    for (int t = tid; t < tile; t += kScanThreads) before += a.tiles[c * a.n_tiles + t];
+    before = block_sum_scan(before, s_wave);
     const int k0 = tile * kScanTile + tid * kScanPer;
     unsigned  x[kScanPer], sum = 0;
 #pragma unroll
@@ -886,8 +888,8 @@ inline int scan_tiles_for(long n) { return (int)(n / kScanTile + 1); }
 template <int LISTS>
 void launch_scan(const BuildWs &w, int tiles_max, hipStream_t st)
 {
-    hipLaunchKernelGGL((scan_tiles_kernel<LISTS>), dim3(tiles_max, 2), dim3(1024), 0, st, w);
-    hipLaunchKernelGGL((scan_apply_kernel<LISTS>), dim3(tiles_max, 2), dim3(1024), 0, st, w);
+    hipLaunchKernelGGL((scan_tiles_kernel<LISTS>), dim3(tiles_max, 2), dim3(kScanThreads), 0, st, w);
+    hipLaunchKernelGGL((scan_apply_kernel<LISTS>), dim3(tiles_max, 2), dim3(kScanThreads), 0, st, w);
 }
 
 __global__ __launch_bounds__(256) void idx_fill_kernel(BuildWs w)
@@ -1053,12 +1055,13 @@ __global__ __launch_bounds__(256) void list_scatter_kernel(BuildWs w)
 // (key, point) order -- what the host's two stable sorts leave.  Metric of a key: the largest number of entries
 // whose key lies in [k_j - win, k_j] over the entries j (the host's sliding window over the sorted keys counts
 // exactly that: float subtraction is monotone).
-constexpr int kListStage = 256; // entries of a cell staged in LDS per wavefront (more: read through the cache)
-constexpr int kSortWaves = 4;   // wavefronts per workgroup, each taking (cell, class) pairs in turn
+constexpr int kListStage = 128; // entries of a cell staged in LDS per wavefront (= kSmallCell: every list this kernel takes)
+constexpr int kSortWaves = 2;   // wavefronts per workgroup, each taking (cell, class) pairs in turn (2 x 128 x 16 B = 4 KB of LDS)
 constexpr int kSmallCell = 128; // lists up to this long: one wavefront, quadratic counting; longer: a workgroup that sorts
 constexpr int kBigCell = 4096;  // entries a workgroup sorts in LDS (longer lists: quadratic through the cache, correct and slow)
+constexpr int kBigCellBeside = 512; // ... of the variant that must fit beside a registration workgroup (4 KB of LDS: slam_icp::build_beside)
 
-__global__ __launch_bounds__(64 * kSortWaves) void list_sort_kernel(BuildWs w)
+__global__ __launch_bounds__(64 * kSortWaves, 8) void list_sort_kernel(BuildWs w)
 {
     ListArgs a;
     if (!list_args(w, a)) return;
@@ -1182,6 +1185,7 @@ __device__ inline void bitonic_sort_lds(float *key, int *val, int N /* power of 
 }
 
 // grid (workgroups, 2): a workgroup takes the cells blockIdx.x, blockIdx.x + gridDim.x, ... of class blockIdx.y
+template <int kBigCell>
 __global__ __launch_bounds__(256) void list_sort_big_kernel(BuildWs w)
 {
     __shared__ float s_key[kBigCell];
@@ -1433,7 +1437,12 @@ int build_begin_device(slam_icp *h, const double *m_ga, int cap_ga, const double
         launch_scan<1>(w, tiles_lst, st);
         hipLaunchKernelGGL((list_scatter_kernel<1>), dim3(pblocks), dim3(256), 0, st, w);
         hipLaunchKernelGGL(list_sort_kernel, dim3(1024), dim3(64 * kSortWaves), 0, st, w);
-        hipLaunchKernelGGL(list_sort_big_kernel, dim3(kSortBigGrid, 2), dim3(256), 0, st, w);
+        // (32 KB of LDS waits for a CU to come free even when no list is long; a caller whose lists are short by construction --
+        // the mapper's thinned window -- takes the 4 KB variant, which runs beside a registration workgroup)
+        if (h->build_beside)
+            hipLaunchKernelGGL((list_sort_big_kernel<kBigCellBeside>), dim3(kSortBigGrid, 2), dim3(256), 0, st, w);
+        else
+            hipLaunchKernelGGL((list_sort_big_kernel<kBigCell>), dim3(kSortBigGrid, 2), dim3(256), 0, st, w);
     }
     SLAM_HIP(hipGetLastError());
     SLAM_HIP(hipMemcpyAsync(pb->h_plan, w.plan, sizeof(DevPlan), hipMemcpyDeviceToHost, st));

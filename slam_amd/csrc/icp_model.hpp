@@ -181,6 +181,7 @@ struct slam_icp {
     int             n_cu = 256;          // CUs of the device the handle was made on
     int             max_cell_points = 0; // points in the fullest cell of the index (either class)
     bool            built_on_device = false;
+    bool            build_beside = false;       // the index build's kernels must fit beside a resident registration workgroup (mapper)
     double          build_ms[4] = {0, 0, 0, 0}; // enqueueing the build, its one wait (the other two: unused since the plan moved to the device)
     slam_icp_pending *pending = nullptr;        // between build_index_begin and build_index_finish
 };

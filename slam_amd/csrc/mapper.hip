@@ -37,7 +37,7 @@ bool takes_spread_form(const slam_icp *h, int n_scans);
 // points per class (d_cnt: int[2] on the device, in stream order; null = exactly cap_*) on st and returns a handle that may
 // only be passed to create_ready / create_finish / slam_icp_destroy; finish makes it usable (its one host wait) or destroys it.
 int  create_begin(const double *d_ga, int cap_ga, const double *d_nga, int cap_nga, const int *d_cnt, const slam_icp_params *params,
-                  hipStream_t st, slam_icp **out);
+                  hipStream_t st, slam_icp **out, bool beside);
 bool create_ready(slam_icp *h);
 int  create_finish(slam_icp *h);
 } // namespace icp
@@ -105,56 +105,76 @@ __device__ inline int thin_cell(const ThinGeom &g, const double2 q)
     return (int)fy * g.nx + (int)fx;
 }
 
+// (The thinning kernels are launched over at most kThinGrid workgroups that stride over the window: with one workgroup per 256
+// points -- 4300 of them -- a rebuild that starts in the same microsecond as a registration kept refilling every CU the
+// registration had not reached yet with small workgroups, kernel after kernel, and the registration's last workgroups, which need
+// a whole CU each, were placed only when the thinning was through: that registration took 490-550 us instead of 370.)
+constexpr int kThinGrid = 256;
+
 __global__ __launch_bounds__(256) void thin_min_kernel(Segs s, ThinGeom g, unsigned *lat)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= s.total) return;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < s.total; i += gridDim.x * 256) {
     double2 q;
     seg_point(s, i, &q);
     const int c = thin_cell(g, q);
-    if (c >= 0) atomicMin(&lat[c], (unsigned)i);
+    // Look first: the lattice only ever goes down, so a cell that already shows a lower rank -- however stale the look -- cannot
+    // be won by this point, and its atomic would change nothing.  The window is 1.1 M points on a few ten thousand wall cells, in
+    // window order: all but the first few points of a cell lose, and without the look their atomics queue up on those cells'
+    // words one after the other (112 + 132 us for the two classes alone on the chip, round 4).
+    if (c >= 0 && __hip_atomic_load(&lat[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned)i) atomicMin(&lat[c], (unsigned)i);
+  }
 }
 
 // PASS 0: winners per block; PASS 1: the winners, every stride-th, written in rank order -- the stride from the total the
 // scan left on the device (more cells than the target may hold: every stride-th), the class's count (prior + kept) with it
 template <int PASS>
-__global__ __launch_bounds__(256) void thin_pick_kernel(Segs s, ThinGeom g, const unsigned *lat, unsigned *block_count,
+__global__ __launch_bounds__(256) void thin_pick_kernel(Segs s, ThinGeom g, unsigned *lat, unsigned *block_count,
                                                         const unsigned *block_off, const unsigned *total, int cap, int prior,
                                                         int *count_out, double2 *out)
 {
     __shared__ unsigned s_w[4];
-    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    double2   q = make_double2(0.0, 0.0);
-    bool      win = false;
-    if (i < s.total) {
-        seg_point(s, i, &q);
-        const int c = thin_cell(g, q);
-        win = c >= 0 && lat[c] == (unsigned)i;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_blocks = (s.total + 255) / 256;
+    // a workgroup takes the 256-point blocks vb = blockIdx.x, blockIdx.x + gridDim.x, ...: counts and offsets stay per block
+    for (int vb = blockIdx.x; vb < n_blocks; vb += gridDim.x) {
+        const int i = vb * 256 + (int)threadIdx.x;
+        double2   q = make_double2(0.0, 0.0);
+        bool      win = false;
+        if (i < s.total) {
+            seg_point(s, i, &q);
+            const int c = thin_cell(g, q);
+            win = c >= 0 && lat[c] == (unsigned)i;
+        }
+        const unsigned long long m = __ballot(win);
+        if (lane == 0) s_w[wave] = (unsigned)__popcll(m);
+        __syncthreads();
+        if (PASS == 0) {
+            if (threadIdx.x == 0) block_count[vb] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+        } else {
+            const unsigned kept = *total, stride = max(1u, (kept + (unsigned)cap - 1u) / (unsigned)max(cap, 1));
+            if (vb == 0 && threadIdx.x == 0) *count_out = prior + (int)((kept + stride - 1u) / stride);
+            unsigned k = block_off[vb] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; ++w) k += s_w[w];
+            if (win && k % stride == 0) out[k / stride] = q;
+            // the winner leaves its cell as it found the lattice: nothing else reads this cell for a match with ITS rank, and a
+            // loser that looks later sees "no rank of mine" either way -- the next rebuild needs no 4 MB fill per class
+            if (win) lat[thin_cell(g, q)] = 0xffffffffu;
+        }
+        __syncthreads(); // s_w is written again for the next block
     }
-    const unsigned long long m = __ballot(win);
-    if (lane == 0) s_w[wave] = (unsigned)__popcll(m);
-    __syncthreads();
-    if (PASS == 0) {
-        if (threadIdx.x == 0) block_count[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-        return;
-    }
-    const unsigned kept = *total, stride = max(1u, (kept + (unsigned)cap - 1u) / (unsigned)max(cap, 1));
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = prior + (int)((kept + stride - 1u) / stride);
-    unsigned k = block_off[blockIdx.x] + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-    for (int w = 0; w < wave; ++w) k += s_w[w];
-    if (win && k % stride == 0) out[k / stride] = q;
 }
 
 __global__ void set_counts_kernel(int *cnt, int a, int b) { cnt[0] = a, cnt[1] = b; }
 
-// exclusive prefix of the block counts (a few thousand), total behind the last; one workgroup
-__global__ __launch_bounds__(1024) void thin_scan_kernel(const unsigned *cnt, int n, unsigned *off, unsigned *total)
+// exclusive prefix of the block counts (a few thousand), total behind the last; one workgroup of four wavefronts (one per
+// SIMD, few registers: it runs beside a registration workgroup instead of waiting for a CU to come free)
+constexpr int kThinScan = 256;
+__global__ __launch_bounds__(kThinScan) void thin_scan_kernel(const unsigned *cnt, int n, unsigned *off, unsigned *total)
 {
-    __shared__ unsigned s_wave[16], s_carry;
+    __shared__ unsigned s_wave[kThinScan / 64], s_carry;
     const int           tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
+    for (int base = 0; base < n; base += kThinScan) {
         const int      i = base + tid;
         const unsigned v = i < n ? cnt[i] : 0u;
         unsigned       x = v;
@@ -168,7 +188,7 @@ __global__ __launch_bounds__(1024) void thin_scan_kernel(const unsigned *cnt, in
         for (int w = 0; w < wave; ++w) before += s_wave[w];
         if (i < n) off[i] = before + x - v;
         __syncthreads();
-        if (tid == 1023) s_carry = before + x;
+        if (tid == kThinScan - 1) s_carry = before + x;
         __syncthreads();
     }
     if (tid == 0) *total = s_carry;
@@ -221,7 +241,7 @@ struct slam_mapper {
     bool               merge_pending = false;
     int                last_rows[2] = {0, -1};
     double             rebuild_ms = 0;         // host time spent enqueueing rebuilds and waiting for their plans
-    int                device = 0;
+    int                device = 0, device_at_create = 0;
     int                max_lag = 0;            // pushes a build may stay un-adopted (0: every rebuild is waited for at once)
     slam_icp_t        *building = nullptr;     // the target whose build is enqueued and not yet adopted
     long               building_chunk = 0;     // m->chunks when it was begun
@@ -244,6 +264,21 @@ inline void xt(const char *label)
     clock_gettime(CLOCK_MONOTONIC, &ts);
     g_trace.push_back({label, ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3});
 }
+// ... and the DEVICE's side of it without a profiler (rocprofv3 slows the host's calls enough to make this pipeline
+// host-bound, which it is not otherwise): a timing event per mark, recorded on the stream the work goes to; written out
+// with the host marks as "DEV <label> <us since the first device mark>".
+std::vector<std::pair<const char *, hipEvent_t>> g_dev;
+inline void dt(const char *label, hipStream_t st)
+{
+    static const bool on = getenv("SLAM_MAPPER_TRACE") != nullptr;
+    if (!on) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess || hipEventRecord(e, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+    }
+    g_dev.push_back({label, e});
+}
 void xt_dump()
 {
     const char *path = getenv("SLAM_MAPPER_TRACE");
@@ -252,12 +287,21 @@ void xt_dump()
         for (size_t i = 0; i < g_trace.size(); ++i)
             fprintf(f, "%-18s %12.1f  +%.1f\n", g_trace[i].first, g_trace[i].second - g_trace[0].second,
                     i ? g_trace[i].second - g_trace[i - 1].second : 0.0);
+        (void)hipDeviceSynchronize();
+        for (size_t i = 0; i < g_dev.size(); ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, g_dev[0].second, g_dev[i].second) != hipSuccess) (void)hipGetLastError();
+            fprintf(f, "DEV %-18s %12.1f\n", g_dev[i].first, ms * 1e3);
+        }
         fclose(f);
     }
+    for (auto &d : g_dev) (void)hipEventDestroy(d.second);
+    g_dev.clear();
     g_trace.clear();
 }
 #else
 inline void xt(const char *) {}
+inline void dt(const char *, hipStream_t) {}
 inline void xt_dump() {}
 #endif
 
@@ -306,7 +350,10 @@ int thin_class(slam_mapper *m, const std::vector<const WindowEntry *> &use, int 
     g.y0 = -0.5 * gy * res;
     const size_t cells = (size_t)g.nx * g.ny;
     const int    blocks = (s.total + 255) / 256;
-    if (!m->d_thin) MAP_HIP(hipMalloc((void **)&m->d_thin, 4 * cells));
+    if (!m->d_thin) {
+        MAP_HIP(hipMalloc((void **)&m->d_thin, 4 * cells));
+        MAP_HIP(hipMemsetAsync(m->d_thin, 0xff, 4 * cells, st));
+    }
     if ((size_t)(2 * blocks + 1) > m->cap_thin_blk) {
         if (m->d_thin_blk) {
             MAP_HIP(hipStreamSynchronize(st)); // (grows once or twice in a mapper's life)
@@ -316,11 +363,12 @@ int thin_class(slam_mapper *m, const std::vector<const WindowEntry *> &use, int 
         MAP_HIP(hipMalloc((void **)&m->d_thin_blk, 4 * m->cap_thin_blk));
     }
     unsigned *cnt = m->d_thin_blk, *off = cnt + blocks, *total = off + blocks;
-    MAP_HIP(hipMemsetAsync(m->d_thin, 0xff, 4 * cells, st));
-    hipLaunchKernelGGL(thin_min_kernel, dim3(blocks), dim3(256), 0, st, s, g, m->d_thin);
-    hipLaunchKernelGGL((thin_pick_kernel<0>), dim3(blocks), dim3(256), 0, st, s, g, m->d_thin, cnt, off, total, cap, prior, count_out, out);
-    hipLaunchKernelGGL(thin_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, blocks, off, total);
-    hipLaunchKernelGGL((thin_pick_kernel<1>), dim3(blocks), dim3(256), 0, st, s, g, m->d_thin, cnt, off, total, cap, prior, count_out, out);
+    // (the lattice is all ones: filled when it was allocated, and every rebuild's winners put it back, thin_pick_kernel<1>)
+    const int grid = std::min(blocks, kThinGrid);
+    hipLaunchKernelGGL(thin_min_kernel, dim3(grid), dim3(256), 0, st, s, g, m->d_thin);
+    hipLaunchKernelGGL((thin_pick_kernel<0>), dim3(grid), dim3(256), 0, st, s, g, m->d_thin, cnt, off, total, cap, prior, count_out, out);
+    hipLaunchKernelGGL(thin_scan_kernel, dim3(1), dim3(kThinScan), 0, st, cnt, blocks, off, total);
+    hipLaunchKernelGGL((thin_pick_kernel<1>), dim3(grid), dim3(256), 0, st, s, g, m->d_thin, cnt, off, total, cap, prior, count_out, out);
     MAP_HIP(hipGetLastError());
     return SLAM_OK;
 }
@@ -363,6 +411,7 @@ int begin_rebuild(slam_mapper *m, hipStream_t st)
     const size_t cap_ga = p_ga + w_ga, cap_nga = p_nga + w_nga;
     if (!thin && cap_ga + cap_nga < 5) return SLAM_OK;
     for (const WindowEntry *w : use) MAP_HIP(hipStreamWaitEvent(st, w->ready, 0));
+    dt("rebuild>", st);
     if (cap_ga + cap_nga > m->cap_model || !m->d_model_ga) {
         if (m->d_model_ga) {
             MAP_HIP(hipStreamSynchronize(st)); // an earlier build may still read the old block (grows once or twice)
@@ -398,7 +447,9 @@ int begin_rebuild(slam_mapper *m, hipStream_t st)
             o_nga += (size_t)w->n_nga;
         }
     }
-    SLAM_TRY(slam::icp::create_begin(d_ga, (int)cap_ga, d_nga, (int)cap_nga, d_cnt, &m->prm.icp, st, &m->building));
+    // (a thinned window has no long halo lists: the build's small-LDS variants, which run beside the registrations' workgroups)
+    SLAM_TRY(slam::icp::create_begin(d_ga, (int)cap_ga, d_nga, (int)cap_nga, d_cnt, &m->prm.icp, st, &m->building, thin));
+    dt("rebuild<", st);
     m->building_chunk = m->chunks;
     m->rebuild_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return SLAM_OK;
@@ -497,6 +548,7 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
     if (rc == SLAM_OK) {
         m->prior_ga.assign(m_ga, m_ga + 2 * (size_t)n_ga);
         m->prior_nga.assign(m_nga, m_nga + 2 * (size_t)n_nga);
+        (void)hipGetDevice(&m->device_at_create);
         if (params->pipelined) {
             // HIP deals the streams of a process over a few hardware queues: a handful for the default priority level,
             // dealt in creation order over everything the application made before, and (as far as the timings tell) one
@@ -519,7 +571,26 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
             // of which anything waits for.  Measured on config 5: own stream on the low level 0.460 ms per chunk, default level
             // 0.469, the registration stream itself 0.52 (the chain sits between two registrations while the raycast of the chunk
             // before holds the CUs), the copy stream 0.75 (the next chunk's copy queues behind it).
-            if (params->window_chunks) hip(hipStreamCreateWithPriority(&m->build_s, hipStreamNonBlocking, least));
+            // Round 4: "a stream of its own" was not a QUEUE of its own.  The runtime deals a process's streams over a few
+            // hardware queues, and the kernel trace of config 5 showed every rebuild kernel on the queue of the copy stream
+            // (profiles/r04_config5_queues.txt): the next chunk's host-to-device copies -- which its registration waits for --
+            // stood behind the rebuild's thirty launches, a 0.25 ms hole in the registrations per rebuild (0.5 ms under the
+            // profiler).  A stream made with a CU mask gets a hardware queue that no other stream is put on
+            // (tools/exp/queues2.hip); the mask here names every CU.
+            if (params->window_chunks) {
+                int n_cu = 0;
+                hip(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, m->device_at_create));
+                std::vector<uint32_t> all((size_t)std::max((n_cu + 31) / 32, 1), 0u);
+                for (int i = 0; i < n_cu; ++i) all[(size_t)i / 32] |= 1u << (i % 32);
+                bool masked = true;
+#ifdef SLAM_MEASURE
+                if (const char *e = getenv("SLAM_MAPPER_BUILD_STREAM")) masked = strcmp(e, "low") != 0; // A/B: the low priority level's stream
+#endif
+                if (!masked || hipExtStreamCreateWithCUMask(&m->build_s, (uint32_t)all.size(), all.data()) != hipSuccess) {
+                    (void)hipGetLastError();
+                    hip(hipStreamCreateWithPriority(&m->build_s, hipStreamNonBlocking, least));
+                }
+            }
         } else {
             hip(hipStreamCreateWithFlags(&m->copy, hipStreamNonBlocking));
             m->icp_s[0] = m->icp_s[1] = m->grid_s = m->build_s = m->copy;
@@ -678,6 +749,7 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     }
 
     // ---- copy
+    dt("copy>", m->copy);
     MAP_HIP(hipMemcpyAsync(b.d_pts, b.h_pts, 16 * (size_t)n_points, hipMemcpyHostToDevice, m->copy));
     MAP_HIP(hipMemcpyAsync(b.d_off, b.h_off, 4 * (size_t)(n_scans + 1), hipMemcpyHostToDevice, m->copy));
     MAP_HIP(hipMemcpyAsync(b.d_nga, b.h_nga, 4 * (size_t)n_scans, hipMemcpyHostToDevice, m->copy));
@@ -685,6 +757,7 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     MAP_HIP(hipMemcpyAsync(b.d_R, b.h_R, 32 * (size_t)n_scans, hipMemcpyHostToDevice, m->copy));
     MAP_HIP(hipMemcpyAsync(b.d_t, b.h_t, 16 * (size_t)n_scans, hipMemcpyHostToDevice, m->copy));
     MAP_HIP(hipEventRecord(b.copied, m->copy));
+    dt("copy<", m->copy);
     xt("copied");
     // ---- register
     // chunks alternate over the two registration streams; the spread form (a handful of scans) takes one call at a time
@@ -694,9 +767,11 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     const int   lane = (!m->two_lanes || slam::icp::takes_spread_form(m->target, n_scans)) ? 0 : (int)(m->chunks & 1);
     hipStream_t icp_s = m->icp_s[lane];
     MAP_HIP(hipStreamWaitEvent(icp_s, b.copied, 0));
+    dt("fit>", icp_s);
     SLAM_TRY(slam_icp_fit_batch_dev(m->target, b.d_pts, b.d_off, b.d_nga, n_scans, b.d_R, b.d_t, m->prm.indist, nullptr, nullptr,
                                     (slam_stream_t)icp_s));
     MAP_HIP(hipEventRecord(m->target_used[lane], icp_s));
+    dt("fit<", icp_s);
     if (m->prm.window_chunks) {
         WindowEntry &w = m->window[(size_t)(m->chunks % (long)m->window.size())];
         const int    sg = stride_for(m, n_ga), sn = stride_for(m, n_nga);
@@ -723,7 +798,9 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
     // ---- map
     MAP_HIP(hipStreamWaitEvent(m->grid_s, b.registered, 0));
     SLAM_TRY(slam_grid_set_pose(m->grid, window_x, window_y, (slam_stream_t)m->grid_s)); // MLS::setPose, mls.cpp:408-479
+    dt("raycast>", m->grid_s);
     SLAM_TRY(slam_grid_raycast_scans_dev(m->grid, b.d_pts, b.d_off, n_scans, n_points, b.d_R, b.d_t, (slam_stream_t)m->grid_s));
+    dt("raycast<", m->grid_s);
     ++m->chunks;
     if (m->prm.merge_every && m->chunks % m->prm.merge_every == 0) {
         if (m->merge_begin) {
