@@ -59,6 +59,18 @@ constexpr bool kSeedEmpty = SLAM_SEED_EMPTY != 0; // ... and skip the cells insi
 // inside the radius the last search proved empty skipped as well (SLAM_SEED_EMPTY): 0.398 ms -- the bookkeeping costs
 // more than the skipped cells, so that half stays off here (the spread form, icp_single.hip, uses both).
 constexpr bool kSeedRing = SLAM_SEED_RING != 0;
+// Round 4, measured and NOT kept (off; -DSLAM_SEED_CHAIN=1 in a measurement build brings it back): a lane's points as CONSECUTIVE
+// beams -- lane group g takes points g * passes + k -- so that a search without a seed of its own (every search of iteration 0;
+// the passes past the three whose seeds stay in registers) starts from the neighbour the lane has just found for the beam
+// before, of the same class.  Exact like every seed, and slower: 0.495 against 0.410 ms for 256 scans one per workgroup,
+// 0.868 against 0.639 ms in pairs (profiles/r04_seed_chain_ab.txt).  With consecutive lane groups per pass a wavefront's 32
+// queries are 32 adjacent beams -- the same few cells, the same ring depth, LDS reads of neighbouring words; with consecutive
+// beams per lane they are every second or third beam of a sector twice as wide, and what the seeds save in iterations 0-1 the
+// divergence costs in all of them.
+#ifndef SLAM_SEED_CHAIN
+#define SLAM_SEED_CHAIN 0
+#endif
+constexpr bool kSeedChain = kSeedRing && SLAM_SEED_CHAIN != 0;
 #ifdef SLAM_MEASURE
 #define SLAM_STAMPS(fa) ((fa).stamps != nullptr)
 #else
@@ -403,10 +415,9 @@ __device__ inline void point_pass(const IndexPtrs<StartT> &ix, const ModelView &
 // points in every iteration, so they are loaded once per scan, not once per iteration).
 template <int GG, typename StartT, int MODE>
 __device__ inline void point_pass_reg(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
-                                      const Pose &T, int n, int nga, int p0, const double2 P, double acc[kNumAcc],
+                                      const Pose &T, int n, int nga, int p, const double2 P, double acc[kNumAcc],
                                       int &far, int tid, int *seed = nullptr, float *empty = nullptr, float move_r = 0.f, float move_t = 0.f)
 {
-    const int p = p0 + tid / GG;
     if (p < n) {
         if (seed)
             accumulate_point<GG, StartT, MODE, true>(ix, mv, fa, T, P, p < nga, tid % GG, acc, far, seed, empty, move_r, move_t);
@@ -442,8 +453,17 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
 
     // the lane's points of the first passes, loaded once
     constexpr int kPerPass = kBlock / (G > 0 ? G : 1);
+    // point of this lane in ring pass k: consecutive beams per lane group (kSeedChain), else consecutive lane groups per pass
+    // (the first n % kPerPass lane groups take one beam more than the others: the last pass is as short as it was with
+    // consecutive lane groups per pass -- 55 points in two wavefronts for a 1081-beam scan -- not a pass of every wavefront)
+    const int     n_full = n / kPerPass, n_rest = n % kPerPass;
+    const auto    ring_point = [&](int k) {
+        const int g = tid / (G > 0 ? G : 1);
+        if (!kSeedChain) return k * kPerPass + g;
+        return (k < n_full || (k == n_full && g < n_rest)) ? g * n_full + min(g, n_rest) + k : n; // n: none
+    };
     const auto    hoisted = [&](int k) {
-        const int p = k * kPerPass + tid / (G > 0 ? G : 1);
+        const int p = SWEEP ? k * kPerPass + tid : ring_point(k);
         return (G > 0 && p < n) ? fa.pts[off + p] : make_double2(0.0, 0.0);
     };
     // named, not an array: stays in registers (the list-sweep kernel has one full pass per 1024 points: one is enough)
@@ -451,7 +471,11 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
     // the three it keeps in registers; one pass of points kept and the seeds of all five -- nine registers instead of fifteen
     // -- made no difference with two lanes per point (0.620 / 0.630 / 1.195 ms for 256 / 512 / 1024 scans against 0.627 /
     // 0.626 / 1.199) and cost 3 % with one)
-    const double2 Pc0 = hoisted(0), Pc1 = SWEEP ? Pc0 : hoisted(1), Pc2 = SWEEP ? Pc0 : hoisted(2);
+    // (the list form of a pair's team with 32-bit starts -- the cell index of a large model, read from HBM by the undecided few --
+    // is the one instantiation that does not fit 128 registers with the pass's point kept: there the point is loaded per
+    // iteration, which ended its 3 spilled registers / 16 bytes of scratch per lane, round 4)
+    constexpr bool kKeepPoint = !(SWEEP && sizeof(StartT) == 4 && TB < icp::kBlock);
+    const double2  Pc0 = kKeepPoint ? hoisted(0) : make_double2(0.0, 0.0), Pc1 = SWEEP ? Pc0 : hoisted(1), Pc2 = SWEEP ? Pc0 : hoisted(2);
 
     int   sd0 = -1, sd1 = -1, sd2 = -1; // ring form: last iteration's neighbour of the lane's point in each hoisted pass
     float em0 = 0.f, em1 = 0.f, em2 = 0.f, move_r = 0.f, move_t = 0.f; // ... the radius it proved empty; the last step's size
@@ -480,7 +504,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
             int       far = 0;       // queries of this lane whose neighbour is beyond the halo lists' certified radius
             if (SLAM_STAMPS(fa)) c0 = __builtin_amdgcn_s_memtime();
 
-            int pass = 0;
+            int pass = 0, chain = -1; // chain: the neighbour found in the pass before (kSeedChain)
             for (int p0 = 0; p0 < n; ++pass) {
                 int rem = n - p0;
                 if (SWEEP) {
@@ -488,7 +512,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                     // undecided and, when fewer than kCoopPerBlock points remain after it, those too
                     int tail = 0;
                     if (rem > kCoopPerBlock) {
-                        const double2 P = pass == 0 ? Pc0 : (p0 + tid < n ? fa.pts[off + p0 + tid] : Pc0);
+                        const double2 P = (pass == 0 && kKeepPoint) ? Pc0 : (p0 + tid < n ? fa.pts[off + p0 + tid] : Pc0);
                         list_pass<MODE>(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back, tid);
                         tail = rem - kBlock;
                         tail = tail > 0 && tail <= kCoopPerBlock ? tail : 0;
@@ -503,20 +527,25 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                     p0 += kBlock + tail;
                     if (p0 < n) tm.sync(); // the queue is reused by the next pass
                 } else if (G > 0) {
-                    double2 P = pass == 0 ? Pc0 : (pass == 1 ? Pc1 : Pc2);
-                    if (pass >= kHoist) {
-                        const int p = p0 + tid / (G > 0 ? G : 1);
-                        P = fa.pts[off + min(p, n - 1)];
-                    }
-                    if (kSeedRing && pass < kHoist) {
+                    const int p = ring_point(pass);
+                    double2   P = pass == 0 ? Pc0 : (pass == 1 ? Pc1 : Pc2);
+                    if (pass >= kHoist) P = fa.pts[off + min(p, n - 1)];
+                    if (kSeedRing && (pass < kHoist || kSeedChain)) {
                         // (the per-pass state is selected by value: a pointer into the three would put them on the stack)
-                        int   sd = pass == 0 ? sd0 : (pass == 1 ? sd1 : sd2);
+                        int   sd = pass == 0 ? sd0 : (pass == 1 ? sd1 : (pass == 2 ? sd2 : -1));
                         float em = pass == 0 ? em0 : (pass == 1 ? em1 : em2);
-                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc, far, tid, &sd, &em, move_r, move_t);
+                        if (kSeedChain) {
+                            // no seed of its own: the neighbour just found for the beam before (the lane's point of the pass before), if
+                            // that beam is of the same class -- a seed is a position in the class's sorted array
+                            const bool same_cls = MODE == SLAM_ICP_P2L || ((p - 1 < nga) == (p < nga));
+                            if (sd < 0 && pass > 0 && same_cls) sd = chain;
+                        }
+                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p, P, acc, far, tid, &sd, &em, move_r, move_t);
                         sd0 = pass == 0 ? sd : sd0, sd1 = pass == 1 ? sd : sd1, sd2 = pass == 2 ? sd : sd2;
                         if (kSeedEmpty) em0 = pass == 0 ? em : em0, em1 = pass == 1 ? em : em1, em2 = pass == 2 ? em : em2;
+                        chain = p < n ? sd : -1;
                     } else {
-                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p0, P, acc, far, tid);
+                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p, P, acc, far, tid);
                     }
                     p0 += kBlock / (G > 0 ? G : 1);
                 } else if (rem * 2 > kBlock) {

@@ -1,7 +1,7 @@
 """Two scans per workgroup (slam_icp_params::pair_scans) against one: event-timed registration of config 2's batch
 (30 iterations fixed) for several batch sizes, and agreement of the results.  python tools/pair_time.py [S ...]"""
 import sys
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from slam_amd import api, synth
 
