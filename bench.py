@@ -288,10 +288,50 @@ def endpoint_leg(api, synth, batch, R, t, grid_size, res, with_cpu):
                     "global atomics (MI355X_MICROARCH.md)", "legs": out}
 
 
-def run_config3(n_clouds):
+def config3_oracle_beside(detail, n_clouds):
+    """What the truth errors of the config-3 leg mean: the CPU oracle's CCICP chain (tests/ccicp_chain.py: ground segmentation,
+    GA/NGA classes, 0.5 m voxel centroids, crop + split, kd-tree ICP; icpTools.cpp:222-298 from oracle pieces) on the SAME
+    matches of the C++ adapter's sequence -- same target cloud, same scene cloud, same initial pose -- its error against the
+    truth beside the GPU's, and the two poses' difference.  Checker code, used here as a reported baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from ccicp_chain import oracle_scan_match
+    from slam_amd import synth
+    t0 = time.perf_counter()
+    clouds = [synth.make_cloud3d(k, n_loop=50)[0] for k in range(n_clouds)]
+    seg = {}
+    e_gpu, e_or, dxy, dyaw = [], [], [], []
+    for m, j in enumerate(detail["target_of"]):
+        if j not in seg:
+            lab = O.gseg_segment(clouds[j])[0]
+            seg[j] = (clouds[j][lab >= O.GSEG_OBSTACLE], clouds[j][lab == O.GSEG_GROUND])
+        e = oracle_scan_match(seg[j][0], seg[j][1], clouds[m + 1], list(detail["init"][m]))
+        g, tr = detail["poses"][m], detail["truth"][m]
+        e_gpu.append(float(np.hypot(g[0] - tr[0], g[1] - tr[1])))
+        e_or.append(float(np.hypot(e["t"][0] - tr[0], e["t"][1] - tr[1])))
+        dxy.append(float(np.hypot(g[0] - e["t"][0], g[1] - e["t"][1])))
+        d = 2.0 * np.arctan2(g[5], g[6]) - e["yaw"]
+        dyaw.append(float(abs((d + np.pi) % (2 * np.pi) - np.pi)))
+    return {"matches": len(e_or), "gpu_mean_xy_error_m": float(np.mean(e_gpu)), "gpu_max_xy_error_m": float(np.max(e_gpu)),
+            "oracle_mean_xy_error_m": float(np.mean(e_or)), "oracle_max_xy_error_m": float(np.max(e_or)),
+            "max_pose_difference_gpu_vs_oracle": {"xy_m": float(np.max(dxy)), "yaw_rad": float(np.max(dyaw))},
+            "oracle_seconds": time.perf_counter() - t0,
+            "meaning": "the error against the truth is the CHAIN's (0.5 m voxel centroids of a 64-ring cloud, a few hundred correspondences, "
+                       "a target up to ten poses back), identical for the CPU oracle and the GPU to the tolerance of north_star "
+                       "(1e-4 m / 1e-5 rad): see max_pose_difference_gpu_vs_oracle"}
+
+
+def run_config3(n_clouds, with_oracle=False):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_config3
-    return bench_config3.measure(n_clouds)
+    out = bench_config3.measure(n_clouds)
+    detail = out.pop("_cpp_detail", None)
+    if with_oracle and detail is not None:
+        try:
+            out["cpp_adapter"]["oracle_beside"] = config3_oracle_beside(detail, n_clouds)
+        except Exception as ex:
+            out["cpp_adapter"]["oracle_beside"] = {"error": repr(ex)}
+    return out
 
 
 def _free_port():
@@ -451,7 +491,7 @@ def main():
         assert world == 1, "config 3 is a single-GPU sequence"
         from slam_amd import api
         api.set_device(0)
-        out = run_config3(args.clouds)
+        out = run_config3(args.clouds, not args.no_cpu_baseline)
         out.update({"n_gpus": 1, "higher_is_better": True, "data": "synthetic", "vs_baseline": None,
                     "dtype": "f64 pose / f32 distance", "device": api.device_info()[0]})
         emit(out)
@@ -879,9 +919,9 @@ def main():
             except Exception as ex:   # the headline line must not depend on the extra leg
                 out["endpoint"] = {"error": repr(ex)}
             try:
-                c3 = run_config3(args.clouds)
-                out["config3"] = {k: c3[k] for k in ("workload", "ms_per_cloud_chain", "cpp_adapter", "ms_per_cloud", "clouds_per_s", "stepwise_clouds_per_s",
-                                                     "model_points", "mean_icp_iterations", "target_model_ms")}
+                c3 = run_config3(args.clouds, not args.no_cpu_baseline)
+                out["config3"] = {k: c3[k] for k in ("workload", "target", "mean_xy_error_m", "max_xy_error_m", "ms_per_cloud_chain", "cpp_adapter", "ms_per_cloud",
+                                                     "clouds_per_s", "stepwise_clouds_per_s", "model_points", "mean_icp_iterations", "target_model_ms")}
             except Exception as ex:   # the headline line must not depend on the extra leg
                 out["config3"] = {"error": str(ex)}
             # short runs of the other GPU configs of BASELINE.json, each in a process of its own (this one stays idle):

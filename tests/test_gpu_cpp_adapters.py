@@ -168,3 +168,54 @@ def test_mls_one_cloud_form_matches_oracle(tmp_path):
     want = {tuple(k) for k in key(gc)}
     assert len(cloud_out) == len(want)
     assert abs(float(cloud_out[:, 2].mean()) - float(gc[:, 2].mean())) < 0.05
+
+
+@pytest.mark.gpu
+def test_ccicp_sequence_with_a_target_replacement_matches_the_oracle_chain(tmp_path):
+    """BASELINE config 3 as scan_registration runs it, in small: ten 64-ring clouds through slam_amd::CCICP
+    (tests/cpp/ccicp_sequence.cpp: setSceneCloud + doICPMatch per cloud, scan_registration.cpp:139-159), the target
+    replaced by the cloud just matched after five (setTargetCloud, :73-104) -- every pose against the oracle chain
+    (tests/ccicp_chain.py) for ITS target, before and after the replacement, and the truth errors of both side by side:
+    what is left against the truth (centimetres to decimetres) is the chain's own -- 0.5 m voxel centroids, a few hundred
+    correspondences -- not the GPU's."""
+    exe = compile_cpp(str(tmp_path), "ccicp_sequence")
+    d = str(tmp_path)
+    n, advance = 10, 5
+    clouds, poses = zip(*[synth.make_cloud3d(k, n_loop=50) for k in range(n)])
+    init, truth, target_of = [], [], []
+    for k in range(1, n):
+        j = ((k - 1) // advance) * advance
+        pa, pb = poses[j], poses[k]
+        ca, sa = np.cos(pa[2]), np.sin(pa[2])
+        rel = (ca * (pb[0] - pa[0]) + sa * (pb[1] - pa[1]), -sa * (pb[0] - pa[0]) + ca * (pb[1] - pa[1]), pb[2] - pa[2])
+        init.append([rel[0] + 0.1, rel[1] - 0.1, 0.0] + _quat_rpy(0.0, 0.0, rel[2] + 0.02))
+        truth.append(list(rel))
+        target_of.append(j)
+    for k, c in enumerate(clouds):
+        np.ascontiguousarray(c, np.float32).tofile(os.path.join(d, "cloud%d.f32" % k))
+    np.array(init, np.float64).tofile(os.path.join(d, "init.f64"))
+    np.array(truth, np.float64).tofile(os.path.join(d, "truth.f64"))
+    p = subprocess.run([exe, d, str(n), str(advance), "1"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    import json
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["matches"] == n - 1 and line["target_updates"] == 2 and line["target_index_builds"] == 2
+    got = np.fromfile(os.path.join(d, "poses_out.f64"), np.float64).reshape(n - 1, 7)
+    segmented = {}
+    err_gpu, err_oracle = [], []
+    for m in range(n - 1):
+        j = target_of[m]
+        if j not in segmented:
+            lab, *_ = O.gseg_segment(clouds[j])
+            segmented[j] = (clouds[j][lab >= O.GSEG_OBSTACLE], clouds[j][lab == O.GSEG_GROUND])
+        out_j, gnd_j = segmented[j]
+        e = oracle_scan_match(out_j, gnd_j, clouds[m + 1], init[m])
+        assert abs(got[m, 0] - e["t"][0]) < 1e-4 and abs(got[m, 1] - e["t"][1]) < 1e-4, (m, j)
+        assert np.abs(got[m, 3:7] - e["q"]).max() < 1e-5, (m, j)
+        z, _, _ = O.ccicp_height(gnd_j, [got[m, 0], got[m, 1], init[m][2]] + list(got[m, 3:7]))
+        assert abs(got[m, 2] - z) < 1e-6, (m, j)
+        err_gpu.append(np.hypot(got[m, 0] - truth[m][0], got[m, 1] - truth[m][1]))
+        err_oracle.append(np.hypot(e["t"][0] - truth[m][0], e["t"][1] - truth[m][1]))
+    assert set(target_of) == {0, 5}
+    assert np.abs(np.array(err_gpu) - np.array(err_oracle)).max() < 2e-4          # the same error against the truth, match by match
+    assert abs(line["mean_xy_error_m"] - float(np.mean(err_oracle))) < 2e-4 and max(err_oracle) < 0.5

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
-"""BASELINE config 3 end to end: 50 clouds of 64 x 2048 rays along the loop, each registered against the first
-one through the CCICP chain (ground segmentation, GA/NGA classification, voxel filter, crop + split, class-
+"""BASELINE config 3 end to end: 50 clouds of 64 x 2048 rays along the loop through the CCICP chain, two drivers:
+the Python-driven device-resident chain registers every cloud against the FIRST one (fixed target: errors grow with the
+distance along the loop); the C++ adapter (tests/cpp/ccicp_sequence.cpp) replaces the target by the cloud just matched
+every 10 clouds, as scan_registration does when graph_slam publishes a new map.  Both say which in their JSON
+(`target`).  The chain: (ground segmentation, GA/NGA classification, voxel filter, crop + split, class-
 constrained ICP with the reference defaults max_iter 20 / min_delta 1e-6, height recovery), device-resident
 through the C-ABI (host loop in Python: test/bench plumbing).  Prints one JSON line (not the headline bench)."""
 import ctypes as C
@@ -20,11 +23,14 @@ def measure_cpp(clouds, poses, advance=10, passes=2):
     import subprocess
     import tempfile
     lib = os.path.join(ROOT, "slam_amd", "lib")
+    # (children of a profiled run must not inherit the profiler: g++ and the C++ program would run with its library preloaded
+    # and leave kernel-stats files of their own beside the parent's)
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTX"))}
     with tempfile.TemporaryDirectory() as d:
         exe = os.path.join(d, "ccicp_sequence")
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"),
                                os.path.join(ROOT, "tests", "cpp", "ccicp_sequence.cpp"), "-o", exe,
-                               "-L" + lib, "-l:libslam_mi355x.so", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
+                               "-L" + lib, "-l:libslam_mi355x.so", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"], env=env)
         init, truth = [], []
         for k in range(1, len(clouds)):
             j = ((k - 1) // advance) * advance if advance > 0 else 0        # the cloud that is the target when k is matched
@@ -38,12 +44,14 @@ def measure_cpp(clouds, poses, advance=10, passes=2):
             np.ascontiguousarray(c, np.float32).tofile(os.path.join(d, "cloud%d.f32" % k))
         np.array(init, np.float64).tofile(os.path.join(d, "init.f64"))
         np.array(truth, np.float64).tofile(os.path.join(d, "truth.f64"))
-        p = subprocess.run([exe, d, str(len(clouds)), str(advance), str(passes)], capture_output=True, text=True, timeout=600)
+        p = subprocess.run([exe, d, str(len(clouds)), str(advance), str(passes)], capture_output=True, text=True, timeout=600, env=env)
         if p.returncode != 0:
             raise RuntimeError("ccicp_sequence failed (%d): %s" % (p.returncode, p.stderr[-500:]))
         out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
         out["poses"] = np.fromfile(os.path.join(d, "poses_out.f64"), np.float64).reshape(-1, 7)
         out["truth"] = np.array(truth)
+        out["init"] = np.array(init)
+        out["target_of"] = [((k - 1) // advance) * advance if advance > 0 else 0 for k in range(1, len(clouds))]
         return out
 
 
@@ -178,14 +186,18 @@ def measure(n_clouds=50, cell=0.0, dump_case=None, advance=10):
         assert np.abs(got[:, :2] - want[:, :2]).max() < 1e-9 and dyaw.max() < 1e-9 and np.abs(got[:, 2] - want[:, 3]).max() < 1e-9, \
             "the C++ adapter and the Python-driven chain disagree"
         cpp = measure_cpp(clouds, poses, advance)
-        cpp.pop("poses"), cpp.pop("truth")
+        cpp_detail = {k: cpp.pop(k) for k in ("poses", "truth", "init", "target_of")}
+        cpp["target"] = "replaced by the cloud just matched every %d clouds (setTargetCloud): a match is against a cloud at most %d poses back" % (advance, advance)
         cpp["equals_python_chain_on_fixed_target"] = True
         cpp["what"] = ("the same clouds through the C++ drop-in slam_amd::CCICP (include/slam_amd/ccicp.hpp; tests/cpp/ccicp_sequence.cpp "
                        "compiled against the shipped library): setSceneCloud + doICPMatch per cloud, the target replaced by the cloud "
                        "just matched every %d clouds (setTargetCloud, SCAN_TO_SCAN); wall clock per match incl. the cloud's H2D" % advance)
     except Exception as ex:     # no g++ on the box, ...: the Python-driven chain above still stands
-        cpp = {"error": repr(ex)}
+        cpp, cpp_detail = {"error": repr(ex)}, None
     return {
+        "_cpp_detail": cpp_detail,          # poses / truth / initial poses / target of every match of the C++ leg (bench.py: the oracle beside it)
+        "target": "fixed: every cloud is registered against cloud 0 (up to %d poses away along the loop)" % n,
+        "mean_xy_error_m": float(np.mean(errs_c)), "max_xy_error_m": float(np.max(errs_c)),
         "metric": "registered_clouds_per_s", "value": n / t_chain, "unit": "clouds/s", "steps": n, "warmup": n,
         "ms_per_step": t_chain / n * 1e3,
         "ms_per_cloud_chain": round(t_chain / n * 1e3, 3),
@@ -212,4 +224,6 @@ def measure(n_clouds=50, cell=0.0, dump_case=None, advance=10):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 50
     cell = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0   # model lattice pitch (0 = library default)
-    print(json.dumps(measure(n, cell, os.environ.get("SLAM_DUMP_CASE"))))
+    out = measure(n, cell, os.environ.get("SLAM_DUMP_CASE"))
+    out.pop("_cpp_detail", None)             # numpy arrays: for bench.py's oracle leg, not for the JSON line
+    print(json.dumps(out))
