@@ -129,6 +129,7 @@ public:
             classify_into(seg_target_, seg_target_n_, false);
         } else {
             // segmentGround + classifyPoints in bin order (no voxel filter) as one chain; the ground cloud is the new ground_target
+            const bool had_scene = scene_ready_; // a scene set before this call stays the scene (:585-608 touch neither seg_scene nor ground_scene)
             upload(raw_, xyz, n, stride);
             reserve(seg_target_, 16 * (size_t)(n + 1));
             reserve(ground_target_, 16 * (size_t)(n + 1));
@@ -142,7 +143,9 @@ public:
                 seg_target_n_ = h_counts()[2];
                 set_ground_target_count(h_counts()[1]);
             }
-            scene_ready_ = false; // (the chain's scene outputs were borrowed)
+            scene_ready_ = false; // (the chain's scene outputs were borrowed ...
+            if (had_scene) enqueue_scene_chain(); // ... and are made again from the scene cloud, which is still held: setSceneCloud,
+                                                  // setTargetCloud, doICPMatch in this order matches that scene, as upstream)
         }
         target_dirty_ = true;
         reset_box();
@@ -160,9 +163,14 @@ public:
         upload(scene_raw_, xyz, n, stride);
         scene_n_in_ = n;
         scene_stride_ = stride;
-        reserve(scene_ground_, 16 * (size_t)(n + 1));
-        ok(slam_ccicp_scene_dev(cc_, gseg_, (const float *)scene_raw_.p, n, stride, 1, 0, 0.0, 0.0, 0.0, ICP_MAX_PTS, d_scene_pts_, io_scan(),
-                                (float *)scene_ground_.p, io_counts(), stream_));
+        enqueue_scene_chain();
+    }
+    // the scene's chain from the cloud in scene_raw_ (setSceneCloud; again after a SCAN_TO_SCAN setTargetCloud borrowed its outputs)
+    void enqueue_scene_chain()
+    {
+        reserve(scene_ground_, 16 * (size_t)(scene_n_in_ + 1));
+        ok(slam_ccicp_scene_dev(cc_, gseg_, (const float *)scene_raw_.p, scene_n_in_, scene_stride_, 1, 0, 0.0, 0.0, 0.0, ICP_MAX_PTS, d_scene_pts_,
+                                io_scan(), (float *)scene_ground_.p, io_counts(), stream_));
         scene_ready_ = true;
         scene_known_ = false;
         seg_scene_valid_ = ground_scene_valid_ = false;

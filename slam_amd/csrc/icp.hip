@@ -1263,7 +1263,7 @@ bool takes_spread_form(const slam_icp *h, int n_scans)
 {
     const int spread_max = h->prm.spread_scans > 0 ? std::min(h->prm.spread_scans, h->n_cu)
                                                    : (h->prm.spread_scans < 0 ? 0 : h->n_cu / kSpreadMinParts);
-    return n_scans >= 1 && n_scans <= spread_max && h->prm.lanes_per_point == 0;
+    return n_scans >= 1 && n_scans <= spread_max && h->prm.lanes_per_point == 0 && !h->skip_spread;
 }
 
 } // namespace icp
@@ -1545,7 +1545,7 @@ int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t
     //   [scan_off 0, n | nGA | pad] [R t] [result] [pose of the last executed step]
     // so that a fit is one copy in, one launch, one copy out (the reference's fit() is synchronous too).
     const size_t pts_bytes = 16 * (size_t)n, hdr = pts_bytes, o_pose_in = hdr + 16, o_res = o_pose_in + 48, o_step = o_res + 16,
-                 total = o_step + 48;
+                 o_redo = o_step + 48, total = o_redo + 16;
     SLAM_TRY(icp->w_pts.reserve(total));
     unsigned char *hp = static_cast<unsigned char *>(pinned_scratch(total));
     SLAM_REQUIRE(hp, SLAM_E_NOMEM, "slam_icp_fit: no pinned staging memory");
@@ -1562,12 +1562,18 @@ int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t
     icp->want_step_pose = true;
     icp->step_pose_off = o_step;
     icp->spread_points_hint = n;
+    icp->skip_spread = icp->spread_backoff > 0; // the spread form lost its CUs a moment ago: not again right away
+    if (icp->skip_spread) --icp->spread_backoff;
+    icp->d_last_redo = nullptr;
+    *reinterpret_cast<int *>(hp + o_redo) = 0;
     const int rc_fit = slam_icp_fit_batch_dev(icp, reinterpret_cast<double *>(dp), reinterpret_cast<int32_t *>(dp + hdr),
                                               reinterpret_cast<int32_t *>(dp + hdr + 8), 1,
                                               reinterpret_cast<double *>(dp + o_pose_in), reinterpret_cast<double *>(dp + o_pose_in + 32),
                                               indist, reinterpret_cast<slam_icp_result *>(dp + o_res), nullptr, st);
     icp->want_step_pose = false;
+    icp->skip_spread = false;
     SLAM_TRY(rc_fit);
+    if (icp->d_last_redo) SLAM_HIP(hipMemcpyAsync(hp + o_redo, icp->d_last_redo, sizeof(int), hipMemcpyDeviceToHost, st));
     icp->last_n = n;
     icp->last_nga = n_tga;
     icp->last_indist = indist;
@@ -1576,6 +1582,7 @@ int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t
     SLAM_HIP(hipStreamSynchronize(st));
     slam_icp_result res;
     memcpy(&res, hp + o_res, sizeof res);
+    if (*reinterpret_cast<const int *>(hp + o_redo) != 0) icp->spread_backoff = 16; // redone by the one-workgroup form: 5 ms late
     // (a scan whose spread-form workgroups did not become resident together was redone by the one-workgroup form inside the
     // call above: there is no outcome without a pose)
     SLAM_REQUIRE(res.iters >= 0, SLAM_E_HIP, "slam_icp_fit: the registration kernels left no result (iters = %d)", res.iters);

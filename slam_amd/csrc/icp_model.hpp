@@ -181,6 +181,12 @@ struct slam_icp {
     int             n_cu = 256;          // CUs of the device the handle was made on
     int             max_cell_points = 0; // points in the fullest cell of the index (either class)
     bool            built_on_device = false;
+    // slam_icp_fit: a spread launch whose workgroups did not become resident together (a persistent kernel of this or another
+    // process holds CUs) costs its 5 ms first-exchange limit before the one-workgroup form redoes the scan.  After such a fit the
+    // handle's next fits go straight to the one-workgroup form and try the spread form again later (icp_single.hip).
+    int             spread_backoff = 0;         // single fits still to be done without the spread form
+    bool            skip_spread = false;        // set around one slam_icp_fit_batch_dev call
+    const int      *d_last_redo = nullptr;      // redo flags of the last spread launch (device, in w_single), or null
     bool            build_beside = false;       // the index build's kernels must fit beside a resident registration workgroup (mapper)
     double          build_ms[4] = {0, 0, 0, 0}; // enqueueing the build, its one wait (the other two: unused since the plan moved to the device)
     slam_icp_pending *pending = nullptr;        // between build_index_begin and build_index_finish

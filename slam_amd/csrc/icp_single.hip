@@ -315,6 +315,7 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
     unsigned long long *gran = static_cast<unsigned long long *>(h->w_single.p);
     int                *flags = reinterpret_cast<int *>(static_cast<unsigned char *>(h->w_single.p) + gran_bytes);
     *redo_flags = flags + n_scans;
+    h->d_last_redo = flags + n_scans;
     std::lock_guard<std::mutex> lk(g_spread_mu);
     hipEvent_t &done = g_spread_done[dev & 15];
     // (a stream that is being captured into a hipGraph may neither wait for an event of uncaptured work nor lend its own to

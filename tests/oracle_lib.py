@@ -12,7 +12,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libslam_oracle.so")
+# SLAM_ORACLE_SANITIZED=1 (tests/test_oracle_sanitized.py): the same C compiled with -fsanitize=address,undefined
+# (make -C oracle asan); the interpreter must then run with libasan preloaded
+SANITIZED = os.environ.get("SLAM_ORACLE_SANITIZED") == "1"
+ORACLE_SO = os.path.join(ORACLE_DIR, "_build", "libslam_oracle_asan.so" if SANITIZED else "libslam_oracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libslam_ref_matrix.so")
 
 _dp = C.POINTER(C.c_double)
@@ -26,7 +29,7 @@ def build_oracle(force=False):
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("slam_oracle.c", "gseg_oracle.c", "ccicp_oracle.c", "slam_oracle.h")]
     if (force or not os.path.exists(ORACLE_SO)
             or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(f) for f in srcs)):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "oracle"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "asan" if SANITIZED else "oracle"], stdout=subprocess.DEVNULL)
     return ORACLE_SO
 
 

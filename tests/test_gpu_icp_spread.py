@@ -162,6 +162,12 @@ def test_spread_hand_over_redoes_the_scans(n_scans, big):
     Ra, ta, ra = a.fit(t_ga, t_nga, batch.R[0], batch.t[0], 5.0)
     assert np.array_equal(Ra.reshape(4), R[0]) and np.array_equal(ta, t[0]) and ra.iters == res["iters"][0]
     assert np.isfinite(a.edge_weight()).all()
+    # ... and a handle whose spread launch was handed over does its next fits without the spread form (16 of them, then it tries
+    # again: slam_icp::spread_backoff): forty fits in a row, through both forms as they alternate, all the same bits
+    for rep in range(40):
+        Rr, tr_, rr = a.fit(t_ga, t_nga, batch.R[0], batch.t[0], 5.0)
+        assert np.array_equal(Rr, Ra) and np.array_equal(tr_, ta) and rr.iters == ra.iters and rr.n_corr == ra.n_corr, rep
+    assert np.isfinite(a.edge_weight()).all()
     a.close()
 
 

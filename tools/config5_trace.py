@@ -1,7 +1,7 @@
 """Host-side timeline of the streaming mapper with a sliding target: per push / wait times, background rebuild on/off.
 python tools/config5_trace.py [background=1] [chunks=40]"""
 import sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from slam_amd import api, synth
 

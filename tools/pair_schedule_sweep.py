@@ -1,6 +1,6 @@
 """Hand-over schedule of the pair kernel (slam_icp_params::first_iterations, far_div): 1024 scans in pairs, event-timed."""
 import itertools, sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from slam_amd import api, synth
 

@@ -19,6 +19,23 @@ for PMC in "FETCH_SIZE" "WRITE_SIZE" \
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc_$i -- $BENCH > $OUT/pmc_$i.json 2> $OUT/pmc_$i.err || echo "pmc pass $i failed"
 done
+# the point-to-line solver (north_star's; SLAM_ICP_P2L): the same passes of `bench.py --mode p2l`
+BENCH_P2L="$BENCH --mode p2l"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_p2l -- $BENCH_P2L > $OUT/stats_p2l.json 2> $OUT/stats_p2l.err || echo "p2l stats pass failed"
+i=0
+for PMC in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" \
+           "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU SQ_INSTS_SMEM" \
+           "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmcp2l_$i -- $BENCH_P2L > $OUT/pmcp2l_$i.json 2> $OUT/pmcp2l_$i.err || echo "p2l pmc pass $i failed"
+done
+# the reference's own grid update (MLS::addToOccupancy's endpoint loops): kernel trace + HBM traffic of bench.py's endpoint leg alone
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_endpoints -- python3 tools/profile_endpoints.py > $OUT/endpoints.json 2> $OUT/endpoints.err || echo "endpoint stats failed"
+for PMC in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_ATOMIC_sum TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmcep_$i -- python3 tools/profile_endpoints.py > /dev/null 2>> $OUT/endpoints.err || echo "endpoint pmc pass failed"
+done
 # the run-length merged raycast (measured slower: the counters say why) and the single-scan / config-3 path
 for PMC in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS"; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $OUT/pmc_merge -- $BENCH --raycast merge > $OUT/pmc_merge.json 2> $OUT/pmc_merge.err || echo "pmc merge pass failed"
@@ -28,6 +45,11 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 timeout -k 10 600 python3 bench.py --config 3 > $OUT/config3.json 2>> $OUT/config3.err || echo "config 3 failed"
 # the N > 1 path with two ranks on this one GPU (the library's merge over its host-staged communicator, gloo carrying the buffers)
 timeout -k 10 600 python3 bench.py --gpus 2 --backend gloo --one-device --steps 10 --warmup 3 --no-cpu-baseline > $OUT/two_ranks_one_gpu.json 2> $OUT/two_ranks.err || echo "two-rank rehearsal failed"
+# ... and with ONE rank over a real RCCL communicator (the N > 1 pipeline: merge_begin / merge_finish in every step), with and without the merge
+timeout -k 10 600 python3 bench.py --force-dist --steps 50 --warmup 5 --no-extras --no-cpu-baseline > $OUT/force_dist.json 2> $OUT/force_dist.err || echo "force-dist failed"
+timeout -k 10 600 python3 bench.py --force-dist --no-merge --steps 50 --warmup 5 --no-extras --no-cpu-baseline > $OUT/force_dist_no_merge.json 2>> $OUT/force_dist.err || echo "force-dist --no-merge failed"
+timeout -k 10 600 python3 bench.py --force-dist --reg-cu-cap 1 --steps 50 --warmup 5 --no-extras --no-cpu-baseline > $OUT/force_dist_cu_cap1.json 2>> $OUT/force_dist.err || echo "force-dist --reg-cu-cap failed"
+timeout -k 10 600 python3 bench.py --mode p2l --steps 50 --warmup 5 --no-extras > $OUT/p2l.json 2> $OUT/p2l.err || echo "p2l bench failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_build -- python3 tools/profile_build.py > $OUT/build.txt 2> $OUT/build.err || echo "build stats failed"
 timeout -k 10 600 python3 bench.py --config 5 > $OUT/config5.json 2> $OUT/config5.err || echo "config 5 failed"
 timeout -k 10 600 python3 bench.py --config 4 --no-extras --no-cpu-baseline > $OUT/config4.json 2> $OUT/config4.err || echo "config 4 failed"

@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from slam_amd import api, synth
 m_ga, m_nga = synth.make_map()

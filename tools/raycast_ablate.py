@@ -5,7 +5,7 @@ kernel switched off (measurement build, SLAM_RAYCAST_ABLATE bits: 1 = no walk, 2
 import os
 import sys
 
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 
 assert os.environ.get("SLAM_AMD_MEASURE") == "1", "needs the measurement build: SLAM_AMD_MEASURE=1"

@@ -3,7 +3,7 @@ python tools/raycast_time.py wg_per_cu=1,2 seg=0,24"""
 import itertools
 import sys
 
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from slam_amd import api, synth
 

@@ -4,7 +4,7 @@ under a timeout after touching those kernels.    timeout -k 10 400 python tools/
 import sys
 import time
 
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from slam_amd import api, synth
 

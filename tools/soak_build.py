@@ -4,7 +4,7 @@ hand after touching the build.    timeout -k 10 400 python tools/soak_build.py [
 import sys
 import time
 
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import numpy as np
 from slam_amd import api, synth
 

@@ -6,8 +6,8 @@ A soak to run by hand after touching the mapper.    timeout -k 10 600 python too
 import sys
 import time
 
-sys.path.insert(0, '/root/repo')
-sys.path.insert(0, '/root/repo/tests')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))), 'tests'))
 import numpy as np
 from slam_amd import api, synth
 

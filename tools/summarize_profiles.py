@@ -46,47 +46,97 @@ if stats:
             w.writerow([kname(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                         r["MinNs"], r["MaxNs"]])
 
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(src, "pmc_*", "*", "*counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
-        acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
-with open(os.path.join(dst, tag + "_pmc.csv"), "w", newline="") as f:
-    w = csv.writer(f)
-    w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch"])
-    for k in sorted(acc):
-        for c, v in sorted(acc[k].items()):
-            w.writerow([k, c, len(v), "%.6g" % (sum(v) / len(v))])
+def csrc_sha():
+    """sha256 over the kernel sources the profile was taken from (bench.py compares it with the sources it runs on)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(root, "slam_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
-traffic = {}
-for k, cs in acc.items():
-    if "FETCH_SIZE" in cs or "WRITE_SIZE" in cs:
-        fetch = sum(cs.get("FETCH_SIZE", [0])) / max(len(cs.get("FETCH_SIZE", [0])), 1)
-        write = sum(cs.get("WRITE_SIZE", [0])) / max(len(cs.get("WRITE_SIZE", [0])), 1)
-        traffic[k] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
-                      "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
-                      "note": "read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE = 1/2 of a wide "
-                              "coalesced read); Infinity-Cache hits are included in these counters"}
-# how busy the vector ALUs were: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the wavefronts, one VALU
-# instruction of a wavefront holds its SIMD for one quad-cycle (MI355X_MICROARCH.md, PMC units); GRBM_GUI_ACTIVE is
-# summed over the 8 XCDs; 1024 SIMDs.  1.0 = every SIMD issued a VALU instruction in every cycle of the kernel.
-for k, cs in acc.items():
-    if "SQ_ACTIVE_INST_VALU" in cs and "GRBM_GUI_ACTIVE" in cs:
+
+def collect(pattern):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(src, pattern, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            acc[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+def write_pmc(acc, path):
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch"])
+        for k in sorted(acc):
+            for c, v in sorted(acc[k].items()):
+                w.writerow([k, c, len(v), "%.6g" % (sum(v) / len(v))])
+
+
+def traffic_of(acc):
+    traffic = {}
+    for k, cs in acc.items():
+        if "FETCH_SIZE" in cs or "WRITE_SIZE" in cs:
+            fetch = sum(cs.get("FETCH_SIZE", [0])) / max(len(cs.get("FETCH_SIZE", [0])), 1)
+            write = sum(cs.get("WRITE_SIZE", [0])) / max(len(cs.get("WRITE_SIZE", [0])), 1)
+            traffic[k] = {"FETCH_SIZE_KiB": fetch, "WRITE_SIZE_KiB": write,
+                          "hbm_bytes_per_launch": (2.0 * fetch + write) * 1024.0,
+                          "note": "read side doubled per MI355X_MICROARCH.md (gfx950 FETCH_SIZE = 1/2 of a wide "
+                                  "coalesced read); Infinity-Cache hits are included in these counters"}
+    # how busy the vector ALUs were: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the wavefronts, one VALU
+    # instruction of a wavefront holds its SIMD for one quad-cycle (MI355X_MICROARCH.md, PMC units); GRBM_GUI_ACTIVE is
+    # summed over the 8 XCDs; 1024 SIMDs.  1.0 = every SIMD issued a VALU instruction in every cycle of the kernel.
+    for k, cs in acc.items():
         mean = lambda c: sum(cs[c]) / len(cs[c])
-        cycles = mean("GRBM_GUI_ACTIVE") / 8.0
-        if cycles > 0:
-            traffic.setdefault(k, {})["valu_busy_frac"] = 4.0 * mean("SQ_ACTIVE_INST_VALU") / (1024.0 * cycles)
-            traffic[k]["kernel_cycles"] = cycles
-    if "SQ_THREAD_CYCLES_VALU" in cs and "SQ_ACTIVE_INST_VALU" in cs:
-        # lanes that did work per issued VALU instruction slot (64 = every lane of every instruction)
-        mean = lambda c: sum(cs[c]) / len(cs[c])
-        if mean("SQ_ACTIVE_INST_VALU") > 0:
-            traffic.setdefault(k, {})["valu_active_lane_share"] = mean("SQ_THREAD_CYCLES_VALU") / (64.0 * mean("SQ_ACTIVE_INST_VALU"))
-    if "SQ_LDS_BANK_CONFLICT" in cs and "SQ_LDS_IDX_ACTIVE" in cs:
-        mean = lambda c: sum(cs[c]) / len(cs[c])
-        if mean("SQ_LDS_IDX_ACTIVE") > 0:
-            traffic.setdefault(k, {})["lds_bank_conflict_share"] = mean("SQ_LDS_BANK_CONFLICT") / mean("SQ_LDS_IDX_ACTIVE")
-json.dump(traffic, open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1, sort_keys=True)
-for name in ("bench.json", "config3.json", "config4.json", "config5.json", "build.txt", "two_ranks_one_gpu.json"):
+        if "SQ_ACTIVE_INST_VALU" in cs and "GRBM_GUI_ACTIVE" in cs:
+            cycles = mean("GRBM_GUI_ACTIVE") / 8.0
+            if cycles > 0:
+                traffic.setdefault(k, {})["valu_busy_frac"] = 4.0 * mean("SQ_ACTIVE_INST_VALU") / (1024.0 * cycles)
+                traffic[k]["kernel_cycles"] = cycles
+        if "SQ_THREAD_CYCLES_VALU" in cs and "SQ_ACTIVE_INST_VALU" in cs:
+            # lanes that did work per issued VALU instruction slot (64 = every lane of every instruction)
+            if mean("SQ_ACTIVE_INST_VALU") > 0:
+                traffic.setdefault(k, {})["valu_active_lane_share"] = mean("SQ_THREAD_CYCLES_VALU") / (64.0 * mean("SQ_ACTIVE_INST_VALU"))
+        if "SQ_LDS_BANK_CONFLICT" in cs and "SQ_LDS_IDX_ACTIVE" in cs:
+            if mean("SQ_LDS_IDX_ACTIVE") > 0:
+                traffic.setdefault(k, {})["lds_bank_conflict_share"] = mean("SQ_LDS_BANK_CONFLICT") / mean("SQ_LDS_IDX_ACTIVE")
+        if "TCC_EA0_ATOMIC_sum" in cs:
+            traffic.setdefault(k, {})["atomic_line_requests_per_launch"] = mean("TCC_EA0_ATOMIC_sum")
+    traffic["_meta"] = {"tag": tag, "csrc_sha256": csrc_sha(),
+                        "what": "csrc_sha256 = sha256 over slam_amd/csrc/*.hip, *.hpp as they were when this profile was summarised: "
+                                "bench.py compares it with the sources it runs on and says `stale` in its roofline.valu block"}
+    return traffic
+
+
+def write_stats(sub, out):
+    st = sorted(glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv")), key=os.path.getmtime)
+    if not st:
+        return
+    rows = list(csv.DictReader(open(st[-1])))
+    with open(os.path.join(dst, tag + "_" + out), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
+        for r in rows:
+            w.writerow([kname(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+
+
+acc = collect("pmc_[0-9]*")
+write_pmc(acc, os.path.join(dst, tag + "_pmc.csv"))
+json.dump(traffic_of(acc), open(os.path.join(dst, tag + "_traffic.json"), "w"), indent=1, sort_keys=True)
+# the point-to-line solver's passes (bench.py --mode p2l) and the endpoint leg's
+acc_p2l = collect("pmcp2l_[0-9]*")
+if acc_p2l:
+    write_pmc(acc_p2l, os.path.join(dst, tag + "_p2l_pmc.csv"))
+    json.dump(traffic_of(acc_p2l), open(os.path.join(dst, tag + "_p2l_traffic.json"), "w"), indent=1, sort_keys=True)
+acc_ep = collect("pmcep_[0-9]*")
+if acc_ep:
+    json.dump(traffic_of(acc_ep), open(os.path.join(dst, tag + "_endpoints_traffic.json"), "w"), indent=1, sort_keys=True)
+write_stats("stats_p2l", "p2l_kernel_stats.csv")
+write_stats("stats_endpoints", "endpoints_kernel_stats.csv")
+for name in ("bench.json", "config3.json", "config4.json", "config5.json", "build.txt", "two_ranks_one_gpu.json", "force_dist.json",
+             "force_dist_no_merge.json", "force_dist_cu_cap1.json", "p2l.json", "endpoints.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, tag + "_" + name))
@@ -111,4 +161,10 @@ if macc:
         for k in sorted(macc):
             for c, v in sorted(macc[k].items()):
                 w.writerow([k, c, len(v), "%.6g" % (sum(v) / len(v))])
-print("wrote", sorted(os.listdir(dst)))
+# registers / scratch / LDS per kernel of the objects as they are built NOW (the last step: the table must describe what ships)
+import subprocess
+regs = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_regs.py")], capture_output=True, text=True)
+if regs.returncode == 0 and regs.stdout:
+    open(os.path.join(dst, tag + "_kernel_registers.txt"), "w").write(
+        "# python tools/kernel_regs.py (llvm-readelf --notes of slam_amd/lib/obj/*.o), csrc sha256 %s\n%s" % (csrc_sha(), regs.stdout))
+print("wrote", sorted(f for f in os.listdir(dst) if f.startswith(tag)))
