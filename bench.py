@@ -137,18 +137,31 @@ def pmc_profile(p2l=False):
         return None, {}
 
 
-def model_build_times(api, synth, m_ga, m_nga):
+def csrc_sha():
+    """sha256 over the kernel sources this run was built from (tools/summarize_profiles.py stamps the committed PMC summary with
+    the same hash: a summary taken from other sources is reported as stale)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "slam_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def model_build_times(api, synth, m_ga, m_nga, **icp_kw):
     """slam_icp_create (Icp::Icp, icp.cpp:26-70: model copy + index) wall time per call, the buffer pool warm:
     the 10 k-point map of the bench and a 2 x 19 999-point model (the CCICP cap, icpTools.h:21)."""
     rs = np.random.RandomState(3)
     big = (rs.randn(19999, 2) * [30.0, 20.0], rs.rand(19999, 2) * [80.0, 60.0] - [40.0, 30.0])
     out = {}
     for name, (ga, nga) in (("map_%d_points" % (len(m_ga) + len(m_nga)), (m_ga, m_nga)), ("model_2x19999_points", big)):
-        api.Icp(ga, nga).close()
+        api.Icp(ga, nga, **icp_kw).close()
         ts, parts = [], None
         for _ in range(12):
             t0 = time.perf_counter()
-            icp = api.Icp(ga, nga)
+            icp = api.Icp(ga, nga, **icp_kw)
             ts.append(time.perf_counter() - t0)
             parts = icp.build_info()
             icp.close()
@@ -157,12 +170,12 @@ def model_build_times(api, synth, m_ga, m_nga):
     return out
 
 
-def single_scan_times(api, synth, m_ga, m_nga):
+def single_scan_times(api, synth, m_ga, m_nga, **icp_kw):
     """BASELINE config 1 on the GPU -- one 1081-beam scan against the 10 k-point map through the host API
     (slam_icp_fit: Icp::fit of one doICPMatch, icpTools.cpp:188), 20 iterations."""
     batch = synth.make_batch(1, n_loop=256)
     t_ga, t_nga = batch.scan(0)
-    icp = api.Icp(m_ga, m_nga, max_iter=20, min_delta=-1.0)
+    icp = api.Icp(m_ga, m_nga, max_iter=20, min_delta=-1.0, **icp_kw)
     icp.fit(t_ga, t_nga, batch.R[0], batch.t[0], 5.0)
     ts = []
     for _ in range(20):
@@ -812,13 +825,20 @@ def main():
                                              "back from the device-tracked range): counts in, evidence + occupancy out; the zeroes it "
                                              "writes back into the counts it has folded are not counted"},
         }
+        prof_file, prof = pmc_profile(p2l)
         for k in kernels.values():
             k["GBps"] = k["alg_bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else 0.0
             k["frac_of_hbm_peak"] = k["GBps"] / HBM_PEAK_GBS
+        # the raycast's 8 B per cell update never reach HBM (the updates are binned in LDS): its algorithmic rate belongs beside
+        # the global-atomic ceiling, and its HBM fraction comes from the MEASURED traffic of the committed counter passes
         kr = kernels["raycast_tiled_kernel (+ beams, work list)"]
-        kr["vs_global_atomic_ceiling"] = kr["GBps"] / ATOMIC_CEILING_GBS
+        kr["alg_GBps_equivalent"] = kr.pop("GBps")
+        kr["vs_global_atomic_ceiling"] = kr["alg_GBps_equivalent"] / ATOMIC_CEILING_GBS
+        ray_traffic = sum(prof.get(n, {}).get("hbm_bytes_per_launch") or 0.0 for n in ("raycast_tiled_kernel", "beams_from_scans_kernel", "tile_items_wg_kernel"))
+        kr["hbm_bytes_per_launch_measured"] = ray_traffic or None
+        kr["GBps"] = (ray_traffic / (kr["ms"] * 1e-3) / 1e9) if (ray_traffic and kr["ms"] > 0 and (S, GRID) == (256, 2000)) else None
+        kr["frac_of_hbm_peak"] = (kr["GBps"] / HBM_PEAK_GBS) if kr["GBps"] else None
         dom = max(kernels, key=lambda n: kernels[n]["ms"])
-        prof_file, prof = pmc_profile(p2l)
         pk = prof.get(dom.split(" ")[0], {})
         busy, lanes = pk.get("valu_busy_frac"), pk.get("valu_active_lane_share")
         held = min(n_cu, (S + 1) // 2 if paired else S) if dom == icp_name else n_cu
@@ -839,6 +859,10 @@ def main():
                          "cus_held_by_one_launch": held,
                          "frac_on_held_cus": (busy * lanes * n_cu / held) if (busy is not None and lanes is not None) else None,
                          "source": prof_file,
+                         "profile_csrc_sha256": prof.get("_meta", {}).get("csrc_sha256"),
+                         "stale": (prof.get("_meta", {}).get("csrc_sha256") != csrc_sha()) if prof_file else None,
+                         "stale_means": "the committed counter summary was taken from kernel sources other than the ones this run was built "
+                                        "from (sha256 over slam_amd/csrc): the fractions describe that build",
                          "meaning": "busy_frac = SIMD cycles (all 1024 SIMDs) that issued a VALU instruction; active_lane_share = "
                                     "SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU); frac = their product = the share of the "
                                     "chip's VALU lane-slots that did work during a launch"},
@@ -884,6 +908,11 @@ def main():
             "max_pose_error_m": pose_err,
             "device": api.device_info()[0],
         }
+        if p2l and world == 1:
+            # the point-to-line handle's own costs: its model build (index + the normals of icpPointToPlane.cpp:279-305, one
+            # 10-neighbour scatter matrix per model point, + a normal per halo-list entry) and one scan through the host API
+            out["model_build_ms"] = model_build_times(api, synth, m_ga, m_nga, **mode_kw)
+            out["single_scan"] = single_scan_times(api, synth, m_ga, m_nga, **mode_kw)
         if multi:
             # what a scaling curve is read with: how many ranks the transport itself counts, what the exchange step moved and
             # what it cost -- per timed step, on rank 0 (the ranks move the same rows: the all-reduce is over their union)
@@ -930,7 +959,8 @@ def main():
             # the solver north_star names (point-to-line, 3x3 normal equations) on the same workload, same pipelined step, the CPU
             # oracle's point-to-line step timed beside it
             out["p2l"] = side_run(["--mode", "p2l", "--steps", "30", "--warmup", "5", "--no-extras"],
-                                  ("value", "ms_per_step", "icp_step", "grid_cell_updates_per_s", "kernel_ms", "roofline", "one_stream", "max_pose_error_m", "cpu_baseline"))
+                                  ("value", "ms_per_step", "icp_step", "grid_cell_updates_per_s", "kernel_ms", "roofline", "one_stream", "model_build_ms", "single_scan",
+                                   "max_pose_error_m", "cpu_baseline"))
             out["config4_share"] = side_run(["--config", "4", "--steps", "12", "--warmup", "3", "--no-extras", "--no-cpu-baseline"],
                                             ("value", "ms_per_step", "grid_cell_updates_per_s", "cell_updates_per_step", "kernel_ms", "max_pose_error_m"))
             out["config5"] = side_run(["--config", "5", "--stream-scans", "4096"],

@@ -574,7 +574,8 @@ class Icp:
         return out.reshape(3, 3)
 
     def normals(self):
-        out = np.zeros((len(self.m_ga) + len(self.m_nga), 2))
+        n = sum(self.n_model) if self.m_ga is None else len(self.m_ga) + len(self.m_nga)
+        out = np.zeros((n, 2))
         check(lib().slam_icp_get_normals(self.h, _ptr(out)))
         return out
 

@@ -351,6 +351,36 @@ def test_point_to_line_host_fit_and_early_exit():
     icp.close()
 
 
+def test_point_to_line_model_from_device_arrays_and_through_the_mapper():
+    """slam_icp_create_dev in point-to-line mode (the model's f64 arrays already in HBM): the same normals and the same fits,
+    bit for bit, as the handle made from host arrays; and the streaming mapper with a fixed point-to-line target registers its
+    chunks as the batch call does.  (A SLIDING target is built deferred, without normals: refused with SLAM_E_UNSUPPORTED.)"""
+    m_ga, m_nga = synth.make_map(6000)
+    batch = synth.make_batch(24, n_loop=256)
+    kw = dict(mode=api.ICP_P2L, normals_k=10, max_iter=12, min_delta=-1.0)
+    host = api.Icp(m_ga, m_nga, **kw)
+    d_ga, d_nga = api.DeviceArray.from_host(m_ga, np.float64), api.DeviceArray.from_host(m_nga, np.float64)
+    dev = api.Icp.from_device(d_ga, len(m_ga), d_nga, len(m_nga), **kw)
+    assert np.array_equal(host.normals(), dev.normals())
+    Rh, th, rh, _ = host.fit_batch(batch)
+    Rd, td, rd, _ = dev.fit_batch(batch)
+    assert np.array_equal(Rh, Rd) and np.array_equal(th, td) and np.array_equal(rh, rd)
+    host.close()
+    dev.close()
+    mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=500, grid_size_y=500, resolution=0.1,
+                    max_scans=batch.n_scans, max_points=batch.n_points, icp=kw)
+    Rm, tm = mp.wait(mp.push(batch))
+    mp.finish()
+    mp.close()
+    assert np.abs(Rm - Rh).max() < 1e-9 and np.abs(tm - th).max() < 1e-9       # (the mapper's batch may take another launch form)
+    assert np.abs(tm - batch.true_poses[:, :2]).max() < 0.03
+    with pytest.raises(api.SlamError):
+        mp2 = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=500, grid_size_y=500, resolution=0.1,
+                         max_scans=batch.n_scans, max_points=batch.n_points, icp=kw, window_chunks=2, rebuild_every=1, thin_res=0.1)
+        for _ in range(3):
+            mp2.wait(mp2.push(batch))
+
+
 def test_edge_weight_matches_oracle(world):
     """getEdgeWeight (icpPointToPoint.cpp:233-316) over the correspondences of the
     last executed fitStep, reference bug (dy = ax - bx) included."""
