@@ -1055,13 +1055,17 @@ __global__ __launch_bounds__(256) void list_scatter_kernel(BuildWs w)
 // (key, point) order -- what the host's two stable sorts leave.  Metric of a key: the largest number of entries
 // whose key lies in [k_j - win, k_j] over the entries j (the host's sliding window over the sorted keys counts
 // exactly that: float subtraction is monotone).
-constexpr int kListStage = 128; // entries of a cell staged in LDS per wavefront (= kSmallCell: every list this kernel takes)
-constexpr int kSortWaves = 2;   // wavefronts per workgroup, each taking (cell, class) pairs in turn (2 x 128 x 16 B = 4 KB of LDS)
+// list_sort_kernel<kSortWaves, kListStage, min wavefronts per SIMD>: wavefronts per workgroup (each takes (cell, class) pairs in
+// turn) and entries of a cell a wavefront stages in LDS (kSmallCell and more: every list the kernel takes).  The build of a
+// handle made by itself: 4 x 256 entries (16 KB), no register cap.  The build that must run BESIDE a registration workgroup
+// (slam_icp::build_beside, the mapper's sliding target): 2 x 128 entries = 4 KB and at most 64 registers (44 against 23 us for
+// the 10 k-point map when alone on the chip -- and no wait for a free CU when it is not).
 constexpr int kSmallCell = 128; // lists up to this long: one wavefront, quadratic counting; longer: a workgroup that sorts
 constexpr int kBigCell = 4096;  // entries a workgroup sorts in LDS (longer lists: quadratic through the cache, correct and slow)
 constexpr int kBigCellBeside = 512; // ... of the variant that must fit beside a registration workgroup (4 KB of LDS: slam_icp::build_beside)
 
-__global__ __launch_bounds__(64 * kSortWaves, 8) void list_sort_kernel(BuildWs w)
+template <int kSortWaves, int kListStage, int kMinWaves>
+__global__ __launch_bounds__(64 * kSortWaves, kMinWaves) void list_sort_kernel(BuildWs w)
 {
     ListArgs a;
     if (!list_args(w, a)) return;
@@ -1436,7 +1440,10 @@ int build_begin_device(slam_icp *h, const double *m_ga, int cap_ga, const double
         hipLaunchKernelGGL((list_scatter_kernel<0>), dim3(pblocks), dim3(256), 0, st, w);
         launch_scan<1>(w, tiles_lst, st);
         hipLaunchKernelGGL((list_scatter_kernel<1>), dim3(pblocks), dim3(256), 0, st, w);
-        hipLaunchKernelGGL(list_sort_kernel, dim3(1024), dim3(64 * kSortWaves), 0, st, w);
+        if (h->build_beside)
+            hipLaunchKernelGGL((list_sort_kernel<2, 128, 8>), dim3(1024), dim3(64 * 2), 0, st, w);
+        else
+            hipLaunchKernelGGL((list_sort_kernel<4, 256, 1>), dim3(1024), dim3(64 * 4), 0, st, w);
         // (32 KB of LDS waits for a CU to come free even when no list is long; a caller whose lists are short by construction --
         // the mapper's thinned window -- takes the 4 KB variant, which runs beside a registration workgroup)
         if (h->build_beside)
