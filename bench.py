@@ -480,6 +480,9 @@ def main():
                          "late 0.363-0.367 ms per step, early 0.373-0.375, no merge 0.343-0.345 -- an early raycast takes CUs from the "
                          "registration that has just started; whether hiding the ranks' exchange behind it pays with 8 ranks is for "
                          "the first multi-GPU lease to say")
+    ap.add_argument("--step-streams", type=int, default=2, help="registration streams of the pipelined step (consecutive steps in turn)")
+    ap.add_argument("--private-queues", action="store_true",
+                    help="the pipelined step's streams each on a hardware queue of their own (CU-masked streams naming every CU)")
     ap.add_argument("--reg-cu-cap", type=int, default=0, metavar="K",
                     help="registration streams leave K CUs of every XCD alone (hipExtStreamCreateWithCUMask), so that the short kernels of "
                          "the other streams -- RCCL's all-reduce, the grid update -- find a CU while 0.6 ms registration workgroups hold "
@@ -599,10 +602,12 @@ def main():
     if launch == "pipeline" and S < 2 * n_cu and args.lanes == 0:
         icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, cell_size=args.cell, pair_scans=2, **mode_kw)
     # three priority levels: never the same hardware queue (see mapper.hip)
-    SA, sb = [api.Stream(reserve_cus_per_xcd=args.reg_cu_cap), api.Stream(priority=-1, reserve_cus_per_xcd=args.reg_cu_cap)], api.Stream(priority=1)
-    SB = [sb] + [api.Stream(priority=1) for _ in grids[1:]]      # one grid stream per grid
+    pq = args.private_queues
+    SA = [api.Stream(priority=None if k % 2 == 0 else -1, reserve_cus_per_xcd=args.reg_cu_cap, private_queue=pq) for k in range(max(args.step_streams, 1))]
+    sb = api.Stream(priority=1, private_queue=pq)
+    SB = [sb] + [api.Stream(priority=1, private_queue=pq) for _ in grids[1:]]      # one grid stream per grid
     sa = SA[0]
-    NB = 4
+    NB = max(4, args.step_streams + 3)      # pose / result buffers: the registrations in flight plus the grid updates two steps behind
     pose = [d_pose] + [api.DeviceArray(d_pose0.shape, np.float64) for _ in range(NB - 1)]
     pR = [p_.view(0, batch.R.shape) for p_ in pose]
     pt = [p_.view(batch.R.size, batch.t.shape) for p_ in pose]
@@ -664,7 +669,7 @@ def main():
             # device); the host's wait for the united row range of step k-2 comes two registrations later, just before the
             # raycast of step k goes behind it on the same grid -- by then that range is normally back (merge.merge_wait_ms)
             for k in range(n):
-                enqueue_icp(k, SA[k % 2], E(k), handle, timed)
+                enqueue_icp(k, SA[k % len(SA)], E(k), handle, timed)
                 if k >= 2:
                     enqueue_grid_fold(k - 2, SB[k % 2], E(k - 2), grids[k % 2])
                 enqueue_grid_update(k, SB[k % 2], E(k), grids[k % 2])
@@ -673,7 +678,7 @@ def main():
         elif pipelined:
             # the host stays two registrations ahead of the grid update it enqueues
             for k in range(n):
-                enqueue_icp(k, SA[k % 2], E(k), handle, timed)
+                enqueue_icp(k, SA[k % len(SA)], E(k), handle, timed)
                 if k >= 2:
                     enqueue_grid(k - 2, SB[(k - 2) % len(SB)], E(k - 2), grids[(k - 2) % len(grids)])
             for k in range(max(n - 2, 0), n):

@@ -72,7 +72,9 @@ int slam_stream_create(slam_stream_t *stream);
 int slam_stream_create_with_priority(slam_stream_t *stream, int priority);
 /* A stream whose kernels leave `reserve_per_xcd` CUs of every XCD alone (hipExtStreamCreateWithCUMask): for work that
  * would otherwise hold every CU for its whole duration -- the registration batches, 0.6 ms per workgroup -- while short
- * kernels of other streams (an RCCL all-reduce, the grid update) wait for a CU to come free.  0 = an ordinary stream. */
+ * kernels of other streams (an RCCL all-reduce, the grid update) wait for a CU to come free.  A stream made here has a hardware
+ * queue of its own (the runtime deals ordinary streams over a few shared queues, where one stream's launches can stand behind
+ * another's: DESIGN.md 4.6) -- with reserve_per_xcd = 0 that is all it differs in from slam_stream_create. */
 int slam_stream_create_reserving_cus(slam_stream_t *stream, int reserve_per_xcd);
 int slam_stream_destroy(slam_stream_t stream);
 int slam_stream_synchronize(slam_stream_t stream);

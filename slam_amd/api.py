@@ -377,11 +377,11 @@ class PinnedArray:
 
 
 class Stream:
-    def __init__(self, priority=None, reserve_cus_per_xcd=0):
-        """reserve_cus_per_xcd > 0: a stream whose kernels leave that many CUs of every XCD alone
-        (slam_stream_create_reserving_cus; such a stream has no priority of its own)."""
+    def __init__(self, priority=None, reserve_cus_per_xcd=0, private_queue=False):
+        """reserve_cus_per_xcd > 0: a stream whose kernels leave that many CUs of every XCD alone; private_queue: a stream with a
+        hardware queue of its own (slam_stream_create_reserving_cus with 0; such streams have no priority of their own)."""
         p = _vp()
-        if reserve_cus_per_xcd:
+        if reserve_cus_per_xcd or private_queue:
             check(lib().slam_stream_create_reserving_cus(C.byref(p), int(reserve_cus_per_xcd)))
         elif priority is None:
             check(lib().slam_stream_create(C.byref(p)))

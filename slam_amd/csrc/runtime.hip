@@ -369,6 +369,8 @@ int slam_stream_create_with_priority(slam_stream_t *stream, int priority)
 int slam_stream_create_reserving_cus(slam_stream_t *stream, int reserve_per_xcd)
 {
     SLAM_REQUIRE(stream && reserve_per_xcd >= 0, SLAM_E_INVALID, "slam_stream_create_reserving_cus: bad arguments");
+    // (reserve_per_xcd = 0 is not slam_stream_create: the mask names every CU, and what is left of a masked stream is its own
+    // hardware queue -- this runtime deals unmasked streams over a few shared ones)
     SLAM_TRY(require_device());
     int dev = 0, n_cu = 0;
     SLAM_HIP(hipGetDevice(&dev));
@@ -376,7 +378,6 @@ int slam_stream_create_reserving_cus(slam_stream_t *stream, int reserve_per_xcd)
     constexpr int kXcd = 8; // MI355X: bit i of a CU mask is a CU of XCD i % 8 (measured: tools/exp/cumask.hip)
     SLAM_REQUIRE(n_cu > 0 && n_cu % kXcd == 0 && reserve_per_xcd < n_cu / kXcd, SLAM_E_INVALID,
                  "slam_stream_create_reserving_cus: cannot keep %d CUs per XCD free on a device of %d CUs", reserve_per_xcd, n_cu);
-    if (reserve_per_xcd == 0) return slam_stream_create(stream);
     const int             words = (n_cu + 31) / 32, off = kXcd * reserve_per_xcd;
     std::vector<uint32_t> mask((size_t)words, 0u);
     for (int i = off; i < n_cu; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
