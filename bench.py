@@ -968,7 +968,9 @@ def main():
                                    "max_pose_error_m", "cpu_baseline"))
             out["config4_share"] = side_run(["--config", "4", "--steps", "12", "--warmup", "3", "--no-extras", "--no-cpu-baseline"],
                                             ("value", "ms_per_step", "grid_cell_updates_per_s", "cell_updates_per_step", "kernel_ms", "max_pose_error_m"))
-            out["config5"] = side_run(["--config", "5", "--stream-scans", "4096"],
+            # (the whole 10 240-scan stream of BASELINE config 5: a leg of 4096 scans is 16 chunks, a quarter of them filling and
+            # draining the pipeline -- 0.43 ms per chunk where the stream runs at 0.41)
+            out["config5"] = side_run(["--config", "5", "--stream-scans", "10240"],
                                       ("value", "ms_per_step", "steps", "grid_cell_updates_per_s", "max_pose_error_m"))
             # the N > 1 path with two ranks on THIS GPU: bench.py launching its own ranks, the library's merge entry points over
             # its host-staged communicator (gloo carries the host buffers; RCCL does not put two ranks on one device).  Not a

@@ -200,7 +200,8 @@ struct Slot {
     // pinned staging the producer fills
     double  *h_pts = nullptr, *h_R = nullptr, *h_t = nullptr;
     int32_t *h_off = nullptr, *h_nga = nullptr, *h_gab = nullptr;
-    hipEvent_t copied = nullptr, registered = nullptr, mapped = nullptr;
+    hipEvent_t copied = nullptr, fitted = nullptr, registered = nullptr, mapped = nullptr; // fitted: behind the registration
+                                                                                          // launch; registered: poses on the host
     bool     busy = false;
     int      n_scans = 0;
 };
@@ -224,6 +225,8 @@ struct slam_mapper {
                                                                                                   // registration stream that read the handle
     hipStream_t        copy = nullptr, icp_s[2] = {nullptr, nullptr}, grid_s = nullptr; // chunks alternate over the two icp streams
     hipStream_t        build_s = nullptr;      // the sliding target's rebuilds
+    hipStream_t        post_s = nullptr;       // what follows a registration and nothing on the registration stream waits for:
+                                               // the window's points, the poses' way back to the host
     Slot               slot[kMaxSlots];
     int                n_slots = 5;
     bool               two_lanes = false;      // chunks alternate over two registration streams
@@ -577,6 +580,17 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
             // stood behind the rebuild's thirty launches, a 0.25 ms hole in the registrations per rebuild (0.5 ms under the
             // profiler).  A stream made with a CU mask gets a hardware queue that no other stream is put on
             // (tools/exp/queues2.hip); the mask here names every CU.
+            {
+                int n_cu = 0;
+                hip(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, m->device_at_create));
+                std::vector<uint32_t> all((size_t)std::max((n_cu + 31) / 32, 1), 0u);
+                for (int i = 0; i < n_cu; ++i) all[(size_t)i / 32] |= 1u << (i % 32);
+                // the stream of what follows a registration (slam_mapper_push): a queue of its own, like the rebuild's
+                if (hipExtStreamCreateWithCUMask(&m->post_s, (uint32_t)all.size(), all.data()) != hipSuccess) {
+                    (void)hipGetLastError();
+                    hip(hipStreamCreateWithPriority(&m->post_s, hipStreamNonBlocking, greatest));
+                }
+            }
             if (params->window_chunks) {
                 int n_cu = 0;
                 hip(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, m->device_at_create));
@@ -616,11 +630,13 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
             hip(hipHostMalloc((void **)&b.h_R, 32 * ns, hipHostMallocDefault));
             hip(hipHostMalloc((void **)&b.h_t, 16 * ns, hipHostMallocDefault));
             hip(hipEventCreateWithFlags(&b.copied, hipEventDisableTiming));
+            hip(hipEventCreateWithFlags(&b.fitted, hipEventDisableTiming));
             hip(hipEventCreateWithFlags(&b.registered, hipEventDisableTiming));
             hip(hipEventCreateWithFlags(&b.mapped, hipEventDisableTiming));
         }
         hip(hipGetDevice(&m->device));
         if (!m->build_s) m->build_s = m->icp_s[0];
+        if (!m->post_s) m->post_s = m->icp_s[0];
         // the window keeps one entry more than it uses: the newest is still being written when a rebuild looks -- and as
         // many more as pushes may pass while a background rebuild reads its entries (it is waited for after max_lag)
         const bool bg = params->window_chunks && params->background_rebuild && !params->strict_window;
@@ -652,7 +668,7 @@ void slam_mapper_destroy(slam_mapper_t *m)
             if (p) (void)hipFree(p);
         for (void *p : {(void *)b.h_pts, (void *)b.h_off, (void *)b.h_nga, (void *)b.h_gab, (void *)b.h_R, (void *)b.h_t})
             if (p) (void)hipHostFree(p);
-        for (hipEvent_t e : {b.copied, b.registered, b.mapped})
+        for (hipEvent_t e : {b.copied, b.fitted, b.registered, b.mapped})
             if (e) (void)hipEventDestroy(e);
     }
     for (WindowEntry &w : m->window) {
@@ -677,6 +693,7 @@ void slam_mapper_destroy(slam_mapper_t *m)
     if (!one && m->icp_s[1] && m->icp_s[1] != m->icp_s[0]) (void)hipStreamDestroy(m->icp_s[1]);
     if (!one && m->grid_s) (void)hipStreamDestroy(m->grid_s);
     if (m->build_s && m->build_s != m->copy && m->build_s != m->icp_s[0] && m->build_s != m->grid_s) (void)hipStreamDestroy(m->build_s);
+    if (m->post_s && m->post_s != m->copy && m->post_s != m->icp_s[0] && m->post_s != m->grid_s) (void)hipStreamDestroy(m->post_s);
     delete m;
 }
 
@@ -772,31 +789,41 @@ int slam_mapper_push(slam_mapper_t *m, int n_scans, int n_points, double window_
                                     (slam_stream_t)icp_s));
     MAP_HIP(hipEventRecord(m->target_used[lane], icp_s));
     dt("fit<", icp_s);
+    // With ONE registration stream (a sliding target) everything else a chunk needs after its registration goes to a stream of its
+    // own behind this event: on the registration stream the window kernel and the two copies were three dispatches between one
+    // registration and the next, 30-40 us in which the chip registered nothing (round 4: 0.413 -> 0.406 ms per chunk of config 5).
+    // With two registration streams in turn the gap on one is covered by the other, and the map update that starts the moment a
+    // registration ends takes CUs from the next one's workgroups (measured: 0.335-0.348 -> 0.357-0.377 ms per chunk): there the
+    // copies stay where they were and the map update waits for them.
+    MAP_HIP(hipEventRecord(b.fitted, icp_s));
+    hipStream_t post_s = m->two_lanes ? icp_s : m->post_s;
+    if (post_s != icp_s) MAP_HIP(hipStreamWaitEvent(post_s, b.fitted, 0));
     if (m->prm.window_chunks) {
         WindowEntry &w = m->window[(size_t)(m->chunks % (long)m->window.size())];
         const int    sg = stride_for(m, n_ga), sn = stride_for(m, n_nga);
         // (no wait for a rebuild in flight: it reads the entries of the window_chunks chunks before the push it was begun at,
         // the ring holds 1 + max_lag entries more than that, and a build is adopted -- complete -- before max_lag pushes have passed)
-        hipLaunchKernelGGL(window_points_kernel, dim3((n_points + 255) / 256), dim3(256), 0, icp_s,
+        hipLaunchKernelGGL(window_points_kernel, dim3((n_points + 255) / 256), dim3(256), 0, post_s,
                            reinterpret_cast<const double2 *>(b.d_pts), b.d_off, b.d_nga, b.d_gab, n_scans, n_points, b.d_R, b.d_t, sg, sn,
                            w.ga, w.nga);
         MAP_HIP(hipGetLastError());
         w.n_ga = (n_ga + sg - 1) / sg;
         w.n_nga = (n_nga + sn - 1) / sn;
         w.chunk = m->chunks;
-        MAP_HIP(hipEventRecord(w.ready, icp_s));
+        MAP_HIP(hipEventRecord(w.ready, post_s));
     }
     // the registered poses go back to the slot's pinned pose buffers on THIS stream (12 KB): slam_mapper_wait then needs no
     // stream of its own -- round 2 read them back on the copy stream and synchronised it, which during a background rebuild
     // (whose launches share that stream) held the producer for the whole rebuild: a 0.4 ms hole in the registrations per rebuild
-    MAP_HIP(hipMemcpyAsync(b.h_R, b.d_R, 32 * (size_t)n_scans, hipMemcpyDeviceToHost, icp_s));
-    MAP_HIP(hipMemcpyAsync(b.h_t, b.d_t, 16 * (size_t)n_scans, hipMemcpyDeviceToHost, icp_s));
-    MAP_HIP(hipEventRecord(b.registered, icp_s));
+    MAP_HIP(hipMemcpyAsync(b.h_R, b.d_R, 32 * (size_t)n_scans, hipMemcpyDeviceToHost, post_s));
+    MAP_HIP(hipMemcpyAsync(b.h_t, b.d_t, 16 * (size_t)n_scans, hipMemcpyDeviceToHost, post_s));
+    MAP_HIP(hipEventRecord(b.registered, post_s));
     xt("fit enqueued");
     // ---- the previous chunk's merge, now that this chunk's registration is in the queue ahead of the wait
     SLAM_TRY(finish_merge(m));
     // ---- map
-    MAP_HIP(hipStreamWaitEvent(m->grid_s, b.registered, 0));
+    MAP_HIP(hipStreamWaitEvent(m->grid_s, m->two_lanes ? b.registered : b.fitted, 0)); // (one lane: the poses are in HBM behind the
+                                                                                      // registration, no need to wait for their copy)
     SLAM_TRY(slam_grid_set_pose(m->grid, window_x, window_y, (slam_stream_t)m->grid_s)); // MLS::setPose, mls.cpp:408-479
     dt("raycast>", m->grid_s);
     SLAM_TRY(slam_grid_raycast_scans_dev(m->grid, b.d_pts, b.d_off, n_scans, n_points, b.d_R, b.d_t, (slam_stream_t)m->grid_s));
@@ -854,6 +881,7 @@ int slam_mapper_finish(slam_mapper_t *m)
     MAP_HIP(hipStreamSynchronize(m->copy));
     MAP_HIP(hipStreamSynchronize(m->icp_s[0]));
     MAP_HIP(hipStreamSynchronize(m->icp_s[1]));
+    MAP_HIP(hipStreamSynchronize(m->post_s));
     MAP_HIP(hipStreamSynchronize(m->grid_s));
     return SLAM_OK;
 }
