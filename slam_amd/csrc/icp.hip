@@ -71,6 +71,15 @@ constexpr bool kSeedRing = SLAM_SEED_RING != 0;
 #define SLAM_SEED_CHAIN 0
 #endif
 constexpr bool kSeedChain = kSeedRing && SLAM_SEED_CHAIN != 0;
+// Round 4, measured and NOT kept (off; -DSLAM_LIST_SEED=1 in a measurement build brings it back): the LIST form starting a query's
+// sweep at the entry it ended on in the iteration before instead of bisecting the list for the query's key.  Exact (the window
+// around any start passes the same key-distance tests), and worth 1-2 % (256 scans in pairs 0.622 against 0.634 ms, 1024 scans
+// 1.207 against 1.219) for one to three spilled registers in the point-to-point pair kernels: the bisection is four or five
+// LDS reads of a chain that has a dozen, not the third of it that the cycle stamps suggested.
+#ifndef SLAM_LIST_SEED
+#define SLAM_LIST_SEED 0
+#endif
+constexpr bool kListSeed = SLAM_LIST_SEED != 0;
 #ifdef SLAM_MEASURE
 #define SLAM_STAMPS(fa) ((fa).stamps != nullptr)
 #else
@@ -104,7 +113,7 @@ __device__ inline float list_key_u(float ux, float uy, float x, float y) { retur
 constexpr int kListWin = 3;  // entries examined on either side of the refined start
 constexpr int kListWalk = 3; // further steps on either side before the query is left to the cooperative round
 
-__device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const ModelView &mv, int cls, float qx, float qy)
+__device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const ModelView &mv, int cls, float qx, float qy, int seed = -1)
 {
     const Lattice &L = mv.llat;
     b.d = FLT_MAX;
@@ -130,8 +139,8 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
     };
     // start: the first entry whose key is not below the query's (binary search: the keys of a list bent around
     // a corner are far from evenly spaced, an interpolated start can be dozens of entries off)
-    int g;
-    {
+    int g = seed;
+    if (!(kListSeed && seed >= a && seed < e)) { // (a seed from another cell's list: the query has crossed a cell border)
         int blo = a, bhi = e;
         while (blo < bhi) {
             const int    mid = (blo + bhi) >> 1;
@@ -266,7 +275,7 @@ struct Team {
 template <int MODE>
 __device__ inline void list_pass(const ListPtrs &lp, const ModelView &mv, const FitArgs &fa, const Pose &T, int n, int nga,
                                  int p0, const double2 P, double acc[kNumAcc], unsigned *wave_cnt, unsigned short *queue,
-                                 int &fell_back, int tid)
+                                 int &fell_back, int tid, int &lseed)
 {
     const int  lane = tid & 63, wave = tid >> 6;
     const int  p = p0 + tid;
@@ -278,7 +287,8 @@ __device__ inline void list_pass(const ListPtrs &lp, const ModelView &mv, const 
         Best   b;
         float2 m;
         transform_query(T, P, qx, qy);
-        done = list_search(b, m, lp, mv, cls, qx, qy);
+        done = list_search(b, m, lp, mv, cls, qx, qy, lseed);
+        lseed = done ? b.pos : -1;
         if (MODE == SLAM_ICP_P2L) { // icpPointToPlane.cpp:55-77: every template point, no gate
             if (done) add_p2l(m, mv.lnormals[mv.lbase[1] + b.pos], qx, qy, acc);
         } else if (done && (double)b.d < fa.indist) {
@@ -513,7 +523,10 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                     int tail = 0;
                     if (rem > kCoopPerBlock) {
                         const double2 P = (pass == 0 && kKeepPoint) ? Pc0 : (p0 + tid < n ? fa.pts[off + p0 + tid] : Pc0);
-                        list_pass<MODE>(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back, tid);
+                        // (the lane's entry of the iteration before, per pass: the ring form's seed registers are free here)
+                        int ls = kListSeed ? (pass == 0 ? sd0 : (pass == 1 ? sd1 : -1)) : -1;
+                        list_pass<MODE>(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back, tid, ls);
+                        if (kListSeed) sd0 = pass == 0 ? ls : sd0, sd1 = pass == 1 ? ls : sd1;
                         tail = rem - kBlock;
                         tail = tail > 0 && tail <= kCoopPerBlock ? tail : 0;
                     } else { // a scan shorter than one cooperative round
