@@ -236,7 +236,9 @@ struct slam_mapper {
     std::vector<double> prior_ga, prior_nga; // host copies of the model given at create
     double            *d_model_ga = nullptr, *d_model_nga = nullptr; // [prior | window part] per class
     size_t             cap_model = 0;          // points reserved (both classes)
-    unsigned          *d_thin = nullptr;      // [2][nx*ny] lowest window rank per lattice cell and class
+    unsigned          *d_thin = nullptr;      // [nx*ny] lowest window rank per lattice cell (one class after the other); all ones
+                                              // between rebuilds: every rebuild's winners put their cells back (thin_pick_kernel<1>)
+    bool               thin_dirty = false;    // a rebuild was abandoned half-way: fill the lattice before the next one
     unsigned          *d_thin_blk = nullptr;  // [2][blocks + blocks + 1] winners per block, their prefix, the total
     size_t             cap_thin_blk = 0;
     slam_mapper_merge_fn merge_begin = nullptr, merge_finish = nullptr;
@@ -355,7 +357,11 @@ int thin_class(slam_mapper *m, const std::vector<const WindowEntry *> &use, int 
     const int    blocks = (s.total + 255) / 256;
     if (!m->d_thin) {
         MAP_HIP(hipMalloc((void **)&m->d_thin, 4 * cells));
+        m->thin_dirty = true;
+    }
+    if (m->thin_dirty) {
         MAP_HIP(hipMemsetAsync(m->d_thin, 0xff, 4 * cells, st));
+        m->thin_dirty = false;
     }
     if ((size_t)(2 * blocks + 1) > m->cap_thin_blk) {
         if (m->d_thin_blk) {
@@ -438,8 +444,12 @@ int begin_rebuild(slam_mapper *m, hipStream_t st)
     const int *d_cnt = nullptr;
     if (thin) {
         hipLaunchKernelGGL(set_counts_kernel, dim3(1), dim3(1), 0, st, m->d_cnt, (int)p_ga, (int)p_nga);
-        SLAM_TRY(thin_class(m, use, 0, (int)w_ga, (int)p_ga, m->d_cnt + 0, reinterpret_cast<double2 *>(d_ga + 2 * p_ga), st));
-        SLAM_TRY(thin_class(m, use, 1, (int)w_nga, (int)p_nga, m->d_cnt + 1, reinterpret_cast<double2 *>(d_nga + 2 * p_nga), st));
+        int rc = thin_class(m, use, 0, (int)w_ga, (int)p_ga, m->d_cnt + 0, reinterpret_cast<double2 *>(d_ga + 2 * p_ga), st);
+        if (rc == SLAM_OK) rc = thin_class(m, use, 1, (int)w_nga, (int)p_nga, m->d_cnt + 1, reinterpret_cast<double2 *>(d_nga + 2 * p_nga), st);
+        if (rc != SLAM_OK) {
+            m->thin_dirty = true; // (a class's passes may have stopped between marking the lattice and putting it back)
+            return rc;
+        }
         d_cnt = m->d_cnt;
     } else {
         size_t o_ga = p_ga, o_nga = p_nga;
