@@ -381,6 +381,43 @@ def test_point_to_line_model_from_device_arrays_and_through_the_mapper():
             mp2.wait(mp2.push(batch))
 
 
+def test_point_to_line_edge_cases_follow_the_oracle():
+    """icpPointToPlane.cpp:37-107 at its edges: a template below 5 points leaves R, t alone (icp.cpp:100-103); a model and
+    templates of one class only; a model that is ONE straight wall -- every normal the same, the translation along the wall
+    unobservable, A^T A singular or nearly so: whatever the reference's Gauss-Jordan makes of it (a refused solve leaves the pose
+    and returns 0, icpPointToPlane.cpp:85), the GPU makes the same of it, step count included."""
+    rs = np.random.RandomState(11)
+    # (a) ordinary small model, all points of class NGA; scans of 5 and of 4 points
+    m_nga = np.stack([np.linspace(-5, 5, 400), 2.0 + 0.01 * rs.randn(400)], 1)
+    m_nga = np.concatenate([m_nga, np.stack([4.0 + 0.01 * rs.randn(300), np.linspace(-4, 2, 300)], 1)])
+    m_ga = np.zeros((0, 2))
+    model = O.IcpModel(m_ga, m_nga, normals_k=10)
+    prm = O.icp_params(12, 1e-6, 5.0, O.NN_BRUTE, O.MODE_P2L)
+    icp = api.Icp(m_ga, m_nga, mode=api.ICP_P2L, normals_k=10, max_iter=12, min_delta=1e-6)
+    th = 0.03
+    R0, t0 = np.array([[np.cos(th), -np.sin(th)], [np.sin(th), np.cos(th)]]), np.array([0.05, -0.04])
+    scan = np.concatenate([m_nga[::90][:4] + 0.002 * rs.randn(4, 2), m_nga[420::60][:3] + 0.002 * rs.randn(3, 2)])
+    for t_ga, t_nga in ((scan[:0], scan), (scan[:3], scan[3:]), (scan[:5], scan[:0])):
+        R, t, res = icp.fit(t_ga, t_nga, R0, t0, 5.0)
+        Ro, to, tr, steps = model.fit(t_ga, t_nga, R0, t0, prm)
+        assert res.iters == steps and res.n_corr == len(t_ga) + len(t_nga)
+        assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL
+    with pytest.raises(api.SlamError):
+        icp.fit(scan[:2], scan[2:4], R0, t0, 5.0)
+    icp.close()
+    # (b) one straight wall: every normal is (0, 1) up to sign, the x translation is unobservable
+    wall = np.stack([np.linspace(-3, 3, 200), np.full(200, 1.0)], 1)
+    model = O.IcpModel(wall[:0], wall, normals_k=10)
+    icp = api.Icp(wall[:0], wall, mode=api.ICP_P2L, normals_k=10, max_iter=12, min_delta=1e-6)
+    assert np.abs(np.abs(icp.normals()[:, 1]) - 1.0).max() < 1e-12
+    sc = wall[20:180:8] + [0.0, 0.07]
+    R, t, res = icp.fit(sc[:0], sc, np.eye(2), np.zeros(2), 5.0)
+    Ro, to, tr, steps = model.fit(sc[:0], sc, np.eye(2), np.zeros(2), prm)
+    assert res.iters == steps
+    assert np.allclose(t, to, atol=1e-9) and np.allclose(R.reshape(2, 2), Ro, atol=1e-9)
+    icp.close()
+
+
 def test_edge_weight_matches_oracle(world):
     """getEdgeWeight (icpPointToPoint.cpp:233-316) over the correspondences of the
     last executed fitStep, reference bug (dy = ax - bx) included."""
