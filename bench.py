@@ -1002,7 +1002,8 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, ba
     # at most 5 k points of the last four chunks
     m_ga, m_nga = synth.make_map(5000)
     mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=GRID, grid_size_y=GRID,
-                    resolution=RES, max_scans=chunk, max_points=max(c.n_points for c in chunks), icp=dict(max_iter=N_ITERS, min_delta=-1.0),
+                    resolution=RES, max_scans=chunk, max_points=max(c.n_points for c in chunks),
+                    icp=dict(max_iter=N_ITERS, min_delta=-1.0, **(dict(mode=api.ICP_P2L, normals_k=10) if args.mode == "p2l" else {})),
                     window_chunks=args.window, rebuild_every=args.rebuild_every, keep_prior=1, target_points=5000,
                     thin_res=args.thin, merge_every=args.merge_every, registration_streams=args.reg_streams, slots=args.slots)
     if comm is not None:
@@ -1045,6 +1046,7 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, ba
             "metric": "registered_scan_points_per_s", "value": pts / elapsed, "unit": "points/s", "n_gpus": world,
             "steps": n_chunks, "warmup": n_warm, "ms_per_step": elapsed / n_chunks * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64 pose / f32 distance / int32 counts", "data": "synthetic",
+            "icp_step": "point-to-line (SLAM_ICP_P2L)" if args.mode == "p2l" else "point-to-point (SLAM_ICP_P2P)",
             "config": {"workload": "BASELINE config 5 per GPU: %d scans streamed in chunks of %d from pinned host memory, %d ICP "
                                    "iterations against %s, Bresenham raycast into %dx%d @%.2f m, merge over the GPUs + finalize every %d chunks"
                                    % (n_chunks * chunk, chunk, N_ITERS,

@@ -855,110 +855,6 @@ __global__ __launch_bounds__(kBlock) void icp_fit_pair_kernel(ModelView mv, FitA
     if (active && tm.tid == 0) store_fit(fa, s, fs, 0);
 }
 
-// Normals for the point-to-line mode, icpPointToPlane.cpp:279-305,340-349: for every model point (GA then NGA, original
-// order) the k nearest model points (itself included, n_nearest_around_point(i, 0, k)), their scatter matrix, and the
-// direction of least spread.  Neighbours are kept ordered by (distance, all-index) with a fully unrolled insertion so the list
-// stays in registers.  (Rounds 1-3 scanned the whole model per point through an LDS tile: 1.5 ms for 10 k points.)
-constexpr int kMaxK = 16;
-
-// From the model's CELL INDEX (a point-to-line model is one class, held as class 1 with oidx = all-index): the K nearest of a
-// model point are found ring by ring around its own cell -- a few dozen candidates -- and kept ordered by (distance, all-index),
-// the order in which a scan of the whole model in index order meets them (the reference makes its matcher, normals included,
-// per match: icpTools.cpp:187).
-template <int K, typename StartT>
-__global__ __launch_bounds__(256) void icp_normals_index_kernel(ModelView mv, int n, double *normals)
-{
-    const IndexPtrs<StartT> ix = make_ptrs<StartT>(mv.blob, mv);
-    const float2 *pts = ix.pts + mv.base[1];
-    const StartT *start = ix.start[1], *oidx = ix.oidx + mv.base[1];
-    const Lattice &L = mv.lat;
-    const int pos_self = blockIdx.x * 256 + threadIdx.x; // the thread takes the point at this position of the sorted array
-    if (pos_self >= n) return;
-    const float2 q = pts[pos_self];
-    float        bd[K];
-    int          bi[K], bp[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) bd[j] = FLT_MAX, bi[j] = 0x7fffffff, bp[j] = -1;
-    const float fx = (q.x - L.x0) * L.inv_h, fy = (q.y - L.y0) * L.inv_h;
-    const int   cx = clampi((int)floorf(fx), 0, L.nx - 1), cy = clampi((int)floorf(fy), 0, L.ny - 1);
-    const bool  finite = q.x - q.x == 0.0f && q.y - q.y == 0.0f;
-    auto        take = [&](int pos) {
-        float d = dist2(pts[pos], q.x, q.y);
-        int   id = (int)oidx[pos], pp = pos;
-        if (!(d < bd[K - 1] || (d == bd[K - 1] && id < bi[K - 1]))) return;
-#pragma unroll
-        for (int s_ = 0; s_ < K; ++s_) {
-            const bool  before = d < bd[s_] || (d == bd[s_] && id < bi[s_]);
-            const float td = before ? bd[s_] : d;
-            const int   ti = before ? bi[s_] : id, tp = before ? bp[s_] : pp;
-            bd[s_] = before ? d : bd[s_];
-            bi[s_] = before ? id : bi[s_];
-            bp[s_] = before ? pp : bp[s_];
-            d = td, id = ti, pp = tp;
-        }
-    };
-    auto row_span = [&](int y, int x0, int x1) {
-        if (x0 > x1) return;
-        for (int pos = (int)start[y * L.nx + x0], e = (int)start[y * L.nx + x1 + 1]; pos < e; ++pos) take(pos);
-    };
-    // (a point with a non-finite coordinate sits in cell 0 and is nobody's neighbour at a finite distance: it scans everything,
-    // as the brute-force kernel does, and gets whatever that arithmetic gives)
-    for (int r = 0;; ++r) {
-        const int y_lo = max(cy - r, 0), y_hi = min(cy + r, L.ny - 1), x_lo = max(cx - r, 0), x_hi = min(cx + r, L.nx - 1);
-        for (int y = y_lo; y <= y_hi; ++y) {
-            if (r > 0 && y > cy - r && y < cy + r) { // the ring's two side cells of this row
-                if (cx - r >= 0) row_span(y, cx - r, cx - r);
-                if (cx + r <= L.nx - 1) row_span(y, cx + r, cx + r);
-            } else if (y == cy - r || y == cy + r || r == 0) {
-                row_span(y, x_lo, x_hi); // the ring's top / bottom row (or the own cell)
-            }
-        }
-        const bool  covers = x_lo == 0 && y_lo == 0 && x_hi == L.nx - 1 && y_hi == L.ny - 1;
-        const float bound = (float)r * L.h - L.margin; // every point outside the square of radius r is farther than this
-        if (covers || (finite && bp[K - 1] >= 0 && bound > 0.0f && bd[K - 1] < bound * bound)) break;
-    }
-    double mx = 0, my = 0;
-    int    k = 0;
-#pragma unroll
-    for (int j = 0; j < K; ++j)
-        if (bp[j] >= 0) {
-            const float2 p = pts[bp[j]];
-            mx += (double)p.x;
-            my += (double)p.y;
-            ++k;
-        }
-    mx /= (double)k;
-    my /= (double)k;
-    double sxx = 0, sxy = 0, syy = 0;
-#pragma unroll
-    for (int j = 0; j < K; ++j)
-        if (bp[j] >= 0) {
-            const float2 p = pts[bp[j]];
-            const double dx = (double)p.x - mx, dy = (double)p.y - my;
-            sxx += dx * dx;
-            sxy += dx * dy;
-            syy += dy * dy;
-        }
-    const double th = 0.5 * atan2(2.0 * sxy, sxx - syy); // eigenvector of the smaller eigenvalue of [[sxx,sxy],[sxy,syy]]
-    const int    i = (int)oidx[pos_self];
-    normals[2 * i] = -sin(th);
-    normals[2 * i + 1] = cos(th);
-}
-
-// Point-to-line with halo lists: the normal of every list ENTRY, so that a list sweep's neighbour has its normal one load
-// away (an entry is a copy of a model point: the exact search finds it at distance zero; among exact duplicates the lowest
-// original index, which is also the one a search for a query there returns).  Runs once per map.
-template <typename StartT>
-__global__ __launch_bounds__(256) void icp_list_normals_kernel(ModelView mv, int n_ent, double2 *out)
-{
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n_ent) return;
-    const IndexPtrs<StartT> ix = make_ptrs<StartT>(mv.blob, mv);
-    const float2            p = reinterpret_cast<const float2 *>(mv.lblob + mv.loff_pts)[e];
-    const Best              b = nn_search<1, StartT>(ix, mv, 1, p.x, p.y, 0, (double)INFINITY);
-    out[e] = b.pos >= 0 ? reinterpret_cast<const double2 *>(mv.normals)[b.oidx] : make_double2(0.0, 0.0);
-}
-
 // IcpPointToPoint::getEdgeWeight, icpPointToPoint.cpp:233-316 (with dy = ax - bx
 // of :262), over the correspondences of the last executed fitStep, i.e. those
 // found from `pose` = R,t as they stood when that step began.  One workgroup.
@@ -1062,54 +958,6 @@ __global__ __launch_bounds__(256) void icp_nearest_kernel(ModelView mv, int cls,
 } // namespace
 
 namespace {
-
-// The normals of a point-to-line model (icpPointToPlane.cpp:340-349 computeNormals) from the index that has just been built,
-// and a normal per halo-list entry; on the library's build stream, one wait.
-template <typename StartT>
-void launch_normals(slam_icp *h, int n, int k, hipStream_t st)
-{
-    const dim3 grid((n + 255) / 256);
-    switch (k) {
-#define SLAM_K(KK) case KK: hipLaunchKernelGGL((icp_normals_index_kernel<KK, StartT>), grid, dim3(256), 0, st, h->mv, n, h->d_normals); break;
-        SLAM_K(2) SLAM_K(3) SLAM_K(4) SLAM_K(5) SLAM_K(6) SLAM_K(7) SLAM_K(8) SLAM_K(9) SLAM_K(10) SLAM_K(11)
-        SLAM_K(12) SLAM_K(13) SLAM_K(14) SLAM_K(15) SLAM_K(16)
-#undef SLAM_K
-    }
-}
-
-int compute_normals(slam_icp *h, int n)
-{
-    const int k = std::min(h->prm.normals_k > 0 ? h->prm.normals_k : 10, n);
-    SLAM_REQUIRE(k >= 2 && k <= kMaxK, SLAM_E_INVALID, "normals_k must be 2..%d (got %d)", kMaxK, k);
-    SLAM_REQUIRE(h->mv.n_cls[0] == 0 && h->mv.n_cls[1] == n, SLAM_E_INVALID, "a point-to-line model is one class");
-    hipStream_t st = build_stream();
-    h->d_normals = static_cast<double *>(pool_alloc(sizeof(double) * 2 * (size_t)n));
-    SLAM_REQUIRE(h->d_normals, SLAM_E_NOMEM, "no device memory for %d normals", n);
-    if (h->start32)
-        launch_normals<uint32_t>(h, n, k, st);
-    else
-        launch_normals<uint16_t>(h, n, k, st);
-    SLAM_HIP(hipGetLastError());
-    h->mv.normals = h->d_normals;
-    h->mv.lnormals = nullptr;
-    if (h->have_lists) { // a normal per halo-list entry (the entries end where the first start array begins)
-        const int n_ent = (int)((h->mv.loff_start[0] - h->mv.loff_pts) / 8u);
-        if (n_ent > 0) {
-            h->d_lnormals = static_cast<double *>(pool_alloc(sizeof(double2) * (size_t)n_ent));
-            SLAM_REQUIRE(h->d_lnormals, SLAM_E_NOMEM, "no device memory for %d list normals", n_ent);
-            double2   *out = reinterpret_cast<double2 *>(h->d_lnormals);
-            const dim3 lgrid((n_ent + 255) / 256);
-            if (h->start32)
-                hipLaunchKernelGGL((icp_list_normals_kernel<uint32_t>), lgrid, dim3(256), 0, st, h->mv, n_ent, out);
-            else
-                hipLaunchKernelGGL((icp_list_normals_kernel<uint16_t>), lgrid, dim3(256), 0, st, h->mv, n_ent, out);
-            SLAM_HIP(hipGetLastError());
-            h->mv.lnormals = out;
-        }
-    }
-    SLAM_HIP(hipStreamSynchronize(st));
-    return SLAM_OK;
-}
 
 template <int G, bool LDS, typename StartT, int MODE, int SWEEP = 0>
 int launch_fit_t(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
@@ -1217,10 +1065,10 @@ int launch_fit(slam_icp *h, const FitArgs &fa_in, int n_scans, hipStream_t st)
     fa.switch_iter = 0;
     fa.far_div = h->far_div;
     if (h->prm.mode == SLAM_ICP_P2L) {
-        SLAM_REQUIRE(h->d_normals, SLAM_E_INVALID, "point-to-line mode needs model normals");
+        SLAM_REQUIRE(h->mv.normals, SLAM_E_INVALID, "point-to-line mode needs model normals");
         // the same schedule as point-to-point (the nine sums differ, nothing else); a model whose index or lists do not fit
         // LDS runs the ring search for every iteration
-        if (h->two_phase && h->have_lists && h->in_lds && h->d_lnormals) return launch_fit_fused<SLAM_ICP_P2L>(h, fa, n_scans, st);
+        if (h->two_phase && h->have_lists && h->in_lds && h->mv.lnormals) return launch_fit_fused<SLAM_ICP_P2L>(h, fa, n_scans, st);
         return launch_fit_m<SLAM_ICP_P2L>(h, fa, n_scans, st);
     }
     if (h->two_phase && h->have_lists && h->in_lds && !h->phase_events && !h->split_launch)
@@ -1327,7 +1175,7 @@ void slam_icp_default_params(slam_icp_params *p)
 namespace {
 
 // the handle of Icp::Icp (icp.cpp:26-70) before its index exists
-int icp_new(const slam_icp_params *params, bool deferred, slam_icp **out)
+int icp_new(const slam_icp_params *params, slam_icp **out)
 {
     *out = nullptr;
     SLAM_TRY(require_device());
@@ -1362,11 +1210,6 @@ int icp_new(const slam_icp_params *params, bool deferred, slam_icp **out)
         set_error("lanes_per_point must be one of 1,2,4,8,16,32,64 (got %d)", h->G);
         rc = SLAM_E_INVALID;
     }
-    if (rc == SLAM_OK && deferred && h->prm.mode == SLAM_ICP_P2L) {
-        set_error("the point-to-line mode needs its model's normals when the handle is made: not through the deferred build "
-                  "(slam_mapper_* with a sliding target)");
-        rc = SLAM_E_UNSUPPORTED;
-    }
     if (rc != SLAM_OK) {
         slam_icp_destroy(h);
         return rc;
@@ -1387,25 +1230,10 @@ int icp_create(const double *m_ga, int n_ga, const double *m_nga, int n_nga, con
     SLAM_REQUIRE(n_ga + n_nga >= 5, SLAM_E_TOO_FEW_MODEL_POINTS,
                  "LIBICP works only with at least 5 model points (got %d)", n_ga + n_nga);
     slam_icp *h = nullptr;
-    SLAM_TRY(icp_new(params, false, &h));
+    SLAM_TRY(icp_new(params, &h));
     int rc;
-    if (h->prm.mode == SLAM_ICP_P2L) {
-        // icpPointToPlane.cpp:55-77 knows no classes: ONE index over all model points, GA then NGA (the order of its
-        // M_normal), held as class 1, so that a query is searched once and a neighbour's original index is its all-index
-        const int    n = n_ga + n_nga;
-        const auto   kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-        hipStream_t  st = build_stream();
-        double      *d_all = static_cast<double *>(pool_alloc(16 * (size_t)n)); // (a handle per match: no hipMalloc / hipFree on this path)
-        hipError_t   e = d_all ? hipSuccess : hipErrorOutOfMemory;
-        if (e == hipSuccess && n_ga) e = hipMemcpyAsync(d_all, m_ga, 16 * (size_t)n_ga, kind, st);
-        if (e == hipSuccess && n_nga) e = hipMemcpyAsync(d_all + 2 * (size_t)n_ga, m_nga, 16 * (size_t)n_nga, kind, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st); // (host arrays are the caller's again; the build below runs on this stream too)
-        rc = e == hipSuccess ? build_index(h, nullptr, 0, d_all, n, true) : hip_fail(e, "point-to-line model upload", __FILE__, __LINE__);
-        if (rc == SLAM_OK) rc = compute_normals(h, n);
-        if (d_all) pool_free(d_all); // (every kernel that read it has completed: build_index and compute_normals wait for theirs)
-    } else {
-        rc = build_index(h, m_ga, n_ga, m_nga, n_nga, on_device);
-    }
+    // (point-to-line: the build itself merges the classes into one index and makes the normals, icp_build.hip)
+    rc = build_index(h, m_ga, n_ga, m_nga, n_nga, on_device);
     if (rc != SLAM_OK) {
         slam_icp_destroy(h);
         return rc;
@@ -1425,7 +1253,7 @@ int create_begin(const double *d_ga, int cap_ga, const double *d_nga, int cap_ng
     SLAM_REQUIRE(out && cap_ga >= 0 && cap_nga >= 0 && (d_ga || cap_ga == 0) && (d_nga || cap_nga == 0), SLAM_E_INVALID,
                  "create_begin: bad model arrays");
     slam_icp *h = nullptr;
-    SLAM_TRY(icp_new(params, true, &h));
+    SLAM_TRY(icp_new(params, &h));
     h->build_beside = beside;
     const int rc = build_index_begin(h, d_ga, cap_ga, d_nga, cap_nga, d_cnt, true, st);
     if (rc != SLAM_OK) {

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "icp_model.hpp"
+#include "icp_search.hpp"
 
 using namespace slam;
 using namespace slam::icp;
@@ -146,10 +147,9 @@ unsigned device_lds_total()
     return std::min<unsigned>((unsigned)lds_cap, kLdsTotal);
 }
 
-void adopt_index_plan(slam_icp *h, const IndexPlan &ip)
+// the index's part of a ModelView from its plan (the host adopting a plan; the device making the view its own kernels need)
+__host__ __device__ inline void view_index(ModelView &mv, const IndexPlan &ip)
 {
-    ModelView &mv = h->mv;
-    memset(&mv, 0, sizeof mv);
     mv.lat = ip.lat;
     for (int c = 0; c < 2; ++c) {
         mv.n_cls[c] = ip.n_cls[c];
@@ -161,6 +161,13 @@ void adopt_index_plan(slam_icp *h, const IndexPlan &ip)
     mv.off_pts = ip.off_pts;
     mv.off_oidx = ip.off_oidx;
     mv.blob_bytes = ip.blob_bytes;
+}
+
+void adopt_index_plan(slam_icp *h, const IndexPlan &ip)
+{
+    ModelView &mv = h->mv;
+    memset(&mv, 0, sizeof mv);
+    view_index(mv, ip);
     h->start32 = ip.start32 != 0;
     h->in_lds = ip.in_lds != 0;
     h->lds_bytes = ip.lds_bytes;
@@ -292,9 +299,8 @@ __host__ __device__ inline bool accept_list_core(const ListCand &c, const unsign
     return true;
 }
 
-void adopt_list_plan(slam_icp *h, const ListPlan &lp)
+__host__ __device__ inline void view_lists(ModelView &mv, const ListPlan &lp)
 {
-    ModelView &mv = h->mv;
     mv.loff_pts = lp.loff_pts;
     for (int k = 0; k < 2; ++k) {
         mv.loff_start[k] = lp.loff_start[k];
@@ -307,6 +313,8 @@ void adopt_list_plan(slam_icp *h, const ListPlan &lp)
     mv.lkeps = lp.lkeps;
     mv.cert2 = lp.cert2;
 }
+
+void adopt_list_plan(slam_icp *h, const ListPlan &lp) { view_lists(h->mv, lp); }
 
 bool accept_list(slam_icp *h, const ListCand &c, const size_t n_ent[2], double budget, float maxabs, float margin_abs)
 {
@@ -555,6 +563,17 @@ struct BuildWs {               // what the host knows when it enqueues the build
     double         cell_size;
     int            force_global, want_lists;
     unsigned       lds_total;
+    // point-to-line (SLAM_ICP_P2L): the two classes as the caller gave them, merged into ONE class (class 1, GA then NGA: the order
+    // of the reference's M_normal) before anything else looks at the model; normals per model point and per halo-list entry
+    const double  *p2l_src[2];  // the caller's classes (device), or null: not a point-to-line build
+    const int     *p2l_src_cnt; // their counts on the device, or null: p2l_host_cnt
+    int            p2l_host_cnt[2];
+    double2       *p2l_all;     // [cap_all] the merged model (m[1] points here)
+    int           *p2l_cnt;     // [2] = {0, n_all} on the device (d_cnt points here)
+    double        *normals;     // [cap_all][2]
+    double2       *lnormals;    // [lnormals_cap]
+    int           *p2l_lidx;    // [lnormals_cap] the model point of every list entry (written by the list sorts)
+    int            lnormals_cap;
 };
 
 struct BuildArgs {
@@ -999,6 +1018,7 @@ struct ListArgs {
     int           lbase[2];
     unsigned char *lblob;
     unsigned      loff_pts, loff_start[2], loff_axis[2];
+    int          *lidx;   // nullable (point-to-line): [entries] the point of every entry in its final, sorted place
 };
 
 __device__ inline bool list_args(const BuildWs &w, ListArgs &a)
@@ -1024,6 +1044,7 @@ __device__ inline bool list_args(const BuildWs &w, ListArgs &a)
         a.loff_start[k] = p.lp.loff_start[k];
         a.loff_axis[k] = p.lp.loff_axis[k];
     }
+    a.lidx = w.p2l_lidx;
     return true;
 }
 
@@ -1161,6 +1182,7 @@ __global__ __launch_bounds__(64 * kSortWaves, kMinWaves) void list_sort_kernel(B
                 rank += (ki < kj || (ki == kj && J(i) < pj)) ? 1 : 0;
             }
             out[rank] = make_float2(X(j), Y(j));
+            if (a.lidx) a.lidx[a.lbase[c] + lo + rank] = pj;
         }
         __builtin_amdgcn_wave_barrier(); // the stage is rewritten by the next pair
     }
@@ -1291,7 +1313,10 @@ __global__ __launch_bounds__(256) void list_sort_big_kernel(BuildWs w)
         }
         __syncthreads();
         bitonic_sort_lds(s_key, s_val, N);
-        for (int k = tid; k < n; k += 256) out[k] = xy[s_val[k]];
+        for (int k = tid; k < n; k += 256) {
+            out[k] = xy[s_val[k]];
+            if (a.lidx) a.lidx[a.lbase[c] + lo + k] = s_val[k];
+        }
     } else {
         for (int j = tid; j < n; j += 256) {
             const int    pj = ent[j];
@@ -1305,9 +1330,73 @@ __global__ __launch_bounds__(256) void list_sort_big_kernel(BuildWs w)
                 rank += (ki < kj || (ki == kj && pi < pj)) ? 1 : 0;
             }
             out[rank] = P;
+            if (a.lidx) a.lidx[a.lbase[c] + lo + rank] = pj;
         }
     }
     } // cell
+}
+
+// ---- point-to-line builds (SLAM_ICP_P2L; icpPointToPlane.cpp:55-77 knows no classes, :279-349 the normals)
+
+// the caller's two classes into one array, GA then NGA, and {0, n} as the build's device-side counts
+__global__ __launch_bounds__(256) void p2l_merge_kernel(BuildWs w)
+{
+    const int n0 = w.p2l_src_cnt ? w.p2l_src_cnt[0] : w.p2l_host_cnt[0], n1 = w.p2l_src_cnt ? w.p2l_src_cnt[1] : w.p2l_host_cnt[1];
+    const int c0 = min(max(n0, 0), w.cap[1]), c1 = min(max(n1, 0), w.cap[1] - c0);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) w.p2l_cnt[0] = 0, w.p2l_cnt[1] = c0 + c1;
+    if (i >= c0 + c1) return;
+    const double2 *g = reinterpret_cast<const double2 *>(w.p2l_src[0]), *ng = reinterpret_cast<const double2 *>(w.p2l_src[1]);
+    w.p2l_all[i] = i < c0 ? g[i] : ng[i - c0];
+}
+
+// the view the normals' device functions take, from the plan as it lies in device memory
+__device__ inline ModelView p2l_view(const BuildWs &w)
+{
+    const DevPlan &p = *w.plan;
+    ModelView      mv;
+    memset(&mv, 0, sizeof mv);
+    view_index(mv, p.ip);
+    mv.blob = w.blob;
+    mv.normals = w.normals;
+    if (p.pick >= 0) {
+        view_lists(mv, p.lp);
+        mv.lblob = w.lblob;
+    }
+    return mv;
+}
+
+// normal_of_model_point for every point of the index just built (one thread per position of the sorted array)
+template <int K>
+__global__ __launch_bounds__(256) void p2l_normals_kernel(BuildWs w)
+{
+    const DevPlan  &p = *w.plan;
+    const ModelView mv = p2l_view(w);
+    const int       n = p.cnt[1], pos = blockIdx.x * 256 + threadIdx.x;
+    if (p.cnt[0] + p.cnt[1] < 5) return; // (the handle will be refused at finish)
+    if (p.ip.start32)
+        normal_of_model_point<K, uint32_t>(mv, n, pos, w.normals);
+    else
+        normal_of_model_point<K, uint16_t>(mv, n, pos, w.normals);
+}
+
+// A normal per halo-list ENTRY, so that a list sweep's neighbour has its normal one load away: the list sorts leave the model
+// point of every entry (class 1 holds the whole model: its index within the class is its index into the normals).  Exact
+// duplicates sit in a list side by side at the same distance from any query: the sweep calls that a tie and leaves the query to
+// the exact search, which takes the lowest index -- an entry's own normal is never used where another's would be right.
+__global__ __launch_bounds__(256) void p2l_list_normals_kernel(BuildWs w)
+{
+    const DevPlan &p = *w.plan;
+    if (p.pick < 0 || p.cnt[0] + p.cnt[1] < 5) return;
+    const int n_ent = min((int)(p.lp.n_ent[0] + p.lp.n_ent[1]), w.lnormals_cap), e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_ent) return;
+    w.lnormals[e] = reinterpret_cast<const double2 *>(w.normals)[w.p2l_lidx[e]];
+}
+
+template <int K>
+void launch_p2l_normals(const BuildWs &w, int cap_all, hipStream_t st)
+{
+    hipLaunchKernelGGL((p2l_normals_kernel<K>), dim3((cap_all + 255) / 256), dim3(256), 0, st, w);
 }
 
 double ms_since(std::chrono::steady_clock::time_point t0)
@@ -1395,6 +1484,29 @@ int build_begin_device(slam_icp *h, const double *m_ga, int cap_ga, const double
         w.m[0] = d_in;
         w.m[1] = d_in + 2 * (size_t)cap_ga;
     }
+    const bool p2l = h->prm.mode == SLAM_ICP_P2L;
+    int        normals_k = 0;
+    if (p2l) {
+        // icpPointToPlane.cpp:55-77 knows no classes: the two arrays become ONE class (class 1), GA then NGA -- the order of the
+        // reference's M_normal -- so that a query is searched once and a neighbour's original index is its index into the normals
+        normals_k = h->prm.normals_k > 0 ? h->prm.normals_k : 10;
+        SLAM_REQUIRE(normals_k >= 2 && normals_k <= kMaxK, SLAM_E_INVALID, "normals_k must be 2..%d (got %d)", kMaxK, normals_k);
+        w.p2l_src[0] = w.m[0];
+        w.p2l_src[1] = w.m[1];
+        w.p2l_src_cnt = d_cnt;
+        w.p2l_host_cnt[0] = cap_ga;
+        w.p2l_host_cnt[1] = cap_nga;
+        w.p2l_all = static_cast<double2 *>(ws_get(pb, 16 * (size_t)std::max(cap_all, 1)));
+        w.p2l_cnt = static_cast<int *>(ws_get(pb, 2 * sizeof(int)));
+        h->d_normals = static_cast<double *>(pool_alloc(16 * (size_t)std::max(cap_all, 1)));
+        if (!w.p2l_all || !w.p2l_cnt || !h->d_normals) return SLAM_E_NOMEM;
+        w.normals = h->d_normals;
+        w.m[0] = nullptr;
+        w.m[1] = reinterpret_cast<const double *>(w.p2l_all);
+        w.cap[0] = w.host_cnt[0] = 0;
+        w.cap[1] = w.host_cnt[1] = cap_all;
+        w.d_cnt = w.p2l_cnt;
+    }
     // ---- what the build can need at most
     const long   cb = cells_bound(cap_all, lds_total);
     const long   lcb = want_lists ? 60000 : 0;
@@ -1424,6 +1536,15 @@ int build_begin_device(slam_icp *h, const double *m_ga, int cap_ga, const double
     w.blob = static_cast<unsigned char *>(h->d_blob);
     w.lblob = static_cast<unsigned char *>(h->d_lblob);
     SLAM_HIP(hipEventCreateWithFlags(&pb->done, hipEventDisableTiming));
+    if (p2l && want_lists) { // a normal per halo-list entry: as many as a list blob can hold at most
+        w.lnormals_cap = (int)(pb->lblob_cap / 8);
+        h->d_lnormals = static_cast<double *>(pool_alloc(16 * (size_t)w.lnormals_cap));
+        if (!h->d_lnormals) return SLAM_E_NOMEM;
+        w.lnormals = reinterpret_cast<double2 *>(h->d_lnormals);
+        w.p2l_lidx = static_cast<int *>(ws_get(pb, 4 * (size_t)w.lnormals_cap));
+        if (!w.p2l_lidx) return SLAM_E_NOMEM;
+    }
+    if (p2l) hipLaunchKernelGGL(p2l_merge_kernel, dim3(pblocks), dim3(256), 0, st, w);
 
     SLAM_HIP(hipMemsetAsync(zero, 0, zero_bytes, st));
     SLAM_HIP(hipMemsetAsync(h->d_blob, 0, pb->blob_cap, st)); // the padding between the arrays is part of the blob
@@ -1450,6 +1571,15 @@ int build_begin_device(slam_icp *h, const double *m_ga, int cap_ga, const double
             hipLaunchKernelGGL((list_sort_big_kernel<kBigCellBeside>), dim3(kSortBigGrid, 2), dim3(256), 0, st, w);
         else
             hipLaunchKernelGGL((list_sort_big_kernel<kBigCell>), dim3(kSortBigGrid, 2), dim3(256), 0, st, w);
+    }
+    if (p2l) { // the normals of icpPointToPlane.cpp:340-349 from the index that now exists, and one per list entry
+        switch (normals_k) {
+#define SLAM_K(KK) case KK: launch_p2l_normals<KK>(w, cap_all, st); break;
+            SLAM_K(2) SLAM_K(3) SLAM_K(4) SLAM_K(5) SLAM_K(6) SLAM_K(7) SLAM_K(8) SLAM_K(9) SLAM_K(10) SLAM_K(11)
+            SLAM_K(12) SLAM_K(13) SLAM_K(14) SLAM_K(15) SLAM_K(16)
+#undef SLAM_K
+        }
+        if (want_lists) hipLaunchKernelGGL(p2l_list_normals_kernel, dim3((w.lnormals_cap + 255) / 256), dim3(256), 0, st, w);
     }
     SLAM_HIP(hipGetLastError());
     SLAM_HIP(hipMemcpyAsync(pb->h_plan, w.plan, sizeof(DevPlan), hipMemcpyDeviceToHost, st));
@@ -1518,6 +1648,10 @@ int build_index_finish(slam_icp *h)
         }
         h->max_cell_points = (int)p.most;
         h->built_on_device = true;
+        if (h->prm.mode == SLAM_ICP_P2L) { // (made by the build's last kernels: p2l_normals_kernel, p2l_list_normals_kernel)
+            h->mv.normals = h->d_normals;
+            h->mv.lnormals = p.pick >= 0 ? reinterpret_cast<const double2 *>(h->d_lnormals) : nullptr;
+        }
     }
     drop_pending(h, false);
     if (rc != SLAM_OK) release_index(h);
@@ -1526,7 +1660,7 @@ int build_index_finish(slam_icp *h)
 
 int build_index(slam_icp *h, const double *m_ga, int n_ga, const double *m_nga, int n_nga, bool on_device)
 {
-    if (h->prm.build_on_host && !on_device) return build_index_host(h, m_ga, n_ga, m_nga, n_nga);
+    if (h->prm.build_on_host && !on_device && h->prm.mode != SLAM_ICP_P2L) return build_index_host(h, m_ga, n_ga, m_nga, n_nga);
     // (device arrays: complete when the call is made -- the build does not order itself behind the default stream: that
     // stream shares a hardware queue with whatever the application runs, and an event on it can sit behind a whole
     // registration launch)

@@ -354,7 +354,7 @@ def test_point_to_line_host_fit_and_early_exit():
 def test_point_to_line_model_from_device_arrays_and_through_the_mapper():
     """slam_icp_create_dev in point-to-line mode (the model's f64 arrays already in HBM): the same normals and the same fits,
     bit for bit, as the handle made from host arrays; and the streaming mapper with a fixed point-to-line target registers its
-    chunks as the batch call does.  (A SLIDING target is built deferred, without normals: refused with SLAM_E_UNSUPPORTED.)"""
+    chunks as the batch call does -- and with a SLIDING one, whose deferred rebuilds make their normals on the device."""
     m_ga, m_nga = synth.make_map(6000)
     batch = synth.make_batch(24, n_loop=256)
     kw = dict(mode=api.ICP_P2L, normals_k=10, max_iter=12, min_delta=-1.0)
@@ -374,11 +374,19 @@ def test_point_to_line_model_from_device_arrays_and_through_the_mapper():
     mp.close()
     assert np.abs(Rm - Rh).max() < 1e-9 and np.abs(tm - th).max() < 1e-9       # (the mapper's batch may take another launch form)
     assert np.abs(tm - batch.true_poses[:, :2]).max() < 0.03
-    with pytest.raises(api.SlamError):
-        mp2 = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=500, grid_size_y=500, resolution=0.1,
-                         max_scans=batch.n_scans, max_points=batch.n_points, icp=kw, window_chunks=2, rebuild_every=1, thin_res=0.1)
-        for _ in range(3):
-            mp2.wait(mp2.push(batch))
+    # a SLIDING point-to-line target: the deferred rebuild merges the classes and makes the normals on the device (round 4)
+    mp2 = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=500, grid_size_y=500, resolution=0.1,
+                     max_scans=batch.n_scans, max_points=batch.n_points + 1000, icp=kw, window_chunks=2, rebuild_every=1, thin_res=0.1,
+                     keep_prior=1, target_points=4000, strict_window=1)
+    for k in range(4):
+        b = synth.make_batch(24, n_loop=256, first=24 * k)
+        Rs, ts = mp2.wait(mp2.push(b))
+        assert np.abs(ts - b.true_poses[:, :2]).max() < 0.03, k
+    mp2.finish()
+    assert mp2.stats()["rebuilds"] >= 3
+    info = mp2.target_index_info()
+    assert info["two_forms"] and info["built_on_device"]
+    mp2.close()
 
 
 def test_point_to_line_edge_cases_follow_the_oracle():
