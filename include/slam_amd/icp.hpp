@@ -5,6 +5,7 @@
 //   class Matrix            matrix.h:50-132     slam_amd::Matrix  (the 2x2 / 2x1 subset fit() uses: val[i][j], m, n)
 //   class Icp               icp.h:33-102        slam_amd::Icp
 //   class IcpPointToPoint   icpPointToPoint.h:26-40   slam_amd::IcpPointToPoint
+//   class IcpPointToPlane   icpPointToPlane.h:26-49   slam_amd::IcpPointToPlane (stale upstream: not in the reference's build)
 //
 // Conventions kept from the reference: the constructor copies the model
 // (icp.cpp:51-60) and logs instead of throwing when it has fewer than 5
@@ -77,18 +78,27 @@ public:
     // icp.h:42 / icp.cpp:26-70
     Icp(double *M_GA, double *M_NGA, const int32_t M_GA_num, const int32_t M_NGA_num, const int32_t dim)
     {
+        slam_icp_params p;
+        slam_icp_default_params(&p);
+        create(M_GA, M_NGA, M_GA_num, M_NGA_num, dim, p);
+    }
+
+protected:
+    Icp() {} // (a derived class that makes the handle with parameters of its own: IcpPointToPlane)
+    void create(double *M_GA, double *M_NGA, const int32_t M_GA_num, const int32_t M_NGA_num, const int32_t dim, const slam_icp_params &p)
+    {
         if (dim != 2) { // the reference also takes 3; this path is the 2-D one (icpTools.cpp:187 passes 2)
             std::fprintf(stderr, "LIBICP works only for data of dimensionality 2 here\n");
             return;
         }
-        slam_icp_params p;
-        slam_icp_default_params(&p);
         const int rc = slam_icp_create(M_GA, M_GA_num, M_NGA, M_NGA_num, &p, &h_);
         if (rc != SLAM_OK) {
             std::fprintf(stderr, "%s\n", slam_last_error()); // ROS_ERROR_STREAM in the reference
             h_ = nullptr;
         }
     }
+
+public:
     virtual ~Icp() { slam_icp_destroy(h_); }
     Icp(const Icp &) = delete;
     Icp &operator=(const Icp &) = delete;
@@ -133,6 +143,47 @@ public:
     IcpPointToPoint(double *M_GA, double *M_NGA, const int32_t M_GA_num, const int32_t M_NGA_num, const int32_t dim)
         : Icp(M_GA, M_NGA, M_GA_num, M_NGA_num, dim) {}
     virtual ~IcpPointToPoint() {}
+};
+
+// icpPointToPlane.h:26-49 -- the point-to-line matcher (2-D branch of icpPointToPlane.cpp:37-107; normals :279-305, :340-349).
+// Upstream this class is stale: its header still has libicp's one-cloud constructor `IcpPointToPlane(M, M_num, dim, num_neighbors,
+// flatness)` over `Icp(M, M_num, dim)`, which this fork's icp.h (two classes of points) no longer offers, and the file is not in
+// ccicp2d/CMakeLists.txt:24.  Both shapes are here: the stale header's, and this fork's two-array shape -- the classes are merged
+// (the point-to-line step has none, :55-77; GA first, the order of M_normal).  `flatness` is accepted and unused, as upstream
+// (computeNormal never reads it, :270-305).
+class IcpPointToPlane : public Icp {
+public:
+    // icpPointToPlane.h:30
+    IcpPointToPlane(double *M, const int32_t M_num, const int32_t dim, const int32_t num_neighbors = 10, const double /*flatness*/ = 5.0)
+    {
+        make(nullptr, M, 0, M_num, dim, num_neighbors);
+    }
+    // the same over this fork's constructor shape (icp.h:42)
+    IcpPointToPlane(double *M_GA, double *M_NGA, const int32_t M_GA_num, const int32_t M_NGA_num, const int32_t dim,
+                    const int32_t num_neighbors = 10, const double /*flatness*/ = 5.0)
+    {
+        make(M_GA, M_NGA, M_GA_num, M_NGA_num, dim, num_neighbors);
+    }
+    virtual ~IcpPointToPlane() {}
+    // libicp's one-cloud fit (what icpPointToPlane.cpp was written against): every template point is active -- the step has
+    // no inlier gate (:55-77) -- so `indist` selects nothing here
+    void fit(double *T, const int32_t T_num, Matrix &R, Matrix &t, const double indist)
+    {
+        Icp::fit(nullptr, T, 0, T_num, R, t, indist, 0.0);
+    }
+    using Icp::fit; // ... and this fork's two-array fit (icp.h:65)
+    // M_normal (icpPointToPlane.h:48): x, y per model point, GA then NGA
+    bool getNormals(double *normals_xy) { return h_ && slam_icp_get_normals(h_, normals_xy) == SLAM_OK; }
+
+private:
+    void make(double *M_GA, double *M_NGA, int32_t n_ga, int32_t n_nga, int32_t dim, int32_t num_neighbors)
+    {
+        slam_icp_params p;
+        slam_icp_default_params(&p);
+        p.mode = SLAM_ICP_P2L;
+        p.normals_k = num_neighbors;
+        create(M_GA, M_NGA, n_ga, n_nga, dim, p);
+    }
 };
 
 } // namespace slam_amd

@@ -54,6 +54,26 @@ int main(int argc, char **argv)
     const double res[4] = {trans.val[0][0], trans.val[1][0], std::atan2(rot.val[1][0], rot.val[0][0]),
                            (double)icp.getNumberCorrespondences()};
 
+    // the point-to-line matcher (icpPointToPlane.h:26-49, stale upstream) in both constructor shapes: libicp's one cloud, and
+    // this fork's two arrays -- the same model (GA then NGA), so the same answer
+    std::vector<double> m_all(m_ga), t_all(t_ga);
+    m_all.insert(m_all.end(), m_nga.begin(), m_nga.end());
+    t_all.insert(t_all.end(), t_nga.begin(), t_nga.end());
+    Matrix rot_l(2, 2), trans_l(2, 1), rot_l2(2, 2), trans_l2(2, 1);
+    for (Matrix *r : {&rot_l, &rot_l2}) {
+        r->val[0][0] = std::cos(init[2]), r->val[0][1] = -std::sin(init[2]);
+        r->val[1][0] = std::sin(init[2]), r->val[1][1] = std::cos(init[2]);
+    }
+    trans_l.val[0][0] = trans_l2.val[0][0] = init[0];
+    trans_l.val[1][0] = trans_l2.val[1][0] = init[1];
+    IcpPointToPlane icp_l(m_all.data(), (int32_t)m_all.size() / 2, (int32_t)2);
+    icp_l.fit(t_all.data(), (int32_t)t_all.size() / 2, rot_l, trans_l, -1);
+    IcpPointToPlane icp_l2(m_ga.data(), m_nga.data(), (int32_t)m_ga.size() / 2, (int32_t)m_nga.size() / 2, (int32_t)2, (int32_t)10);
+    icp_l2.fit(t_ga.data(), t_nga.data(), (int32_t)t_ga.size() / 2, (int32_t)t_nga.size() / 2, rot_l2, trans_l2, 5, 0);
+    const bool same_l = trans_l.val[0][0] == trans_l2.val[0][0] && trans_l.val[1][0] == trans_l2.val[1][0] && rot_l.val[1][0] == rot_l2.val[1][0];
+    const double res_l[5] = {trans_l.val[0][0], trans_l.val[1][0], std::atan2(rot_l.val[1][0], rot_l.val[0][0]),
+                             (double)icp_l.getNumberCorrespondences(), same_l ? 1.0 : 0.0};
+
     // too few model points: logs, object unusable, fit leaves R,t alone (icp.cpp:38-43)
     double few[6] = {0, 0, 1, 1, 2, 2};
     IcpPointToPoint bad(few, few, 2, 1, 2);
@@ -74,6 +94,9 @@ int main(int argc, char **argv)
     const double meta[4] = {g.info.resolution, (double)g.info.width, g.info.origin_x, g.info.origin_y};
     std::fwrite(meta, sizeof meta, 1, f);
     std::fwrite(g.data.data(), 1, g.data.size(), f);
+    std::fclose(f);
+    f = std::fopen((out + ".p2l").c_str(), "wb");
+    std::fwrite(res_l, sizeof res_l, 1, f);
     std::fclose(f);
     return 0;
 }

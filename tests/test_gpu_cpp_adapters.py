@@ -61,6 +61,12 @@ def test_adapters_match_oracle(tmp_path):
     assert abs(res[2] - np.arctan2(R[1, 0], R[0, 0])) < 1e-5
     assert int(res[3]) == int(trace[-1, 7])
     assert flag == 1.0                                  # icp.cpp:38-43 behaviour
+    # slam_amd::IcpPointToPlane (icpPointToPlane.h:26-49): libicp's one-cloud shape and this fork's two-array shape, against the oracle
+    res_l = np.fromfile(out + ".p2l", np.float64)
+    model_l = O.IcpModel(m_ga, m_nga, normals_k=10)
+    Rl, tl, trace_l, steps_l = model_l.fit(t_ga, t_nga, R0, t0, O.icp_params(20, 1e-6, 5.0, O.NN_BRUTE, O.MODE_P2L))
+    assert abs(res_l[0] - tl[0]) < 1e-4 and abs(res_l[1] - tl[1]) < 1e-4 and abs(res_l[2] - np.arctan2(Rl[1, 0], Rl[0, 0])) < 1e-5
+    assert int(res_l[3]) == len(t_ga) + len(t_nga) and res_l[4] == 1.0
     assert tuple(meta) == (0.2, 200.0, -20.0, -20.0)    # mls.h:167-175
     gp = O.grid_params(200, 200, 0.2, min_cluster_points=20, rolling=1)
     num = np.zeros(40000)
