@@ -483,6 +483,10 @@ def main():
     ap.add_argument("--step-streams", type=int, default=2, help="registration streams of the pipelined step (consecutive steps in turn)")
     ap.add_argument("--private-queues", action="store_true",
                     help="the pipelined step's streams each on a hardware queue of their own (CU-masked streams naming every CU)")
+    ap.add_argument("--grid-lag", type=int, default=3,
+                    help="pipelined launch: the host enqueues the grid update of step k - LAG after the registration of step k (with N>1 that "
+                         "call waits for the united row range of step k - LAG: a larger lag is more registrations queued while it waits; 100 steps, "
+                         "two runs each: lag 2 0.3374 ms per step, 3 0.3353; one rank over RCCL 0.3626 / 0.3600 / 0.3605 for 2 / 3 / 4)")
     ap.add_argument("--reg-cu-cap", type=int, default=0, metavar="K",
                     help="registration streams leave K CUs of every XCD alone (hipExtStreamCreateWithCUMask), so that the short kernels of "
                          "the other streams -- RCCL's all-reduce, the grid update -- find a CU while 0.6 ms registration workgroups hold "
@@ -607,7 +611,7 @@ def main():
     sb = api.Stream(priority=1, private_queue=pq)
     SB = [sb] + [api.Stream(priority=1, private_queue=pq) for _ in grids[1:]]      # one grid stream per grid
     sa = SA[0]
-    NB = max(4, args.step_streams + 3)      # pose / result buffers: the registrations in flight plus the grid updates two steps behind
+    NB = max(4, args.step_streams + args.grid_lag + 1)      # pose / result buffers: the registrations in flight plus the grid updates two steps behind
     pose = [d_pose] + [api.DeviceArray(d_pose0.shape, np.float64) for _ in range(NB - 1)]
     pR = [p_.view(0, batch.R.shape) for p_ in pose]
     pt = [p_.view(batch.R.size, batch.t.shape) for p_ in pose]
@@ -664,6 +668,7 @@ def main():
         if n <= 0:
             return
         E = (lambda k: events[k]) if events else (lambda k: None)
+        lag = max(args.grid_lag, 1)      # registrations the host stays ahead of the grid update it enqueues
         if pipelined and merging and len(grids) == 2 and args.merge_order == "early":
             # N>1: a step's raycast and the start of its merge are enqueued WITH its registration (they wait for it on the
             # device); the host's wait for the united row range of step k-2 comes two registrations later, just before the
@@ -679,9 +684,9 @@ def main():
             # the host stays two registrations ahead of the grid update it enqueues
             for k in range(n):
                 enqueue_icp(k, SA[k % len(SA)], E(k), handle, timed)
-                if k >= 2:
-                    enqueue_grid(k - 2, SB[(k - 2) % len(SB)], E(k - 2), grids[(k - 2) % len(grids)])
-            for k in range(max(n - 2, 0), n):
+                if k >= lag:
+                    enqueue_grid(k - lag, SB[(k - lag) % len(SB)], E(k - lag), grids[(k - lag) % len(grids)])
+            for k in range(max(n - lag, 0), n):
                 enqueue_grid(k, SB[k % len(SB)], E(k), grids[k % len(grids)])
         else:
             for k in range(n):
