@@ -109,4 +109,26 @@ void ref_orthonormal_from_omega(double w, double R_out[4])
         for (int j = 0; j < 2; j++) R_out[2 * i + j] = R_.val[i][j];
 }
 
+// icpPointToPlane.cpp:279-305 (computeNormal, dim 2) from the k neighbours' coordinates as xy rows
+void ref_normal2(const double *nb_xy, int k, double n_out[2])
+{
+    Matrix P(k, 2);
+    Matrix mu(1, 2);
+    for (int i = 0; i < k; i++) {
+        double x = nb_xy[2 * i];
+        double y = nb_xy[2 * i + 1];
+        P.val[i][0] = x;
+        P.val[i][1] = y;
+        mu.val[0][0] += x;
+        mu.val[0][1] += y;
+    }
+    mu = mu / (double)k;
+    Matrix Q = P - Matrix::ones(k, 1) * mu;
+    Matrix H = ~Q * Q;
+    Matrix U, W, V;
+    H.svd(U, W, V);
+    n_out[0] = U.val[0][1];
+    n_out[1] = U.val[1][1];
+}
+
 } // extern "C"

@@ -480,39 +480,53 @@ void oicp_free(oicp_model *m)
 
 /* icpPointToPlane.cpp:279-305 (2-D computeNormal): scatter of the k nearest
  * neighbours; the normal is the direction of least spread.  The reference
- * takes column 1 of U from its unsorted NR svd; for the symmetric PSD 2x2
- * scatter the oracle uses the eigenvector of the smaller eigenvalue (sign is
- * irrelevant: A and b of the step flip together). */
+ * takes column 1 of U from H.svd(U,W,V), whose singular values come out
+ * sorted (matrix.cpp:762): for the symmetric PSD 2x2 scatter that column is
+ * the eigenvector of the smaller eigenvalue, which the oracle writes in closed
+ * form.  Its sign is the svd's business and is irrelevant to the step (A and b
+ * flip together).  Pinned against the compiled matrix.cpp up to that sign
+ * (tests/test_oracle_solves.py, tests/golden/solve_golden.npz nm_*). */
+void o_normal2(const double *nb_xy, int k, double n_out[2])
+{
+    double mx = 0, my = 0;
+    for (int j = 0; j < k; j++) {
+        mx += nb_xy[2 * j];
+        my += nb_xy[2 * j + 1];
+    }
+    mx /= (double)k;
+    my /= (double)k;
+    double sxx = 0, sxy = 0, syy = 0;
+    for (int j = 0; j < k; j++) {
+        double dx = nb_xy[2 * j] - mx;
+        double dy = nb_xy[2 * j + 1] - my;
+        sxx += dx * dx;
+        sxy += dx * dy;
+        syy += dy * dy;
+    }
+    /* smaller-eigenvalue eigenvector of [[sxx,sxy],[sxy,syy]]:
+     * major axis angle th = 0.5*atan2(2 sxy, sxx - syy); normal = (-sin th, cos th) */
+    double th = 0.5 * atan2(2.0 * sxy, sxx - syy);
+    n_out[0] = -sin(th);
+    n_out[1] = cos(th);
+}
+
 void oicp_compute_normals(oicp_model *m, int k)
 {
     int n = m->n_ga + m->n_nga;
     if (k > n) k = n;
     free(m->normals);
     m->normals = (double *)malloc(sizeof(double) * 2 * (size_t)n);
-    int *nb = (int *)malloc(sizeof(int) * (size_t)k);
+    int    *nb = (int *)malloc(sizeof(int) * (size_t)(k > 0 ? k : 1));
+    double *P = (double *)malloc(sizeof(double) * 2 * (size_t)(k > 0 ? k : 1));
     for (int i = 0; i < n; i++) {
         obf_knn(m->all, n, m->all[2 * i], m->all[2 * i + 1], k, nb);
-        double mx = 0, my = 0;
         for (int j = 0; j < k; j++) {
-            mx += (double)m->all[2 * nb[j]];
-            my += (double)m->all[2 * nb[j] + 1];
+            P[2 * j] = (double)m->all[2 * nb[j]];
+            P[2 * j + 1] = (double)m->all[2 * nb[j] + 1];
         }
-        mx /= (double)k;
-        my /= (double)k;
-        double sxx = 0, sxy = 0, syy = 0;
-        for (int j = 0; j < k; j++) {
-            double dx = (double)m->all[2 * nb[j]] - mx;
-            double dy = (double)m->all[2 * nb[j] + 1] - my;
-            sxx += dx * dx;
-            sxy += dx * dy;
-            syy += dy * dy;
-        }
-        /* smaller-eigenvalue eigenvector of [[sxx,sxy],[sxy,syy]]:
-         * major axis angle th = 0.5*atan2(2 sxy, sxx - syy); normal = (-sin th, cos th) */
-        double th = 0.5 * atan2(2.0 * sxy, sxx - syy);
-        m->normals[2 * i] = -sin(th);
-        m->normals[2 * i + 1] = cos(th);
+        o_normal2(P, k, m->normals + 2 * i);
     }
+    free(P);
     free(nb);
 }
 

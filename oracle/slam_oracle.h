@@ -68,6 +68,7 @@ oicp_model *oicp_create(const double *m_ga, int n_ga, const double *m_nga, int n
 void        oicp_free(oicp_model *m);
 /* computes per-model-point normals for the point-to-line mode over ALL model
  * points (GA then NGA) with k nearest neighbours (reference: 10). */
+void        o_normal2(const double *nb_xy, int k, double n_out[2]); /* icpPointToPlane.cpp:279-305 */
 void        oicp_compute_normals(oicp_model *m, int k);
 const double *oicp_normals(const oicp_model *m);
 

@@ -8,7 +8,8 @@ Run in the build container (needs /root/reference for `make -C oracle ref`):
 solve_golden.npz  -- outputs of the COMPILED REFERENCE Matrix class
                      (oracle/_ref, built from the reference's matrix.cpp):
                      H -> V*U^T, full fitStep solve halves, 3x3 solves,
-                     U*V^T re-orthonormalisation.  These pin the oracle.
+                     U*V^T re-orthonormalisation, computeNormal's U column.
+                     These pin the oracle.
 icp_chain_golden.npz -- BASELINE config 1 (scan 0 vs the 10k map, 20 iters):
                      per iteration, correspondences from the oracle's kd-tree
                      restatement fed through the compiled reference solve
@@ -96,7 +97,30 @@ def main():
             om_w.append(w)
             om_R.append(O.ref_orthonormal_from_omega(w).reshape(4))
 
+    # ---- computeNormal (icpPointToPlane.cpp:279-305): k neighbours -> column 1 of U.  Wall-like, corner-like and
+    # loose neighbourhoods at map coordinates, stored as the reference stores points (float)
+    nm_P, nm_k, nm_n = [], [], []
+    for i in range(600):
+        k = rs.randint(3, 17)
+        kind = i % 3
+        if kind == 0:
+            th = rs.uniform(0, np.pi)
+            u = rs.uniform(-1, 1, k) * rs.uniform(0.05, 2)
+            P = np.c_[u * np.cos(th), u * np.sin(th)] + rs.randn(k, 2) * 10 ** rs.uniform(-4, -1.5)
+        elif kind == 1:
+            u = rs.uniform(0, 1, k)
+            leg = rs.rand(k) < 0.5
+            P = np.where(leg[:, None], np.c_[u, 0 * u], np.c_[0 * u, u]) + rs.randn(k, 2) * 0.01
+            th = rs.uniform(0, np.pi)
+            P = P @ np.array([[np.cos(th), np.sin(th)], [-np.sin(th), np.cos(th)]])
+        else:
+            P = rs.randn(k, 2) * rs.uniform(0.01, 3, 2)
+        P = (P + rs.uniform(-60, 60, 2)).astype(np.float32).astype(np.float64)
+        buf = np.zeros((16, 2)); buf[:k] = P
+        nm_P.append(buf); nm_k.append(k); nm_n.append(O.ref_normal2(P))
+
     np.savez_compressed(os.path.join(HERE, "solve_golden.npz"),
+                        nm_P=np.array(nm_P), nm_k=np.array(nm_k), nm_n=np.array(nm_n),
                         H=Hs, R_=Rs,
                         fs_pm=np.array(fs_pm), fs_pt=np.array(fs_pt), fs_n=np.array(fs_n),
                         fs_R=np.array(fs_R), fs_t=np.array(fs_t), fs_Ro=np.array(fs_Ro),

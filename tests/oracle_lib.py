@@ -79,6 +79,7 @@ def lib():
     L.oicp_create.restype = C.c_void_p
     L.oicp_create.argtypes = [_dp, C.c_int, _dp, C.c_int]
     L.oicp_free.argtypes = [C.c_void_p]
+    L.o_normal2.argtypes = [_dp, C.c_int, _dp]
     L.oicp_compute_normals.argtypes = [C.c_void_p, C.c_int]
     L.oicp_normals.restype = _dp
     L.oicp_normals.argtypes = [C.c_void_p]
@@ -170,6 +171,13 @@ def solve3(A, b):
     b = as_f64(b).reshape(3).copy()
     ok = lib().o_solve3(_d(A), _d(b))
     return ok, b
+
+
+def normal2(nb_xy):
+    nb = as_f64(nb_xy).reshape(-1, 2)
+    out = np.zeros(2)
+    lib().o_normal2(_d(nb), len(nb), _d(out))
+    return out
 
 
 def orthonormal_from_omega(w):
@@ -385,6 +393,7 @@ def ref():
         R.ref_solve3.argtypes = [_dp, _dp, _dp]
         R.ref_inv3.argtypes = [_dp, _dp]
         R.ref_orthonormal_from_omega.argtypes = [C.c_double, _dp]
+        R.ref_normal2.argtypes = [_dp, C.c_int, _dp]
         _ref = R
     return _ref
 
@@ -418,6 +427,13 @@ def ref_solve3(A, b):
     x = np.zeros(3)
     ok = ref().ref_solve3(_d(A), _d(b), _d(x))
     return ok, x
+
+
+def ref_normal2(nb_xy):
+    nb = as_f64(nb_xy).reshape(-1, 2)
+    out = np.zeros(2)
+    ref().ref_normal2(_d(nb), len(nb), _d(out))
+    return out
 
 
 def ref_orthonormal_from_omega(w):

@@ -63,6 +63,33 @@ def test_orthonormal_from_omega(G):
         assert np.abs(O.orthonormal_from_omega(w).reshape(4) - R_).max() < 1e-12
 
 
+def test_normal_matches_reference_svd_column(G):
+    # icpPointToPlane.cpp:279-305: normal = column 1 of U from H.svd on the neighbours' scatter; the oracle's closed form
+    # is that vector up to the svd's sign (which the step does not see: A and b flip together)
+    assert len(G["nm_k"]) == 600
+    for P, k, n_ref in zip(G["nm_P"], G["nm_k"], G["nm_n"]):
+        n = O.normal2(P[:k])
+        sgn = 1.0 if n @ n_ref >= 0 else -1.0
+        assert np.abs(n - sgn * n_ref).max() < 1e-12
+        assert abs(n @ n - 1.0) < 1e-14
+
+
+@pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built")
+def test_live_reference_normals_of_a_model():
+    # the oracle model's own neighbour sets (K = 10) through the compiled reference
+    from slam_amd import synth
+    m_ga, m_nga = synth.make_map(n_points=2000)
+    model = O.IcpModel(m_ga, m_nga, normals_k=10)
+    nrm = model.normals()
+    pts = np.concatenate([m_ga, m_nga]).astype(np.float32)
+    d2 = ((pts[:, None, :].astype(np.float64) - pts[None, :, :].astype(np.float64)) ** 2).sum(-1)
+    for i in range(0, len(pts), 7):
+        nb = np.argsort(d2[i], kind="stable")[:10]
+        n_ref = O.ref_normal2(pts[nb])
+        sgn = 1.0 if nrm[i] @ n_ref >= 0 else -1.0
+        assert np.abs(nrm[i] - sgn * n_ref).max() < 1e-9, i
+
+
 @pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref not built")
 def test_live_reference_matrix_agrees():
     rs = np.random.RandomState(5)
