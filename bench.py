@@ -473,7 +473,7 @@ def main():
     ap.add_argument("--no-merge", action="store_true",
                     help="N>1 without the exchange step: every rank runs the N=1 step on its own shard and nothing is summed -- the "
                          "scaling of independent ranks, to set beside the default N>1 run (its difference is the cost of the merge)")
-    ap.add_argument("--merge-order", choices=["early", "late"], default="late",
+    ap.add_argument("--merge-order", choices=["early", "late"], default=None,
                     help="N>1 pipelined: late (default) = a step's raycast, merge_begin and merge_finish are enqueued together two "
                          "registrations later; early = raycast and merge_begin with the step's own registration (they wait for it on the "
                          "device), merge_finish two registrations later.  With ONE rank (--force-dist, 100 steps, three runs each): "
@@ -487,10 +487,15 @@ def main():
                     help="pipelined launch: the host enqueues the grid update of step k - LAG after the registration of step k (with N>1 that "
                          "call waits for the united row range of step k - LAG: a larger lag is more registrations queued while it waits; 100 steps, "
                          "two runs each: lag 2 0.3374 ms per step, 3 0.3353; one rank over RCCL 0.3626 / 0.3600 / 0.3605 for 2 / 3 / 4)")
-    ap.add_argument("--reg-cu-cap", type=int, default=0, metavar="K",
+    ap.add_argument("--reg-cu-cap", type=int, default=None, metavar="K",
                     help="registration streams leave K CUs of every XCD alone (hipExtStreamCreateWithCUMask), so that the short kernels of "
                          "the other streams -- RCCL's all-reduce, the grid update -- find a CU while 0.6 ms registration workgroups hold "
                          "the rest (0 = ordinary streams)")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="N>1 over RCCL: before the warm-up, time a few steps with each of --reg-cu-cap 0/1 x --merge-order late/early "
+                         "(whichever of the two was not given), take the maximum over the ranks and keep the fastest; reported as "
+                         "merge.calibration.  On by default with more than one rank (no multi-GPU lease has measured which setting RCCL's "
+                         "kernels need beside 0.6 ms registration workgroups); with --force-dist only when asked for")
     ap.add_argument("--dry-launch", action="store_true",
                     help="print the launch `python bench.py --gpus N` would make of its N ranks (one JSON line) and exit")
     args = ap.parse_args()
@@ -607,7 +612,18 @@ def main():
         icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, cell_size=args.cell, pair_scans=2, **mode_kw)
     # three priority levels: never the same hardware queue (see mapper.hip)
     pq = args.private_queues
-    SA = [api.Stream(priority=None if k % 2 == 0 else -1, reserve_cus_per_xcd=args.reg_cu_cap, private_queue=pq) for k in range(max(args.step_streams, 1))]
+    calibrating = merging and args.backend == "nccl" and launch == "pipeline" and (world > 1 or args.calibrate) and \
+        (args.reg_cu_cap is None or args.merge_order is None)
+    cal_caps = [args.reg_cu_cap] if args.reg_cu_cap is not None else [0, 1]
+    cal_orders = [args.merge_order] if args.merge_order is not None else ["late", "early"]
+    if args.reg_cu_cap is None:
+        args.reg_cu_cap = 0
+    if args.merge_order is None:
+        args.merge_order = "late"
+
+    def reg_streams(cap):
+        return [api.Stream(priority=None if k % 2 == 0 else -1, reserve_cus_per_xcd=cap, private_queue=pq) for k in range(max(args.step_streams, 1))]
+    SA = reg_streams(args.reg_cu_cap)
     sb = api.Stream(priority=1, private_queue=pq)
     SB = [sb] + [api.Stream(priority=1, private_queue=pq) for _ in grids[1:]]      # one grid stream per grid
     sa = SA[0]
@@ -697,6 +713,42 @@ def main():
         e_.record(sb)
     for g_ in grids:
         g_.clear()
+    calibration = None
+    if calibrating:
+        # which launch setting leaves RCCL's kernels room on THIS node: a few steps of each, the slowest rank's clock, the
+        # fastest setting kept for the warm-up and the timed steps (every rank sees the same all-reduced times: same choice)
+        calibration = {"tried": []}
+        streams_of = {c: reg_streams(c) for c in cal_caps}
+        settings = [(c, o) for c in cal_caps for o in cal_orders]
+        best_ms = {}
+        run_steps(20)                  # the start-of-run transient (DESIGN Appendix A) belongs to no setting
+        for rnd in range(3):           # interleaved rounds, the best round of a setting counts
+            for cap_, order_ in settings:
+                SA, args.merge_order = streams_of[cap_], order_
+                sa = SA[0]
+                run_steps(4)
+                sync(); barrier()
+                t_c = time.perf_counter()
+                run_steps(30)
+                sync(); barrier()
+                tt = torch.tensor([time.perf_counter() - t_c], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                best_ms[(cap_, order_)] = min(best_ms.get((cap_, order_), 1e9), float(tt.item()) / 30 * 1e3)
+        calibration["tried"] = [{"reg_cu_cap_per_xcd": c, "merge_order": o, "ms_per_step": best_ms[(c, o)]} for c, o in settings]
+        # the first setting (the one-GPU default unless the command line says otherwise) stays unless another is 3 % faster
+        best = min(calibration["tried"], key=lambda c_: c_["ms_per_step"])
+        if best["ms_per_step"] > 0.97 * calibration["tried"][0]["ms_per_step"]:
+            best = calibration["tried"][0]
+        args.reg_cu_cap, args.merge_order = best["reg_cu_cap_per_xcd"], best["merge_order"]
+        SA = streams_of[args.reg_cu_cap]
+        sa = SA[0]
+        calibration["kept"] = {"reg_cu_cap_per_xcd": args.reg_cu_cap, "merge_order": args.merge_order}
+        calibration["what"] = ("before the warm-up: three interleaved rounds of 30 steps per setting, the slowest rank's clock, the best round of "
+                               "each; the first setting is kept unless another is 3 % faster; the timed steps run with the one kept")
+        merge_rows_seen.clear()
+        sync()
+        for g_ in grids:
+            g_.clear()                 # (the update counter starts again: the warm-up's steps are counted below)
     run_steps(args.warmup, pipelined=launch == "pipeline")
     sync()
     upd_per_step = None
@@ -903,7 +955,7 @@ def main():
                        "map_points": M, "icp_index": info, "raycast": args.raycast,
                        "raycast_worklist": grid.raycast_stats(),
                        "merge_rows": list(merge_rows_seen[-1]) if merging and merge_rows_seen else None,
-                       "reg_cu_cap_per_xcd": args.reg_cu_cap},
+                       "reg_cu_cap_per_xcd": args.reg_cu_cap, "merge_order": args.merge_order if merging else None},
             "grid_cell_updates_per_s": total_upd * args.steps / elapsed,
             "cell_updates_per_step": total_upd,
             "point_iterations_per_s": total_pts * N_ITERS * args.steps / elapsed,
@@ -941,6 +993,8 @@ def main():
                 "what": "merge_wait_ms = host time inside slam_grid_merge_finish waiting for the united row range (per merge); "
                         "allreduce_ms = HIP events around the grouped row all-reduces on the grid stream (includes the time their "
                         "kernels waited for a CU beside the registration workgroups); both from slam_comm_get_stats"}
+            if merging:
+                out["merge"]["calibration"] = calibration
             out["no_merge"] = bool(args.no_merge)
         if world == 1 and not args.no_extras:
             # the model build reported separately; metric (1) with the transfers in; the reference's own

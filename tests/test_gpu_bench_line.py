@@ -65,6 +65,25 @@ def test_bench_force_dist_runs_the_n_gt_1_pipeline_over_a_real_rccl_communicator
 
 
 @pytest.mark.gpu
+def test_bench_calibrates_the_n_gt_1_launch_setting():
+    """With more than one rank the bench first times reg-cu-cap 0/1 x merge-order late/early and keeps the fastest (no multi-GPU
+    lease has said which one RCCL's kernels need); --calibrate runs that with the one rank of this box."""
+    d = _bench("--force-dist", "--calibrate", "--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline")
+    c = d["merge"]["calibration"]
+    assert [(t["reg_cu_cap_per_xcd"], t["merge_order"]) for t in c["tried"]] == [(0, "late"), (0, "early"), (1, "late"), (1, "early")]
+    best = min(c["tried"], key=lambda t: t["ms_per_step"])
+    if best["ms_per_step"] > 0.97 * c["tried"][0]["ms_per_step"]:       # the default stays unless another setting is 3 % faster
+        best = c["tried"][0]
+    assert c["kept"] == {"reg_cu_cap_per_xcd": best["reg_cu_cap_per_xcd"], "merge_order": best["merge_order"]}
+    assert d["config"]["reg_cu_cap_per_xcd"] == c["kept"]["reg_cu_cap_per_xcd"] and d["config"]["merge_order"] == c["kept"]["merge_order"]
+    assert all(0.2 < t["ms_per_step"] < 5.0 for t in c["tried"])
+    assert d["merge"]["merges_in_timed_region"] == 4 and d["max_pose_error_m"] < 0.05
+    # a setting given on the command line is not calibrated over
+    d = _bench("--force-dist", "--calibrate", "--merge-order", "late", "--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline")
+    assert [(t["reg_cu_cap_per_xcd"], t["merge_order"]) for t in d["merge"]["calibration"]["tried"]] == [(0, "late"), (1, "late")]
+
+
+@pytest.mark.gpu
 def test_bench_no_merge_and_reserved_cus():
     """--no-merge: the same ranks with the exchange step left out (what the merge costs is the difference to the default
     run); --reg-cu-cap: registration streams that leave CUs of every XCD to the other streams' kernels."""
