@@ -425,6 +425,9 @@ def side_run(argv, keys, timeout=420):
 
 def main():
     global GRID
+    # dmabuf IPC between the ranks' processes (RCCL needs it on this driver); already exported on the boxes, set here for a launcher
+    # that starts the ranks with an environment of its own.  Before anything loads the HIP runtime.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
