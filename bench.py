@@ -499,6 +499,12 @@ def main():
                          "(whichever of the two was not given), take the maximum over the ranks and keep the fastest; reported as "
                          "merge.calibration.  On by default with more than one rank (no multi-GPU lease has measured which setting RCCL's "
                          "kernels need beside 0.6 ms registration workgroups); with --force-dist only when asked for")
+    ap.add_argument("--start-stagger-us", type=float, default=125.0,
+                    help="pipelined launch: the host waits this long between enqueueing the first registration of a run and the second "
+                         "(on the other registration stream), so that the two streams are out of step from the start as they are in "
+                         "the steady state -- inside the timed region, like everything the host does there.  The driver's own command (20 steps, "
+                         "5 warm-up), five runs each, median ms per step: 0 us 0.368, 100 0.359, 150 0.359, 200 0.360, 250 0.364, 300 0.366, "
+                         "400 0.372 (tools/exp/start_sweep.sh); over 100 steps it is within the noise")
     ap.add_argument("--dry-launch", action="store_true",
                     help="print the launch `python bench.py --gpus N` would make of its N ranks (one JSON line) and exit")
     args = ap.parse_args()
@@ -635,7 +641,8 @@ def main():
     pR = [p_.view(0, batch.R.shape) for p_ in pose]
     pt = [p_.view(batch.R.size, batch.t.shape) for p_ in pose]
     res = [d_res] + [api.DeviceArray((S,), api.RESULT_DTYPE) for _ in range(NB - 1)]
-    icp_done = [api.Event() for _ in range(NB)]
+    icp_done_own = [api.Event() for _ in range(NB)]
+    icp_done = list(icp_done_own)
     grid_done = [api.Event() for _ in range(NB)]
     merge_rows_seen = []
     # (start, end) events around the registration launches of the timed region, on the stream of each
@@ -653,8 +660,8 @@ def main():
         # (slam_icp_fit_batch_from_dev: no copy of the initial poses into the in/out arrays, no launch gap behind it)
         (handle or icp).fit_batch_from_dev(d_pts, d_off, d_nga, S, d_R0, d_t0, pR[s_], pt[s_], 5.0, res[s_], None, a)
         if e: e[1].record(a)
-        if timed and k < len(live):
-            live[k][1].record(a)
+        # (a timed step's end-of-launch event is also the one its grid update waits for: one record behind the launch, not two)
+        icp_done[s_] = live[k][1] if (timed and k < len(live)) else icp_done_own[s_]
         icp_done[s_].record(a)
 
     def enqueue_grid_update(k, b, e=None, g=None):
@@ -703,6 +710,10 @@ def main():
             # the host stays two registrations ahead of the grid update it enqueues
             for k in range(n):
                 enqueue_icp(k, SA[k % len(SA)], E(k), handle, timed)
+                if k == 0 and args.start_stagger_us > 0 and n > 1:
+                    t_s = time.perf_counter()
+                    while (time.perf_counter() - t_s) * 1e6 < args.start_stagger_us:
+                        pass
                 if k >= lag:
                     enqueue_grid(k - lag, SB[(k - lag) % len(SB)], E(k - lag), grids[(k - lag) % len(grids)])
             for k in range(max(n - lag, 0), n):
