@@ -512,11 +512,13 @@ typedef struct {
     int    strict_window;      /* 1 = the push a rebuild is due at waits for it: the chunk meets the target built from every
                                   chunk before it (reproducible; the pipeline drains once per rebuild); 0 = the build is
                                   enqueued (same window) and adopted by a later push, see background_rebuild */
-    int    slots;              /* chunks in flight (device + pinned buffers each): 2..8; 0 = default: 5 with a fixed target -- the
+    int    slots;              /* chunks in flight (device + pinned buffers each): 2..8; 0 = default: 5 -- with a fixed target the
                                   host enqueues chunk k while two registrations run on the two registration streams and
                                   the chunks before them are mapped and read back (256-scan chunks: two 0.54 ms per chunk,
-                                  three 0.43, four 0.38, five 0.37) -- and 4 with a sliding target, whose chunks register
-                                  one after the other (config 5: three 0.460 ms per chunk, four 0.448, five 0.447, six 0.459) */
+                                  three 0.43, four 0.38, five 0.37); with a sliding target, whose chunks register one after
+                                  the other (config 5, rebuilt every 4 chunks): four 0.410 ms per chunk, five 0.396, six
+                                  0.397-0.436, eight 0.408-0.414 -- four is slow only where it equals rebuild_every (every 3 /
+                                  5 / 8 chunks: four and five slots within 1 % of each other) */
     double thin_res;           /* > 0: the window is thinned to one point per cell of this pitch (metres) and class over
                                   the grid's extent, the oldest measurement of a cell kept (where pcl::VoxelGrid keeps a
                                   centroid, icpTools.cpp:620-633); 0: every stride-th point of a chunk instead */

@@ -624,7 +624,7 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
             hip(hipEventCreateWithFlags(&m->retired_used[k], hipEventDisableTiming));
         }
         const size_t np = (size_t)params->max_points, ns = (size_t)params->max_scans;
-        m->n_slots = params->slots >= 2 && params->slots <= kMaxSlots ? params->slots : (params->window_chunks ? 4 : 5);
+        m->n_slots = params->slots >= 2 && params->slots <= kMaxSlots ? params->slots : 5;
         for (int k = 0; k < m->n_slots; ++k) {
             Slot &b = m->slot[k];
             hip(hipMalloc((void **)&b.d_pts, 16 * np));
