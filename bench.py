@@ -936,6 +936,7 @@ def main():
                          "frac_on_held_cus": (busy * lanes * n_cu / held) if (busy is not None and lanes is not None) else None,
                          "source": prof_file,
                          "profile_csrc_sha256": prof.get("_meta", {}).get("csrc_sha256"),
+                         "run_csrc_sha256": csrc_sha(),
                          "stale": (prof.get("_meta", {}).get("csrc_sha256") != csrc_sha()) if prof_file else None,
                          "stale_means": "the committed counter summary was taken from kernel sources other than the ones this run was built "
                                         "from (sha256 over slam_amd/csrc): the fractions describe that build",

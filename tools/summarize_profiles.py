@@ -140,6 +140,26 @@ for name in ("bench.json", "config3.json", "config4.json", "config5.json", "buil
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, tag + "_" + name))
+        if name.endswith(".json"):
+            # a line of this round was taken BEFORE the counter summary it stands beside existed: its `stale` compared the run's
+            # sources with the summary committed then.  Restated against the summary written above (same tag): stale = the run's own
+            # sources (run_csrc_sha256, recorded by bench.py) differ from the ones this summary is stamped with
+            def restate(o):
+                if isinstance(o, dict):
+                    if "run_csrc_sha256" in o and "stale" in o:
+                        o["profile_csrc_sha256"] = csrc_sha()
+                        o["stale"] = o["run_csrc_sha256"] != csrc_sha()
+                    for v in o.values():
+                        restate(v)
+                elif isinstance(o, list):
+                    for v in o:
+                        restate(v)
+            try:
+                d = json.load(open(os.path.join(dst, tag + "_" + name)))
+                restate(d)
+                json.dump(d, open(os.path.join(dst, tag + "_" + name), "w"))
+            except ValueError:
+                pass
 # the side runs: kernel stats of the merged raycast, config 3 and the index build; counters of the merged raycast
 for sub, out in (("stats_merge", "raycast_merge_kernel_stats.csv"), ("stats_c3", "config3_kernel_stats.csv"), ("stats_build", "build_kernel_stats.csv")):
     st = sorted(glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv")), key=os.path.getmtime)
