@@ -113,6 +113,12 @@ __device__ inline float list_key_u(float ux, float uy, float x, float y) { retur
 constexpr int kListWin = 3;  // entries examined on either side of the refined start
 constexpr int kListWalk = 3; // further steps on either side before the query is left to the cooperative round
 
+// MED3: how an exact tie is noticed.  false: a flag, set whenever a candidate equals the best so far (a compare, an AND and an OR per
+// candidate).  true: best and SECOND best of everything examined, one v_med3 per candidate; a tie is second == best at the end.
+// Both are exact (a tie sends the query to the exact pass); which is faster is the register allocator's business: the
+// two-scans-per-workgroup kernels gain 2.5 % with the second form (256 scans 0.629 -> 0.612 ms, 1024 scans 1.207 -> 1.178; fewer
+// spilled scalar registers), the one-scan-per-workgroup kernels lose 1.5 % with it (0.394 -> 0.400; more) -- so each takes its own.
+template <bool MED3>
 __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const ModelView &mv, int cls, float qx, float qy, int seed = -1)
 {
     const Lattice &L = mv.llat;
@@ -153,9 +159,9 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
         g = min(blo, e - 1);
     }
     const int lo = max(a, g - kListWin), hi = min(e - 1, g + kListWin);
-    float     d = FLT_MAX, klo = 0.f, khi = 0.f;
-    int       pos = -1;
-    bool      tie = false;
+    float d = FLT_MAX, d2nd = FLT_MAX, klo = 0.f, khi = 0.f;
+    int   pos = -1;
+    bool  tie = false;
 #pragma unroll
     for (int j = 0; j <= 2 * kListWin; ++j) {
         const int    i = lo + j;
@@ -165,7 +171,10 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
         const float  kj = list_key_u(ux, uy, p.x, p.y);
         if (j == 0) klo = kj;
         khi = ok ? kj : khi;
-        tie |= ok & (dj == d);
+        if (MED3)
+            d2nd = __builtin_amdgcn_fmed3f(d, dj, d2nd);
+        else
+            tie |= ok & (dj == d);
         const bool up = dj < d;
         d = up ? dj : d;
         pos = up ? i : pos;
@@ -185,9 +194,12 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
         {
             const float dk = list_key_u(ux, uy, ml.x, ml.y) - kq;
             const bool  in = Lft & !((dk < 0.f) & far(dk, d));
-            const float dd = dist2(ml, qx, qy);
-            tie |= in & (dd == d);
-            const bool up = in & (dd < d);
+            const float dd = in ? dist2(ml, qx, qy) : FLT_MAX;
+            if (MED3)
+                d2nd = __builtin_amdgcn_fmed3f(d, dd, d2nd);
+            else
+                tie |= in & (dd == d);
+            const bool up = dd < d;
             d = up ? dd : d;
             pos = up ? il : pos;
             --il;
@@ -196,9 +208,12 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
         {
             const float dk = list_key_u(ux, uy, mr.x, mr.y) - kq;
             const bool  in = Rgt & !((dk > 0.f) & far(dk, d));
-            const float dd = dist2(mr, qx, qy);
-            tie |= in & (dd == d);
-            const bool up = in & (dd < d);
+            const float dd = in ? dist2(mr, qx, qy) : FLT_MAX;
+            if (MED3)
+                d2nd = __builtin_amdgcn_fmed3f(d, dd, d2nd);
+            else
+                tie |= in & (dd == d);
+            const bool up = dd < d;
             d = up ? dd : d;
             pos = up ? ir : pos;
             ++ir;
@@ -207,7 +222,7 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
     }
     b.d = d;
     b.pos = pos;
-    if (tie || pos < 0 || (Lft | Rgt) || !(d < mv.cert2)) return false;
+    if ((MED3 ? d2nd == d : tie) || pos < 0 || (Lft | Rgt) || !(d < mv.cert2)) return false;
     m = pts[pos];
     return true;
 }
@@ -272,7 +287,7 @@ struct Team {
 // would wait for a few lanes): its offset goes to the wavefront's region of a queue in LDS (fixed regions:
 // the order does not depend on timing, so sums stay bitwise reproducible) that all wavefronts drain
 // together afterwards (drain_queue).
-template <int MODE>
+template <int MODE, bool MED3>
 __device__ inline void list_pass(const ListPtrs &lp, const ModelView &mv, const FitArgs &fa, const Pose &T, int n, int nga,
                                  int p0, const double2 P, double acc[kNumAcc], unsigned *wave_cnt, unsigned short *queue,
                                  int &fell_back, int tid, int &lseed)
@@ -287,7 +302,7 @@ __device__ inline void list_pass(const ListPtrs &lp, const ModelView &mv, const 
         Best   b;
         float2 m;
         transform_query(T, P, qx, qy);
-        done = list_search(b, m, lp, mv, cls, qx, qy, lseed);
+        done = list_search<MED3>(b, m, lp, mv, cls, qx, qy, lseed);
         lseed = done ? b.pos : -1;
         if (MODE == SLAM_ICP_P2L) { // icpPointToPlane.cpp:55-77: every template point, no gate
             if (done) add_p2l(m, mv.lnormals[mv.lbase[1] + b.pos], qx, qy, acc);
@@ -525,7 +540,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                         const double2 P = (pass == 0 && kKeepPoint) ? Pc0 : (p0 + tid < n ? fa.pts[off + p0 + tid] : Pc0);
                         // (the lane's entry of the iteration before, per pass: the ring form's seed registers are free here)
                         int ls = kListSeed ? (pass == 0 ? sd0 : (pass == 1 ? sd1 : -1)) : -1;
-                        list_pass<MODE>(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back, tid, ls);
+                        list_pass<MODE, (TB < icp::kBlock)>(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back, tid, ls);
                         if (kListSeed) sd0 = pass == 0 ? ls : sd0, sd1 = pass == 1 ? ls : sd1;
                         tail = rem - kBlock;
                         tail = tail > 0 && tail <= kCoopPerBlock ? tail : 0;
