@@ -80,6 +80,8 @@ constexpr bool kSeedChain = kSeedRing && SLAM_SEED_CHAIN != 0;
 #define SLAM_LIST_SEED 0
 #endif
 constexpr bool kListSeed = SLAM_LIST_SEED != 0;
+// The ring passes scan cell ranges in the packed-distance, second-best form (icp_search.hpp, `PK`): round 4, -4.5 % per launch.
+constexpr bool kTunedScan = true;
 #ifdef SLAM_MEASURE
 #define SLAM_STAMPS(fa) ((fa).stamps != nullptr)
 #else
@@ -113,12 +115,9 @@ __device__ inline float list_key_u(float ux, float uy, float x, float y) { retur
 constexpr int kListWin = 3;  // entries examined on either side of the refined start
 constexpr int kListWalk = 3; // further steps on either side before the query is left to the cooperative round
 
-// MED3: how an exact tie is noticed.  false: a flag, set whenever a candidate equals the best so far (a compare, an AND and an OR per
-// candidate).  true: best and SECOND best of everything examined, one v_med3 per candidate; a tie is second == best at the end.
-// Both are exact (a tie sends the query to the exact pass); which is faster is the register allocator's business: the
-// two-scans-per-workgroup kernels gain 2.5 % with the second form (256 scans 0.629 -> 0.612 ms, 1024 scans 1.207 -> 1.178; fewer
-// spilled scalar registers), the one-scan-per-workgroup kernels lose 1.5 % with it (0.394 -> 0.400; more) -- so each takes its own.
-template <bool MED3>
+// An exact tie is noticed through the SECOND best of everything examined (one v_med3_f32 per candidate; a tie is second == best at
+// the end) -- round 4: the flag this replaced (set whenever a candidate equalled the best so far: a compare, an AND and an OR per
+// candidate) cost 2.5 % of a pair launch.  Either way a tie sends the query to the exact pass.
 __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const ModelView &mv, int cls, float qx, float qy, int seed = -1)
 {
     const Lattice &L = mv.llat;
@@ -161,7 +160,6 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
     const int lo = max(a, g - kListWin), hi = min(e - 1, g + kListWin);
     float d = FLT_MAX, d2nd = FLT_MAX, klo = 0.f, khi = 0.f;
     int   pos = -1;
-    bool  tie = false;
 #pragma unroll
     for (int j = 0; j <= 2 * kListWin; ++j) {
         const int    i = lo + j;
@@ -171,10 +169,7 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
         const float  kj = list_key_u(ux, uy, p.x, p.y);
         if (j == 0) klo = kj;
         khi = ok ? kj : khi;
-        if (MED3)
-            d2nd = __builtin_amdgcn_fmed3f(d, dj, d2nd);
-        else
-            tie |= ok & (dj == d);
+        d2nd = __builtin_amdgcn_fmed3f(d, dj, d2nd);
         const bool up = dj < d;
         d = up ? dj : d;
         pos = up ? i : pos;
@@ -195,10 +190,7 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
             const float dk = list_key_u(ux, uy, ml.x, ml.y) - kq;
             const bool  in = Lft & !((dk < 0.f) & far(dk, d));
             const float dd = in ? dist2(ml, qx, qy) : FLT_MAX;
-            if (MED3)
-                d2nd = __builtin_amdgcn_fmed3f(d, dd, d2nd);
-            else
-                tie |= in & (dd == d);
+            d2nd = __builtin_amdgcn_fmed3f(d, dd, d2nd);
             const bool up = dd < d;
             d = up ? dd : d;
             pos = up ? il : pos;
@@ -209,10 +201,7 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
             const float dk = list_key_u(ux, uy, mr.x, mr.y) - kq;
             const bool  in = Rgt & !((dk > 0.f) & far(dk, d));
             const float dd = in ? dist2(mr, qx, qy) : FLT_MAX;
-            if (MED3)
-                d2nd = __builtin_amdgcn_fmed3f(d, dd, d2nd);
-            else
-                tie |= in & (dd == d);
+            d2nd = __builtin_amdgcn_fmed3f(d, dd, d2nd);
             const bool up = dd < d;
             d = up ? dd : d;
             pos = up ? ir : pos;
@@ -222,7 +211,7 @@ __device__ inline bool list_search(Best &b, float2 &m, const ListPtrs &lp, const
     }
     b.d = d;
     b.pos = pos;
-    if ((MED3 ? d2nd == d : tie) || pos < 0 || (Lft | Rgt) || !(d < mv.cert2)) return false;
+    if (d2nd == d || pos < 0 || (Lft | Rgt) || !(d < mv.cert2)) return false;
     m = pts[pos];
     return true;
 }
@@ -287,7 +276,7 @@ struct Team {
 // would wait for a few lanes): its offset goes to the wavefront's region of a queue in LDS (fixed regions:
 // the order does not depend on timing, so sums stay bitwise reproducible) that all wavefronts drain
 // together afterwards (drain_queue).
-template <int MODE, bool MED3>
+template <int MODE>
 __device__ inline void list_pass(const ListPtrs &lp, const ModelView &mv, const FitArgs &fa, const Pose &T, int n, int nga,
                                  int p0, const double2 P, double acc[kNumAcc], unsigned *wave_cnt, unsigned short *queue,
                                  int &fell_back, int tid, int &lseed)
@@ -302,7 +291,7 @@ __device__ inline void list_pass(const ListPtrs &lp, const ModelView &mv, const 
         Best   b;
         float2 m;
         transform_query(T, P, qx, qy);
-        done = list_search<MED3>(b, m, lp, mv, cls, qx, qy, lseed);
+        done = list_search(b, m, lp, mv, cls, qx, qy, lseed);
         lseed = done ? b.pos : -1;
         if (MODE == SLAM_ICP_P2L) { // icpPointToPlane.cpp:55-77: every template point, no gate
             if (done) add_p2l(m, mv.lnormals[mv.lbase[1] + b.pos], qx, qy, acc);
@@ -387,7 +376,7 @@ __device__ inline void drain_queue(const IndexPtrs<StartT> &ix, const ListPtrs &
 
 // One scene point, searched by GG lanes (sub = lane within that group); the
 // group's lane 0 adds the correspondence to its running sums.
-template <int GG, typename StartT, int MODE, bool SEEDED = false>
+template <int GG, typename StartT, int MODE, bool SEEDED = false, bool PK = false>
 __device__ inline void accumulate_point(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
                                         const Pose &T, const double2 P, bool is_ga, int sub, double acc[kNumAcc],
                                         int &far, int *seed = nullptr, float *empty = nullptr, float move_r = 0.f, float move_t = 0.f)
@@ -401,11 +390,11 @@ __device__ inline void accumulate_point(const IndexPtrs<StartT> &ix, const Model
             if (SEEDED) { // last iteration's neighbour of this scene point prunes the search from the start
                 const float move = move_r * (fabsf((float)P.x) + fabsf((float)P.y) + 1.0e-3f) + move_t;
                 float       e_out;
-                b = nn_search_seeded<GG, StartT>(ix, mv, cls, qx, qy, sub, fa.indist, *seed, kSeedEmpty ? *empty : 0.0f, move, e_out);
+                b = nn_search_seeded<GG, StartT, PK>(ix, mv, cls, qx, qy, sub, fa.indist, *seed, kSeedEmpty ? *empty : 0.0f, move, e_out);
                 *seed = b.pos;
                 *empty = e_out;
             } else {
-                b = nn_search<GG, StartT>(ix, mv, cls, qx, qy, sub, fa.indist);
+                b = nn_search<GG, StartT, PK>(ix, mv, cls, qx, qy, sub, fa.indist);
             }
             if (sub == 0 && b.pos >= 0 && (double)b.d < fa.indist) add_p2p<StartT>(ix, mv, cls, b, qx, qy, acc); // :76
             far += (sub == 0 && !(b.pos >= 0 && b.d < mv.cert2)) ? 1 : 0; // beyond what the halo lists certify
@@ -415,10 +404,10 @@ __device__ inline void accumulate_point(const IndexPtrs<StartT> &ix, const Model
         Best b;
         if (SEEDED) {
             float e_out;
-            b = nn_search_seeded<GG, StartT>(ix, mv, 1, qx, qy, sub, (double)INFINITY, *seed, 0.0f, 0.0f, e_out);
+            b = nn_search_seeded<GG, StartT, PK>(ix, mv, 1, qx, qy, sub, (double)INFINITY, *seed, 0.0f, 0.0f, e_out);
             *seed = b.pos;
         } else {
-            b = nn_search<GG, StartT>(ix, mv, 1, qx, qy, sub, (double)INFINITY);
+            b = nn_search<GG, StartT, PK>(ix, mv, 1, qx, qy, sub, (double)INFINITY);
         }
         if (sub == 0 && b.pos >= 0)
             add_p2l(ix.pts[mv.base[1] + b.pos], reinterpret_cast<const double2 *>(mv.normals)[b.oidx], qx, qy, acc);
@@ -438,16 +427,16 @@ __device__ inline void point_pass(const IndexPtrs<StartT> &ix, const ModelView &
 
 // The same with the lane's point already in registers (the first kHoist passes: a lane meets the same
 // points in every iteration, so they are loaded once per scan, not once per iteration).
-template <int GG, typename StartT, int MODE>
+template <int GG, typename StartT, int MODE, bool PK = false>
 __device__ inline void point_pass_reg(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
                                       const Pose &T, int n, int nga, int p, const double2 P, double acc[kNumAcc],
                                       int &far, int tid, int *seed = nullptr, float *empty = nullptr, float move_r = 0.f, float move_t = 0.f)
 {
     if (p < n) {
         if (seed)
-            accumulate_point<GG, StartT, MODE, true>(ix, mv, fa, T, P, p < nga, tid % GG, acc, far, seed, empty, move_r, move_t);
+            accumulate_point<GG, StartT, MODE, true, PK>(ix, mv, fa, T, P, p < nga, tid % GG, acc, far, seed, empty, move_r, move_t);
         else
-            accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, P, p < nga, tid % GG, acc, far);
+            accumulate_point<GG, StartT, MODE, false, PK>(ix, mv, fa, T, P, p < nga, tid % GG, acc, far);
     }
 }
 
@@ -540,7 +529,7 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                         const double2 P = (pass == 0 && kKeepPoint) ? Pc0 : (p0 + tid < n ? fa.pts[off + p0 + tid] : Pc0);
                         // (the lane's entry of the iteration before, per pass: the ring form's seed registers are free here)
                         int ls = kListSeed ? (pass == 0 ? sd0 : (pass == 1 ? sd1 : -1)) : -1;
-                        list_pass<MODE, (TB < icp::kBlock)>(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back, tid, ls);
+                        list_pass<MODE>(lp, mv, fa, T, n, nga, p0, P, acc, wave_cnt, queue, fell_back, tid, ls);
                         if (kListSeed) sd0 = pass == 0 ? ls : sd0, sd1 = pass == 1 ? ls : sd1;
                         tail = rem - kBlock;
                         tail = tail > 0 && tail <= kCoopPerBlock ? tail : 0;
@@ -568,12 +557,12 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                             const bool same_cls = MODE == SLAM_ICP_P2L || ((p - 1 < nga) == (p < nga));
                             if (sd < 0 && pass > 0 && same_cls) sd = chain;
                         }
-                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p, P, acc, far, tid, &sd, &em, move_r, move_t);
+                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE, kTunedScan>(ix, mv, fa, T, n, nga, p, P, acc, far, tid, &sd, &em, move_r, move_t);
                         sd0 = pass == 0 ? sd : sd0, sd1 = pass == 1 ? sd : sd1, sd2 = pass == 2 ? sd : sd2;
                         if (kSeedEmpty) em0 = pass == 0 ? em : em0, em1 = pass == 1 ? em : em1, em2 = pass == 2 ? em : em2;
                         chain = p < n ? sd : -1;
                     } else {
-                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE>(ix, mv, fa, T, n, nga, p, P, acc, far, tid);
+                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE, kTunedScan>(ix, mv, fa, T, n, nga, p, P, acc, far, tid);
                     }
                     p0 += kBlock / (G > 0 ? G : 1);
                 } else if (rem * 2 > kBlock) {

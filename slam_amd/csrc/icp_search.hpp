@@ -22,6 +22,48 @@ __device__ inline float dist2(const float2 m, float qx, float qy)
     return __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
 }
 
+// The same value for the loops that scan a cell range four candidates at a time: written on two-element vectors so that the
+// difference and the squares are ONE packed instruction each (v_pk_add_f32, v_pk_mul_f32: a model point is an aligned register
+// pair as it comes from ds_read_b64 / global_load_dwordx2), and the sum as an instruction of its own -- left to itself the
+// vectoriser packs across neighbouring candidates instead and pays three register moves per pair (16 instructions per four
+// candidates; 12 this way).  Every operation is an IEEE single operation as before (-ffp-contract=off: nothing is fused).
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ inline float dist2p(const float2 m, float qx, float qy)
+{
+    const v2f p = {m.x, m.y}, q = {qx, qy};
+    const v2f dl = p - q;
+    const v2f sq = dl * dl;
+    float     r;
+    asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(sq.x), "v"(sq.y));
+    return r;
+}
+// One candidate of a fast (EXACT = false) scan in the second-best form: best, its position, and the SECOND best of everything this
+// call has examined together with the best it was given -- one v_med3_f32 where the flag form spends a compare, an AND and an OR.
+// An exact tie is second == best when the call ends (scan_tie); a tie between candidates that were both beaten later is no tie.
+__device__ inline void scan_step(Best &b, float &d2nd, float d, int i)
+{
+    d2nd = __builtin_amdgcn_fmed3f(b.d, d, d2nd);
+    const bool up = d < b.d;
+    b.d = up ? d : b.d;
+    b.pos = up ? i : b.pos;
+}
+__device__ inline bool scan_tie(const Best &b, float d2nd) { return (d2nd == b.d) & (b.pos >= 0); }
+// A seeded search in this form starts from the seed's distance ONE ULP UP (d >= 0: the next float is the next integer pattern): the
+// seed is met again by whichever lane's share of a span holds it -- every cell the disk of its distance touches is scanned -- and
+// must then beat the starting value instead of equalling it (which would read as a tie with itself).
+__device__ inline float ulp_above(float d) { return __int_as_float(__float_as_int(d) + 1); }
+
+// PK: which forms a fast scan uses -- false: dist2, minimum tree of four, tie flag (what rounds 1-3 ran; the spread form, the
+// cooperative rounds, the normals and slam_icp_nearest still do); true: dist2p, scan_step / scan_tie (the batch kernels' ring passes).
+// Measured one by one on config 2's scans (tools/pair_time.py, 256 scans in pairs / one per workgroup): the list form's second best
+// 0.629 -> 0.612 / 0.394 -> 0.400; + packed distances 0.603 / 0.397; + second best in the ring scans **0.583 / 0.375 ms** (1024 scans in
+// pairs 1.207 -> 1.122) -- the first two alone cost the one-scan-per-workgroup kernels a per cent each, all three together gain 4.6.
+template <bool PK>
+__device__ inline float dist2s(const float2 m, float qx, float qy)
+{
+    return PK ? dist2p(m, qx, qy) : dist2(m, qx, qy);
+}
+
 // Candidate i at squared distance d.  Ties go to the lowest ORIGINAL index (the
 // reference leaves ties to the kd-tree's visit order; this is the brute-force
 // arbiter's rule, kdtree.cpp:360-375): the index is only read when d == best.
@@ -42,14 +84,15 @@ __device__ inline void consider(Best &b, float d, int i, const StartT *oidx)
 // EXACT = false is the fast form: branch-free minimum by (distance, position)
 // plus a flag that says whether an exact tie d == best was ever seen; the
 // caller then repeats the search with EXACT = true (ties by original index).
-template <int G, typename StartT, bool EXACT>
+template <int G, typename StartT, bool EXACT, bool PK = false>
 __device__ inline void scan_range(Best &b, bool &tie, const float2 *pts, const StartT *oidx, int a, int e, int sub, float qx,
                                   float qy)
 {
-    int i = a + sub;
+    int   i = a + sub;
+    float d2nd = FLT_MAX;
     for (; i + 3 * G < e; i += 4 * G) {
         const float2 m0 = pts[i], m1 = pts[i + G], m2 = pts[i + 2 * G], m3 = pts[i + 3 * G];
-        const float  d0 = dist2(m0, qx, qy), d1 = dist2(m1, qx, qy), d2 = dist2(m2, qx, qy), d3 = dist2(m3, qx, qy);
+        const float  d0 = dist2s<PK>(m0, qx, qy), d1 = dist2s<PK>(m1, qx, qy), d2 = dist2s<PK>(m2, qx, qy), d3 = dist2s<PK>(m3, qx, qy);
         if (EXACT) {
             if (fminf(fminf(d0, d1), fminf(d2, d3)) <= b.d) {
                 consider<StartT>(b, d0, i, oidx);
@@ -57,6 +100,11 @@ __device__ inline void scan_range(Best &b, bool &tie, const float2 *pts, const S
                 consider<StartT>(b, d2, i + 2 * G, oidx);
                 consider<StartT>(b, d3, i + 3 * G, oidx);
             }
+        } else if (PK) {
+            scan_step(b, d2nd, d0, i);
+            scan_step(b, d2nd, d1, i + G);
+            scan_step(b, d2nd, d2, i + 2 * G);
+            scan_step(b, d2nd, d3, i + 3 * G);
         } else {
             // min of the four (first position wins), then one compare against the running best
             const bool  s01 = d1 < d0, s23 = d3 < d2;
@@ -75,6 +123,8 @@ __device__ inline void scan_range(Best &b, bool &tie, const float2 *pts, const S
         const float d = dist2(pts[i], qx, qy);
         if (EXACT) {
             consider<StartT>(b, d, i, oidx);
+        } else if (PK) {
+            scan_step(b, d2nd, d, i);
         } else {
             tie |= (d == b.d);
             const bool up = d < b.d;
@@ -82,14 +132,15 @@ __device__ inline void scan_range(Best &b, bool &tie, const float2 *pts, const S
             b.pos = up ? i : b.pos;
         }
     }
+    if (!EXACT && PK) tie |= scan_tie(b, d2nd);
 }
 
-template <int G, typename StartT, bool EXACT>
+template <int G, typename StartT, bool EXACT, bool PK = false>
 __device__ inline void scan_span(Best &b, bool &tie, const StartT *start, const float2 *pts, const StartT *oidx,
                                  int row_base, int c0, int c1, int sub, float qx, float qy)
 {
     if (c0 > c1) return;
-    scan_range<G, StartT, EXACT>(b, tie, pts, oidx, (int)start[row_base + c0], (int)start[row_base + c1 + 1], sub, qx, qy);
+    scan_range<G, StartT, EXACT, PK>(b, tie, pts, oidx, (int)start[row_base + c0], (int)start[row_base + c1 + 1], sub, qx, qy);
 }
 
 // Fast-path minimum over the G lanes of a group: (distance, position) only, on the DPP cross-lane path for
@@ -146,18 +197,18 @@ __device__ inline void group_min(Best &b, const StartT *oidx)
     }
 }
 
-template <int G, typename StartT, bool EXACT>
+template <int G, typename StartT, bool EXACT, bool PK = false>
 __device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, float qx, float qy,
                                       int sub, double gate, bool &tie);
 
 // The search proper: fast pass, and the exact pass only for a group that met an
 // exact distance tie (measure zero on noisy data, common on gridded maps).
-template <int G, typename StartT>
+template <int G, typename StartT, bool PK = false>
 __device__ inline Best nn_search(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls,
                                  float qx, float qy, int sub, double gate)
 {
     bool tie = false;
-    Best b = nn_search_impl<G, StartT, false>(ix, mv, cls, qx, qy, sub, gate, tie); // `tie` is group-wide
+    Best b = nn_search_impl<G, StartT, false, PK>(ix, mv, cls, qx, qy, sub, gate, tie); // `tie` is group-wide
     if (tie) {
         bool unused = false;
         b = nn_search_impl<G, StartT, true>(ix, mv, cls, qx, qy, sub, gate, unused);
@@ -179,7 +230,7 @@ __device__ inline Best nn_search(const IndexPtrs<StartT> &ix, const ModelView &m
 // is below the distance to the ring's outer edge (minus a margin that absorbs
 // the f32 rounding of the cell assignment), when that edge is beyond the
 // inlier gate, or when the ring covers the whole lattice.
-template <int G, typename StartT, bool EXACT>
+template <int G, typename StartT, bool EXACT, bool PK>
 __device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls,
                                       float qx, float qy, int sub, double gate, bool &tie)
 {
@@ -198,7 +249,7 @@ __device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelVi
     const int   cx = clampi((int)floorf(fx), 0, L.nx - 1);
     const int   cy = clampi((int)floorf(fy), 0, L.ny - 1);
 
-    scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, cy * L.nx, cx, cx, sub, qx, qy);
+    scan_span<G, StartT, EXACT, PK>(b, tie, start, pts, oidx, cy * L.nx, cx, cx, sub, qx, qy);
     if (G > 1) {
         if (EXACT)
             group_min<G, StartT>(b, oidx);
@@ -223,10 +274,10 @@ __device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelVi
         for (int y = y_lo; y <= y_hi; ++y) {
             const int row = y * L.nx;
             if (y >= cy - rp && y <= cy + rp) {
-                scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, row, x_lo, min(x_hi, cx - rp - 1), sub, qx, qy);
-                scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, row, max(x_lo, cx + rp + 1), x_hi, sub, qx, qy);
+                scan_span<G, StartT, EXACT, PK>(b, tie, start, pts, oidx, row, x_lo, min(x_hi, cx - rp - 1), sub, qx, qy);
+                scan_span<G, StartT, EXACT, PK>(b, tie, start, pts, oidx, row, max(x_lo, cx + rp + 1), x_hi, sub, qx, qy);
             } else {
-                scan_span<G, StartT, EXACT>(b, tie, start, pts, oidx, row, x_lo, x_hi, sub, qx, qy);
+                scan_span<G, StartT, EXACT, PK>(b, tie, start, pts, oidx, row, x_lo, x_hi, sub, qx, qy);
             }
         }
         if (G > 1) {
@@ -248,14 +299,15 @@ __device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelVi
 // scan_range with the number of lanes that share the span known only at run time.  Seed-aware: the running
 // best may be a point of this very span (a search seeded with last iteration's neighbour meets it again), which
 // is not a tie.
-template <typename StartT, bool EXACT>
+template <typename StartT, bool EXACT, bool PK = false>
 __device__ inline void scan_range_rt(Best &b, bool &tie, const float2 *pts, const StartT *oidx, int a, int e, int sub, int G,
                                      float qx, float qy)
 {
-    int i = a + sub;
+    int   i = a + sub;
+    float d2nd = FLT_MAX;
     for (; i + 3 * G < e; i += 4 * G) {
         const float2 m0 = pts[i], m1 = pts[i + G], m2 = pts[i + 2 * G], m3 = pts[i + 3 * G];
-        const float  d0 = dist2(m0, qx, qy), d1 = dist2(m1, qx, qy), d2 = dist2(m2, qx, qy), d3 = dist2(m3, qx, qy);
+        const float  d0 = dist2s<PK>(m0, qx, qy), d1 = dist2s<PK>(m1, qx, qy), d2 = dist2s<PK>(m2, qx, qy), d3 = dist2s<PK>(m3, qx, qy);
         if (EXACT) {
             if (fminf(fminf(d0, d1), fminf(d2, d3)) <= b.d) {
                 consider<StartT>(b, d0, i, oidx);
@@ -263,6 +315,11 @@ __device__ inline void scan_range_rt(Best &b, bool &tie, const float2 *pts, cons
                 consider<StartT>(b, d2, i + 2 * G, oidx);
                 consider<StartT>(b, d3, i + 3 * G, oidx);
             }
+        } else if (PK) { // (the caller has put a seed's distance one ulp up: meeting the seed again is an update, not a tie)
+            scan_step(b, d2nd, d0, i);
+            scan_step(b, d2nd, d1, i + G);
+            scan_step(b, d2nd, d2, i + 2 * G);
+            scan_step(b, d2nd, d3, i + 3 * G);
         } else {
             const bool  s01 = d1 < d0, s23 = d3 < d2;
             const float m01 = s01 ? d1 : d0, m23 = s23 ? d3 : d2;
@@ -280,6 +337,8 @@ __device__ inline void scan_range_rt(Best &b, bool &tie, const float2 *pts, cons
         const float d = dist2(pts[i], qx, qy);
         if (EXACT) {
             consider<StartT>(b, d, i, oidx);
+        } else if (PK) {
+            scan_step(b, d2nd, d, i);
         } else {
             tie |= (d == b.d) & (i != b.pos);
             const bool up = d < b.d;
@@ -287,6 +346,7 @@ __device__ inline void scan_range_rt(Best &b, bool &tie, const float2 *pts, cons
             b.pos = up ? i : b.pos;
         }
     }
+    if (!EXACT && PK) tie |= scan_tie(b, d2nd);
 }
 
 // A long span by all G lanes of the group, eight loads in flight per lane (a span of thousands of points is a
@@ -322,7 +382,7 @@ __device__ inline void scan_range_deep(Best &b, bool &tie, const float2 *pts, co
 // unseeded search reads its first non-empty ring whole.  When that disk touches at most 3 x 3 cells they are
 // read in one pass and the search is over (every cell the disk touches has been seen); otherwise the rings run
 // as usual from the seeded best.  Same result as nn_search.
-template <int G, typename StartT, bool EXACT>
+template <int G, typename StartT, bool EXACT, bool PK = false>
 __device__ inline Best nn_search_seeded_impl(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, float qx, float qy,
                                              int sub, double gate, bool &tie, int seed, float empty_in, float move, float &empty_out)
 {
@@ -343,13 +403,14 @@ __device__ inline Best nn_search_seeded_impl(const IndexPtrs<StartT> &ix, const 
     const int   cy = clampi((int)floorf(fy), 0, L.ny - 1);
     if (seed >= 0) {
         b.d = dist2(pts[seed], qx, qy);
+        if (PK && !EXACT) b.d = ulp_above(b.d);
         b.pos = seed;
         const float R = (__fsqrt_rn(b.d) + L.margin) * L.inv_h;
         const int   x_lo = max(0, (int)floorf(fx - R)), x_hi = min(L.nx - 1, (int)floorf(fx + R));
         const int   y_lo = max(0, (int)floorf(fy - R)), y_hi = min(L.ny - 1, (int)floorf(fy + R));
         if (x_hi - x_lo <= 2 && y_hi - y_lo <= 2 && x_lo <= x_hi && y_lo <= y_hi) {
             for (int y = y_lo; y <= y_hi; ++y)
-                scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, (int)start[y * L.nx + x_lo], (int)start[y * L.nx + x_hi + 1], sub, G, qx, qy);
+                scan_range_rt<StartT, EXACT, PK>(b, tie, pts, oidx, (int)start[y * L.nx + x_lo], (int)start[y * L.nx + x_hi + 1], sub, G, qx, qy);
             if (G > 1) {
                 if (EXACT)
                     group_min<G, StartT>(b, oidx);
@@ -368,7 +429,7 @@ __device__ inline Best nn_search_seeded_impl(const IndexPtrs<StartT> &ix, const 
         if (D > 0.0f) rp = (int)floorf(fminf(D * L.inv_h * 0.70710677f, (float)(L.nx + L.ny))) - 1;
     }
     if (rp < 0) { // the usual start: the query's own cell
-        scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, (int)start[cy * L.nx + cx], (int)start[cy * L.nx + cx + 1], sub, G, qx, qy);
+        scan_range_rt<StartT, EXACT, PK>(b, tie, pts, oidx, (int)start[cy * L.nx + cx], (int)start[cy * L.nx + cx + 1], sub, G, qx, qy);
         if (G > 1) {
             if (EXACT)
                 group_min<G, StartT>(b, oidx);
@@ -394,10 +455,10 @@ __device__ inline Best nn_search_seeded_impl(const IndexPtrs<StartT> &ix, const 
             const int row = y * L.nx;
             if (y >= cy - rp && y <= cy + rp) {
                 const int l1 = min(x_hi, cx - rp - 1), f2 = max(x_lo, cx + rp + 1);
-                if (x_lo <= l1) scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, (int)start[row + x_lo], (int)start[row + l1 + 1], sub, G, qx, qy);
-                if (f2 <= x_hi) scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, (int)start[row + f2], (int)start[row + x_hi + 1], sub, G, qx, qy);
+                if (x_lo <= l1) scan_range_rt<StartT, EXACT, PK>(b, tie, pts, oidx, (int)start[row + x_lo], (int)start[row + l1 + 1], sub, G, qx, qy);
+                if (f2 <= x_hi) scan_range_rt<StartT, EXACT, PK>(b, tie, pts, oidx, (int)start[row + f2], (int)start[row + x_hi + 1], sub, G, qx, qy);
             } else if (x_lo <= x_hi) {
-                scan_range_rt<StartT, EXACT>(b, tie, pts, oidx, (int)start[row + x_lo], (int)start[row + x_hi + 1], sub, G, qx, qy);
+                scan_range_rt<StartT, EXACT, PK>(b, tie, pts, oidx, (int)start[row + x_lo], (int)start[row + x_hi + 1], sub, G, qx, qy);
             }
         }
         if (G > 1) {
@@ -420,12 +481,12 @@ __device__ inline Best nn_search_seeded_impl(const IndexPtrs<StartT> &ix, const 
     return b;
 }
 
-template <int G, typename StartT>
+template <int G, typename StartT, bool PK = false>
 __device__ inline Best nn_search_seeded(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, float qx, float qy, int sub,
                                         double gate, int seed, float empty_in, float move, float &empty_out)
 {
     bool tie = false;
-    Best b = nn_search_seeded_impl<G, StartT, false>(ix, mv, cls, qx, qy, sub, gate, tie, seed, empty_in, move, empty_out);
+    Best b = nn_search_seeded_impl<G, StartT, false, PK>(ix, mv, cls, qx, qy, sub, gate, tie, seed, empty_in, move, empty_out);
     if (tie) { // rare: the plain exact search (the seed changes the cost of a search, never its result)
         bool unused = false;
         b = nn_search_impl<G, StartT, true>(ix, mv, cls, qx, qy, sub, gate, unused);
