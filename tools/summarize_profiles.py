@@ -149,6 +149,17 @@ for name in ("bench.json", "config3.json", "config4.json", "config5.json", "buil
                     if "run_csrc_sha256" in o and "stale" in o:
                         o["profile_csrc_sha256"] = csrc_sha()
                         o["stale"] = o["run_csrc_sha256"] != csrc_sha()
+                    # ... and the counter-derived figures of a roofline block are those of the summary written above, not of the
+                    # one that was committed when the line was taken
+                    v_ = o.get("valu")
+                    if isinstance(v_, dict) and "kernel" in o and v_.get("source") and v_.get("run_csrc_sha256") == csrc_sha():
+                        tf = os.path.join(dst, os.path.basename(v_["source"]))
+                        k_ = json.load(open(tf)).get(o["kernel"].split(" ")[0], {}) if os.path.exists(tf) else {}
+                        busy, lanes = k_.get("valu_busy_frac"), k_.get("valu_active_lane_share")
+                        if busy is not None and lanes is not None:
+                            held = v_.get("cus_held_by_one_launch") or 256
+                            v_.update(busy_frac=busy, active_lane_share=lanes, frac=busy * lanes, frac_on_held_cus=busy * lanes * 256 / held)
+                            o["traffic"] = k_.get("hbm_bytes_per_launch")
                     for v in o.values():
                         restate(v)
                 elif isinstance(o, list):
