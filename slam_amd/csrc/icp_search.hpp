@@ -64,6 +64,19 @@ __device__ inline float dist2s(const float2 m, float qx, float qy)
     return PK ? dist2p(m, qx, qy) : dist2(m, qx, qy);
 }
 
+// (int)floorf(x) as the ONE instruction the hardware has for it (v_cvt_flr_i32_f32: same value for every finite x in range, same
+// clamping outside, 0 for NaN; the compiler emits v_floor_f32 + v_cvt_i32_f32).
+__device__ inline int ifloor(float x)
+{
+    int r;
+    asm("v_cvt_flr_i32_f32_e32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// The radius of the disk a search still has to look at, from the best SQUARED distance: the hardware's v_sqrt_f32 as it is (one ulp;
+// the correctly rounded sqrtf is six instructions around it) -- the lattice margin (h / 1024 and more) is what makes the disk safe.
+__device__ inline float disk_radius(float d2) { return __builtin_amdgcn_sqrtf(d2); }
+
 // Candidate i at squared distance d.  Ties go to the lowest ORIGINAL index (the
 // reference leaves ties to the kd-tree's visit order; this is the brute-force
 // arbiter's rule, kdtree.cpp:360-375): the index is only read when d == best.
@@ -246,8 +259,8 @@ __device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelVi
     if (mv.n_cls[cls] <= 0) return b;
 
     const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
-    const int   cx = clampi((int)floorf(fx), 0, L.nx - 1);
-    const int   cy = clampi((int)floorf(fy), 0, L.ny - 1);
+    const int   cx = clampi(ifloor(fx), 0, L.nx - 1);
+    const int   cy = clampi(ifloor(fy), 0, L.ny - 1);
 
     scan_span<G, StartT, EXACT, PK>(b, tie, start, pts, oidx, cy * L.nx, cx, cx, sub, qx, qy);
     if (G > 1) {
@@ -265,11 +278,11 @@ __device__ inline Best nn_search_impl(const IndexPtrs<StartT> &ix, const ModelVi
         const bool covers = (x_lo == 0) & (y_lo == 0) & (x_hi == L.nx - 1) & (y_hi == L.ny - 1);
         if (b.d < FLT_MAX) {
             // points of a column (row) above cell(q + R) have x (y) > q + R: the cell map is monotone
-            const float R = (__fsqrt_rn(b.d) + L.margin) * L.inv_h;
-            x_lo = max(x_lo, (int)floorf(fx - R));
-            x_hi = min(x_hi, (int)floorf(fx + R));
-            y_lo = max(y_lo, (int)floorf(fy - R));
-            y_hi = min(y_hi, (int)floorf(fy + R));
+            const float R = (disk_radius(b.d) + L.margin) * L.inv_h;
+            x_lo = max(x_lo, ifloor(fx - R));
+            x_hi = min(x_hi, ifloor(fx + R));
+            y_lo = max(y_lo, ifloor(fy - R));
+            y_hi = min(y_hi, ifloor(fy + R));
         }
         for (int y = y_lo; y <= y_hi; ++y) {
             const int row = y * L.nx;
@@ -399,15 +412,15 @@ __device__ inline Best nn_search_seeded_impl(const IndexPtrs<StartT> &ix, const 
     if (mv.n_cls[cls] <= 0) return b;
 
     const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
-    const int   cx = clampi((int)floorf(fx), 0, L.nx - 1);
-    const int   cy = clampi((int)floorf(fy), 0, L.ny - 1);
+    const int   cx = clampi(ifloor(fx), 0, L.nx - 1);
+    const int   cy = clampi(ifloor(fy), 0, L.ny - 1);
     if (seed >= 0) {
         b.d = dist2(pts[seed], qx, qy);
         if (PK && !EXACT) b.d = ulp_above(b.d);
         b.pos = seed;
-        const float R = (__fsqrt_rn(b.d) + L.margin) * L.inv_h;
-        const int   x_lo = max(0, (int)floorf(fx - R)), x_hi = min(L.nx - 1, (int)floorf(fx + R));
-        const int   y_lo = max(0, (int)floorf(fy - R)), y_hi = min(L.ny - 1, (int)floorf(fy + R));
+        const float R = (disk_radius(b.d) + L.margin) * L.inv_h;
+        const int   x_lo = max(0, ifloor(fx - R)), x_hi = min(L.nx - 1, ifloor(fx + R));
+        const int   y_lo = max(0, ifloor(fy - R)), y_hi = min(L.ny - 1, ifloor(fy + R));
         if (x_hi - x_lo <= 2 && y_hi - y_lo <= 2 && x_lo <= x_hi && y_lo <= y_hi) {
             for (int y = y_lo; y <= y_hi; ++y)
                 scan_range_rt<StartT, EXACT, PK>(b, tie, pts, oidx, (int)start[y * L.nx + x_lo], (int)start[y * L.nx + x_hi + 1], sub, G, qx, qy);
@@ -426,7 +439,7 @@ __device__ inline Best nn_search_seeded_impl(const IndexPtrs<StartT> &ix, const 
     int rp = -1, r = 0;
     if (empty_in > 0.0f && fx >= 0.0f && fx < (float)L.nx && fy >= 0.0f && fy < (float)L.ny) {
         const float D = empty_in - move - 2.0f * L.margin;
-        if (D > 0.0f) rp = (int)floorf(fminf(D * L.inv_h * 0.70710677f, (float)(L.nx + L.ny))) - 1;
+        if (D > 0.0f) rp = ifloor(fminf(D * L.inv_h * 0.70710677f, (float)(L.nx + L.ny))) - 1;
     }
     if (rp < 0) { // the usual start: the query's own cell
         scan_range_rt<StartT, EXACT, PK>(b, tie, pts, oidx, (int)start[cy * L.nx + cx], (int)start[cy * L.nx + cx + 1], sub, G, qx, qy);
@@ -445,11 +458,11 @@ __device__ inline Best nn_search_seeded_impl(const IndexPtrs<StartT> &ix, const 
         int x_lo = max(cx - r, 0), x_hi = min(cx + r, L.nx - 1);
         const bool covers = (x_lo == 0) & (y_lo == 0) & (x_hi == L.nx - 1) & (y_hi == L.ny - 1);
         if (b.d < FLT_MAX) {
-            const float R = (__fsqrt_rn(b.d) + L.margin) * L.inv_h;
-            x_lo = max(x_lo, (int)floorf(fx - R));
-            x_hi = min(x_hi, (int)floorf(fx + R));
-            y_lo = max(y_lo, (int)floorf(fy - R));
-            y_hi = min(y_hi, (int)floorf(fy + R));
+            const float R = (disk_radius(b.d) + L.margin) * L.inv_h;
+            x_lo = max(x_lo, ifloor(fx - R));
+            x_hi = min(x_hi, ifloor(fx + R));
+            y_lo = max(y_lo, ifloor(fy - R));
+            y_hi = min(y_hi, ifloor(fy + R));
         }
         for (int y = y_lo; y <= y_hi; ++y) {
             const int row = y * L.nx;
@@ -531,8 +544,8 @@ __device__ inline Best nn_search_rows_impl(const IndexPtrs<StartT> &ix, const Mo
     if (mv.n_cls[cls] <= 0) return b;
 
     const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
-    const int   cx = clampi((int)floorf(fx), 0, L.nx - 1);
-    const int   cy = clampi((int)floorf(fy), 0, L.ny - 1);
+    const int   cx = clampi(ifloor(fx), 0, L.nx - 1);
+    const int   cy = clampi(ifloor(fy), 0, L.ny - 1);
     const int   group_base = ((int)threadIdx.x & 63) & ~(G - 1); // first lane of this query's group in the wavefront
 
     int rp = -1, r = 1; // radius of the square already known (visited or proven empty), radius of the next level
@@ -551,7 +564,7 @@ __device__ inline Best nn_search_rows_impl(const IndexPtrs<StartT> &ix, const Mo
         }
         if (D > 0.0f) {
             const float cells = fminf(D * L.inv_h * 0.70710677f, (float)(L.nx + L.ny)); // (rp + 1) h sqrt(2) <= D
-            rp = (int)floorf(cells) - 1;
+            rp = ifloor(cells) - 1;
             if (rp >= 0) r = rp + 1;
         }
     }
@@ -566,11 +579,11 @@ __device__ inline Best nn_search_rows_impl(const IndexPtrs<StartT> &ix, const Mo
         int x_lo = max(cx - r, 0), x_hi = min(cx + r, L.nx - 1);
         const bool covers = (x_lo == 0) & (y_lo == 0) & (x_hi == L.nx - 1) & (y_hi == L.ny - 1);
         if (b.d < FLT_MAX) {
-            const float R = (__fsqrt_rn(b.d) + L.margin) * L.inv_h;
-            x_lo = max(x_lo, (int)floorf(fx - R));
-            x_hi = min(x_hi, (int)floorf(fx + R));
-            y_lo = max(y_lo, (int)floorf(fy - R));
-            y_hi = min(y_hi, (int)floorf(fy + R));
+            const float R = (disk_radius(b.d) + L.margin) * L.inv_h;
+            x_lo = max(x_lo, ifloor(fx - R));
+            x_hi = min(x_hi, ifloor(fx + R));
+            y_lo = max(y_lo, ifloor(fy - R));
+            y_hi = min(y_hi, ifloor(fy + R));
         }
         const int nrows = y_hi - y_lo + 1;
         // lanes per row: the largest power of two that still gives every row of the level a slot (at least one)
@@ -868,10 +881,12 @@ __device__ inline void add_p2p_xy(const ModelView &mv, const float2 m, float qx,
     acc[2] += ay;
     acc[3] += bx;
     acc[4] += by;
-    acc[5] += bx * ax; // H[a][b] = sum q_t[a]*q_m[b]  (:159)
-    acc[6] += bx * ay;
-    acc[7] += by * ax;
-    acc[8] += by * ay;
+    // H[a][b] = sum q_t[a]*q_m[b] (:159).  Fused: one rounding per term instead of two -- the sums are compared with the reference's
+    // two-pass form within a tolerance either way (it centres first, this shifts by the model's centroid and corrects in p2p_step)
+    acc[5] = fma(bx, ax, acc[5]);
+    acc[6] = fma(bx, ay, acc[6]);
+    acc[7] = fma(by, ax, acc[7]);
+    acc[8] = fma(by, ay, acc[8]);
 }
 
 // icpPointToPlane.cpp:61-82: one correspondence of the point-to-line step -- model point d = m, its normal n, template
@@ -882,17 +897,18 @@ __device__ inline void add_p2l(const float2 m, const double2 nrm, float qx, floa
     const double nx = nrm.x, ny = nrm.y;
     const double dx = (double)m.x, dy = (double)m.y;
     const double sx = (double)qx, sy = (double)qy;
-    const double a0 = ny * sx - nx * sy, a1 = nx, a2 = ny;
-    const double bb = nx * dx + ny * dy - nx * sx - ny * sy;
-    acc[0] += a0 * a0;
-    acc[1] += a0 * a1;
-    acc[2] += a0 * a2;
-    acc[3] += a1 * a1;
-    acc[4] += a1 * a2;
-    acc[5] += a2 * a2;
-    acc[6] += a0 * bb;
-    acc[7] += a1 * bb;
-    acc[8] += a2 * bb;
+    // (fused multiply-adds: the row and b = n . (d - s) with one rounding per term, the nine sums likewise)
+    const double a0 = fma(ny, sx, -(nx * sy)), a1 = nx, a2 = ny;
+    const double bb = fma(nx, dx - sx, ny * (dy - sy));
+    acc[0] = fma(a0, a0, acc[0]);
+    acc[1] = fma(a0, a1, acc[1]);
+    acc[2] = fma(a0, a2, acc[2]);
+    acc[3] = fma(a1, a1, acc[3]);
+    acc[4] = fma(a1, a2, acc[4]);
+    acc[5] = fma(a2, a2, acc[5]);
+    acc[6] = fma(a0, bb, acc[6]);
+    acc[7] = fma(a1, bb, acc[7]);
+    acc[8] = fma(a2, bb, acc[8]);
 }
 
 // One point-to-line step from the nine sums S = {A^T A upper triangle, A^T b}: icpPointToPlane.cpp:80-107.  The 3x3
@@ -943,7 +959,7 @@ __device__ inline void normal_of_model_point(const ModelView &mv, int n, int pos
 #pragma unroll
     for (int j = 0; j < K; ++j) bd[j] = FLT_MAX, bi[j] = 0x7fffffff, bp[j] = -1;
     const float fx = (q.x - L.x0) * L.inv_h, fy = (q.y - L.y0) * L.inv_h;
-    const int   cx = clampi((int)floorf(fx), 0, L.nx - 1), cy = clampi((int)floorf(fy), 0, L.ny - 1);
+    const int   cx = clampi(ifloor(fx), 0, L.nx - 1), cy = clampi(ifloor(fy), 0, L.ny - 1);
     const bool  finite = q.x - q.x == 0.0f && q.y - q.y == 0.0f;
     auto        take = [&](int pos) {
         float d = dist2(pts[pos], q.x, q.y);
