@@ -90,6 +90,7 @@ int slam_event_create(slam_event_t *ev);
 int slam_event_destroy(slam_event_t ev);
 int slam_event_record(slam_event_t ev, slam_stream_t stream);
 int slam_event_synchronize(slam_event_t ev);
+int slam_event_query(slam_event_t ev, int *done);   /* hipEventQuery without blocking: *done = 1 when everything recorded before the event has finished (or it was never recorded) */
 int slam_event_elapsed_ms(slam_event_t start, slam_event_t stop, float *ms);
 
 /* ------------------------------------------------------------------- ICP

@@ -79,7 +79,7 @@ EXPORTS = [
     "slam_graph_launch", "slam_graph_destroy",
     "slam_stream_create", "slam_stream_create_with_priority", "slam_stream_create_reserving_cus", "slam_stream_destroy", "slam_stream_synchronize",
     "slam_device_synchronize", "slam_event_create", "slam_event_destroy", "slam_event_record",
-    "slam_event_synchronize", "slam_event_elapsed_ms",
+    "slam_event_synchronize", "slam_event_query", "slam_event_elapsed_ms",
     "slam_icp_default_params", "slam_icp_create", "slam_icp_create_dev", "slam_icp_destroy",
     "slam_icp_build_info", "slam_icp_index_blob",
     "slam_icp_set_max_iterations", "slam_icp_set_min_delta", "slam_icp_set_subsampling_step",
@@ -167,6 +167,7 @@ def lib():
     L.slam_event_destroy.argtypes = [_vp]
     L.slam_event_record.argtypes = [_vp, _vp]
     L.slam_event_synchronize.argtypes = [_vp]
+    L.slam_event_query.argtypes = [_vp, C.POINTER(C.c_int)]
     L.slam_event_elapsed_ms.argtypes = [_vp, _vp, C.POINTER(C.c_float)]
     L.slam_device_info.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_size_t)]
     L.slam_icp_create.argtypes = [_vp, C.c_int, _vp, C.c_int, C.POINTER(IcpParams), C.POINTER(_vp)]
@@ -439,6 +440,12 @@ class Event:
 
     def synchronize(self):
         check(lib().slam_event_synchronize(self.ptr))
+
+    def query(self):
+        """True when the work recorded before the event has finished (no wait)."""
+        d = C.c_int()
+        check(lib().slam_event_query(self.ptr, C.byref(d)))
+        return bool(d.value)
 
     def elapsed_ms(self, later):
         ms = C.c_float()

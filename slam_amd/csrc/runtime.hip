@@ -477,6 +477,20 @@ int slam_event_synchronize(slam_event_t ev)
     return SLAM_OK;
 }
 
+int slam_event_query(slam_event_t ev, int *done)
+{
+    SLAM_REQUIRE(done, SLAM_E_INVALID, "slam_event_query: null out pointer");
+    const hipError_t e = hipEventQuery((hipEvent_t)ev);
+    if (e == hipErrorNotReady) {
+        (void)hipGetLastError();
+        *done = 0;
+        return SLAM_OK;
+    }
+    SLAM_HIP(e);
+    *done = 1;
+    return SLAM_OK;
+}
+
 int slam_event_elapsed_ms(slam_event_t start, slam_event_t stop, float *ms)
 {
     SLAM_REQUIRE(ms, SLAM_E_INVALID, "slam_event_elapsed_ms: null out pointer");
