@@ -112,8 +112,12 @@ __device__ inline ListPtrs make_list_ptrs(const unsigned char *base, const Model
 // the same with the direction vector already in registers (one multiply-add pair per key, no selects)
 __device__ inline float list_key_u(float ux, float uy, float x, float y) { return __fadd_rn(__fmul_rn(ux, x), __fmul_rn(uy, y)); }
 
-constexpr int kListWin = 3;  // entries examined on either side of the refined start
-constexpr int kListWalk = 3; // further steps on either side before the query is left to the cooperative round
+// Entries examined on either side of the refined start, branch-free, and further steps on either side (a loop the whole wavefront
+// runs while any of its lanes needs it) before the query is left to the cooperative round.  Re-tuned in round 4 once a candidate
+// had become four instructions cheaper: a window of 7 / 9 / 11 / 13 entries -> 0.573 / 0.564 / 0.560 / 0.561 ms per launch of 256
+// scans in pairs (one scan per workgroup 0.373 / 0.368 / 0.366 / 0.363); 2 steps instead of 3: the same.
+constexpr int kListWin = 5;
+constexpr int kListWalk = 3;
 
 // An exact tie is noticed through the SECOND best of everything examined (one v_med3_f32 per candidate; a tie is second == best at
 // the end) -- round 4: the flag this replaced (set whenever a candidate equalled the best so far: a compare, an AND and an OR per
