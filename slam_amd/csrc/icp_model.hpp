@@ -16,7 +16,8 @@ constexpr int kNumAcc = 9;            // doubles reduced per iteration
 constexpr int kStampSlots = 9;        // diagnostic stamps per wavefront
 constexpr int kHoist = 3;             // passes whose points stay in registers across iterations
 constexpr unsigned kLdsTotal = 160u * 1024u;
-constexpr int kCoop = 8;                       // lanes per query in the cooperative rounds
+constexpr int kCoop = 4;                       // lanes per query in the cooperative rounds (8 until round 4: 256 scans in pairs
+                                               // 0.562 -> 0.548 ms; 2 lanes: 0.567 -- a scan's tail of 55 points is 14 queries per wavefront-round now)
 constexpr int kCoopPerWave = 64 / kCoop;       // queries a wavefront searches at a time
 constexpr int kCoopPerBlock = kWaves * kCoopPerWave;
 constexpr unsigned kReduceBytes = (2u * kWaves * kNumAcc + 2u * 8u) * sizeof(double); // reduction + broadcast
