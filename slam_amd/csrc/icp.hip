@@ -426,7 +426,7 @@ __device__ inline void point_pass(const IndexPtrs<StartT> &ix, const ModelView &
 {
     const int p = p0 + tid / GG;
     int       far = 0;
-    if (p < n) accumulate_point<GG, StartT, MODE>(ix, mv, fa, T, fa.pts[off + p], p < nga, tid % GG, acc, far);
+    if (p < n) accumulate_point<GG, StartT, MODE, false, kTunedScan>(ix, mv, fa, T, fa.pts[off + p], p < nga, tid % GG, acc, far);
 }
 
 // The same with the lane's point already in registers (the first kHoist passes: a lane meets the same
