@@ -610,8 +610,16 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
             if (wave == 0) {
                 const double *all = partial + (iter & 1) * kWaves * kNumAcc;
                 double        mine = 0.0;
-                if (lane < kNumAcc)
-                    for (int w = 0; w < kWaves; ++w) mine += all[w * kNumAcc + lane];
+                if (lane < kNumAcc) {
+                    // (all loads first, then the additions in the same fixed order: left as one loop the compiler waits for each
+                    // pair of partials before it adds them -- kWaves / 2 LDS round trips on the one wavefront everybody waits for)
+                    double v[kWaves];
+#pragma unroll
+                    for (int w = 0; w < kWaves; ++w) v[w] = all[w * kNumAcc + lane];
+                    __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): every partial has arrived
+#pragma unroll
+                    for (int w = 0; w < kWaves; ++w) mine += v[w];
+                }
                 double S[kNumAcc];
 #pragma unroll
                 for (int k = 0; k < kNumAcc; ++k)
