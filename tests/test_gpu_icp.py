@@ -560,3 +560,39 @@ def test_two_form_schedule_edge_iteration_counts(world):
         assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL
         assert np.abs(res["delta"] - delta).max() < 1e-9
         icp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("form", ["fused", "pairs", "ring", "lists", "per_pass"])
+def test_exact_ties_through_every_batch_form(form):
+    """A gridded model with duplicated points, queries that sit exactly between four model points (identity pose: the ties are
+    exact in float) or on a model point that exists twice: the fast scans notice a tie as second best == best (and a seeded search
+    meets its own seed again one ulp below its starting value, which is no tie), the exact pass settles it by the lowest ORIGINAL
+    index -- the brute-force arbiter's rule (kdtree.cpp:360-375).  Every launch form of the batch kernels, step by step."""
+    from test_gpu_icp_spread import check_against_oracle
+    kw = {"fused": dict(spread_scans=-1), "pairs": dict(spread_scans=-1, pair_scans=2), "ring": dict(spread_scans=-1, lanes_per_point=2),
+          "lists": dict(spread_scans=-1, lanes_per_point=-2), "per_pass": dict(spread_scans=-1, lanes_per_point=-1)}[form]
+    rs = np.random.RandomState(23)
+    gx, gy = np.meshgrid(np.arange(60) * 0.5, np.arange(40) * 0.5)
+    grid = np.stack([gx.ravel(), gy.ravel()], 1)
+    m_nga = np.concatenate([grid, grid[:600]])                 # the first 600 grid points exist twice
+    m_ga = np.concatenate([grid[1000:1400] + [0.25, 0.0], grid[1000:1100] + [0.25, 0.0]])
+    scans, nga, Rs, ts = [], [], [], []
+    for k in range(24):
+        kind = k % 3
+        pick = grid[rs.choice(len(grid), 400)]
+        if kind == 0:
+            pts, pose = pick + 0.25, (0.0, 0.0, 0.0)           # equidistant from four model points, identity pose
+        elif kind == 1:
+            pts, pose = pick.copy(), (0.0, 0.0, 0.0)           # on model points (some of them duplicated), identity pose
+        else:
+            pts, pose = pick + rs.randn(400, 2) * 0.03, (0.05, -0.04, 0.004)
+        n_ga = 60 if k % 2 else 0                                 # some scans carry class-GA points (their own, smaller model)
+        R0, t0 = synth.pose_to_Rt(*pose)
+        scans.append(pts); nga.append(n_ga); Rs.append(R0.reshape(4)); ts.append(t0)
+    off = np.cumsum([0] + [len(x) for x in scans]).astype(np.int32)
+    batch = synth.ScanBatch(np.ascontiguousarray(np.concatenate(scans)), off, np.array(nga, np.int32), np.array(Rs), np.array(ts),
+                            np.zeros((len(scans), 3)))
+    icp, R, t, res, tr = check_against_oracle(m_ga, m_nga, batch, 12, 1e-9, nn=O.NN_BRUTE, **kw)
+    assert (res["n_corr"] > 300).all()
+    icp.close()
