@@ -191,7 +191,8 @@ def single_scan_times(api, synth, m_ga, m_nga, **icp_kw):
 def stream_rate(api, synth, m_ga, m_nga, batch, grid_size, n_chunks=48, **kw):
     """The same batch fed from pinned host memory through the streaming mapper (H2D | ICP | raycast on three streams):
     seconds per chunk in steady state, PCIe inclusive."""
-    mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=grid_size, grid_size_y=grid_size,
+    mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20, raycast_wg_per_cu=kw.pop("raycast_wg_per_cu", 0)),
+                    grid_size_x=grid_size, grid_size_y=grid_size,
                     resolution=RES, max_scans=batch.n_scans, max_points=batch.n_points,
                     icp=dict(max_iter=N_ITERS, min_delta=-1.0), **kw)
     for s in [mp.push(batch) for _ in range(mp.n_slots)]:   # warm-up: every slot, every scratch buffer
@@ -455,7 +456,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip model build, single scan, streaming and config-3 legs")
     ap.add_argument("--raycast-seg", type=int, default=0, help="slam_grid_params::raycast_seg_items (0 = library default)")
-    ap.add_argument("--raycast-wg", type=int, default=0, help="slam_grid_params::raycast_wg_per_cu (0 = library default)")
+    ap.add_argument("--raycast-wg", type=int, default=None,
+                    help="slam_grid_params::raycast_wg_per_cu (0 = library default, two per CU: the fastest raycast call by itself).  "
+                         "Not given: 1 for config 2's pipelined step -- beside two registration launches half as many private copies of a "
+                         "hot tile are written back, which is worth more than the call's own 20 us: 50 steps, three runs each, point-to-"
+                         "point 0.3080 -> 0.3049 ms per step, point-to-line 0.3216 -> 0.3081 (its normals come from L2, which the "
+                         "write-backs sweep; tools/exp/rc_sweep.sh) -- and the library default for configs 4 and 5 and the streaming "
+                         "mapper, where it makes no difference (tools/exp/rc_sweep2.sh)")
     ap.add_argument("--raycast-max-wg", type=int, default=0, help="slam_grid_params::raycast_max_workgroups (0 = no cap)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not overlap the grid update of step k-1 with the registration of step k (one stream: a captured "
@@ -508,6 +515,8 @@ def main():
     ap.add_argument("--dry-launch", action="store_true",
                     help="print the launch `python bench.py --gpus N` would make of its N ranks (one JSON line) and exit")
     args = ap.parse_args()
+    if args.raycast_wg is None:
+        args.raycast_wg = 1 if (args.config == 2 and not args.no_pipeline) else 0
     S = args.scans or (1024 if args.config == 4 else N_SCANS)
     GRID = args.grid or (4000 if args.config == 4 else GRID)
 
@@ -1078,7 +1087,7 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, ba
     # the local map stays small enough for the index to live in LDS (about 10 k points): a 5 k-point prior map plus
     # at most 5 k points of the last four chunks
     m_ga, m_nga = synth.make_map(5000)
-    mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=GRID, grid_size_y=GRID,
+    mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20, raycast_wg_per_cu=args.raycast_wg), grid_size_x=GRID, grid_size_y=GRID,
                     resolution=RES, max_scans=chunk, max_points=max(c.n_points for c in chunks),
                     icp=dict(max_iter=N_ITERS, min_delta=-1.0, **(dict(mode=api.ICP_P2L, normals_k=10) if args.mode == "p2l" else {})),
                     window_chunks=args.window, rebuild_every=args.rebuild_every, keep_prior=1, target_points=5000,
