@@ -375,3 +375,28 @@ def test_finalize_reset_inside_a_replayed_graph():
     assert grids[0].total_updates() == grids[1].total_updates()
     for g in grids:
         g.close()
+
+
+@pytest.mark.gpu
+def test_event_query_does_not_block_and_tells_the_truth():
+    """slam_event_query: hipEventQuery behind the C-ABI -- false while the work recorded before the event runs, true once it has
+    finished, true for an event never recorded; what a caller that pipelines batches asks before it enqueues a wait packet."""
+    import time
+    g = api.Grid(2000, 2000, 0.05, rolling=0, min_cluster_points=20)
+    st, ev, fresh = api.Stream(), api.Event(), api.Event()
+    assert fresh.query() is True
+    rs = np.random.RandomState(3)
+    org = np.zeros((400000, 2), np.float32)
+    end = (rs.uniform(-45, 45, (400000, 2))).astype(np.float32)
+    d_org, d_end = api.DeviceArray.from_host(org, np.float32), api.DeviceArray.from_host(end, np.float32)
+    seen_false = False
+    for _ in range(20):                         # a few hundred microseconds of work per call: the query comes back while it runs
+        g.raycast_dev(d_org, d_end, len(end), st)
+    ev.record(st)
+    t0 = time.perf_counter()
+    while not ev.query():
+        seen_false = True
+        assert time.perf_counter() - t0 < 30.0
+    st.synchronize()
+    assert ev.query() is True and seen_false
+    g.close()
