@@ -229,7 +229,12 @@ def endpoint_inputs(api, synth, batch, R, t):
     seg = api.GroundSegmentation()
     lab = seg.segment(xyz)
     seg.close()
+    # ... and the kernel where neither the launch nor one hot wall bounds it: 8 M points spread over the grid's 100 m x 100 m
+    rs = np.random.RandomState(77)
+    wide = np.concatenate([rs.uniform(-49.9, 49.9, (8_000_000, 2)), np.zeros((8_000_000, 1))], 1).astype(np.float32)
     return [("config 2: the %d registered endpoints of the batch as obstacle points" % len(ends), ends, np.zeros((0, 3), np.float32)),
+            ("at size: 8 000 000 obstacle points spread uniformly over the grid (no hot wall, launch latency amortised)", wide,
+             np.zeros((0, 3), np.float32)),
             ("config 3: one 64-ring cloud, segmented: %d drv (obstacle) + %d ground points" %
              (int((lab == api.GSEG_OBSTACLE).sum()), int((lab == api.GSEG_GROUND).sum())),
              np.ascontiguousarray(xyz[lab == api.GSEG_OBSTACLE]), np.ascontiguousarray(xyz[lab == api.GSEG_GROUND]))]
