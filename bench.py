@@ -213,7 +213,7 @@ def stream_rate(api, synth, m_ga, m_nga, batch, grid_size, n_chunks=48, **kw):
     return dt, R, t, st
 
 
-def endpoint_inputs(api, synth, batch, R, t):
+def endpoint_inputs(api, synth, batch, R, t, at_size=True):
     """The two inputs of the endpoint leg, as float32 xyz rows: (name, obstacle set, ground set).
     config 2: every registered scan point as an obstacle endpoint in the map frame ((float)(R p + t), icpPointToPoint.cpp:69-70's
     rounding); config 3: one 64-ring cloud split by the ground segmentation into its drv (obstacle below the robot's height)
@@ -232,22 +232,22 @@ def endpoint_inputs(api, synth, batch, R, t):
     # ... and the kernel where neither the launch nor one hot wall bounds it: 8 M points spread over the grid's 100 m x 100 m
     rs = np.random.RandomState(77)
     wide = np.concatenate([rs.uniform(-49.9, 49.9, (8_000_000, 2)), np.zeros((8_000_000, 1))], 1).astype(np.float32)
-    return [("config 2: the %d registered endpoints of the batch as obstacle points" % len(ends), ends, np.zeros((0, 3), np.float32)),
-            ("at size: 8 000 000 obstacle points spread uniformly over the grid (no hot wall, launch latency amortised)", wide,
-             np.zeros((0, 3), np.float32)),
+    return [("config 2: the %d registered endpoints of the batch as obstacle points" % len(ends), ends, np.zeros((0, 3), np.float32))] + \
+           ([("at size: 8 000 000 obstacle points spread uniformly over the grid (no hot wall, launch latency amortised)", wide,
+              np.zeros((0, 3), np.float32))] if at_size else []) + [
             ("config 3: one 64-ring cloud, segmented: %d drv (obstacle) + %d ground points" %
              (int((lab == api.GSEG_OBSTACLE).sum()), int((lab == api.GSEG_GROUND).sum())),
              np.ascontiguousarray(xyz[lab == api.GSEG_OBSTACLE]), np.ascontiguousarray(xyz[lab == api.GSEG_GROUND]))]
 
 
-def endpoint_leg(api, synth, batch, R, t, grid_size, res, with_cpu):
+def endpoint_leg(api, synth, batch, R, t, grid_size, res, with_cpu, at_size=True):
     """The grid update the reference actually performs -- MLS::addToOccupancy's endpoint binning (mls.cpp:73-142: one counter
     per accepted point, no free-space traversal) -- through slam_grid_add_endpoints_dev + slam_grid_finalize_reset.
     SURVEY 8(d): 16 B per cell update (8 B point xy + 8 B counter read-modify-write) against the ~1.3 TB/s ceiling of global
     atomics.  The CPU oracle's loop (ogrid_add_endpoints, one thread: the reference's execution model) is timed beside it."""
     out, reps = [], 40
     st = api.Stream()
-    for name, obs, gnd in endpoint_inputs(api, synth, batch, R, t):
+    for name, obs, gnd in endpoint_inputs(api, synth, batch, R, t, at_size):
         g = api.Grid(grid_size, grid_size, res, rolling=0, min_cluster_points=20)
         d_obs = api.DeviceArray.from_host(obs if len(obs) else np.zeros((1, 3), np.float32))
         d_gnd = api.DeviceArray.from_host(gnd if len(gnd) else np.zeros((1, 3), np.float32))
