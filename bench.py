@@ -44,6 +44,7 @@ def log(*a):
 
 
 _JSON_FD = None
+_RK = None       # slam_amd.ranks.Ranks of an N > 1 run: a failure anywhere is announced through it (main guard at the bottom)
 
 
 def quiet_stdout():
@@ -121,6 +122,24 @@ def cpu_baseline(m_ga, m_nga, batch, grid_size, res, p2l=False):
         "grid_cell_updates_per_s_1thread": upd1 / t_grid1,
         "host_cores": cores,
     }
+
+
+def rccl_channels():
+    """What RCCL's own INIT log (NCCL_DEBUG_FILE, set in main() on rank 0) says about the communicator: collective channels =
+    the workgroups one of its all-reduce kernels occupies.  None when the log is absent or says nothing recognisable."""
+    import re
+    f = os.environ.get("NCCL_DEBUG_FILE")
+    if not f or not os.path.exists(f):
+        return None
+    try:
+        txt = open(f, errors="replace").read()
+    except Exception:
+        return None
+    m = re.findall(r"(\d+) coll channels", txt)
+    if m:
+        return int(m[-1])
+    m = re.findall(r"Channel \d+/(\d+)", txt)
+    return int(m[-1]) if m else None
 
 
 def pmc_profile(p2l=False):
@@ -498,7 +517,7 @@ def main():
     ap.add_argument("--step-streams", type=int, default=2, help="registration streams of the pipelined step (consecutive steps in turn)")
     ap.add_argument("--private-queues", action="store_true",
                     help="the pipelined step's streams each on a hardware queue of their own (CU-masked streams naming every CU)")
-    ap.add_argument("--grid-lag", type=int, default=3,
+    ap.add_argument("--grid-lag", type=int, default=None,
                     help="pipelined launch: the host enqueues the grid update of step k - LAG after the registration of step k (with N>1 that "
                          "call waits for the united row range of step k - LAG: a larger lag is more registrations queued while it waits; 100 steps, "
                          "two runs each: lag 2 0.3374 ms per step, 3 0.3353; one rank over RCCL 0.3626 / 0.3600 / 0.3605 for 2 / 3 / 4)")
@@ -517,6 +536,14 @@ def main():
                          "the steady state -- inside the timed region, like everything the host does there.  The driver's own command (20 steps, "
                          "5 warm-up), five runs each, median ms per step: 0 us 0.368, 100 0.359, 150 0.359, 200 0.360, 250 0.364, 300 0.366, "
                          "400 0.372 (tools/exp/start_sweep.sh); over 100 steps it is within the noise")
+    ap.add_argument("--merge-thread", type=int, default=1, choices=[0, 1],
+                    help="N>1 pipelined: 1 (default) = slam_grid_merge_async: the merge of a step (key, the wait for the united range, the "
+                         "rows' all-reduce, finalize) is issued by the communicator's helper thread, the enqueue thread never waits for the "
+                         "device; 0 = slam_grid_merge_begin/_finish on the enqueue thread (rounds 2-4: it slept 0.26 of every 0.31 ms there)")
+    ap.add_argument("--merge-timeout", type=float, default=30.0, help="N>1: seconds after which a merge whose united range has not arrived fails (SLAM_E_TIMEOUT)")
+    ap.add_argument("--rank-timeout", type=float, default=120.0, help="N>1: time-out of every barrier / control-plane collective, seconds")
+    ap.add_argument("--dead-after", type=float, default=15.0, help="N>1: a rank whose heartbeat has not moved for this long is lost: the others exit")
+    ap.add_argument("--no-rccl-log", action="store_true", help="N>1: do not ask RCCL for its INIT log (merge.rccl_channels stays null)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="print the launch `python bench.py --gpus N` would make of its N ranks (one JSON line) and exit")
     args = ap.parse_args()
@@ -556,40 +583,51 @@ def main():
     api.set_device(local_rank)
     multi = world > 1 or args.force_dist
     merging = multi and not args.no_merge
-    comm = None
+    comm = rk = None
     if multi:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        # control plane (rendezvous, barriers, the maximum over the ranks' clocks) over gloo; the data plane -- the
-        # planes' rows -- goes through the library's own RCCL communicator, whose id rank 0 hands out here
-        dist.init_process_group("gloo")
+        # control plane (rendezvous, barriers with a time-out, the maximum over the ranks' clocks, a watchdog that ends this rank
+        # when another is lost: slam_amd/ranks.py) over gloo; the data plane -- the planes' rows -- goes through the library's own
+        # RCCL communicator, whose id rank 0 hands out here
+        global _RK
+        from slam_amd import ranks
+        if merging and args.backend == "nccl" and rank == 0 and "NCCL_DEBUG" not in os.environ and not args.no_rccl_log:
+            # what RCCL chose for this communicator (channels = workgroups per collective kernel): its own INIT log, to a file
+            os.environ["NCCL_DEBUG"] = "INFO"
+            os.environ["NCCL_DEBUG_SUBSYS"] = "INIT"
+            os.environ["NCCL_DEBUG_FILE"] = os.path.join(os.environ.get("TMPDIR", "/tmp"), "slam_rccl_init_%d.log" % os.getpid())
+        _RK = rk = ranks.Ranks(timeout_s=args.rank_timeout, dead_after_s=args.dead_after)
         if merging and args.backend == "gloo":
             # rehearsal (several ranks on ONE GPU, where RCCL cannot run): the library's own merge entry points over its
             # host-staged communicator (slam_comm_create_host), gloo carrying the host buffers
             def gloo_allreduce(a, op):
-                dist.all_reduce(torch.from_numpy(a), op=dist.ReduceOp.SUM if op == api.COMM_SUM else dist.ReduceOp.MIN)
+                rk.dist.all_reduce(torch.from_numpy(a), op=rk.dist.ReduceOp.SUM if op == api.COMM_SUM else rk.dist.ReduceOp.MIN)
             comm = api.Comm.host(rank, world, gloo_allreduce)
         if merging and args.backend == "nccl":
-            ids = [api.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            comm = api.Comm(ids[0], rank, world)     # (RCCL's version banner goes where quiet_stdout() sent descriptor 1)
+            comm = api.Comm(rk.broadcast_object(api.Comm.unique_id() if rank == 0 else None), rank, world)
+            # (RCCL's version banner goes where quiet_stdout() sent descriptor 1)
+        if comm is not None:
+            comm.set_timeout(args.merge_timeout)     # a united range that takes longer is a lost rank: SLAM_E_TIMEOUT, not a hang
 
     m_ga, m_nga = synth.make_map(MAP_POINTS)
 
     def barrier():
         if multi:
-            dist.barrier()
+            rk.barrier()
 
     def sync():
+        if comm is not None:
+            comm.drain()             # merges still with the communicator's helper thread are enqueued first
         api.synchronize()
         if torch is not None:
             torch.cuda.synchronize()
 
     if args.config == 5:
-        run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist if multi else None, sync, barrier)
+        run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, rk if multi else None, sync, barrier)
         return
 
     # ---- synthetic inputs of BASELINE config 2 (per rank: its own 256 scans of the loop)
@@ -636,13 +674,17 @@ def main():
     # three priority levels: never the same hardware queue (see mapper.hip)
     pq = args.private_queues
     calibrating = merging and args.backend == "nccl" and launch == "pipeline" and (world > 1 or args.calibrate) and \
-        (args.reg_cu_cap is None or args.merge_order is None)
-    cal_caps = [args.reg_cu_cap] if args.reg_cu_cap is not None else [0, 1]
+        (args.reg_cu_cap is None or args.merge_order is None or args.grid_lag is None)
+    cal_caps = [args.reg_cu_cap] if args.reg_cu_cap is not None else [0, 1, 2, 4]
     cal_orders = [args.merge_order] if args.merge_order is not None else ["late", "early"]
+    cal_lags = [args.grid_lag] if args.grid_lag is not None else [3, 4, 6]
     if args.reg_cu_cap is None:
         args.reg_cu_cap = 0
     if args.merge_order is None:
         args.merge_order = "late"
+    if args.grid_lag is None:
+        args.grid_lag = 3
+    max_lag = max(cal_lags) if calibrating else args.grid_lag
 
     def reg_streams(cap):
         return [api.Stream(priority=None if k % 2 == 0 else -1, reserve_cus_per_xcd=cap, private_queue=pq) for k in range(max(args.step_streams, 1))]
@@ -650,7 +692,7 @@ def main():
     sb = api.Stream(priority=1, private_queue=pq)
     SB = [sb] + [api.Stream(priority=1, private_queue=pq) for _ in grids[1:]]      # one grid stream per grid
     sa = SA[0]
-    NB = max(4, args.step_streams + args.grid_lag + 1)      # pose / result buffers: the registrations in flight plus the grid updates two steps behind
+    NB = max(4, args.step_streams + max_lag + 1)      # pose / result buffers: the registrations in flight plus the grid updates two steps behind
     pose = [d_pose] + [api.DeviceArray(d_pose0.shape, np.float64) for _ in range(NB - 1)]
     pR = [p_.view(0, batch.R.shape) for p_ in pose]
     pt = [p_.view(batch.R.size, batch.t.shape) for p_ in pose]
@@ -661,6 +703,8 @@ def main():
     merge_rows_seen = []
     # (start, end) events around the registration launches of the timed region, on the stream of each
     live = [(api.Event(), api.Event()) for _ in range(min(args.steps, 64))]
+    t_enq = [None] * len(live)           # host clock when the enqueue of registration k had returned (timed region)
+    ev_ref = api.Event()                 # device clock <-> host clock: recorded on an idle stream just before the timed region
 
     d_R0, d_t0 = d_pose0.view(0, batch.R.shape), d_pose0.view(batch.R.size, batch.t.shape)
 
@@ -681,21 +725,39 @@ def main():
         icp_done[s_] = live[k][1] if (timed and k < len(live)) else icp_done_own[s_]
         icp_done[s_].record(a)
 
+    # N>1, pipelined: the merge of a step belongs to the communicator's helper thread (slam_grid_merge_async) -- the enqueue
+    # thread posts it and goes on.  What stays on this thread is a host-to-host wait before a grid (and its stream) is used
+    # again two steps later: by then the helper has long enqueued that merge (merge.merge_wait_ms says how long it was not so).
+    use_thread = merging and bool(args.merge_thread)
+    mode = {"thread": False}                            # set per run_steps call: only the pipelined, un-instrumented steps post to the helper
+    ticket_of = {}                                      # id(grid) -> ticket of the merge that still owns the grid and its stream
+
+    def settle(g):
+        t_ = ticket_of.pop(id(g), None)
+        if t_ is not None:
+            merge_rows_seen.append(comm.ticket_wait(t_))
+
     def enqueue_grid_update(k, b, e=None, g=None):
         """raycast of step k behind its registration [N>1: + the ranks' row ranges start travelling]; no host wait"""
         s_ = k % NB
         g = g or grid
+        settle(g)
         b.wait_event(icp_done[s_])
         # (every step starts from zero counts: the step before on this grid ended with slam_grid_finalize_reset)
         g.raycast_scans_dev(d_pts, d_off, S, P, pR[s_], pt[s_], b)
         if e: e[2].record(b)
-        if merging:
+        if merging and not mode["thread"]:
             comm.merge_begin(g, b)
 
     def enqueue_grid_fold(k, b, e=None, g=None):
-        """[N>1: the host's one wait of a step -- the united row range of step k -- then the all-reduce of those rows,] finalize"""
+        """[N>1: the united row range of step k, the all-reduce of those rows,] finalize"""
         s_ = k % NB
         g = g or grid
+        if mode["thread"]:
+            # the poses of this step have been read once the raycast is through: that is all a later registration waits for
+            grid_done[s_].record(b)
+            ticket_of[id(g)] = comm.merge_async(g, b, api.MERGE_THEN_FINALIZE_RESET)
+            return
         if merging:
             merge_rows_seen.append(comm.merge_finish(g, b))
         if e: e[3].record(b)
@@ -711,8 +773,11 @@ def main():
         if n <= 0:
             return
         E = (lambda k: events[k]) if events else (lambda k: None)
-        lag = max(args.grid_lag, 1)      # registrations the host stays ahead of the grid update it enqueues
-        if pipelined and merging and len(grids) == 2 and args.merge_order == "early":
+        mode["thread"] = use_thread and pipelined and not events
+        # registrations the host stays ahead of the grid update it enqueues; with the helper thread "early" is simply no lag: the
+        # step's raycast and its whole merge are posted with its registration (they wait for it on the device)
+        lag = 0 if (mode["thread"] and args.merge_order == "early") else max(args.grid_lag, 1)
+        if pipelined and merging and len(grids) == 2 and args.merge_order == "early" and not mode["thread"]:
             # N>1: a step's raycast and the start of its merge are enqueued WITH its registration (they wait for it on the
             # device); the host's wait for the united row range of step k-2 comes two registrations later, just before the
             # raycast of step k goes behind it on the same grid -- by then that range is normally back (merge.merge_wait_ms)
@@ -727,6 +792,8 @@ def main():
             # the host stays two registrations ahead of the grid update it enqueues
             for k in range(n):
                 enqueue_icp(k, SA[k % len(SA)], E(k), handle, timed)
+                if timed and k < len(t_enq):
+                    t_enq[k] = time.perf_counter()
                 if k == 0 and args.start_stagger_us > 0 and n > 1:
                     t_s = time.perf_counter()
                     while (time.perf_counter() - t_s) * 1e6 < args.start_stagger_us:
@@ -750,32 +817,36 @@ def main():
         # fastest setting kept for the warm-up and the timed steps (every rank sees the same all-reduced times: same choice)
         calibration = {"tried": []}
         streams_of = {c: reg_streams(c) for c in cal_caps}
-        settings = [(c, o) for c in cal_caps for o in cal_orders]
+        # late: the grid update (and the merge) of a step is enqueued `lag` registrations after its own; early: with it (no lag)
+        settings = [(c, l, "late") for c in cal_caps for l in cal_lags if "late" in cal_orders] + \
+                   [(c, 0, "early") for c in cal_caps if "early" in cal_orders]
         best_ms = {}
         run_steps(20)                  # the start-of-run transient (DESIGN Appendix A) belongs to no setting
         for rnd in range(3):           # interleaved rounds, the best round of a setting counts
-            for cap_, order_ in settings:
+            for cap_, lag_, order_ in settings:
                 SA, args.merge_order = streams_of[cap_], order_
+                args.grid_lag = lag_ or args.grid_lag
                 sa = SA[0]
                 run_steps(4)
                 sync(); barrier()
                 t_c = time.perf_counter()
                 run_steps(30)
                 sync(); barrier()
-                tt = torch.tensor([time.perf_counter() - t_c], dtype=torch.float64)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                best_ms[(cap_, order_)] = min(best_ms.get((cap_, order_), 1e9), float(tt.item()) / 30 * 1e3)
-        calibration["tried"] = [{"reg_cu_cap_per_xcd": c, "merge_order": o, "ms_per_step": best_ms[(c, o)]} for c, o in settings]
+                best_ms[(cap_, lag_, order_)] = min(best_ms.get((cap_, lag_, order_), 1e9), rk.max_over_ranks(time.perf_counter() - t_c) / 30 * 1e3)
+        calibration["tried"] = [{"reg_cu_cap_per_xcd": c, "grid_lag": l, "merge_order": o, "ms_per_step": best_ms[(c, l, o)]} for c, l, o in settings]
         # the first setting (the one-GPU default unless the command line says otherwise) stays unless another is 3 % faster
         best = min(calibration["tried"], key=lambda c_: c_["ms_per_step"])
         if best["ms_per_step"] > 0.97 * calibration["tried"][0]["ms_per_step"]:
             best = calibration["tried"][0]
         args.reg_cu_cap, args.merge_order = best["reg_cu_cap_per_xcd"], best["merge_order"]
+        args.grid_lag = best["grid_lag"] or cal_lags[0]
         SA = streams_of[args.reg_cu_cap]
         sa = SA[0]
-        calibration["kept"] = {"reg_cu_cap_per_xcd": args.reg_cu_cap, "merge_order": args.merge_order}
-        calibration["what"] = ("before the warm-up: three interleaved rounds of 30 steps per setting, the slowest rank's clock, the best round of "
-                               "each; the first setting is kept unless another is 3 % faster; the timed steps run with the one kept")
+        calibration["kept"] = {"reg_cu_cap_per_xcd": args.reg_cu_cap, "grid_lag": args.grid_lag, "merge_order": args.merge_order}
+        calibration["what"] = ("before the warm-up: three interleaved rounds of 30 steps per setting (registration streams leaving 0/1/2/4 CUs "
+                               "per XCD alone x the grid update 3/4/6 registrations behind, or with its registration = early), the slowest "
+                               "rank's clock, the best round of each; the first setting is kept unless another is 3 % faster; the timed "
+                               "steps run with the one kept")
         merge_rows_seen.clear()
         sync()
         for g_ in grids:
@@ -811,6 +882,10 @@ def main():
             sa = sb = api.Stream()
             run_steps(1, pipelined=False)
             sync()
+    t_ref0 = time.perf_counter()
+    ev_ref.record(SA[0] if launch == "pipeline" else sa)
+    ev_ref.synchronize()
+    t_ref1 = time.perf_counter()         # the event's device time lies between the two host readings
     t0 = time.perf_counter()
     if graph is not None:
         for k in range(args.steps):
@@ -821,10 +896,27 @@ def main():
     barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    for g_ in grids:
+        settle(g_)
     merge_stats = comm.stats() if comm is not None else None
     if upd_per_step is None:      # no warm-up to count them in: the timed steps' own updates, before anything else runs
         upd_per_step = sum(g_.total_updates() for g_ in grids) // max(args.steps, 1)
     live_ms = [a_.elapsed_ms(b_) for a_, b_ in live] if (graph is None and args.steps > 0) else []
+    # How far ahead of the device the enqueue thread ran: registrations k and k + len(SA) share a stream, and that stream never runs
+    # dry as long as the enqueue of the later one has returned before the earlier one ends on the device.  Device end times come
+    # from the launches' own events, placed on the host's clock through ev_ref (read between two host readings just before t0).
+    slack = None
+    if live_ms and launch == "pipeline" and len(live) > len(SA):
+        t_ref = 0.5 * (t_ref0 + t_ref1)
+        end_host = [t_ref + ev_ref.elapsed_ms(b_) * 1e-3 for _, b_ in live]
+        d_ = len(SA)
+        sl_ = [(end_host[k - d_] - t_enq[k]) * 1e3 for k in range(d_, len(live)) if t_enq[k] is not None]
+        if sl_:
+            slack = {"min_ms": float(min(sl_)), "mean_ms": float(np.mean(sl_)), "registrations": len(sl_),
+                     "clock_uncertainty_ms": (t_ref1 - t_ref0) * 0.5e3,
+                     "what": "end of registration k - %d on the device minus the host time at which the enqueue of registration k (same "
+                             "stream) had returned: positive = the launch was in the queue before its predecessor ended, the stream did not "
+                             "run dry; over the first %d registrations of the timed region" % (d_, len(live))}
     # the same K steps one after the other on one stream (outside the timed region, N=1): what the pipelining buys
     seq_ms = None
     if launch == "pipeline" and not multi:
@@ -843,11 +935,8 @@ def main():
     grid = grids[(len(ev) - 1) % len(grids)]            # the grid of the last step: what the checks below read
 
     if multi:
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        cnt = torch.tensor([P, upd_per_step], dtype=torch.int64)
-        dist.all_reduce(cnt)
+        elapsed = rk.max_over_ranks(elapsed)
+        cnt = rk.all_reduce(torch.tensor([P, upd_per_step], dtype=torch.int64), what="sum of the ranks' points and updates")
         total_pts, total_upd = int(cnt[0].item()), int(cnt[1].item())
     if merging:
         # one more update, merged but not yet folded away (a step ends with finalize_reset, which zeroes the counts): the
@@ -987,7 +1076,8 @@ def main():
                        "map_points": M, "icp_index": info, "raycast": args.raycast,
                        "raycast_worklist": grid.raycast_stats(),
                        "merge_rows": list(merge_rows_seen[-1]) if merging and merge_rows_seen else None,
-                       "reg_cu_cap_per_xcd": args.reg_cu_cap, "merge_order": args.merge_order if merging else None},
+                       "reg_cu_cap_per_xcd": args.reg_cu_cap, "grid_lag": args.grid_lag, "merge_order": args.merge_order if merging else None,
+                       "merge_thread": bool(use_thread) if merging else None},
             "grid_cell_updates_per_s": total_upd * args.steps / elapsed,
             "cell_updates_per_step": total_upd,
             "point_iterations_per_s": total_pts * N_ITERS * args.steps / elapsed,
@@ -998,6 +1088,7 @@ def main():
             "kernel_ms": {"icp": float(ms_icp), "raycast": float(ms_ray), "merge": float(ms_merge),
                           "finalize": float(ms_fin)},
             "kernels": kernels,
+            "host_enqueue_slack_ms": slack,
             "roofline": roof,
             "max_pose_error_m": pose_err,
             "device": api.device_info()[0],
@@ -1019,10 +1110,16 @@ def main():
                 "merges_in_timed_region": ms_.get("merges"),
                 "rows_per_merge": ms_.get("rows", 0) / n_m, "bytes_per_merge_per_rank": ms_.get("bytes", 0) / n_m,
                 "merge_wait_ms": ms_.get("wait_ms", 0.0) / n_m,
+                "helper_wait_ms": ms_.get("helper_wait_ms", 0.0) / n_m,
+                "merges_by_helper_thread": ms_.get("async_merges"),
+                "rccl_channels": rccl_channels() if args.backend == "nccl" else None,
                 "allreduce_ms": (ms_.get("allreduce_ms", 0.0) / ms_["timed"]) if ms_.get("timed") else None,
                 "allreduce_GBps_per_rank": (ms_.get("bytes", 0) / n_m) / (ms_["allreduce_ms"] / ms_["timed"] * 1e-3) / 1e9
                 if ms_.get("timed") and ms_.get("allreduce_ms") else None,
-                "what": "merge_wait_ms = host time inside slam_grid_merge_finish waiting for the united row range (per merge); "
+                "what": "merge_wait_ms = time the ENQUEUE thread spent waiting for anything of a merge (per merge; with the helper "
+                        "thread: for a ticket or a place in its queue; without: inside slam_grid_merge_finish for the united row range); "
+                        "helper_wait_ms = the helper thread's wait for the united row range (device time of raycast + 24-byte all-reduce, hidden "
+                        "from the enqueue thread); rccl_channels = workgroups per RCCL collective kernel, from RCCL's INIT log; "
                         "allreduce_ms = HIP events around the grouped row all-reduces on the grid stream (includes the time their "
                         "kernels waited for a CU beside the registration workgroups); both from slam_comm_get_stats"}
             if merging:
@@ -1072,13 +1169,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(m_ga, m_nga, batch, GRID, RES, p2l)
         emit(out)
     if multi:
-        dist.barrier()
+        rk.barrier("end of run")
         if comm is not None:
             comm.close()
-        dist.destroy_process_group()
+        rk.close()
 
 
-def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, barrier):
+def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, rk, sync, barrier):
     """BASELINE config 5: a stream of scans per GPU through slam_mapper_* -- pinned chunks -> H2D | ICP | raycast on
     three streams, sliding-window target (last 4 chunks, rebuilt every 4), merge over the GPUs + finalize every 8
     chunks.  PCIe inclusive by construction."""
@@ -1126,11 +1223,8 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, ba
     elapsed = time.perf_counter() - t0
     upd = mp.grid.total_updates() - upd_warm
     st = mp.stats()
-    if dist is not None:
-        import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    if rk is not None:
+        elapsed = rk.max_over_ranks(elapsed)
     if rank == 0:
         pts = sum(c.n_points for c in chunks) * world
         emit({
@@ -1148,12 +1242,21 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, dist, sync, ba
                        "pcie_inclusive": True, "mapper": st, "target_index": mp.target_index_info()},
             "grid_cell_updates_per_s": upd * world / elapsed, "max_pose_error_m": worst, "device": api.device_info()[0]})
     mp.close()
-    if dist is not None:
-        dist.barrier()
+    if rk is not None:
+        rk.barrier("end of run")
         if comm is not None:
             comm.close()
-        dist.destroy_process_group()
+        rk.close()
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as ex:      # with N > 1: say which rank failed and why, tell the others, exit non-zero -- never hang
+        if _RK is not None:
+            import traceback
+            traceback.print_exc()
+            _RK.fail("%s: %s" % (type(ex).__name__, ex))
+        raise

@@ -42,6 +42,8 @@ extern "C" {
 #define SLAM_E_TOO_FEW_SCENE_POINTS  -5 /* icp.cpp:100-103, icpTools.cpp:179-184 */
 #define SLAM_E_NOMEM                 -6
 #define SLAM_E_UNSUPPORTED           -7
+#define SLAM_E_TIMEOUT               -8 /* slam_mi355x_rccl.h: a merge's united range did not arrive: another rank has stopped */
+#define SLAM_E_COMM                  -9 /* slam_mi355x_rccl.h: the communicator (or the host transport) reports a failure */
 
 typedef void *slam_stream_t; /* a hipStream_t; NULL = the default stream */
 typedef void *slam_event_t;  /* a hipEvent_t */

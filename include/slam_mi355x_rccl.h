@@ -52,6 +52,8 @@ typedef struct slam_comm_stats {
     double    wait_ms;         /* host time spent inside slam_grid_merge_finish waiting for the united row range */
     double    allreduce_ms;    /* device time of the row all-reduces of the last `timed` merges (HIP events around them on */
     long long timed;           /* their stream: includes the time their kernels waited for a CU) */
+    double    helper_wait_ms;  /* slam_grid_merge_async: the helper thread's waits for united ranges (wait_ms stays the CALLER's */
+    long long async_merges;    /* thread: its waits in _finish, _ticket_wait and for a place in the helper's queue); merges it ran */
 } slam_comm_stats;
 int  slam_comm_get_stats(slam_comm_t *comm, slam_comm_stats *out); /* waits for the timed all-reduces to complete */
 int  slam_comm_stats_reset(slam_comm_t *comm);
@@ -73,6 +75,37 @@ int  slam_grid_allreduce_rows(slam_grid_t *grid, slam_comm_t *comm, int row_lo, 
  * another grid, before it finishes this one's); they finish in the order they were begun, every rank the same. */
 int  slam_grid_merge_begin(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream);
 int  slam_grid_merge_finish(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream, int *row_lo, int *row_hi);
+/* The same merge with NO host wait on the caller's thread: begin, the wait for the united range, the rows' all-reduce and
+ * what follows it are issued on `stream` by the communicator's helper thread (started on first use), whole merges one after
+ * the other in the order posted -- the ranks post their merges in the same order, so their collectives meet in the same
+ * order, and one thread at a time talks to RCCL.  Returns at once with a ticket.
+ *   then : what the helper enqueues behind the rows' sum on `stream`:
+ *          SLAM_MERGE_THEN_FINALIZE_RESET = slam_grid_finalize_reset (a batch per step: evidence + occupancy, counts zero),
+ *          SLAM_MERGE_THEN_FOLD_FINALIZE  = slam_grid_fold of the united rows + slam_grid_finalize (a running map),
+ *          SLAM_MERGE_THEN_NOTHING;
+ *   done : (optional) an event recorded on `stream` behind all of that.  Other streams may wait for it only AFTER
+ *          slam_comm_ticket_wait(ticket) has returned (an event not yet recorded waits for nothing).
+ * Contract: what the merge covers is fixed when this call returns (the grid updates enqueued on `stream` so far); from
+ * then until slam_comm_ticket_wait(ticket) returns, the caller enqueues nothing on `stream` and makes no call on `grid`
+ * -- normally a wait that is long over when it is asked for (two grids in turn: the ticket of two steps ago).
+ * slam_comm_ticket_wait returns the merge's status and united row range; slam_comm_drain waits for every merge posted
+ * (before a device synchronisation that is meant to cover them).  The begin / finish pair above stays for callers that
+ * want the range on their own thread; it first waits for the helper's queue to empty. */
+#define SLAM_MERGE_THEN_NOTHING        0
+#define SLAM_MERGE_THEN_FINALIZE_RESET 1
+#define SLAM_MERGE_THEN_FOLD_FINALIZE  2
+int  slam_grid_merge_async(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream, int then, slam_event_t done,
+                           unsigned long long *ticket);
+int  slam_comm_ticket_wait(slam_comm_t *comm, unsigned long long ticket, int *row_lo, int *row_hi);
+int  slam_comm_drain(slam_comm_t *comm);
+/* Fail fast.  A rank that dies leaves the others inside a collective that never completes; nothing in RCCL ends that within
+ * a node (the peers' flags simply never change).  So every host wait of a merge is a POLL of its event: with the
+ * communicator's health (ncclCommGetAsyncError) asked every millisecond, and a time-out (default 60 s) after which the
+ * merge fails with SLAM_E_TIMEOUT.  On SLAM_E_COMM / SLAM_E_TIMEOUT the communicator is aborted (ncclCommAbort: this rank's
+ * own enqueued collectives end, its streams drain) and every later call on it returns the same code; slam_last_error() names
+ * the rank that noticed.  slam_comm_check asks the health without waiting for anything. */
+int  slam_comm_set_timeout(slam_comm_t *comm, double seconds);
+int  slam_comm_check(slam_comm_t *comm);
 /* the streaming mapper's periodic merge (slam_mapper_params::merge_every) over this communicator */
 int  slam_mapper_use_comm(slam_mapper_t *mapper, slam_comm_t *comm);
 

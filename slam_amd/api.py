@@ -16,8 +16,8 @@ LIB_PATH = os.path.join(HERE, "lib", "libslam_mi355x_measure.so" if os.environ.g
 RCCL_LIB_PATH = os.path.join(HERE, "lib", "libslam_mi355x_rccl.so")
 
 SLAM_OK = 0
-E_INVALID, E_NO_DEVICE, E_HIP, E_TOO_FEW_MODEL, E_TOO_FEW_SCENE, E_NOMEM, E_UNSUPPORTED = \
-    -1, -2, -3, -4, -5, -6, -7
+E_INVALID, E_NO_DEVICE, E_HIP, E_TOO_FEW_MODEL, E_TOO_FEW_SCENE, E_NOMEM, E_UNSUPPORTED, E_TIMEOUT, E_COMM = \
+    -1, -2, -3, -4, -5, -6, -7, -8, -9
 ICP_P2P, ICP_P2L = 0, 1
 RAYCAST_TILED, RAYCAST_GLOBAL, RAYCAST_TILED_MERGE = 0, 1, 2
 
@@ -997,10 +997,12 @@ class Ccicp:
 _rccl = None
 RCCL_EXPORTS = ["slam_comm_unique_id", "slam_comm_create", "slam_comm_create_host", "slam_comm_adopt", "slam_comm_destroy",
                 "slam_comm_info", "slam_comm_get_stats", "slam_comm_stats_reset", "slam_grid_allreduce", "slam_grid_allreduce_rows", "slam_grid_merge_begin",
-                "slam_grid_merge_finish", "slam_mapper_use_comm"]
+                "slam_grid_merge_finish", "slam_grid_merge_async", "slam_comm_ticket_wait", "slam_comm_drain", "slam_comm_set_timeout",
+                "slam_comm_check", "slam_mapper_use_comm"]
 
 
 COMM_SUM, COMM_MIN = 0, 1
+MERGE_THEN_NOTHING, MERGE_THEN_FINALIZE_RESET, MERGE_THEN_FOLD_FINALIZE = 0, 1, 2
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, C.POINTER(C.c_int32), C.c_size_t, C.c_int)
 
 
@@ -1026,6 +1028,11 @@ def rccl_lib():
     R.slam_grid_allreduce_rows.argtypes = [_vp, _vp, C.c_int, C.c_int, _vp]
     R.slam_grid_merge_begin.argtypes = [_vp, _vp, _vp]
     R.slam_grid_merge_finish.argtypes = [_vp, _vp, _vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    R.slam_grid_merge_async.argtypes = [_vp, _vp, _vp, C.c_int, _vp, C.POINTER(C.c_ulonglong)]
+    R.slam_comm_ticket_wait.argtypes = [_vp, C.c_ulonglong, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    R.slam_comm_drain.argtypes = [_vp]
+    R.slam_comm_set_timeout.argtypes = [_vp, C.c_double]
+    R.slam_comm_check.argtypes = [_vp]
     R.slam_mapper_use_comm.argtypes = [_vp, _vp]
     _rccl = R
     return R
@@ -1034,7 +1041,7 @@ def rccl_lib():
 class CommStats(C.Structure):
     _fields_ = [("rank", C.c_int), ("n_ranks", C.c_int), ("transport", C.c_int), ("rccl_version", C.c_int),
                 ("merges", C.c_longlong), ("rows", C.c_longlong), ("bytes", C.c_longlong), ("wait_ms", C.c_double),
-                ("allreduce_ms", C.c_double), ("timed", C.c_longlong)]
+                ("allreduce_ms", C.c_double), ("timed", C.c_longlong), ("helper_wait_ms", C.c_double), ("async_merges", C.c_longlong)]
 
 
 class Comm:
@@ -1103,6 +1110,29 @@ class Comm:
         lo, hi = C.c_int(), C.c_int()
         check(rccl_lib().slam_grid_merge_finish(grid.h, self.h, _sp(stream), C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
+
+    def merge_async(self, grid, stream=None, then=MERGE_THEN_FINALIZE_RESET, done=None):
+        """slam_grid_merge_async: the whole merge (+ what follows it on the stream) from the communicator's helper thread;
+        returns a ticket at once.  Nothing else goes to `stream` / `grid` before ticket_wait(ticket)."""
+        t = C.c_ulonglong()
+        check(rccl_lib().slam_grid_merge_async(grid.h, self.h, _sp(stream), int(then), done.ptr if done is not None else None, C.byref(t)))
+        return t.value
+
+    def ticket_wait(self, ticket):
+        """The status and united row range (row_lo, row_hi) of a merge posted with merge_async (waits for the helper thread
+        to have enqueued it; raises SlamError with E_TIMEOUT / E_COMM when a rank is lost)."""
+        lo, hi = C.c_int(), C.c_int()
+        check(rccl_lib().slam_comm_ticket_wait(self.h, int(ticket), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def drain(self):
+        check(rccl_lib().slam_comm_drain(self.h))
+
+    def set_timeout(self, seconds):
+        check(rccl_lib().slam_comm_set_timeout(self.h, float(seconds)))
+
+    def check(self):
+        check(rccl_lib().slam_comm_check(self.h))
 
     def close(self):
         if getattr(self, "h", None):

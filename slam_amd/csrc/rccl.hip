@@ -1,9 +1,14 @@
 // rccl.hip -- RCCL merge of the grid count planes (slam_mi355x_rccl.h).
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <new>
+#include <thread>
 
 #include "common.hpp"
 #include "slam_mi355x_rccl.h"
@@ -23,15 +28,46 @@ struct slam_comm {
     void      *host_ctx = nullptr;
     // merges in flight, oldest first: begin takes the next slot, finish the oldest (a pipelined caller begins the merge of
     // batch k + 1 -- on another grid -- before it finishes that of batch k)
-    static constexpr int kSlots = 4;
+    static constexpr int kSlots = 4;   // the caller's own merges in flight (slam_grid_merge_begin / _finish)
+    static constexpr int kMaxPosted = 8; // merges handed to the helper thread and not yet through
     struct Slot {
         int       *d_key = nullptr;   // [kKeyInts] this rank's key
         int       *d_range = nullptr; // [kKeyInts] the minimum over the ranks
         int       *h_range = nullptr; // pinned copy
         hipEvent_t ev_range = nullptr;
         slam_grid_t *grid = nullptr;  // the grid the merge was begun on
-    } slot[kSlots];
+    } slot[1 + kSlots];               // [0]: the helper thread's
     unsigned long long begun = 0, finished = 0;
+    // ---- slam_grid_merge_async: a helper thread takes the host's one wait of a merge off the caller's thread.
+    // Jobs run in the order posted; a ticket's outcome stays readable while fewer than kDone newer ones have completed.
+    struct Job {
+        unsigned long long ticket;
+        slam_grid_t   *grid;
+        hipStream_t    st;
+        int            then;
+        hipEvent_t     done;
+        const int32_t *d_dirty;
+        int            cell_x, cell_y;
+    };
+    struct Outcome {
+        unsigned long long ticket = 0;
+        int  rc = SLAM_OK, lo = 0, hi = -1;
+        char err[256] = "";
+    };
+    static constexpr int kDone = 16;
+    std::thread             worker;
+    std::mutex              mu;
+    std::condition_variable cv_job, cv_done;
+    std::deque<Job>         jobs;
+    unsigned long long      posted = 0, completed = 0;
+    Outcome                 outcome[kDone];
+    bool                    stop = false;
+    int                     device = 0;
+    std::atomic<int>        failed{SLAM_OK};      // sticky: the first failure of a merge (a peer gone, a time-out)
+    bool                    aborted = false;      // ncclCommAbort has run: `comm` is gone
+    char                    failed_msg[256] = "";
+    double                  timeout_s = 60.0;     // a united range that has not arrived by then is a lost rank
+    double                  helper_wait_ms = 0.0; // the helper thread's waits for united ranges
     int32_t   *h_stage = nullptr;   // pinned staging of the host-staged transport
     size_t     cap_stage = 0;       // ints
     // statistics (slam_comm_get_stats)
@@ -56,7 +92,7 @@ __global__ void merge_key_kernel(const int *dirty, int cell_x, int cell_y, int *
     key[5] = -cell_y;
 }
 
-bool usable(const slam_comm *c) { return c && (c->comm || c->host_fn); }
+bool usable(const slam_comm *c) { return c && !c->aborted && (c->comm || c->host_fn); }
 
 int stage_reserve(slam_comm *c, size_t ints)
 {
@@ -83,6 +119,81 @@ int host_sum_rows(slam_comm *c, int32_t *planes, size_t cells, size_t first, siz
     SLAM_HIP(hipMemcpyAsync(planes + cells + first, c->h_stage + count, count * sizeof(int32_t), hipMemcpyHostToDevice, st));
     SLAM_HIP(hipStreamSynchronize(st)); // the staging buffer is free again
     return SLAM_OK;
+}
+
+// What RCCL says about the communicator without blocking: SLAM_OK, or SLAM_E_COMM with the text (a failed peer or
+// transport shows up here; a peer that simply stopped shows up as the time-out of wait_range).
+int comm_health(slam_comm *c)
+{
+    if (c->failed.load() != SLAM_OK) {
+        set_error("%s", c->failed_msg);
+        return c->failed.load();
+    }
+    if (!c->comm || c->aborted) return SLAM_OK;
+    ncclResult_t st = ncclSuccess;
+    const ncclResult_t r = ncclCommGetAsyncError(c->comm, &st);
+    if (r == ncclSuccess && (st == ncclSuccess || st == ncclInProgress)) return SLAM_OK;
+    const ncclResult_t bad = r != ncclSuccess ? r : st;
+    set_error("rank %d of %d: RCCL reports an asynchronous error on the communicator: %d (%s)", c->rank, c->n_ranks, (int)bad,
+              ncclGetErrorString(bad));
+    return SLAM_E_COMM;
+}
+
+void mark_failed(slam_comm *c, int rc)
+{
+    if (c->failed.load() != SLAM_OK) return;
+    snprintf(c->failed_msg, sizeof c->failed_msg, "%s", slam_last_error());
+    c->failed.store(rc);
+    // whatever this rank still has enqueued on the communicator would wait for the lost rank for ever: abort it, so that the
+    // streams drain and the process can report and exit (the communicator is not usable after this: every later call on it
+    // returns the same failure)
+    if (c->comm && c->owned && !c->aborted) {
+        c->aborted = true;
+        (void)ncclCommAbort(c->comm);
+    }
+}
+
+// The host's one wait of a merge: the united range's event, polled -- so that a lost rank ends in an error code and not in a
+// process asleep inside hipEventSynchronize.  Every millisecond the communicator's health is asked as well.
+int wait_range(slam_comm *c, hipEvent_t ev, double *waited_ms)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    auto       next_health = t0 + std::chrono::milliseconds(1);
+    int        rc = SLAM_OK;
+    for (unsigned spin = 0;; ++spin) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) {
+            rc = hip_fail(e, "hipEventQuery(united range)", __FILE__, __LINE__);
+            break;
+        }
+        const auto now = clk::now();
+        if (now >= next_health) {
+            if ((rc = comm_health(c)) != SLAM_OK) break;
+            next_health = now + std::chrono::milliseconds(1);
+            const double s = std::chrono::duration<double>(now - t0).count();
+            if (s > c->timeout_s) {
+                set_error("rank %d of %d: the united row range of a merge has not arrived after %.1f s: another rank has stopped "
+                          "(or never began this merge)", c->rank, c->n_ranks, s);
+                rc = SLAM_E_TIMEOUT;
+                break;
+            }
+        }
+        if (spin < 2000)
+            std::this_thread::yield();
+        else
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+    if (waited_ms) *waited_ms += std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+    return rc;
+}
+
+// every job posted so far has run (the caller's thread waits; a job's own wait is bounded by the time-out)
+void drain(slam_comm *c)
+{
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->cv_done.wait(lk, [&] { return c->completed == c->posted; });
 }
 
 } // namespace
@@ -165,6 +276,14 @@ int slam_comm_adopt(void *nccl_comm, slam_comm_t **out)
 void slam_comm_destroy(slam_comm_t *comm)
 {
     if (!comm) return;
+    if (comm->worker.joinable()) { // the helper thread works its queue off (a job's wait is bounded by the time-out) and ends
+        {
+            std::lock_guard<std::mutex> lk(comm->mu);
+            comm->stop = true;
+        }
+        comm->cv_job.notify_all();
+        comm->worker.join();
+    }
     for (auto &sl : comm->slot) {
         if (sl.d_range) (void)hipFree(sl.d_range);
         if (sl.d_key) (void)hipFree(sl.d_key);
@@ -175,7 +294,7 @@ void slam_comm_destroy(slam_comm_t *comm)
     for (auto &pr : comm->ev_ar)
         for (hipEvent_t e : pr)
             if (e) (void)hipEventDestroy(e);
-    if (comm->owned && comm->comm) (void)ncclCommDestroy(comm->comm);
+    if (comm->owned && comm->comm && !comm->aborted) (void)ncclCommDestroy(comm->comm);
     delete comm;
 }
 
@@ -190,11 +309,12 @@ int slam_comm_info(slam_comm_t *comm, int *rank, int *n_ranks)
 int slam_comm_get_stats(slam_comm_t *comm, slam_comm_stats *out)
 {
     SLAM_REQUIRE(comm && out, SLAM_E_INVALID, "slam_comm_get_stats: bad arguments");
+    drain(comm); // (the helper thread keeps these books while it has jobs)
     memset(out, 0, sizeof *out);
     out->rank = comm->rank;
     out->n_ranks = comm->n_ranks;
     out->transport = comm->comm ? 0 : 1;
-    if (comm->comm) { // what the transport itself says, not what the caller passed
+    if (comm->comm && !comm->aborted) { // what the transport itself says, not what the caller passed
         (void)ncclCommUserRank(comm->comm, &out->rank);
         (void)ncclCommCount(comm->comm, &out->n_ranks);
         int v = 0;
@@ -204,6 +324,8 @@ int slam_comm_get_stats(slam_comm_t *comm, slam_comm_stats *out)
     out->rows = comm->rows;
     out->bytes = comm->bytes;
     out->wait_ms = comm->wait_ms;
+    out->helper_wait_ms = comm->helper_wait_ms;
+    out->async_merges = (long long)comm->completed;
     const long long n = comm->ar_recorded < slam_comm::kTimed ? comm->ar_recorded : slam_comm::kTimed;
     for (long long i = 0; i < n; ++i) {
         hipEvent_t *ev = comm->ev_ar[i];
@@ -219,15 +341,16 @@ int slam_comm_get_stats(slam_comm_t *comm, slam_comm_stats *out)
 int slam_comm_stats_reset(slam_comm_t *comm)
 {
     SLAM_REQUIRE(comm, SLAM_E_INVALID, "null communicator");
+    drain(comm);
     comm->merges = comm->rows = comm->bytes = 0;
-    comm->wait_ms = 0.0;
+    comm->wait_ms = comm->helper_wait_ms = 0.0;
     comm->ar_recorded = 0;
     return SLAM_OK;
 }
 
 int slam_grid_allreduce(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream)
 {
-    SLAM_REQUIRE(grid && usable(comm), SLAM_E_INVALID, "slam_grid_allreduce: bad arguments");
+    SLAM_REQUIRE(grid && usable(comm), SLAM_E_INVALID, "slam_grid_allreduce: bad arguments (or a communicator that has failed)");
     int32_t *planes = nullptr;
     size_t   n = 0;
     SLAM_TRY(slam_grid_counts_dev(grid, &planes, &n));
@@ -279,56 +402,40 @@ int slam_grid_allreduce_rows(slam_grid_t *grid, slam_comm_t *comm, int row_lo, i
     return slam_grid_mark_rows(grid, row_lo, row_hi, stream); // rows this rank did not touch hold the others' counts now
 }
 
-int slam_grid_merge_begin(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream)
+// ---- the two halves of a merge, on whichever thread issues the communicator's calls (the caller's, or the helper's)
+
+// first half: this rank's key, the minimum over the ranks, on its way to the host
+static int begin_body(slam_comm *comm, slam_comm::Slot &sl, slam_grid_t *grid, hipStream_t st, const int32_t *d_dirty, int cell_x, int cell_y)
 {
-    SLAM_REQUIRE(grid && usable(comm), SLAM_E_INVALID, "slam_grid_merge_begin: bad arguments");
-    SLAM_REQUIRE(comm->begun - comm->finished < (unsigned long long)slam_comm::kSlots, SLAM_E_INVALID,
-                 "slam_grid_merge_begin: %d merges are in flight already; finish the oldest first", slam_comm::kSlots);
-    slam_comm::Slot &sl = comm->slot[comm->begun % slam_comm::kSlots];
-    if (!sl.d_range) {
-        SLAM_HIP(hipMalloc((void **)&sl.d_range, kKeyInts * sizeof(int)));
-        SLAM_HIP(hipMalloc((void **)&sl.d_key, kKeyInts * sizeof(int)));
-        SLAM_HIP(hipHostMalloc((void **)&sl.h_range, kKeyInts * sizeof(int), hipHostMallocDefault));
+    if (!sl.ev_range) { // (ev_range is made last: a slot whose allocation failed half way is completed, not used as it is)
+        if (!sl.d_range) SLAM_HIP(hipMalloc((void **)&sl.d_range, kKeyInts * sizeof(int)));
+        if (!sl.d_key) SLAM_HIP(hipMalloc((void **)&sl.d_key, kKeyInts * sizeof(int)));
+        if (!sl.h_range) SLAM_HIP(hipHostMalloc((void **)&sl.h_range, kKeyInts * sizeof(int), hipHostMallocDefault));
         SLAM_HIP(hipEventCreateWithFlags(&sl.ev_range, hipEventDisableTiming));
     }
-    int32_t *d_dirty = nullptr;
-    int      cell_x = 0, cell_y = 0;
-    SLAM_TRY(slam_grid_dirty_rows_dev(grid, &d_dirty));
-    SLAM_TRY(slam_grid_window_cell(grid, &cell_x, &cell_y)); // as of the updates enqueued so far (slam_grid_set_pose keeps it on the host)
-    hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(merge_key_kernel, dim3(1), dim3(64), 0, st, d_dirty, cell_x, cell_y, sl.d_key);
     SLAM_HIP(hipGetLastError());
     if (comm->comm) {
         SLAM_NCCL(ncclAllReduce(sl.d_key, sl.d_range, kKeyInts, ncclInt32, ncclMin, comm->comm, st));
         SLAM_HIP(hipMemcpyAsync(sl.h_range, sl.d_range, kKeyInts * sizeof(int), hipMemcpyDeviceToHost, st));
-    } else { // host-staged: this rank's key travels to the host now, the minimum over the ranks is taken in finish
+    } else { // host-staged: this rank's key travels to the host now, the minimum over the ranks is taken in the second half
         SLAM_HIP(hipMemcpyAsync(sl.h_range, sl.d_key, kKeyInts * sizeof(int), hipMemcpyDeviceToHost, st));
     }
     SLAM_HIP(hipEventRecord(sl.ev_range, st));
     sl.grid = grid;
-    ++comm->begun;
     return SLAM_OK;
 }
 
-int slam_grid_merge_finish(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream, int *row_lo, int *row_hi)
+// second half: the host's wait for the united range, the consistency of the ranks' windows, the rows' all-reduce on `st`
+static int finish_body(slam_comm *comm, slam_comm::Slot &sl, slam_grid_t *grid, hipStream_t st, double *waited_ms, int *row_lo, int *row_hi)
 {
-    SLAM_REQUIRE(grid && usable(comm) && comm->begun > comm->finished, SLAM_E_INVALID, "slam_grid_merge_finish: no merge in flight");
-    slam_comm::Slot &sl = comm->slot[comm->finished % slam_comm::kSlots];
-    SLAM_REQUIRE(sl.grid == grid, SLAM_E_INVALID,
-                 "slam_grid_merge_finish: merges finish in the order they were begun, and the oldest one in flight is another grid's");
-    ++comm->finished;
-    {
-        const auto t0 = std::chrono::steady_clock::now();
-        const hipError_t e = hipEventSynchronize(sl.ev_range); // the one host wait of a merge
-        comm->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        SLAM_HIP(e);
-    }
+    *row_lo = 0;
+    *row_hi = -1;
+    SLAM_TRY(wait_range(comm, sl.ev_range, waited_ms));
     int *k = sl.h_range;
     if (!comm->comm)
-        SLAM_REQUIRE(comm->host_fn(comm->host_ctx, k, kKeyInts, SLAM_COMM_MIN) == 0, SLAM_E_HIP,
+        SLAM_REQUIRE(comm->host_fn(comm->host_ctx, k, kKeyInts, SLAM_COMM_MIN) == 0, SLAM_E_COMM,
                      "the host transport's all-reduce (minimum of %d ints) failed", kKeyInts);
-    if (row_lo) *row_lo = 0;
-    if (row_hi) *row_hi = -1;
     // every rank sees the same six numbers, so every rank takes the same branch: nobody is left waiting in a collective
     SLAM_REQUIRE(k[2] == -k[3] && k[4] == -k[5], SLAM_E_INVALID,
                  "slam_grid_merge_finish: the ranks' rolling windows sit on different cells (x %d..%d, y %d..%d): storage rows "
@@ -337,12 +444,191 @@ int slam_grid_merge_finish(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t s
     int sy = 0;
     SLAM_TRY(slam_grid_info(grid, nullptr, &sy, nullptr, nullptr, nullptr));
     const bool none = k[0] > sy;
-    const int  lo = none ? 0 : k[0], hi = none ? -1 : -k[1];
+    *row_lo = none ? 0 : k[0];
+    *row_hi = none ? -1 : -k[1];
+    comm->in_merge = true;
+    const int rc = slam_grid_allreduce_rows(grid, comm, *row_lo, *row_hi, (slam_stream_t)st);
+    comm->in_merge = false;
+    return rc;
+}
+
+// The helper thread of slam_grid_merge_async.  While jobs are posted it is the ONLY thread that issues calls on the
+// communicator, one whole merge after the other in the order posted: the ranks' collectives meet in the same order on every
+// rank (RCCL matches them by order, and takes calls from one thread at a time).
+static void worker_main(slam_comm *c)
+{
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        slam_comm::Job job;
+        {
+            std::unique_lock<std::mutex> lk(c->mu);
+            c->cv_job.wait(lk, [&] { return c->stop || !c->jobs.empty(); });
+            if (c->jobs.empty()) return; // (stop: only after the queue has been worked off)
+            job = c->jobs.front();
+            c->jobs.pop_front();
+        }
+        slam_comm::Slot &sl = c->slot[0]; // one merge at a time here: no ring needed
+        int lo = 0, hi = -1;
+        int rc = comm_health(c);
+        if (rc == SLAM_OK) rc = begin_body(c, sl, job.grid, job.st, job.d_dirty, job.cell_x, job.cell_y);
+        if (rc == SLAM_OK) rc = finish_body(c, sl, job.grid, job.st, &c->helper_wait_ms, &lo, &hi);
+        // what the caller asked to have enqueued behind the rows' sum, on the same stream
+        if (rc == SLAM_OK && job.then == SLAM_MERGE_THEN_FINALIZE_RESET) rc = slam_grid_finalize_reset(job.grid, (slam_stream_t)job.st);
+        if (rc == SLAM_OK && job.then == SLAM_MERGE_THEN_FOLD_FINALIZE) {
+            rc = slam_grid_fold(job.grid, lo, hi, (slam_stream_t)job.st);
+            if (rc == SLAM_OK) rc = slam_grid_finalize(job.grid, (slam_stream_t)job.st);
+        }
+        if (rc == SLAM_OK && job.done) {
+            const hipError_t e = hipEventRecord(job.done, job.st);
+            if (e != hipSuccess) rc = hip_fail(e, "hipEventRecord(done)", __FILE__, __LINE__);
+        }
+        {
+            std::lock_guard<std::mutex> lk(c->mu);
+            if (rc != SLAM_OK && rc != SLAM_E_INVALID) mark_failed(c, rc);
+            slam_comm::Outcome &o = c->outcome[job.ticket % slam_comm::kDone];
+            o.ticket = job.ticket;
+            o.rc = rc;
+            o.lo = lo;
+            o.hi = hi;
+            snprintf(o.err, sizeof o.err, "%s", rc == SLAM_OK ? "" : slam_last_error());
+            ++c->completed;
+        }
+        c->cv_done.notify_all();
+    }
+}
+
+#define SLAM_COMM_ALIVE(comm)                                  \
+    do {                                                       \
+        if ((comm) && (comm)->failed.load() != SLAM_OK) {      \
+            set_error("%s", (comm)->failed_msg);               \
+            return (comm)->failed.load();                      \
+        }                                                      \
+    } while (0)
+
+int slam_grid_merge_begin(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream)
+{
+    SLAM_COMM_ALIVE(comm);
+    SLAM_REQUIRE(grid && usable(comm), SLAM_E_INVALID, "slam_grid_merge_begin: bad arguments");
+    drain(comm); // merges handed to the helper thread come first: one thread at a time issues the communicator's calls
+    SLAM_COMM_ALIVE(comm);
+    SLAM_REQUIRE(comm->begun - comm->finished < (unsigned long long)slam_comm::kSlots, SLAM_E_INVALID,
+                 "slam_grid_merge_begin: %d merges are in flight already; finish the oldest first", slam_comm::kSlots);
+    int32_t *d_dirty = nullptr;
+    int      cell_x = 0, cell_y = 0;
+    SLAM_TRY(slam_grid_dirty_rows_dev(grid, &d_dirty));
+    SLAM_TRY(slam_grid_window_cell(grid, &cell_x, &cell_y)); // as of the updates enqueued so far (slam_grid_set_pose keeps it on the host)
+    // (slot 0 is the helper thread's; the caller's own merges in flight go round the others)
+    slam_comm::Slot &sl = comm->slot[1 + comm->begun % (slam_comm::kSlots)];
+    SLAM_TRY(begin_body(comm, sl, grid, as_stream(stream), d_dirty, cell_x, cell_y));
+    ++comm->begun;
+    return SLAM_OK;
+}
+
+int slam_grid_merge_finish(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream, int *row_lo, int *row_hi)
+{
+    SLAM_COMM_ALIVE(comm);
+    SLAM_REQUIRE(grid && usable(comm), SLAM_E_INVALID, "slam_grid_merge_finish: bad arguments");
+    drain(comm);
+    SLAM_COMM_ALIVE(comm);
+    SLAM_REQUIRE(comm->begun > comm->finished, SLAM_E_INVALID, "slam_grid_merge_finish: no merge in flight");
+    slam_comm::Slot &sl = comm->slot[1 + comm->finished % (slam_comm::kSlots)];
+    SLAM_REQUIRE(sl.grid == grid, SLAM_E_INVALID,
+                 "slam_grid_merge_finish: merges finish in the order they were begun, and the oldest one in flight is another grid's");
+    int lo = 0, hi = -1;
+    const int rc = finish_body(comm, sl, grid, as_stream(stream), &comm->wait_ms, &lo, &hi); // the one host wait of a merge
+    ++comm->finished;
     if (row_lo) *row_lo = lo;
     if (row_hi) *row_hi = hi;
-    comm->in_merge = true;
-    const int rc = slam_grid_allreduce_rows(grid, comm, lo, hi, stream);
-    comm->in_merge = false;
+    if (rc != SLAM_OK && rc != SLAM_E_INVALID) {
+        std::lock_guard<std::mutex> lk(comm->mu);
+        mark_failed(comm, rc);
+    }
+    return rc;
+}
+
+int slam_grid_merge_async(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream, int then, slam_event_t done,
+                          unsigned long long *ticket)
+{
+    SLAM_COMM_ALIVE(comm);
+    SLAM_REQUIRE(grid && usable(comm) && ticket, SLAM_E_INVALID, "slam_grid_merge_async: bad arguments");
+    SLAM_REQUIRE(then == SLAM_MERGE_THEN_NOTHING || then == SLAM_MERGE_THEN_FINALIZE_RESET || then == SLAM_MERGE_THEN_FOLD_FINALIZE,
+                 SLAM_E_INVALID, "slam_grid_merge_async: unknown continuation %d", then);
+    SLAM_REQUIRE(comm->begun == comm->finished, SLAM_E_INVALID,
+                 "slam_grid_merge_async: finish the merges begun with slam_grid_merge_begin first (one order of collectives per communicator)");
+    slam_comm::Job job{};
+    job.grid = grid;
+    job.st = as_stream(stream);
+    job.then = then;
+    job.done = reinterpret_cast<hipEvent_t>(done);
+    // what the merge is about is fixed HERE, as of the updates the caller has enqueued so far: the dirty-range buffer in use
+    // (slam_grid_finalize_reset alternates between two) and the window's cell
+    int32_t *d_dirty = nullptr;
+    SLAM_TRY(slam_grid_dirty_rows_dev(grid, &d_dirty));
+    job.d_dirty = d_dirty;
+    SLAM_TRY(slam_grid_window_cell(grid, &job.cell_x, &job.cell_y));
+    std::unique_lock<std::mutex> lk(comm->mu);
+    if (!comm->worker.joinable()) {
+        SLAM_HIP(hipGetDevice(&comm->device));
+        comm->worker = std::thread(worker_main, comm);
+    }
+    if (comm->posted - comm->completed >= (unsigned long long)slam_comm::kMaxPosted) { // back-pressure on the caller's thread
+        const auto t0 = std::chrono::steady_clock::now();
+        comm->cv_done.wait(lk, [&] { return comm->posted - comm->completed < (unsigned long long)slam_comm::kMaxPosted; });
+        comm->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    job.ticket = ++comm->posted;
+    comm->jobs.push_back(job);
+    *ticket = job.ticket;
+    lk.unlock();
+    comm->cv_job.notify_one();
+    return SLAM_OK;
+}
+
+int slam_comm_ticket_wait(slam_comm_t *comm, unsigned long long ticket, int *row_lo, int *row_hi)
+{
+    SLAM_REQUIRE(comm, SLAM_E_INVALID, "null communicator");
+    std::unique_lock<std::mutex> lk(comm->mu);
+    SLAM_REQUIRE(ticket >= 1 && ticket <= comm->posted, SLAM_E_INVALID, "slam_comm_ticket_wait: no such ticket");
+    if (comm->completed < ticket) {
+        const auto t0 = std::chrono::steady_clock::now();
+        comm->cv_done.wait(lk, [&] { return comm->completed >= ticket; });
+        comm->wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    const slam_comm::Outcome &o = comm->outcome[ticket % slam_comm::kDone];
+    if (row_lo) *row_lo = 0;
+    if (row_hi) *row_hi = -1;
+    if (o.ticket != ticket) { // long gone: only the communicator's sticky state can still be told
+        SLAM_COMM_ALIVE(comm);
+        return SLAM_OK;
+    }
+    if (row_lo) *row_lo = o.lo;
+    if (row_hi) *row_hi = o.hi;
+    if (o.rc != SLAM_OK) set_error("%s", o.err);
+    return o.rc;
+}
+
+int slam_comm_drain(slam_comm_t *comm)
+{
+    SLAM_REQUIRE(comm, SLAM_E_INVALID, "null communicator");
+    drain(comm);
+    SLAM_COMM_ALIVE(comm);
+    return SLAM_OK;
+}
+
+int slam_comm_set_timeout(slam_comm_t *comm, double seconds)
+{
+    SLAM_REQUIRE(comm && seconds > 0, SLAM_E_INVALID, "slam_comm_set_timeout: bad arguments");
+    std::lock_guard<std::mutex> lk(comm->mu);
+    comm->timeout_s = seconds;
+    return SLAM_OK;
+}
+
+int slam_comm_check(slam_comm_t *comm)
+{
+    SLAM_REQUIRE(comm, SLAM_E_INVALID, "null communicator");
+    std::lock_guard<std::mutex> lk(comm->mu);
+    const int rc = comm_health(comm);
+    if (rc != SLAM_OK) mark_failed(comm, rc);
     return rc;
 }
 

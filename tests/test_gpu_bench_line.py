@@ -62,25 +62,36 @@ def test_bench_force_dist_runs_the_n_gt_1_pipeline_over_a_real_rccl_communicator
     assert m["bytes_per_merge_per_rank"] == m["rows_per_merge"] * 2000 * 8            # [hits | misses] int32 of those rows
     assert m["merge_wait_ms"] >= 0.0 and m["allreduce_ms"] > 0.0
     assert d["max_pose_error_m"] < 0.05
+    # round 5: the merges are the helper thread's (slam_grid_merge_async); the enqueue thread does not wait for the device
+    assert d["config"]["merge_thread"] is True and m["merges_by_helper_thread"] >= 4
+    assert m["merge_wait_ms"] < 0.1 and m["helper_wait_ms"] > 0.0
+    sl = d["host_enqueue_slack_ms"]
+    assert sl is not None and sl["registrations"] >= 1 and sl["min_ms"] <= sl["mean_ms"]
+    # ... and the same steps with the merge on the enqueue thread (rounds 2-4), still there behind a switch
+    d0 = _bench("--force-dist", "--merge-thread", "0", "--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline")
+    assert d0["config"]["merge_thread"] is False and d0["merge"]["merges_by_helper_thread"] == 0
+    assert d0["merge"]["merges_in_timed_region"] == 4 and d0["config"]["merge_rows"] == d["config"]["merge_rows"]
 
 
 @pytest.mark.gpu
 def test_bench_calibrates_the_n_gt_1_launch_setting():
-    """With more than one rank the bench first times reg-cu-cap 0/1 x merge-order late/early and keeps the fastest (no multi-GPU
-    lease has said which one RCCL's kernels need); --calibrate runs that with the one rank of this box."""
+    """With more than one rank the bench first times reg-cu-cap 0/1/2/4 x (grid-lag 3/4/6 | early) and keeps the fastest (no
+    multi-GPU lease has said which one RCCL's kernels need); --calibrate runs that with the one rank of this box."""
     d = _bench("--force-dist", "--calibrate", "--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline")
     c = d["merge"]["calibration"]
-    assert [(t["reg_cu_cap_per_xcd"], t["merge_order"]) for t in c["tried"]] == [(0, "late"), (0, "early"), (1, "late"), (1, "early")]
+    assert [(t["reg_cu_cap_per_xcd"], t["grid_lag"], t["merge_order"]) for t in c["tried"]] == \
+        [(cap, lag, "late") for cap in (0, 1, 2, 4) for lag in (3, 4, 6)] + [(cap, 0, "early") for cap in (0, 1, 2, 4)]
     best = min(c["tried"], key=lambda t: t["ms_per_step"])
     if best["ms_per_step"] > 0.97 * c["tried"][0]["ms_per_step"]:       # the default stays unless another setting is 3 % faster
         best = c["tried"][0]
-    assert c["kept"] == {"reg_cu_cap_per_xcd": best["reg_cu_cap_per_xcd"], "merge_order": best["merge_order"]}
+    assert c["kept"] == {"reg_cu_cap_per_xcd": best["reg_cu_cap_per_xcd"], "grid_lag": best["grid_lag"] or 3, "merge_order": best["merge_order"]}
     assert d["config"]["reg_cu_cap_per_xcd"] == c["kept"]["reg_cu_cap_per_xcd"] and d["config"]["merge_order"] == c["kept"]["merge_order"]
     assert all(0.2 < t["ms_per_step"] < 5.0 for t in c["tried"])
     assert d["merge"]["merges_in_timed_region"] == 4 and d["max_pose_error_m"] < 0.05
     # a setting given on the command line is not calibrated over
-    d = _bench("--force-dist", "--calibrate", "--merge-order", "late", "--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline")
-    assert [(t["reg_cu_cap_per_xcd"], t["merge_order"]) for t in d["merge"]["calibration"]["tried"]] == [(0, "late"), (1, "late")]
+    d = _bench("--force-dist", "--calibrate", "--merge-order", "late", "--grid-lag", "3", "--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline")
+    assert [(t["reg_cu_cap_per_xcd"], t["grid_lag"], t["merge_order"]) for t in d["merge"]["calibration"]["tried"]] == \
+        [(0, 3, "late"), (1, 3, "late"), (2, 3, "late"), (4, 3, "late")]
 
 
 @pytest.mark.gpu

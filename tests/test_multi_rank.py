@@ -234,3 +234,59 @@ def test_bench_two_ranks_rccl_merge():
     lo, hi = d["config"]["merge_rows"]
     assert 0 <= lo <= hi < 2000
     assert "RCCL" in d["config"]["workload"]
+
+
+def _run_two_ranks(how, dead_after=4.0, timeout=20.0):
+    """Two CPU processes on slam_amd.ranks (tests/mp_ranks_failfast.py); returns [(exit code, stderr, seconds)] per rank."""
+    import signal
+    import subprocess
+    import time
+    port = _free_port()
+    procs = []
+    t0 = time.monotonic()
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SLAM_RANKS_DEAD_AFTER=str(dead_after), SLAM_RANKS_TIMEOUT=str(timeout))
+        # (the ranks run no oracle code: when this suite runs under the sanitizer -- test_oracle_sanitized.py preloads libasan --
+        # the children are plain interpreters, so that an exit code is the rank's own and not the sanitizer's)
+        for k_ in ("LD_PRELOAD", "ASAN_OPTIONS", "UBSAN_OPTIONS"):
+            env.pop(k_, None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_ranks_failfast.py"), how],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    out = []
+    try:
+        for r, p in enumerate(procs):
+            if how == "stop" and r == 1:
+                continue             # (stopped: it never ends by itself)
+            try:
+                _, err = p.communicate(timeout=60)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                _, err = p.communicate()
+                err += "\n[test] still running after 60 s"
+            out.append((p.returncode, err, time.monotonic() - t0))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGKILL)
+                p.wait()
+    return out
+
+
+def test_ranks_all_finish_when_nobody_fails():
+    res = _run_two_ranks("none")
+    assert [rc for rc, _, _ in res] == [0, 0], res
+
+
+@pytest.mark.parametrize("how", ["kill", "fail", "stop"])
+def test_a_lost_rank_ends_the_other_within_30_s(how):
+    """one of two gloo ranks is killed (SIGKILL), announces a failure, or goes silent (SIGSTOP, with the
+    survivor asleep as in a device wait): the other exits non-zero within 30 s and names the rank."""
+    from slam_amd.ranks import EXIT_PEER_LOST, EXIT_SELF_FAILED
+    res = _run_two_ranks(how)
+    rc0, err0, secs0 = res[0]
+    assert rc0 in (EXIT_PEER_LOST, EXIT_SELF_FAILED), (rc0, err0)
+    assert secs0 < 30.0, secs0
+    assert "rank 1" in err0 or "Rank 1" in err0 or "ranks 1" in err0.lower(), err0
+    if how == "fail":
+        assert res[1][0] == EXIT_SELF_FAILED and "FAILED" in res[1][1]
