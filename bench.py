@@ -462,6 +462,14 @@ def main():
                          "share: 1024 scans, 4000^2 grid), 5 (streaming mapper)")
     ap.add_argument("--scans", type=int, default=None, help="scans per GPU (default: 256; config 4: 1024)")
     ap.add_argument("--grid", type=int, default=None, help="grid side in cells (default: 2000; config 4: 4000)")
+    ap.add_argument("--map-points", type=int, default=MAP_POINTS,
+                    help="model points of the registration target (default 10 000: BASELINE configs 1/2/4).  The reference's own cap is "
+                         "2 x 19 999 (icpTools.h:21, icpTools.cpp:255-274): --map-points 39998")
+    ap.add_argument("--map-kind", choices=["room", "uniform"], default="room",
+                    help="room = the synthetic room's walls and pillars sampled more densely (SURVEY 8(d)); uniform = half the points per "
+                         "class uniformly random over the room's 40 m x 30 m (no structure for the index to exploit, and nothing to register "
+                         "against: timing only, the pose check is skipped)")
+    ap.add_argument("--wave-tiles", type=int, default=0, help="slam_icp_params::wave_tiles (1 = per-wavefront model tiles in LDS for models too large for LDS; 0 = library default, off)")
     ap.add_argument("--clouds", type=int, default=50, help="config 3: clouds of the sequence")
     ap.add_argument("--stream-scans", type=int, default=10240, help="config 5: scans of the stream per GPU")
     ap.add_argument("--chunk", type=int, default=256, help="config 5: scans per chunk")
@@ -613,7 +621,13 @@ def main():
         if comm is not None:
             comm.set_timeout(args.merge_timeout)     # a united range that takes longer is a lost rank: SLAM_E_TIMEOUT, not a hang
 
-    m_ga, m_nga = synth.make_map(MAP_POINTS)
+    if args.map_kind == "uniform":
+        rs_ = np.random.RandomState(4242)
+        half = args.map_points // 2
+        m_ga = rs_.rand(half, 2) * [synth.ROOM_W, synth.ROOM_H] - [synth.ROOM_W / 2, synth.ROOM_H / 2]
+        m_nga = rs_.rand(args.map_points - half, 2) * [synth.ROOM_W, synth.ROOM_H] - [synth.ROOM_W / 2, synth.ROOM_H / 2]
+    else:
+        m_ga, m_nga = synth.make_map(args.map_points)
 
     def barrier():
         if multi:
@@ -635,6 +649,8 @@ def main():
     P = batch.n_points
     p2l = args.mode == "p2l"
     mode_kw = dict(mode=api.ICP_P2L, normals_k=10) if p2l else {}
+    if args.wave_tiles:
+        mode_kw["wave_tiles"] = args.wave_tiles
     icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, lanes_per_point=args.lanes, cell_size=args.cell, **mode_kw)
     grid_kw = dict(rolling=0, min_cluster_points=20, raycast_wg_per_cu=args.raycast_wg, raycast_max_workgroups=args.raycast_max_wg, raycast_seg_items=args.raycast_seg or 0,
                    raycast_impl={"tiled": api.RAYCAST_TILED, "merge": api.RAYCAST_TILED_MERGE, "global": api.RAYCAST_GLOBAL}[args.raycast])
@@ -962,7 +978,7 @@ def main():
     t_fin = d_t.download()
     assert (res["iters"] == N_ITERS).all(), "not every scan ran %d iterations" % N_ITERS
     pose_err = float(np.abs(t_fin - batch.true_poses[:, :2]).max())
-    assert pose_err < 0.05, "registered poses are off by %.3f m" % pose_err
+    assert pose_err < 0.05 or args.map_kind != "room", "registered poses are off by %.3f m" % pose_err
 
     # the storage rows one step's finalize (and count reset) covers: the rows the step's raycast touched -- with N>1 the
     # rows any rank touched (the merge's united range); read back from the device-tracked range, outside the timed region
@@ -1073,7 +1089,8 @@ def main():
                                                    ("slam_grid_merge_begin/_finish over RCCL" if args.backend == "nccl" else "slam_grid_merge_begin/_finish over the host-staged communicator, gloo rehearsal") if merging
                                                    else (", NO merge (--no-merge: independent ranks)" if multi else "")),
                        "scans_per_gpu": S, "icp_iters": N_ITERS, "grid": [GRID, GRID], "grid_buffers": len(grids), "resolution": RES,
-                       "map_points": M, "icp_index": info, "raycast": args.raycast,
+                       "map_points": M, "map_kind": args.map_kind, "map_points_per_class": [len(m_ga), len(m_nga)],
+                       "icp_index": info, "raycast": args.raycast,
                        "raycast_worklist": grid.raycast_stats(),
                        "merge_rows": list(merge_rows_seen[-1]) if merging and merge_rows_seen else None,
                        "reg_cu_cap_per_xcd": args.reg_cu_cap, "grid_lag": args.grid_lag, "merge_order": args.merge_order if merging else None,

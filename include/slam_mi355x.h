@@ -132,6 +132,13 @@ typedef struct {
                                become resident before the scan is handed to the one-workgroup form instead (another
                                spread launch, another process or a persistent kernel may hold the CUs they need; a fit
                                never fails for it, icp.cpp:80-114); 0 = library default (5000), < 0 = hand over at once */
+    int    wave_tiles;      /* a model whose index does not fit LDS (the reference's cap is 2 x 19 999 points, icpTools.h:21):
+                               1 = every wavefront stages the model TILE of its two passes -- the union of its queries' 3 x 3 cell
+                               blocks, one contiguous span per lattice row -- into its own 9 KB of the otherwise empty LDS, keeps it
+                               over the iterations and searches there; 0 = library default: every query through L2.  Measured in
+                               round 5: the tiles halve the kernel's L2 traffic and make it 20-30 % SLOWER -- the
+                               kernel is bound by instruction issue, not by its loads -- so the default is off; the tiled form is
+                               kept for models sparse enough to stage once (tests/test_gpu_icp_tile.py pins its results) */
 } slam_icp_params;
 
 typedef struct {

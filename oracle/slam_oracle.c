@@ -559,8 +559,22 @@ static double fit_step_p2p(const oicp_model *m, const double *t_ga, int n_tga,
                            const oicp_params *p, int *n_corr, int *corr_idx)
 {
     int     total = n_tga + n_tnga;
-    double *pm = (double *)malloc(sizeof(double) * 2 * (size_t)(total ? total : 1));
-    double *pt = (double *)malloc(sizeof(double) * 2 * (size_t)(total ? total : 1));
+    /* the correspondence lists p_m, p_t: one block per THREAD, grown on demand and kept (the reference allocates its
+     * Matrix temporaries per step; as the CPU baseline of bench.py this port should not pay malloc's arena locks 30 times
+     * per scan on every core of the host) */
+    static __thread double *scratch = NULL;
+    static __thread size_t  scratch_cap = 0;
+    size_t                  need = 4 * (size_t)(total ? total : 1);
+    if (need > scratch_cap) {
+        free(scratch);
+        scratch = (double *)malloc(sizeof(double) * need);
+        scratch_cap = scratch ? need : 0;
+        if (!scratch) {
+            *n_corr = 0;
+            return -1.0;
+        }
+    }
+    double *pm = scratch, *pt = scratch + need / 2;
     double  mu_m[2] = {0, 0}, mu_t[2] = {0, 0};
     int     in = 0;
     double  r00 = R[0], r01 = R[1], r10 = R[2], r11 = R[3], t0 = t[0], t1 = t[1];
@@ -597,11 +611,7 @@ static double fit_step_p2p(const oicp_model *m, const double *t_ga, int n_tga,
         }
     }
     *n_corr = in;
-    if (in == 0) { /* :128-131 */
-        free(pm);
-        free(pt);
-        return -1.0;
-    }
+    if (in == 0) return -1.0; /* :128-131 */
     mu_m[0] = mu_m[0] / (double)in;
     mu_m[1] = mu_m[1] / (double)in;
     mu_t[0] = mu_t[0] / (double)in;
@@ -636,8 +646,6 @@ static double fit_step_p2p(const oicp_model *m, const double *t_ga, int n_tga,
     double a0 = R_[0] - 1.0, a3 = R_[3] - 1.0;
     double nr = sqrt(a0 * a0 + R_[1] * R_[1] + R_[2] * R_[2] + a3 * a3);
     double nt = sqrt(t_[0] * t_[0] + t_[1] * t_[1]);
-    free(pm);
-    free(pt);
     return nr > nt ? nr : nt;
 }
 

@@ -419,6 +419,61 @@ __device__ inline void accumulate_point(const IndexPtrs<StartT> &ix, const Model
     }
 }
 
+// accumulate_point for an index in HBM/L2 with the wavefront's model tile in LDS (icp_search.hpp): called by EVERY lane of the
+// wavefront (`valid` = the lane has a point), because the staging is the wavefront's.  A seeded query whose disk touches at most
+// 3 x 3 cells is searched in the tile; everything else -- no seed yet, a large disk, the other class, a block too large to
+// stage, an exact tie -- takes the ordinary searches on the index in L2.  Same neighbour either way.  The seed is last
+// iteration's neighbour: its position AND its coordinates (registers: no load to learn the disk).
+template <int GG, typename StartT, int MODE, bool PK>
+__device__ __forceinline__ void accumulate_point_tile(const WaveTile &wt, TileState &ts, const IndexPtrs<StartT> &ix, const ModelView &mv,
+                                                      const FitArgs &fa, const Pose &T, const double2 P, bool valid, bool is_ga, int sub,
+                                                      double acc[kNumAcc], int &far, int &seed, float2 &seed_xy, bool allow)
+{
+    static_assert(PK, "the tile scan is written for the packed, second-best form");
+    float qx, qy;
+    transform_query(T, P, qx, qy);
+    const int    cls = MODE == SLAM_ICP_P2L ? 1 : (is_ga ? 0 : 1);
+    const bool   ok = valid && (MODE == SLAM_ICP_P2L || mv.n_cls[cls] > 3); // icpPointToPoint.cpp:59,93
+    const double gate = MODE == SLAM_ICP_P2L ? (double)INFINITY : fa.indist;
+    Best         b;
+    b.d = FLT_MAX;
+    b.oidx = 0xffffffffu;
+    b.pos = -1;
+    SeedBox bx = {0, -1, 0, -1, false};
+    if (ok && seed >= 0) {
+        b.d = ulp_above(dist2(seed_xy, qx, qy));
+        b.pos = seed;
+        bx = seed_box(mv.lat, qx, qy, b.d);
+    }
+    const bool in_tile = wave_tile_ready<StartT>(wt, ts, ix, mv, bx.small && allow, cls, bx);
+    if (!ok) return;
+    float2 m;
+    bool   have_m = false;
+    if (in_tile) {
+        bool tie = false;
+        wave_tile_scan<GG, PK>(b, m, tie, wt, ts, bx, sub, qx, qy);
+        have_m = !tie;
+        if (tie) { // rare: the plain exact search, as in nn_search_seeded
+            bool unused = false;
+            b = nn_search_impl<GG, StartT, true>(ix, mv, cls, qx, qy, sub, gate, unused);
+        } else if (MODE == SLAM_ICP_P2L) {
+            b.oidx = (unsigned)ix.oidx[mv.base[1] + b.pos]; // (the normals are indexed by it)
+        }
+    } else {
+        float e_out;
+        b = nn_search_seeded<GG, StartT, PK>(ix, mv, cls, qx, qy, sub, gate, seed, 0.0f, 0.0f, e_out);
+    }
+    if (!have_m && b.pos >= 0) m = ix.pts[mv.base[cls] + b.pos];
+    seed = b.pos;
+    seed_xy = m;
+    if (MODE == SLAM_ICP_P2P) {
+        if (sub == 0 && b.pos >= 0 && (double)b.d < fa.indist) add_p2p_xy(mv, m, qx, qy, acc); // :76
+    } else if (sub == 0 && b.pos >= 0) {
+        add_p2l(m, reinterpret_cast<const double2 *>(mv.normals)[b.oidx], qx, qy, acc);
+    }
+    far += (sub == 0 && !(b.pos >= 0 && b.d < mv.cert2)) ? 1 : 0;
+}
+
 // One pass of the workgroup over kBlock/GG consecutive scene points from p0.
 template <int GG, typename StartT, int MODE>
 __device__ inline void point_pass(const IndexPtrs<StartT> &ix, const ModelView &mv, const FitArgs &fa,
@@ -452,11 +507,12 @@ __device__ inline void point_pass_reg(const IndexPtrs<StartT> &ix, const ModelVi
 // Iterations fs.iters .. max_iter-1 of the workgroup's scan in one search form (SWEEP 0: ring search with G lanes
 // per point on the cell index `ix`; SWEEP 2: list sweeps on the halo lists `lp`, the undecided few on `ix`).
 // phase 1 stops from fa.switch_iter on with fs.hand_over set as soon as the list form can take over (see the guard).
-template <int G, typename StartT, int MODE, int SWEEP, int TB = kBlock>
+template <int G, typename StartT, int MODE, int SWEEP, int TB = kBlock, bool TILE = false>
 __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArgs &fa, const IndexPtrs<StartT> &ix,
                                                const ListPtrs &lp, unsigned char *smem /* the team's scratch */, int s, int off,
                                                int n, int nga, int phase, FitState &fs, Team<TB> &tm)
 {
+    static_assert(!TILE || (TB == icp::kBlock && SWEEP == 0 && G >= 1), "wave tiles: the ring form of a whole workgroup");
     constexpr int      kWaves = TeamDims<TB>::kW, kBlock = TB, kCoopPerBlock = TeamDims<TB>::kCoopBlock; // of the TEAM, from here on
     constexpr unsigned kReduceBytes = TeamDims<TB>::kReduce;
     double *partial = reinterpret_cast<double *>(smem); // [2][kWaves][kNumAcc]
@@ -465,6 +521,8 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
     unsigned short *queue = reinterpret_cast<unsigned short *>(smem + kReduceBytes + 4 * kWaves); // [kWaves][64]
     const int tid = tm.tid;
     const int lane = tid & 63, wave = tid >> 6;
+    // TILE: behind the scratch, one region per wavefront for the model tile of its pass (icp_search.hpp)
+    const WaveTile wtile = wave_tile_at(smem + TeamDims<TB>::kScratch + (TILE ? (unsigned)wave * kWaveTileBytes : 0u));
     const int iter_begin = fs.iters;
     double    r00 = fs.r00, r01 = fs.r01, r10 = fs.r10, r11 = fs.r11, t0 = fs.t0, t1 = fs.t1, delta = fs.delta;
     int       iters = fs.iters, n_corr = fs.n_corr;
@@ -475,8 +533,12 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
     // (the first n % kPerPass lane groups take one beam more than the others: the last pass is as short as it was with
     // consecutive lane groups per pass -- 55 points in two wavefronts for a 1081-beam scan -- not a pass of every wavefront)
     const int     n_full = n / kPerPass, n_rest = n % kPerPass;
+    // TILE: the two passes of a WAVEFRONT are neighbours -- it takes 64 / G adjacent beams in pass 0 and the next 64 / G in pass 1,
+    // so that one tile in LDS covers both (a scan of more than one pass; the same points per pass as a workgroup either way)
+    const bool    tile_pairs = TILE && G > 0 && n > kPerPass;
     const auto    ring_point = [&](int k) {
         const int g = tid / (G > 0 ? G : 1);
+        if (tile_pairs && k < 2) return (2 * wave + k) * (64 / (G > 0 ? G : 1)) + (lane / (G > 0 ? G : 1));
         if (!kSeedChain) return k * kPerPass + g;
         return (k < n_full || (k == n_full && g < n_rest)) ? g * n_full + min(g, n_rest) + k : n; // n: none
     };
@@ -495,6 +557,8 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
     constexpr bool kKeepPoint = !(SWEEP && sizeof(StartT) == 4 && TB < icp::kBlock);
     const double2  Pc0 = kKeepPoint ? hoisted(0) : make_double2(0.0, 0.0), Pc1 = SWEEP ? Pc0 : hoisted(1), Pc2 = SWEEP ? Pc0 : hoisted(2);
 
+    TileState ts = {0, 0, -1, -1, 0, false, false, false};               // TILE: the wavefront's tile, kept over the iterations
+    float2    sxy0 = make_float2(0.f, 0.f), sxy1 = make_float2(0.f, 0.f); // ... and the coordinates of the seeds of its two passes
     int   sd0 = -1, sd1 = -1, sd2 = -1; // ring form: last iteration's neighbour of the lane's point in each hoisted pass
     float em0 = 0.f, em1 = 0.f, em2 = 0.f, move_r = 0.f, move_t = 0.f; // ... the radius it proved empty; the last step's size
     bool hand_over = false;
@@ -561,7 +625,12 @@ __device__ __forceinline__ void fit_iterations(const ModelView &mv, const FitArg
                             const bool same_cls = MODE == SLAM_ICP_P2L || ((p - 1 < nga) == (p < nga));
                             if (sd < 0 && pass > 0 && same_cls) sd = chain;
                         }
-                        point_pass_reg<(G > 0 ? G : 1), StartT, MODE, kTunedScan>(ix, mv, fa, T, n, nga, p, P, acc, far, tid, &sd, &em, move_r, move_t);
+                        if (TILE && pass < 2) {
+                            float2 sxy = pass == 0 ? sxy0 : sxy1;
+                            accumulate_point_tile<(G > 0 ? G : 1), StartT, MODE, kTunedScan>(wtile, ts, ix, mv, fa, T, P, p < n, p < nga, tid % (G > 0 ? G : 1), acc, far, sd, sxy, iter >= iter_begin + kTileFirstIter);
+                            sxy0 = pass == 0 ? sxy : sxy0, sxy1 = pass == 1 ? sxy : sxy1;
+                        } else
+                            point_pass_reg<(G > 0 ? G : 1), StartT, MODE, kTunedScan>(ix, mv, fa, T, n, nga, p, P, acc, far, tid, &sd, &em, move_r, move_t);
                         sd0 = pass == 0 ? sd : sd0, sd1 = pass == 1 ? sd : sd1, sd2 = pass == 2 ? sd : sd2;
                         if (kSeedEmpty) em0 = pass == 0 ? em : em0, em1 = pass == 1 ? em : em1, em2 = pass == 2 ? em : em2;
                         chain = p < n ? sd : -1;
@@ -753,9 +822,10 @@ __device__ inline FitState load_fit(const FitArgs &fa, int s, int iter_begin)
     return fs;
 }
 
-template <int G, bool LDS, typename StartT, int MODE, int SWEEP>
+template <int G, bool LDS, typename StartT, int MODE, int SWEEP, bool TILE = false>
 __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs fa)
 {
+    static_assert(!(TILE && LDS), "a wave tile is for an index that is NOT in LDS");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr unsigned kScratch = kScratchBytes;
     static_assert(kScratch % 16 == 0, "scratch keeps the blob 16-B aligned");
@@ -784,7 +854,7 @@ __global__ __launch_bounds__(kBlock) void icp_fit_kernel(ModelView mv, FitArgs f
     }
     FitState     fs = load_fit(fa, s, iter_begin);
     Team<kBlock> tm = {(int)threadIdx.x, nullptr, 0u};
-    fit_iterations<G, StartT, MODE, SWEEP>(mv, fa, ix, lp, smem, s, off, n, nga, fa.phase, fs, tm);
+    fit_iterations<G, StartT, MODE, SWEEP, kBlock, TILE>(mv, fa, ix, lp, smem, s, off, n, nga, fa.phase, fs, tm);
     if (threadIdx.x == 0) store_fit(fa, s, fs, fa.phase);
 }
 
@@ -1003,10 +1073,28 @@ int launch_fit_sweep(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st
     return SLAM_E_UNSUPPORTED;
 }
 
+// the ring form on an index in HBM/L2 with the wavefronts' model tiles in the otherwise empty LDS (two lanes per point: a
+// wavefront's pass is 32 adjacent beams, whose 3 x 3 blocks one tile holds)
+template <typename StartT, int MODE>
+int launch_fit_tiled(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
+{
+    auto         kern = icp_fit_kernel<2, false, StartT, MODE, 0, true>;
+    const size_t lds = kScratchBytes + (size_t)kWaves * kWaveTileBytes;
+    static_assert(kScratchBytes + kWaves * kWaveTileBytes <= kLdsTotal, "sixteen wave tiles beside the scratch");
+    SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(n_scans), dim3(kBlock), lds, st, h->mv, fa);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
 template <int G, int MODE>
 int launch_fit_g(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t st)
 {
     if (h->in_lds) return launch_fit_t<G, true, uint16_t, MODE>(h, fa, n_scans, st);
+    if constexpr (G == 2) {
+        if (h->prm.wave_tiles > 0 && fa.phase == 0)
+            return h->start32 ? launch_fit_tiled<uint32_t, MODE>(h, fa, n_scans, st) : launch_fit_tiled<uint16_t, MODE>(h, fa, n_scans, st);
+    }
     if (h->start32) return launch_fit_t<G, false, uint32_t, MODE>(h, fa, n_scans, st);
     return launch_fit_t<G, false, uint16_t, MODE>(h, fa, n_scans, st);
 }
@@ -1184,6 +1272,7 @@ void slam_icp_default_params(slam_icp_params *p)
     p->spread_scans = 0;
     p->pair_scans = 0;
     p->spread_wait_us = 0;
+    p->wave_tiles = 0;
 }
 
 } // extern "C"

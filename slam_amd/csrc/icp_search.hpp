@@ -508,6 +508,188 @@ __device__ inline Best nn_search_seeded(const IndexPtrs<StartT> &ix, const Model
     return b;
 }
 
+// ---- The model TILE of a wavefront (round 5).  A model too large for LDS (the reference's own cap is 2 x 19 999 points,
+// icpTools.h:21) leaves the index in HBM/L2, where a query is a chain of dependent gathers: 221 M lane-loads per launch of 256
+// scans, each its own trip through the texture path, six or seven round trips deep.  But LDS is then EMPTY, and the queries of a
+// wavefront are ADJACENT beams: their 3 x 3 cell blocks overlap and lie along one stretch of wall.  So the wavefront stages the
+// union of those blocks (a cell of margin around it) -- per lattice row one CONTIGUOUS span of the sorted array, read with
+// coalesced loads, every line once -- into its own LDS region together with the cell starts of the block, and KEEPS it: a
+// converging scan moves by millimetres per iteration, so the tile staged around iteration 3 serves the other twenty-seven.  Its
+// queries then run the seeded 3 x 3 scan of nn_search_seeded_impl out of LDS, with no load from L2 at all (the seed's coordinates
+// stay in registers, the neighbour's come from the tile).
+// Exact like the path it replaces: the same cells are scanned for every query (a cell's points are the same bytes, staged);
+// queries whose disk is larger than 3 x 3 cells (the first iterations), lanes of the other class, queries that have left the
+// staged block (it is staged again around them) and wavefronts whose block does not fit take the ordinary path through L2.
+constexpr int      kTilePts = 960, kTileCells = 736, kTileRows = 48;
+constexpr unsigned kWaveTileBytes = 8u * kTilePts + 2u * kTileCells + 4u * kTileRows + 2u * kTileRows;
+constexpr int      kTileMaxFail = 3, kTileMaxRestage = 20; // a wavefront whose block does not fit, or that keeps staging (two classes in
+                                                           // turn, a scan that will not settle), stops trying
+constexpr int      kTileFirstIter = 3; // no staging before: the first steps move a query by cells, a tile staged then is stale at once
+static_assert(kWaveTileBytes % 16 == 0, "wave tiles keep 16-byte alignment");
+
+struct WaveTile {
+    float2         *pts;  // [kTilePts] the staged spans, row after row
+    unsigned short *cell; // [rows][ncol] cell starts (ncol - 1 cells and the end of the last), relative to the row's first staged point
+    int            *rowA; // [kTileRows] position of the row's first staged point in the class's sorted array
+    unsigned short *rowOff; // [kTileRows] where the row's points start in pts
+};
+
+// what a wavefront knows about its tile from one iteration to the next (the same in every lane)
+struct TileState {
+    int  X0, Y0, X1, Y1; // the staged block of cells, inclusive
+    int  restages;
+    bool staged, cls1, off;
+};
+
+__device__ inline WaveTile wave_tile_at(unsigned char *base)
+{
+    WaveTile t;
+    t.pts = reinterpret_cast<float2 *>(base);
+    t.cell = reinterpret_cast<unsigned short *>(base + 8u * kTilePts);
+    t.rowA = reinterpret_cast<int *>(base + 8u * kTilePts + 2u * kTileCells);
+    t.rowOff = reinterpret_cast<unsigned short *>(base + 8u * kTilePts + 2u * kTileCells + 4u * kTileRows);
+    return t;
+}
+
+__device__ inline int wave_min_i32(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+
+// The box of cells the disk of a seeded query's current best distance touches, as nn_search_seeded_impl computes it.
+struct SeedBox {
+    int  x_lo, x_hi, y_lo, y_hi;
+    bool small; // at most 3 x 3 cells: one pass over them ends the search
+};
+
+__device__ inline SeedBox seed_box(const Lattice &L, float qx, float qy, float d)
+{
+    const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
+    const float R = (disk_radius(d) + L.margin) * L.inv_h;
+    SeedBox     bx;
+    bx.x_lo = max(0, ifloor(fx - R));
+    bx.x_hi = min(L.nx - 1, ifloor(fx + R));
+    bx.y_lo = max(0, ifloor(fy - R));
+    bx.y_hi = min(L.ny - 1, ifloor(fy + R));
+    bx.small = bx.x_hi - bx.x_lo <= 2 && bx.y_hi - bx.y_lo <= 2 && bx.x_lo <= bx.x_hi && bx.y_lo <= bx.y_hi;
+    return bx;
+}
+
+// Stages the block of cells [X0, X1] x [Y0, Y1] of one class into the wavefront's tile; all arguments are the same in every lane
+// (scalar registers), every lane takes part.  False (nothing usable staged) when the block does not fit.
+template <typename StartT>
+__device__ __forceinline__ bool wave_tile_fill(const WaveTile &wt, const IndexPtrs<StartT> &ix, const ModelView &mv, bool cls1, int X0,
+                                               int Y0, int X1, int Y1)
+{
+    const int lane = (int)threadIdx.x & 63;
+    const int nrow = Y1 - Y0 + 1, ncol = X1 - X0 + 2;
+    if (nrow > kTileRows || nrow * ncol > kTileCells) return false;
+    const Lattice &L = mv.lat;
+    const StartT  *start = cls1 ? ix.start[1] : ix.start[0]; // (selects: an index would put the arrays on the stack)
+    const float2  *pts = ix.pts + (cls1 ? mv.base[1] : mv.base[0]);
+    int            A = 0, cnt = 0; // lane r: the span of row Y0 + r
+    if (lane < nrow) {
+        const int row = (Y0 + lane) * L.nx;
+        A = (int)start[row + X0];
+        cnt = (int)start[row + X1 + 1] - A;
+    }
+    int incl = cnt; // inclusive prefix over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int up = __shfl_up(incl, o);
+        incl += lane >= o ? up : 0;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total > kTilePts) return false;
+    const int off = incl - cnt;
+    if (lane < nrow) {
+        wt.rowA[lane] = A;
+        wt.rowOff[lane] = (unsigned short)off;
+    }
+    for (int r = 0; r < nrow; ++r) {
+        const int Ar = __builtin_amdgcn_readlane(A, r), nr = __builtin_amdgcn_readlane(cnt, r), offr = __builtin_amdgcn_readlane(off, r);
+        const int row = (Y0 + r) * L.nx + X0;
+        for (int c = lane; c < ncol; c += 64) wt.cell[r * ncol + c] = (unsigned short)((int)start[row + c] - Ar);
+        for (int i = lane; i < nr; i += 64) wt.pts[offr + i] = pts[Ar + i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); // LDS serves a wavefront's accesses in order: what the lanes wrote is
+    __builtin_amdgcn_wave_barrier();                        // there for the reads that follow; the compiler must not move them up
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return true;
+}
+
+// Called by ALL lanes of a wavefront (the control flow around the staging is uniform).  `want` = this lane has a seeded query of
+// class `cls` whose box `bx` is small.  Returns true for the lanes whose box lies in the wavefront's tile (staged now or in an
+// earlier iteration): their scan reads the tile.  False = take the ordinary path.
+template <typename StartT>
+__device__ __forceinline__ bool wave_tile_ready(const WaveTile &wt, TileState &ts, const IndexPtrs<StartT> &ix, const ModelView &mv,
+                                                bool want, int cls, const SeedBox &bx)
+{
+    if (ts.off) return false;
+    const unsigned long long any = __ballot(want);
+    if (__popcll(any) < 8) return false; // too few takers to pay for a staging (the first iterations; a nearly empty pass)
+    const bool cls1 = __builtin_amdgcn_readlane(cls, __builtin_ctzll(any)) != 0; // the wavefront's class: its first taker's
+    const bool mine = want && (cls != 0) == cls1;
+    const bool have = ts.staged && ts.cls1 == cls1;
+    const bool inside = have && bx.x_lo >= ts.X0 && bx.x_hi <= ts.X1 && bx.y_lo >= ts.Y0 && bx.y_hi <= ts.Y1;
+    if (__ballot(mine && !inside)) { // somebody's block is not staged: stage again, around everybody (uniform branch)
+        const Lattice &L = mv.lat;
+        // (the same in every lane, and SAID so: the loops of the staging then run on scalar registers)
+        int X0 = __builtin_amdgcn_readfirstlane(wave_min_i32(mine ? bx.x_lo : 0x7fffffff)) - 1;
+        int Y0 = __builtin_amdgcn_readfirstlane(wave_min_i32(mine ? bx.y_lo : 0x7fffffff)) - 1;
+        int X1 = -__builtin_amdgcn_readfirstlane(wave_min_i32(mine ? -bx.x_hi : 0x7fffffff)) + 1;
+        int Y1 = -__builtin_amdgcn_readfirstlane(wave_min_i32(mine ? -bx.y_hi : 0x7fffffff)) + 1;
+        X0 = max(X0, 0), Y0 = max(Y0, 0), X1 = min(X1, L.nx - 1), Y1 = min(Y1, L.ny - 1);
+        bool ok = false;
+        if (have) // the other pass of this wavefront lives in the same tile: keep its block in
+            ok = wave_tile_fill<StartT>(wt, ix, mv, cls1, min(X0, ts.X0), min(Y0, ts.Y0), max(X1, ts.X1), max(Y1, ts.Y1));
+        if (ok) {
+            X0 = min(X0, ts.X0), Y0 = min(Y0, ts.Y0), X1 = max(X1, ts.X1), Y1 = max(Y1, ts.Y1);
+        } else {
+            ok = wave_tile_fill<StartT>(wt, ix, mv, cls1, X0, Y0, X1, Y1);
+        }
+        ts.staged = ok;
+        ts.cls1 = cls1;
+        ts.X0 = X0, ts.Y0 = Y0, ts.X1 = X1, ts.Y1 = Y1;
+        ts.restages += ok ? 1 : (kTileMaxRestage / kTileMaxFail + 1); // (a failure weighs as much as a third of the budget)
+        if (ts.restages > kTileMaxRestage) ts.off = true;            // (this staging still serves this pass)
+        return mine && ok;
+    }
+    return mine && inside;
+}
+
+// The seeded 3 x 3 scan of nn_search_seeded_impl out of the wavefront's tile.  b comes in as the seed (distance one ulp up, PK form)
+// and leaves as the group's best, m as its coordinates; positions are those of the class's sorted array, as everywhere.
+template <int G, bool PK>
+__device__ __forceinline__ void wave_tile_scan(Best &b, float2 &m, bool &tie, const WaveTile &wt, const TileState &ts, const SeedBox &bx,
+                                               int sub, float qx, float qy)
+{
+    constexpr int kHere = 0x7ffffff0; // "the best so far is not of this row"
+    const int     ncol = ts.X1 - ts.X0 + 2;
+    for (int y = bx.y_lo; y <= bx.y_hi; ++y) {
+        const int r = y - ts.Y0;
+        const int a = (int)wt.cell[r * ncol + (bx.x_lo - ts.X0)], e = (int)wt.cell[r * ncol + (bx.x_hi + 1 - ts.X0)];
+        Best      bl;
+        bl.d = b.d;
+        bl.pos = kHere;
+        bl.oidx = 0xffffffffu;
+        scan_range_rt<unsigned short, false, PK>(bl, tie, wt.pts + (int)wt.rowOff[r], nullptr, a, e, sub, G, qx, qy);
+        if (bl.pos != kHere) {
+            b.d = bl.d;
+            b.pos = wt.rowA[r] + bl.pos;
+        }
+    }
+    if (G > 1) group_min_lean<G>(b, tie);
+    // the winner's coordinates, from the tile: it lies in one of the rows of the box (the seed too: it is inside its own disk)
+    m = make_float2(0.f, 0.f);
+    for (int y = bx.y_lo; y <= bx.y_hi; ++y) {
+        const int r = y - ts.Y0, rel = b.pos - wt.rowA[r];
+        if (rel >= 0 && rel < (int)wt.cell[r * ncol + ncol - 1]) m = wt.pts[(int)wt.rowOff[r] + rel];
+    }
+}
+
 // What a finished search proves about the query and what the next iteration's search of the same scene
 // point starts from (icp_single.hip): the neighbour's position in the sorted array, and a radius within which
 // the class has no point (the neighbour's distance, or the edge of the last ring when the inlier gate ended
