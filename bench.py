@@ -523,6 +523,7 @@ def main():
                          "class uniformly random over the room's 40 m x 30 m (no structure for the index to exploit, and nothing to register "
                          "against: timing only, the pose check is skipped)")
     ap.add_argument("--wave-tiles", type=int, default=0, help="slam_icp_params::wave_tiles (1 = per-wavefront model tiles in LDS for models too large for LDS; 0 = library default, off)")
+    ap.add_argument("--list-min-halo", type=float, default=0.0, help="slam_icp_params::list_min_halo in metres (0 = library default, < 0 = the finest lattice that fits)")
     ap.add_argument("--clouds", type=int, default=50, help="config 3: clouds of the sequence")
     ap.add_argument("--stream-scans", type=int, default=10240, help="config 5: scans of the stream per GPU")
     ap.add_argument("--chunk", type=int, default=256, help="config 5: scans per chunk")
@@ -704,6 +705,8 @@ def main():
     mode_kw = dict(mode=api.ICP_P2L, normals_k=10) if p2l else {}
     if args.wave_tiles:
         mode_kw["wave_tiles"] = args.wave_tiles
+    if args.list_min_halo:
+        mode_kw["list_min_halo"] = args.list_min_halo
     icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, lanes_per_point=args.lanes, cell_size=args.cell, **mode_kw)
     grid_kw = dict(rolling=0, min_cluster_points=20, raycast_wg_per_cu=args.raycast_wg, raycast_max_workgroups=args.raycast_max_wg, raycast_seg_items=args.raycast_seg or 0,
                    raycast_impl={"tiled": api.RAYCAST_TILED, "merge": api.RAYCAST_TILED_MERGE, "global": api.RAYCAST_GLOBAL}[args.raycast])
@@ -800,10 +803,21 @@ def main():
     use_thread = merging and bool(args.merge_thread)
     mode = {"thread": False}                            # set per run_steps call: only the pipelined, un-instrumented steps post to the helper
     ticket_of = {}                                      # id(grid) -> ticket of the merge that still owns the grid and its stream
+    ray_done = {id(g_): api.Event() for g_ in grids}    # behind the raycast whose merge the ticket stands for
+    pace = {"ms": 0.0, "n": 0}                          # the enqueue thread's wait for the DEVICE (back-pressure), apart from the merge's
 
     def settle(g):
         t_ = ticket_of.pop(id(g), None)
         if t_ is not None:
+            # Two waits, told apart: (1) for the device to have finished the raycast this merge belongs to -- back-pressure: a bounded
+            # pipeline whose consumer is the slower side holds its producer exactly here, by a whole step per step, and that is what
+            # keeps the host a fixed number of registrations AHEAD (host_enqueue_slack_ms); (2) for the helper thread to have posted the
+            # merge behind it -- the 24-byte MIN over the ranks, the helper's wake-up, the enqueue of the row all-reduce: the part that
+            # grows with rank count and skew (merge.merge_wait_ms, from slam_comm_get_stats).
+            t_p = time.perf_counter()
+            ray_done[id(g)].synchronize()
+            pace["ms"] += (time.perf_counter() - t_p) * 1e3
+            pace["n"] += 1
             merge_rows_seen.append(comm.ticket_wait(t_))
 
     def enqueue_grid_update(k, b, e=None, g=None):
@@ -825,6 +839,7 @@ def main():
         if mode["thread"]:
             # the poses of this step have been read once the raycast is through: that is all a later registration waits for
             grid_done[s_].record(b)
+            ray_done[id(g)].record(b)
             ticket_of[id(g)] = comm.merge_async(g, b, api.MERGE_THEN_FINALIZE_RESET)
             return
         if merging:
@@ -933,6 +948,7 @@ def main():
     sync()
     if comm is not None:
         comm.stats_reset()           # the merge statistics of the JSON line are those of the timed steps
+    pace["ms"], pace["n"] = 0.0, 0
     graph = None
     if launch == "graph":
         try:
@@ -965,6 +981,7 @@ def main():
     barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    pace_timed = dict(pace)
     for g_ in grids:
         settle(g_)
     merge_stats = comm.stats() if comm is not None else None
@@ -1180,6 +1197,7 @@ def main():
                 "merges_in_timed_region": ms_.get("merges"),
                 "rows_per_merge": ms_.get("rows", 0) / n_m, "bytes_per_merge_per_rank": ms_.get("bytes", 0) / n_m,
                 "merge_wait_ms": ms_.get("wait_ms", 0.0) / n_m,
+                "backpressure_wait_ms": (pace_timed["ms"] / max(pace_timed["n"], 1)) if use_thread else None,
                 "helper_wait_ms": ms_.get("helper_wait_ms", 0.0) / n_m,
                 "merges_by_helper_thread": ms_.get("async_merges"),
                 "rccl_channels": rccl_channels() if args.backend == "nccl" else None,
@@ -1187,7 +1205,10 @@ def main():
                 "allreduce_GBps_per_rank": (ms_.get("bytes", 0) / n_m) / (ms_["allreduce_ms"] / ms_["timed"] * 1e-3) / 1e9
                 if ms_.get("timed") and ms_.get("allreduce_ms") else None,
                 "what": "merge_wait_ms = time the ENQUEUE thread spent waiting for anything of a merge (per merge; with the helper "
-                        "thread: for a ticket or a place in its queue; without: inside slam_grid_merge_finish for the united row range); "
+                        "thread: for a ticket or a place in its queue, AFTER the device had finished the raycast the merge belongs to; "
+                        "without: inside slam_grid_merge_finish for the united row range, the raycast's device time included); "
+                        "backpressure_wait_ms = the enqueue thread's wait, just before that, for the device to finish that raycast (two "
+                        "steps old: what holds a producer that is faster than the chip; host_enqueue_slack_ms says how far ahead it stays); "
                         "helper_wait_ms = the helper thread's wait for the united row range (device time of raycast + 24-byte all-reduce, hidden "
                         "from the enqueue thread); rccl_channels = workgroups per RCCL collective kernel, from RCCL's INIT log; "
                         "allreduce_ms = HIP events around the grouped row all-reduces on the grid stream (includes the time their "
@@ -1261,7 +1282,8 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, rk, sync, barr
     m_ga, m_nga = synth.make_map(5000)
     mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20, raycast_wg_per_cu=args.raycast_wg), grid_size_x=GRID, grid_size_y=GRID,
                     resolution=RES, max_scans=chunk, max_points=max(c.n_points for c in chunks),
-                    icp=dict(max_iter=N_ITERS, min_delta=-1.0, **(dict(mode=api.ICP_P2L, normals_k=10) if args.mode == "p2l" else {})),
+                    icp=dict(max_iter=N_ITERS, min_delta=-1.0, list_min_halo=args.list_min_halo,
+                             **(dict(mode=api.ICP_P2L, normals_k=10) if args.mode == "p2l" else {})),
                     window_chunks=args.window, rebuild_every=args.rebuild_every, keep_prior=1, target_points=5000,
                     thin_res=args.thin, merge_every=args.merge_every, registration_streams=args.reg_streams, slots=args.slots)
     if comm is not None:

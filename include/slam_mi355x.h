@@ -139,6 +139,10 @@ typedef struct {
                                round 5: the tiles halve the kernel's L2 traffic and make it 20-30 % SLOWER -- the
                                kernel is bound by instruction issue, not by its loads -- so the default is off; the tiled form is
                                kept for models sparse enough to stage once (tests/test_gpu_icp_tile.py pins its results) */
+    double list_min_halo;   /* halo lists: the lattice built is the first -- finest -- candidate whose lists fit LDS;
+                               with this set, the first whose HALO is at least this many metres, if one fits (any, otherwise).  A
+                               list answers a query whose neighbour is nearer than its halo; the others go to the cooperative
+                               round.  0 = library default, < 0 = no preference (the finest that fits) */
 } slam_icp_params;
 
 typedef struct {

@@ -1273,6 +1273,7 @@ void slam_icp_default_params(slam_icp_params *p)
     p->pair_scans = 0;
     p->spread_wait_us = 0;
     p->wave_tiles = 0;
+    p->list_min_halo = 0.0;
 }
 
 } // extern "C"

@@ -184,6 +184,10 @@ int plan_index(slam_icp *h, int n_ga, int n_nga, const BBox &bb, unsigned *lds_t
     return SLAM_OK;
 }
 
+// slam_icp_params::list_min_halo resolved (0 = the library's default)
+constexpr double kListMinHaloDefault = 0.125; // round 5: one launch of 256 scans against a 5 k-point model 0.68 -> 0.48 ms in pairs (tools/exp/halo_forms.py)
+inline double list_min_halo_of(const slam_icp_params &prm) { return prm.list_min_halo > 0 ? prm.list_min_halo : (prm.list_min_halo < 0 ? 0.0 : kListMinHaloDefault); }
+
 // The list lattices tried, in order: the first whose lists fit LDS beside the scratch is built.
 struct ListCand {
     double frac, hs, pad_m, x0, y0;
@@ -373,6 +377,10 @@ int build_lists_host(slam_icp *h, const std::vector<float> xy[2], const int cnt[
     };
     std::vector<ListCand> cands;
     list_candidates(bb, margin_abs, cands);
+    // the candidates whose halo reaches list_min_halo come first (in their order), then the others: a halo the converged
+    // neighbour distances do not fit under sends the queries to the cooperative round one by one (list_min_halo, slam_mi355x.h)
+    const double min_halo = list_min_halo_of(h->prm);
+    std::stable_partition(cands.begin(), cands.end(), [&](const ListCand &c) { return c.pad_m >= min_halo; });
     for (const ListCand &cand : cands) {
         const ListGeom g = geom_of(cand);
         const long     nx = cand.nx;
@@ -562,6 +570,7 @@ struct BuildWs {               // what the host knows when it enqueues the build
     unsigned char *blob, *lblob;
     double         cell_size;
     int            force_global, want_lists;
+    double         list_min_halo;
     unsigned       lds_total;
     // point-to-line (SLAM_ICP_P2L): the two classes as the caller gave them, merged into ONE class (class 1, GA then NGA: the order
     // of the reference's M_normal) before anything else looks at the model; normals per model point and per halo-list entry
@@ -974,13 +983,15 @@ __global__ __launch_bounds__(256) void list_cand_kernel(BuildWs w)
     }
 }
 
-// One wavefront: the first candidate, in the host's order, whose lists fit
+// One wavefront: the first candidate, in the host's order, whose lists fit -- among those whose halo reaches list_min_halo
+// if there is one (build_lists_host's partition), among all otherwise
 __global__ __launch_bounds__(64) void list_plan_kernel(BuildWs w)
 {
     DevPlan  &p = *w.plan;
     const int lane = threadIdx.x;
     int       pick = -1;
     ListPlan  lp;
+    for (int tier = 0; tier < 2 && pick < 0; ++tier)
     for (int k0 = 0; k0 < p.nc && pick < 0; k0 += 64) {
         const int k = k0 + lane;
         bool      ok = false;
@@ -995,7 +1006,7 @@ __global__ __launch_bounds__(64) void list_plan_kernel(BuildWs w)
             c.nx = g.nx;
             c.ny = g.ny;
             const unsigned long long n_ent[2] = {p.n_ent[k][0], p.n_ent[k][1]};
-            ok = accept_list_core(c, n_ent, p.budget, p.ip.maxabs, p.margin_abs, lp);
+            ok = (tier == 1 || c.pad_m >= w.list_min_halo) && accept_list_core(c, n_ent, p.budget, p.ip.maxabs, p.margin_abs, lp);
         }
         const unsigned long long m = __ballot(ok);
         if (m) {
@@ -1473,6 +1484,7 @@ int build_begin_device(slam_icp *h, const double *m_ga, int cap_ga, const double
     w.cell_size = h->prm.cell_size;
     w.force_global = h->prm.force_global;
     w.want_lists = want_lists ? 1 : 0;
+    w.list_min_halo = list_min_halo_of(h->prm);
     w.lds_total = lds_total;
     w.m[0] = m_ga;
     w.m[1] = m_nga;

@@ -17,8 +17,9 @@ api.set_device(0)
 chunks = [synth.make_batch(chunk, n_loop=n_chunks * chunk, first=k * chunk) for k in range(n_chunks)]
 m_ga, m_nga = synth.make_map(5000)
 mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20), grid_size_x=2000, grid_size_y=2000, resolution=0.05, max_scans=chunk,
-                max_points=max(c.n_points for c in chunks), icp=dict(max_iter=30, min_delta=-1.0), window_chunks=window, rebuild_every=every,
-                keep_prior=1, target_points=5000, thin_res=0.1, merge_every=8)
+                max_points=max(c.n_points for c in chunks), icp=dict(max_iter=30, min_delta=-1.0, list_min_halo=float(kw.get("min_halo", 0))), window_chunks=window, rebuild_every=every,
+                keep_prior=1, target_points=5000, thin_res=0.1, merge_every=8, registration_streams=int(kw.get("reg_streams", 0)),
+                slots=int(kw.get("slots", 0)))
 t0 = time.perf_counter()
 pending = []
 for k in range(n_chunks):
