@@ -25,6 +25,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -105,6 +106,8 @@ public:
         if (icp_) slam_icp_destroy(icp_);
         for (Cloud *c : {&raw_, &scene_raw_, &labels_, &obs_, &flags_, &seg_target_, &seg_scene_, &ground_target_, &ground_scene_, &scene_ground_})
             slam_free(c->p);
+        free_ahead();
+        free_seq();
         slam_free(d_ga_);
         slam_free(d_nga_);
         slam_free(d_scene_pts_);
@@ -160,6 +163,11 @@ public:
     // :611-634: segmentGround, classifyPoints, VoxelGrid 0.5 x 0.5 x 2 -- enqueued, nothing waited for
     void setSceneCloud(const float *xyz, int n, int stride)
     {
+        if (ahead_.pending && ahead_.xyz == xyz && ahead_.n == n && ahead_.stride == stride) {
+            adopt_ahead();
+            return;
+        }
+        ahead_.pending = false;
         upload(scene_raw_, xyz, n, stride);
         scene_n_in_ = n;
         scene_stride_ = stride;
@@ -222,6 +230,52 @@ public:
         }
         return result_from_io(initPose, pitch0, roll0);
     }
+
+    // ---- Throughput forms (round 5; the reference is one cloud at a time, scan_registration.cpp:109-173, and so are the calls above).
+    //
+    // (a) Two chains in flight.  prepareSceneCloud(cloud k+1) while cloud k is being matched: the upload and the scene chain
+    // (segmentGround + classifyPoints + voxel filter + split) of the NEXT cloud run on a second stream with buffers of their own
+    // -- they do not depend on the match in flight (only on roll / pitch / z of the incoming pose, which the caller has applied,
+    // scan_registration.cpp:128-138).  The next setSceneCloud with the same pointer and size adopts what was prepared instead of
+    // making it again; any other cloud is made from scratch as before.  The pointer must stay valid until then (pinned memory,
+    // slam_host_alloc, makes the upload asynchronous).
+    void prepareSceneCloud(const float *xyz, int n, int stride)
+    {
+        if (!ahead_.made && !make_ahead()) return;
+        Ahead &a = ahead_;
+        reserve_on(a.raw, sizeof(float) * (size_t)(n + 1) * stride, a.stream);
+        reserve_on(a.ground, 16 * (size_t)(n + 1), a.stream);
+        if (n > 0) ok(slam_memcpy_h2d_async(a.raw.p, xyz, sizeof(float) * (size_t)n * stride, a.stream));
+        ok(slam_ccicp_scene_dev(a.cc, a.gseg, (const float *)a.raw.p, n, stride, 1, 0, 0.0, 0.0, 0.0, ICP_MAX_PTS, a.d_pts,
+                                reinterpret_cast<int32_t *>(a.d_io + kOffScan), (float *)a.ground.p,
+                                reinterpret_cast<int32_t *>(a.d_io + kOffCounts), a.stream));
+        ok(slam_event_record(a.done, a.stream));
+        a.xyz = xyz, a.n = n, a.stride = stride;
+        a.pending = true;
+    }
+
+    // (b) A sequence whose initial poses are known beforehand (an offline log, a re-run against a new map): every scene's chain on
+    // one of kSeqLanes streams, the fits of up to kSeqBatch scenes as ONE slam_icp_fit_batch_dev, the heights on the lanes again, one
+    // read-back per batch.  Against the target as the calls above left it (setTargetCloud); the crop window of every pose applies as
+    // in doICPMatch (:225-239) -- a window that changes what the target's index is built from ends a batch.  Same poses as
+    // setSceneCloud + doICPMatch one by one (tests/test_gpu_cpp_adapters.py).  A scene with fewer than 5 points returns
+    // orientation.w == 9999 in its place (:179-184).
+    static constexpr int kSeqLanes = 4, kSeqBatch = 16;
+    std::vector<Pose> matchSequence(const float *const *scenes, const int *n_points, int count, int stride, const Pose *init)
+    {
+        std::vector<Pose> out((size_t)std::max(count, 0));
+        if (count <= 0 || !make_seq()) return out;
+        int k0 = 0;
+        while (k0 < count) {
+            ensure_target(init[k0]);
+            int k1 = k0 + 1;
+            while (k1 < count && k1 - k0 < kSeqBatch && target_stays(init[k1])) ++k1; // (target_stays narrows the crop box as doICPMatch would)
+            match_batch(scenes + k0, n_points + k0, k1 - k0, stride, init + k0, out.data() + k0);
+            k0 = k1;
+        }
+        return out;
+    }
+    int sequenceBatches() const { return seq_batches_; }
 
     double getResidual() const { return -1; } // :637-641 ("TODO: calculate this somehow")
     // :644-650: copies of seg_target, seg_scene, ground_target, ground_scene as x, y, z per point
@@ -329,14 +383,30 @@ private:
     // The model of this match: seg_target inside the intersection of every crop window since setTargetCloud (the reference
     // filters seg_target in place, :226-239), split by class with the cap (:263-276).  The index is rebuilt only when that
     // selects other points than it was built from.
-    void ensure_target(const Pose &initPose)
+    // the crop box after this pose's window (the intersection so far, :226-239) and whether the index built last still holds exactly
+    // the points it selects
+    bool next_box(const Pose &initPose, float nb[4]) const
     {
         const double crop_dist = 75;
         const float  win[4] = {(float)(-crop_dist + initPose.x), (float)(crop_dist + initPose.x), (float)(-crop_dist + initPose.y),
                                (float)(crop_dist + initPose.y)}; // setFilterLimits takes floats (:231,:236)
-        const float  nb[4] = {std::fmax(box_[0], win[0]), std::fmin(box_[1], win[1]), std::fmax(box_[2], win[2]), std::fmin(box_[3], win[3])};
-        const bool   same = !target_dirty_ && ((covers(nb) && covers(built_box_)) ||
-                                             (nb[0] == built_box_[0] && nb[1] == built_box_[1] && nb[2] == built_box_[2] && nb[3] == built_box_[3]));
+        nb[0] = std::fmax(box_[0], win[0]), nb[1] = std::fmin(box_[1], win[1]), nb[2] = std::fmax(box_[2], win[2]), nb[3] = std::fmin(box_[3], win[3]);
+        return !target_dirty_ && ((covers(nb) && covers(built_box_)) ||
+                                  (nb[0] == built_box_[0] && nb[1] == built_box_[1] && nb[2] == built_box_[2] && nb[3] == built_box_[3]));
+    }
+    // matchSequence: true = this pose's match runs against the index as it is (and the box is narrowed as its doICPMatch would);
+    // false = it needs another index: nothing changed, the batch ends before it
+    bool target_stays(const Pose &initPose)
+    {
+        float nb[4];
+        if (!next_box(initPose, nb)) return false;
+        for (int k = 0; k < 4; ++k) box_[k] = nb[k];
+        return true;
+    }
+    void ensure_target(const Pose &initPose)
+    {
+        float      nb[4];
+        const bool same = next_box(initPose, nb);
         for (int k = 0; k < 4; ++k) box_[k] = nb[k];
         if (same) return;
         if (icp_) {
@@ -482,6 +552,223 @@ private:
                 continue;
             xyz.insert(xyz.end(), p, p + 3);
         }
+    }
+
+    // ---- (a) the scene prepared ahead
+    struct Ahead {
+        bool          made = false, pending = false;
+        slam_gseg_t  *gseg = nullptr;
+        slam_ccicp_t *cc = nullptr;
+        slam_stream_t stream = nullptr;
+        slam_event_t  done = nullptr;
+        Cloud         raw, ground;
+        double       *d_pts = nullptr;
+        unsigned char *d_io = nullptr;
+        const float  *xyz = nullptr;
+        int           n = 0, stride = 3;
+    } ahead_;
+    static void reserve_on(Cloud &c, size_t bytes, slam_stream_t st)
+    {
+        if (bytes <= c.cap) return;
+        slam_stream_synchronize(st); // (the old block may be in use by work enqueued on its stream)
+        slam_free(c.p);
+        c.p = nullptr;
+        c.cap = 0;
+        const size_t want = bytes + bytes / 4;
+        if (slam_malloc(&c.p, want) == SLAM_OK) c.cap = want;
+    }
+    bool make_ahead()
+    {
+        Ahead &a = ahead_;
+        bool   good = slam_gseg_create(nullptr, &a.gseg) == SLAM_OK && slam_ccicp_create(&a.cc) == SLAM_OK && slam_stream_create(&a.stream) == SLAM_OK &&
+                    slam_event_create(&a.done) == SLAM_OK && slam_malloc((void **)&a.d_pts, 16 * 2 * (size_t)ICP_MAX_PTS) == SLAM_OK &&
+                    slam_malloc((void **)&a.d_io, kIoBytes) == SLAM_OK;
+        if (good) good = slam_memset(a.d_io, 0, kIoBytes, a.stream) == SLAM_OK;
+        if (!good) std::fprintf(stderr, "CCICP: %s\n", slam_last_error());
+        a.made = good;
+        return good;
+    }
+    void free_ahead()
+    {
+        Ahead &a = ahead_;
+        if (a.cc) slam_ccicp_destroy(a.cc);
+        if (a.gseg) slam_gseg_destroy(a.gseg);
+        slam_free(a.raw.p);
+        slam_free(a.ground.p);
+        slam_free(a.d_pts);
+        slam_free(a.d_io);
+        if (a.done) slam_event_destroy(a.done);
+        if (a.stream) slam_stream_destroy(a.stream);
+    }
+    // the prepared scene becomes THE scene: its buffers, handles and chain outputs change places with the current ones (the match's
+    // stream waits for the chain; nothing is copied)
+    void adopt_ahead()
+    {
+        Ahead &a = ahead_;
+        a.pending = false;
+        ok(slam_stream_wait_event(stream_, a.done));
+        ok(slam_event_record(a.done, stream_)); // ... and the second stream for whatever the match's stream still does with the buffers it gets
+        ok(slam_stream_wait_event(a.stream, a.done));
+        std::swap(scene_raw_, a.raw);
+        std::swap(scene_ground_, a.ground);
+        std::swap(d_scene_pts_, a.d_pts);
+        std::swap(gseg_, a.gseg); // (the chain's scratch -- what slam_ccicp_scene_cloud_dev reads -- lives in the handles)
+        std::swap(cc_, a.cc);
+        // the scan block and the counts of the chain: into the match's io block, device to device (32 bytes)
+        ok(slam_memcpy_d2d(d_io_ + kOffScan, a.d_io + kOffScan, kOffNgt - kOffScan, stream_));
+        scene_n_in_ = a.n;
+        scene_stride_ = a.stride;
+        scene_ready_ = true;
+        scene_known_ = false;
+        seg_scene_valid_ = ground_scene_valid_ = false;
+    }
+
+    // ---- (b) the sequence form
+    struct SeqLane {
+        slam_gseg_t  *gseg = nullptr;
+        slam_ccicp_t *cc = nullptr;
+        slam_stream_t stream = nullptr;
+        Cloud         raw, ground;
+    };
+    struct SeqIo { // per scene, device and pinned mirror: [scan {0, n, n_ga, -} | counts {obs, gnd, flt, err}]
+        int32_t scan[4], counts[4];
+    };
+    SeqLane       lane_[kSeqLanes];
+    bool          seq_made_ = false;
+    int           seq_batches_ = 0;
+    double       *d_seq_slots_ = nullptr, *d_seq_pack_ = nullptr; // [kSeqBatch][2 * ICP_MAX_PTS] points each
+    SeqIo        *d_seq_io_ = nullptr, *h_seq_io_ = nullptr;
+    double       *d_seq_pose_ = nullptr, *h_seq_pose_ = nullptr;  // [kSeqBatch][4] R, [kSeqBatch][2] t, [kSeqBatch][2] z + neighbours
+    slam_icp_result *d_seq_res_ = nullptr, *h_seq_res_ = nullptr;
+    int32_t      *d_seq_off_ = nullptr;                            // [kSeqBatch + 1] scan_off, [kSeqBatch] scan_nga
+    slam_event_t  seq_ev_[kSeqBatch] = {}, seq_fit_ = nullptr, seq_lane_ev_[kSeqLanes] = {};
+    static constexpr size_t kSlotPts = 2 * (size_t)ICP_MAX_PTS, kPoseDoubles = 8 * (size_t)kSeqBatch;
+    bool make_seq()
+    {
+        if (seq_made_) return true;
+        bool good = true;
+        auto g = [&](int rc) { good = good && rc == SLAM_OK; };
+        for (SeqLane &l : lane_) {
+            g(slam_gseg_create(nullptr, &l.gseg));
+            g(slam_ccicp_create(&l.cc));
+            g(slam_stream_create(&l.stream));
+        }
+        g(slam_malloc((void **)&d_seq_slots_, 16 * kSlotPts * kSeqBatch));
+        g(slam_malloc((void **)&d_seq_pack_, 16 * kSlotPts * kSeqBatch));
+        g(slam_malloc((void **)&d_seq_io_, sizeof(SeqIo) * kSeqBatch));
+        g(slam_host_alloc((void **)&h_seq_io_, sizeof(SeqIo) * kSeqBatch));
+        g(slam_malloc((void **)&d_seq_pose_, 8 * kPoseDoubles));
+        g(slam_host_alloc((void **)&h_seq_pose_, 8 * kPoseDoubles));
+        g(slam_malloc((void **)&d_seq_res_, sizeof(slam_icp_result) * kSeqBatch));
+        g(slam_host_alloc((void **)&h_seq_res_, sizeof(slam_icp_result) * kSeqBatch));
+        g(slam_malloc((void **)&d_seq_off_, 4 * (2 * (size_t)kSeqBatch + 1)));
+        for (slam_event_t &e : seq_ev_) g(slam_event_create(&e));
+        for (slam_event_t &e : seq_lane_ev_) g(slam_event_create(&e));
+        g(slam_event_create(&seq_fit_));
+        if (good) g(slam_memset(d_seq_io_, 0, sizeof(SeqIo) * kSeqBatch, stream_));
+        if (!good) std::fprintf(stderr, "CCICP: %s\n", slam_last_error());
+        seq_made_ = good;
+        return good;
+    }
+    void free_seq()
+    {
+        for (SeqLane &l : lane_) {
+            if (l.cc) slam_ccicp_destroy(l.cc);
+            if (l.gseg) slam_gseg_destroy(l.gseg);
+            slam_free(l.raw.p);
+            slam_free(l.ground.p);
+            if (l.stream) slam_stream_destroy(l.stream);
+        }
+        slam_free(d_seq_slots_);
+        slam_free(d_seq_pack_);
+        slam_free(d_seq_io_);
+        slam_host_free(h_seq_io_);
+        slam_free(d_seq_pose_);
+        slam_host_free(h_seq_pose_);
+        slam_free(d_seq_res_);
+        slam_host_free(h_seq_res_);
+        slam_free(d_seq_off_);
+        for (slam_event_t e : seq_ev_)
+            if (e) slam_event_destroy(e);
+        for (slam_event_t e : seq_lane_ev_)
+            if (e) slam_event_destroy(e);
+        if (seq_fit_) slam_event_destroy(seq_fit_);
+    }
+    // n <= kSeqBatch scenes against the index as ensure_target / target_stays left it
+    void match_batch(const float *const *scenes, const int *n_points, int n, int stride, const Pose *init, Pose *out)
+    {
+        ++seq_batches_;
+        ahead_.pending = false;
+        double *hR = h_seq_pose_, *ht = h_seq_pose_ + 4 * kSeqBatch, *hz = h_seq_pose_ + 6 * kSeqBatch;
+        double *dR = d_seq_pose_, *dt = d_seq_pose_ + 4 * kSeqBatch, *dz = d_seq_pose_ + 6 * kSeqBatch;
+        std::vector<double> yaw0((size_t)n), pitch0((size_t)n), roll0((size_t)n);
+        const double       *pts[kSeqBatch];
+        const int32_t      *scan[kSeqBatch];
+        // every scene's chain on its lane (lanes in turn: a lane's stream orders the uploads into its buffers behind the chain before)
+        for (int k = 0; k < n; ++k) {
+            SeqLane &l = lane_[k % kSeqLanes];
+            const int np = n_points[k];
+            reserve_on(l.raw, sizeof(float) * (size_t)(np + 1) * stride, l.stream);
+            reserve_on(l.ground, 16 * (size_t)(np + 1), l.stream);
+            if (np > 0) ok(slam_memcpy_h2d_async(l.raw.p, scenes[k], sizeof(float) * (size_t)np * stride, l.stream));
+            double *slot = d_seq_slots_ + 2 * kSlotPts * (size_t)k;
+            ok(slam_ccicp_scene_dev(l.cc, l.gseg, (const float *)l.raw.p, np, stride, 1, 0, 0.0, 0.0, 0.0, ICP_MAX_PTS, slot, d_seq_io_[k].scan,
+                                    (float *)l.ground.p, d_seq_io_[k].counts, l.stream));
+            ok(slam_event_record(seq_ev_[k], l.stream));
+            pts[k] = slot;
+            scan[k] = d_seq_io_[k].scan;
+            detail::euler_ypr(init[k], yaw0[k], pitch0[k], roll0[k]); // tf::getYaw (:174)
+            hR[4 * k + 0] = std::cos(yaw0[k]), hR[4 * k + 1] = -std::sin(yaw0[k]), hR[4 * k + 2] = std::sin(yaw0[k]), hR[4 * k + 3] = std::cos(yaw0[k]);
+            ht[2 * k + 0] = init[k].x, ht[2 * k + 1] = init[k].y;
+            hz[2 * k + 0] = init[k].z, hz[2 * k + 1] = 0;
+            std::memset(&h_seq_res_[k], 0, sizeof(slam_icp_result));
+        }
+        // the fits as one batch on the match's stream
+        ok(slam_memcpy_h2d_async(d_seq_pose_, h_seq_pose_, 8 * kPoseDoubles, stream_));
+        ok(slam_memcpy_h2d_async(d_seq_res_, h_seq_res_, sizeof(slam_icp_result) * (size_t)n, stream_));
+        for (int k = 0; k < n; ++k) ok(slam_stream_wait_event(stream_, seq_ev_[k]));
+        int32_t *d_off = d_seq_off_, *d_nga = d_seq_off_ + kSeqBatch + 1;
+        ok(slam_ccicp_pack_scans_dev(n, pts, scan, d_seq_pack_, d_off, d_nga, stream_));
+        if (icp_) ok(slam_icp_fit_batch_dev(icp_, d_seq_pack_, d_off, d_nga, n, dR, dt, 5.0, d_seq_res_, nullptr, stream_));
+        ok(slam_event_record(seq_fit_, stream_));
+        // doHeightInterpolate (:295) of every pose on the lanes again (the handles' scratch is per lane)
+        for (int k = 0; k < n; ++k) {
+            SeqLane &l = lane_[k % kSeqLanes];
+            if (k < kSeqLanes) ok(slam_stream_wait_event(l.stream, seq_fit_));
+            ok(slam_ccicp_height_rpy_pose_dev(l.cc, (const float *)ground_target_.p, reinterpret_cast<const int32_t *>(d_io_ + kOffNgt),
+                                              ground_target_n_, 4, dR + 4 * k, dt + 2 * k, init[k].z, roll0[k], pitch0[k], dz + 2 * k, l.stream));
+        }
+        for (int j = 0; j < std::min(n, (int)kSeqLanes); ++j) {
+            ok(slam_event_record(seq_lane_ev_[j], lane_[j].stream));
+            ok(slam_stream_wait_event(stream_, seq_lane_ev_[j]));
+        }
+        ok(slam_memcpy_d2h_async(h_seq_pose_, d_seq_pose_, 8 * kPoseDoubles, stream_));
+        ok(slam_memcpy_d2h_async(h_seq_res_, d_seq_res_, sizeof(slam_icp_result) * (size_t)n, stream_));
+        ok(slam_memcpy_d2h_async(h_seq_io_, d_seq_io_, sizeof(SeqIo) * (size_t)n, stream_));
+        ok(slam_stream_synchronize(stream_));
+        for (int k = 0; k < n; ++k) {
+            const SeqIo &io = h_seq_io_[k];
+            if (io.counts[3] != 0) { // the voxel lattice did not fit the chain's accumulator: this scene through the stepwise entry points
+                setSceneCloud(scenes[k], n_points[k], stride);
+                out[k] = doICPMatch(init[k]);
+                continue;
+            }
+            Pose r;
+            if (io.scan[1] < 5) { // :179-184
+                std::fprintf(stderr, "ERROR: Total Scene has %d points\n", io.scan[1]);
+                r.qw = 9999;
+                out[k] = r;
+                continue;
+            }
+            num_corr_ = icp_ ? h_seq_res_[k].n_corr : 0;
+            last_iters_ = icp_ ? h_seq_res_[k].iters : 0;
+            r.x = ht[2 * k + 0];
+            r.y = ht[2 * k + 1];
+            detail::quat_from_rpy(roll0[k], pitch0[k], std::atan2(hR[4 * k + 2], hR[4 * k + 0]), r); // :197, :205-212
+            r.z = hz[2 * k + 0];
+            out[k] = r;
+        }
+        scene_ready_ = false; // (the scenes of a batch lived in the lanes' buffers)
     }
 
     slam_gseg_t  *gseg_ = nullptr;

@@ -494,6 +494,13 @@ int slam_ccicp_height_pose_dev(slam_ccicp_t *h, const float *d_ground, const int
 int slam_ccicp_height_rpy_pose_dev(slam_ccicp_t *h, const float *d_ground, const int32_t *d_n_ground, int n_capacity,
                                    int stride, const double *d_R, const double *d_t, double z0, double roll, double pitch,
                                    double *d_out, slam_stream_t stream);
+/* The throughput form of a sequence of matches (BASELINE config 3; scan_registration.cpp:109-173 is one cloud at a time): n <= 32
+ * scenes made by slam_ccicp_scene_dev -- on as many streams as the caller likes, each with its own slam_ccicp_t / slam_gseg_t --
+ * gathered into ONE batch for slam_icp_fit_batch_dev: d_out_pts = their points one scene after the other (room for the sum),
+ * d_scan_off[n + 1] / d_scan_nga[n] as that call reads them.  d_pts[k] / d_scan[k]: the d_pts / d_scan of scene k (host arrays of
+ * device pointers; the sizes stay on the device).  Asynchronous: the caller makes `stream` wait for the scenes' streams first. */
+int slam_ccicp_pack_scans_dev(int n, const double *const *d_pts, const int32_t *const *d_scan, double *d_out_pts, int32_t *d_scan_off,
+                              int32_t *d_scan_nga, slam_stream_t stream);
 /* The filtered cloud of the last slam_ccicp_scene_dev call (x, y, z, ground_adj records: seg_scene / seg_target of
  * icpTools.h:77-78; d_counts[2] of that call says how many are valid) copied to d_out_xyzg, at most `capacity` records. */
 int slam_ccicp_scene_cloud_dev(slam_ccicp_t *h, float *d_out_xyzg, int capacity, slam_stream_t stream);

@@ -605,6 +605,28 @@ struct slam_ccicp {
     long long chain_voxels = 1ll << 21;         // accumulator capacity of the chain (64 MB): 0.5 x 0.5 x 2 m over 360 x 360 x 30 m
 };
 
+// Several scenes of slam_ccicp_scene_dev as ONE batch for slam_icp_fit_batch_dev (the throughput form of config 3): scene k's
+// points behind those of the scenes before it, scan_off / scan_nga as that call reads them.  blockIdx.y = scene.
+constexpr int kPackMax = 32;
+struct PackArgs {
+    const double2 *pts[kPackMax];
+    const int32_t *scan[kPackMax]; // {0, n, n_ga} of each scene, on the device
+    int            n;
+};
+__global__ __launch_bounds__(256) void pack_scans_kernel(PackArgs a, double2 *out, int32_t *scan_off, int32_t *scan_nga)
+{
+    const int k = blockIdx.y;
+    int       base = 0;
+    for (int j = 0; j < k; ++j) base += a.scan[j][1];
+    const int n = a.scan[k][1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        scan_off[k] = base;
+        scan_nga[k] = a.scan[k][2];
+        if (k == a.n - 1) scan_off[a.n] = base + n;
+    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) out[base + i] = a.pts[k][i];
+}
+
 extern "C" {
 
 int slam_ccicp_create(slam_ccicp_t **out)
@@ -913,6 +935,25 @@ int slam_ccicp_height_rpy_pose_dev(slam_ccicp_t *h, const float *d_ground, const
                            make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), c->best,
                            c->q, d_n_ground);
     hipLaunchKernelGGL(height_fit_kernel, dim3(1), dim3(64), 0, st, d_ground, stride, c->best, z0, d_out);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
+int slam_ccicp_pack_scans_dev(int n, const double *const *d_pts, const int32_t *const *d_scan, double *d_out_pts, int32_t *d_scan_off,
+                              int32_t *d_scan_nga, slam_stream_t stream)
+{
+    SLAM_REQUIRE(n >= 1 && n <= kPackMax && d_pts && d_scan && d_out_pts && d_scan_off && d_scan_nga, SLAM_E_INVALID,
+                 "slam_ccicp_pack_scans_dev: bad arguments (1..%d scenes)", kPackMax);
+    PackArgs a;
+    memset(&a, 0, sizeof a);
+    a.n = n;
+    for (int k = 0; k < n; ++k) {
+        SLAM_REQUIRE(d_pts[k] && d_scan[k], SLAM_E_INVALID, "slam_ccicp_pack_scans_dev: scene %d is null", k);
+        a.pts[k] = reinterpret_cast<const double2 *>(d_pts[k]);
+        a.scan[k] = d_scan[k];
+    }
+    hipLaunchKernelGGL(pack_scans_kernel, dim3(16, n), dim3(256), 0, as_stream(stream), a, reinterpret_cast<double2 *>(d_out_pts), d_scan_off,
+                       d_scan_nga);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }

@@ -177,8 +177,12 @@ def test_mls_one_cloud_form_matches_oracle(tmp_path):
 
 
 @pytest.mark.gpu
-def test_ccicp_sequence_with_a_target_replacement_matches_the_oracle_chain(tmp_path):
-    """BASELINE config 3 as scan_registration runs it, in small: ten 64-ring clouds through slam_amd::CCICP
+@pytest.mark.parametrize("form", ["seq", "ahead", "batch"])
+def test_ccicp_sequence_with_a_target_replacement_matches_the_oracle_chain(tmp_path, form):
+    """(form: "seq" = one cloud at a time, the reference's own usage; round 5's throughput forms: "ahead" = the next cloud's scene
+    chain on a second stream while the current one is matched, CCICP::prepareSceneCloud; "batch" = CCICP::matchSequence, the
+    clouds between two target replacements as one registration batch.  Same oracle, same tolerances.)
+    BASELINE config 3 as scan_registration runs it, in small: ten 64-ring clouds through slam_amd::CCICP
     (tests/cpp/ccicp_sequence.cpp: setSceneCloud + doICPMatch per cloud, scan_registration.cpp:139-159), the target
     replaced by the cloud just matched after five (setTargetCloud, :73-104) -- every pose against the oracle chain
     (tests/ccicp_chain.py) for ITS target, before and after the replacement, and the truth errors of both side by side:
@@ -201,10 +205,11 @@ def test_ccicp_sequence_with_a_target_replacement_matches_the_oracle_chain(tmp_p
         np.ascontiguousarray(c, np.float32).tofile(os.path.join(d, "cloud%d.f32" % k))
     np.array(init, np.float64).tofile(os.path.join(d, "init.f64"))
     np.array(truth, np.float64).tofile(os.path.join(d, "truth.f64"))
-    p = subprocess.run([exe, d, str(n), str(advance), "1"], capture_output=True, text=True, timeout=600)
+    p = subprocess.run([exe, d, str(n), str(advance), "1", form], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-2000:]
     import json
     line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["form"] == form
     assert line["matches"] == n - 1 and line["target_updates"] == 2 and line["target_index_builds"] == 2
     got = np.fromfile(os.path.join(d, "poses_out.f64"), np.float64).reshape(n - 1, 7)
     segmented = {}

@@ -16,7 +16,7 @@ from slam_amd import api, synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def measure_cpp(clouds, poses, advance=10, passes=2):
+def measure_cpp(clouds, poses, advance=10, passes=2, forms=("seq",)):
     """The same sequence through the C++ drop-in (include/slam_amd/ccicp.hpp, what ros/scan_registration_node.cpp calls where
     the reference calls icpTools.cpp:222-298): tests/cpp/ccicp_sequence.cpp compiled with g++ against the shipped library,
     clouds handed over as files, the target advanced every `advance` clouds.  Returns the program's JSON line as a dict."""
@@ -44,11 +44,25 @@ def measure_cpp(clouds, poses, advance=10, passes=2):
             np.ascontiguousarray(c, np.float32).tofile(os.path.join(d, "cloud%d.f32" % k))
         np.array(init, np.float64).tofile(os.path.join(d, "init.f64"))
         np.array(truth, np.float64).tofile(os.path.join(d, "truth.f64"))
-        p = subprocess.run([exe, d, str(len(clouds)), str(advance), str(passes)], capture_output=True, text=True, timeout=600, env=env)
-        if p.returncode != 0:
-            raise RuntimeError("ccicp_sequence failed (%d): %s" % (p.returncode, p.stderr[-500:]))
-        out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
-        out["poses"] = np.fromfile(os.path.join(d, "poses_out.f64"), np.float64).reshape(-1, 7)
+        out = None
+        for form in forms:
+            p = subprocess.run([exe, d, str(len(clouds)), str(advance), str(passes), form], capture_output=True, text=True, timeout=600, env=env)
+            if p.returncode != 0:
+                raise RuntimeError("ccicp_sequence %s failed (%d): %s" % (form, p.returncode, p.stderr[-500:]))
+            line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+            got = np.fromfile(os.path.join(d, "poses_out.f64"), np.float64).reshape(-1, 7)
+            if out is None:
+                out = line
+                out["poses"] = got
+            else:
+                # a throughput form beside the sequential one: its rate, and that it gives the same poses
+                out.setdefault("throughput_forms", {})[form] = {
+                    "ms_per_match": line["ms_per_match"], "clouds_per_s": line["clouds_per_s"],
+                    "ms_per_cloud_with_target_updates": line["ms_per_cloud_with_target_updates"],
+                    "max_xy_error_m": line["max_xy_error_m"],
+                    "max_pose_difference_vs_seq": {"xy_m": float(np.abs(got[:, :2] - out["poses"][:, :2]).max()),
+                                                   "z_m": float(np.abs(got[:, 2] - out["poses"][:, 2]).max()),
+                                                   "quat": float(np.abs(got[:, 3:] - out["poses"][:, 3:]).max())}}
         out["truth"] = np.array(truth)
         out["init"] = np.array(init)
         out["target_of"] = [((k - 1) // advance) * advance if advance > 0 else 0 for k in range(1, len(clouds))]
@@ -185,7 +199,13 @@ def measure(n_clouds=50, cell=0.0, dump_case=None, advance=10):
         dyaw = np.abs((yaw - want[:, 2] + np.pi) % (2 * np.pi) - np.pi)
         assert np.abs(got[:, :2] - want[:, :2]).max() < 1e-9 and dyaw.max() < 1e-9 and np.abs(got[:, 2] - want[:, 3]).max() < 1e-9, \
             "the C++ adapter and the Python-driven chain disagree"
-        cpp = measure_cpp(clouds, poses, advance)
+        cpp = measure_cpp(clouds, poses, advance, forms=("seq", "ahead", "batch"))
+        if "throughput_forms" in cpp:
+            cpp["throughput_forms"]["what"] = (
+                "beside the sequential form (one cloud at a time: the reference's usage and this adapter's default): 'ahead' = "
+                "CCICP::prepareSceneCloud(cloud k+1) before doICPMatch(cloud k), the next cloud's upload and scene chain on a second "
+                "stream; 'batch' = CCICP::matchSequence, the clouds between two target replacements with their scene chains on four "
+                "streams and their fits as ONE slam_icp_fit_batch_dev (initial poses known beforehand); clouds in pinned host memory")
         cpp_detail = {k: cpp.pop(k) for k in ("poses", "truth", "init", "target_of")}
         cpp["target"] = "replaced by the cloud just matched every %d clouds (setTargetCloud): a match is against a cloud at most %d poses back" % (advance, advance)
         cpp["equals_python_chain_on_fixed_target"] = True
