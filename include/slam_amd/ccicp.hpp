@@ -26,6 +26,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -255,12 +256,12 @@ public:
     }
 
     // (b) A sequence whose initial poses are known beforehand (an offline log, a re-run against a new map): every scene's chain on
-    // one of kSeqLanes streams, the fits of up to kSeqBatch scenes as ONE slam_icp_fit_batch_dev, the heights on the lanes again, one
+    // one of kSeqLanes streams (a hipGraph replay from a scene slot's third use on), the fits of up to kSeqBatch scenes as ONE slam_icp_fit_batch_dev, the heights on the lanes again, one
     // read-back per batch.  Against the target as the calls above left it (setTargetCloud); the crop window of every pose applies as
     // in doICPMatch (:225-239) -- a window that changes what the target's index is built from ends a batch.  Same poses as
     // setSceneCloud + doICPMatch one by one (tests/test_gpu_cpp_adapters.py).  A scene with fewer than 5 points returns
     // orientation.w == 9999 in its place (:179-184).
-    static constexpr int kSeqLanes = 4, kSeqBatch = 16;
+    static constexpr int kSeqLanes = 8, kSeqBatch = 16;
     std::vector<Pose> matchSequence(const float *const *scenes, const int *n_points, int count, int stride, const Pose *init)
     {
         std::vector<Pose> out((size_t)std::max(count, 0));
@@ -276,6 +277,9 @@ public:
         return out;
     }
     int sequenceBatches() const { return seq_batches_; }
+    void setSequenceGraphs(bool graphs) { use_graphs_ = graphs; } // (measurements: the scene chains call by call)
+    // host clock of the batches so far, ms: scene chains enqueued | everything enqueued | results back (cumulative within a batch)
+    const double *sequenceTimes() const { return seq_ms_; }
 
     double getResidual() const { return -1; } // :637-641 ("TODO: calculate this somehow")
     // :644-650: copies of seg_target, seg_scene, ground_target, ground_scene as x, y, z per point
@@ -633,9 +637,16 @@ private:
     struct SeqIo { // per scene, device and pinned mirror: [scan {0, n, n_ga, -} | counts {obs, gnd, flt, err}]
         int32_t scan[4], counts[4];
     };
+    struct SeqSlot { // what the chain of scene k of a batch was last enqueued with, and its captured replay
+        slam_graph_t graph = nullptr;
+        int          n = -1, stride = 0;
+        const void  *raw = nullptr, *ground = nullptr;
+    };
     SeqLane       lane_[kSeqLanes];
-    bool          seq_made_ = false;
+    SeqSlot       seq_slot_[kSeqBatch];
+    bool          seq_made_ = false, use_graphs_ = true;
     int           seq_batches_ = 0;
+    double        seq_ms_[3] = {0, 0, 0};
     double       *d_seq_slots_ = nullptr, *d_seq_pack_ = nullptr; // [kSeqBatch][2 * ICP_MAX_PTS] points each
     SeqIo        *d_seq_io_ = nullptr, *h_seq_io_ = nullptr;
     double       *d_seq_pose_ = nullptr, *h_seq_pose_ = nullptr;  // [kSeqBatch][4] R, [kSeqBatch][2] t, [kSeqBatch][2] z + neighbours
@@ -651,6 +662,8 @@ private:
         for (SeqLane &l : lane_) {
             g(slam_gseg_create(nullptr, &l.gseg));
             g(slam_ccicp_create(&l.cc));
+            // (ordinary streams, which the runtime deals over its four shared hardware queues.  A queue of its own per lane,
+            // slam_stream_create_reserving_cus(.., 0), was measured: 1.85 -> 3.3-3.6 ms per batch of ten, and one run never came back)
             g(slam_stream_create(&l.stream));
         }
         g(slam_malloc((void **)&d_seq_slots_, 16 * kSlotPts * kSeqBatch));
@@ -672,6 +685,8 @@ private:
     }
     void free_seq()
     {
+        for (SeqSlot &q : seq_slot_)
+            if (q.graph) slam_graph_destroy(q.graph);
         for (SeqLane &l : lane_) {
             if (l.cc) slam_ccicp_destroy(l.cc);
             if (l.gseg) slam_gseg_destroy(l.gseg);
@@ -699,22 +714,57 @@ private:
     {
         ++seq_batches_;
         ahead_.pending = false;
+        const auto t_begin = std::chrono::steady_clock::now();
+        auto since = [&](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count(); };
         double *hR = h_seq_pose_, *ht = h_seq_pose_ + 4 * kSeqBatch, *hz = h_seq_pose_ + 6 * kSeqBatch;
         double *dR = d_seq_pose_, *dt = d_seq_pose_ + 4 * kSeqBatch, *dz = d_seq_pose_ + 6 * kSeqBatch;
         std::vector<double> yaw0((size_t)n), pitch0((size_t)n), roll0((size_t)n);
         const double       *pts[kSeqBatch];
         const int32_t      *scan[kSeqBatch];
         // every scene's chain on its lane (lanes in turn: a lane's stream orders the uploads into its buffers behind the chain before)
-        for (int k = 0; k < n; ++k) {
+        auto enqueue_scene = [&](int k) {
             SeqLane &l = lane_[k % kSeqLanes];
             const int np = n_points[k];
             reserve_on(l.raw, sizeof(float) * (size_t)(np + 1) * stride, l.stream);
             reserve_on(l.ground, 16 * (size_t)(np + 1), l.stream);
             if (np > 0) ok(slam_memcpy_h2d_async(l.raw.p, scenes[k], sizeof(float) * (size_t)np * stride, l.stream));
             double *slot = d_seq_slots_ + 2 * kSlotPts * (size_t)k;
-            ok(slam_ccicp_scene_dev(l.cc, l.gseg, (const float *)l.raw.p, np, stride, 1, 0, 0.0, 0.0, 0.0, ICP_MAX_PTS, slot, d_seq_io_[k].scan,
-                                    (float *)l.ground.p, d_seq_io_[k].counts, l.stream));
+            // The chain is some thirty short launches: enqueued one by one they cost the host 0.08 ms per scene; replayed as a hipGraph
+            // 0.01 (measured, tools/exp/c3_batch_time.sh: the batch itself is bound by the device either way).  A scene of the same size as the one this slot held before (a lidar's clouds
+            // are) replays the chain as a hipGraph captured on its second use: same kernels, same arguments, one launch.
+            SeqSlot &q = seq_slot_[k];
+            const bool same = q.n == np && q.stride == stride && q.raw == l.raw.p && q.ground == l.ground.p;
+            auto chain = [&]() {
+                ok(slam_ccicp_scene_dev(l.cc, l.gseg, (const float *)l.raw.p, np, stride, 1, 0, 0.0, 0.0, 0.0, ICP_MAX_PTS, slot, d_seq_io_[k].scan,
+                                        (float *)l.ground.p, d_seq_io_[k].counts, l.stream));
+            };
+            if (same && q.graph) {
+                ok(slam_graph_launch(q.graph, l.stream));
+            } else if (same && np > 0 && use_graphs_) { // second use: every scratch buffer of the chain exists, nothing in it allocates
+                if (q.graph) slam_graph_destroy(q.graph);
+                q.graph = nullptr;
+                if (slam_graph_begin_capture(l.stream) == SLAM_OK) {
+                    chain();
+                    if (slam_graph_end_capture(l.stream, &q.graph) != SLAM_OK) q.graph = nullptr;
+                }
+                if (q.graph)
+                    ok(slam_graph_launch(q.graph, l.stream));
+                else {
+                    use_graphs_ = false; // (a runtime that cannot capture this chain: call by call from here on)
+                    chain();
+                }
+            } else {
+                if (q.graph) slam_graph_destroy(q.graph);
+                q.graph = nullptr;
+                chain();
+                q.n = np, q.stride = stride, q.raw = l.raw.p, q.ground = l.ground.p;
+            }
             ok(slam_event_record(seq_ev_[k], l.stream));
+        };
+        for (int k = 0; k < n; ++k) enqueue_scene(k);
+        seq_ms_[0] += since(t_begin);
+        for (int k = 0; k < n; ++k) {
+            double *slot = d_seq_slots_ + 2 * kSlotPts * (size_t)k;
             pts[k] = slot;
             scan[k] = d_seq_io_[k].scan;
             detail::euler_ypr(init[k], yaw0[k], pitch0[k], roll0[k]); // tf::getYaw (:174)
@@ -745,7 +795,9 @@ private:
         ok(slam_memcpy_d2h_async(h_seq_pose_, d_seq_pose_, 8 * kPoseDoubles, stream_));
         ok(slam_memcpy_d2h_async(h_seq_res_, d_seq_res_, sizeof(slam_icp_result) * (size_t)n, stream_));
         ok(slam_memcpy_d2h_async(h_seq_io_, d_seq_io_, sizeof(SeqIo) * (size_t)n, stream_));
+        seq_ms_[1] += since(t_begin);
         ok(slam_stream_synchronize(stream_));
+        seq_ms_[2] += since(t_begin);
         for (int k = 0; k < n; ++k) {
             const SeqIo &io = h_seq_io_[k];
             if (io.counts[3] != 0) { // the voxel lattice did not fit the chain's accumulator: this scene through the stepwise entry points

@@ -62,11 +62,16 @@ int main(int argc, char **argv)
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 
     slam_amd::CCICP icp(slam_amd::SCAN_TO_SCAN);
+    if (std::getenv("SEQ_NO_GRAPHS")) icp.setSequenceGraphs(false); // (measurements)
     double t_match = 0, t_target = 0, worst = 0, sum_err = 0, iters = 0, corr = 0;
     int    n_match = 0, n_target = 0, builds0 = 0;
     std::vector<double> poses;
+    int    seq_b0 = 0;
+    double seq_t0[3] = {0, 0, 0};
     for (int pass = 0; pass < passes; ++pass) {
         t_match = t_target = worst = sum_err = iters = corr = 0;
+        seq_b0 = icp.sequenceBatches();
+        for (int j = 0; j < 3; ++j) seq_t0[j] = icp.sequenceTimes()[j];
         n_match = n_target = 0;
         poses.clear();
         builds0 = icp.targetBuilds();
@@ -131,6 +136,11 @@ int main(int argc, char **argv)
                 ++n_target;
             }
         }
+    }
+    if (form == "batch" && icp.sequenceBatches() > seq_b0) { // the last pass's batches
+        const int nb = icp.sequenceBatches() - seq_b0;
+        std::fprintf(stderr, "matchSequence: %d batches; host ms per batch: scene chains enqueued %.3f, all enqueued %.3f, results back %.3f\n", nb,
+                     (icp.sequenceTimes()[0] - seq_t0[0]) / nb, (icp.sequenceTimes()[1] - seq_t0[1]) / nb, (icp.sequenceTimes()[2] - seq_t0[2]) / nb);
     }
     if (FILE *f = std::fopen((dir + "/poses_out.f64").c_str(), "wb")) {
         std::fwrite(poses.data(), 8, poses.size(), f);

@@ -20,7 +20,7 @@ def compile_adapter_test(tmp):
     build.build()
     exe = os.path.join(tmp, "adapter_test")
     lib = os.path.join(ROOT, "slam_amd", "lib")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "adapter_test.cpp"), "-o", exe,
                            "-L" + lib, "-l:libslam_mi355x.so", "-Wl,-rpath," + lib,
                            "-Wl,-rpath,/opt/rocm/lib"])
@@ -81,7 +81,7 @@ def compile_cpp(tmp, name):
     build.build()
     exe = os.path.join(tmp, name)
     lib = os.path.join(ROOT, "slam_amd", "lib")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", name + ".cpp"), "-o", exe,
                            "-L" + lib, "-l:libslam_mi355x.so", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
     return exe

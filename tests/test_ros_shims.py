@@ -25,7 +25,7 @@ def _compile(src, exe, extra_inc=()):
     build.build()
     lib = os.path.join(ROOT, "slam_amd", "lib")
     inc = [os.path.join(ROOT, "tests", "cpp", "ros_stub"), os.path.join(ROOT, "include"), os.path.join(ROOT, "ros")] + list(extra_inc)
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-Wno-unused-function"] +
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-Wall", "-Wextra", "-Werror", "-Wno-unused-parameter", "-Wno-unused-function"] +
                           [a for i in inc for a in ("-I", i)] + [src, "-o", exe, "-L" + lib, "-l:libslam_mi355x.so",
                                                                  "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"])
     return exe

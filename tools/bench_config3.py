@@ -28,7 +28,7 @@ def measure_cpp(clouds, poses, advance=10, passes=2, forms=("seq",)):
     env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTX"))}
     with tempfile.TemporaryDirectory() as d:
         exe = os.path.join(d, "ccicp_sequence")
-        subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"),
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(ROOT, "include"),
                                os.path.join(ROOT, "tests", "cpp", "ccicp_sequence.cpp"), "-o", exe,
                                "-L" + lib, "-l:libslam_mi355x.so", "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"], env=env)
         init, truth = [], []
@@ -204,7 +204,7 @@ def measure(n_clouds=50, cell=0.0, dump_case=None, advance=10):
             cpp["throughput_forms"]["what"] = (
                 "beside the sequential form (one cloud at a time: the reference's usage and this adapter's default): 'ahead' = "
                 "CCICP::prepareSceneCloud(cloud k+1) before doICPMatch(cloud k), the next cloud's upload and scene chain on a second "
-                "stream; 'batch' = CCICP::matchSequence, the clouds between two target replacements with their scene chains on four "
+                "stream; 'batch' = CCICP::matchSequence, the clouds between two target replacements with their scene chains on eight "
                 "streams and their fits as ONE slam_icp_fit_batch_dev (initial poses known beforehand); clouds in pinned host memory")
         cpp_detail = {k: cpp.pop(k) for k in ("poses", "truth", "init", "target_of")}
         cpp["target"] = "replaced by the cloud just matched every %d clouds (setTargetCloud): a match is against a cloud at most %d poses back" % (advance, advance)
