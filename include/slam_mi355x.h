@@ -76,7 +76,13 @@ int slam_stream_create_with_priority(slam_stream_t *stream, int priority);
  * would otherwise hold every CU for its whole duration -- the registration batches, 0.6 ms per workgroup -- while short
  * kernels of other streams (an RCCL all-reduce, the grid update) wait for a CU to come free.  A stream made here has a hardware
  * queue of its own (the runtime deals ordinary streams over a few shared queues, where one stream's launches can stand behind
- * another's: DESIGN.md 4.6) -- with reserve_per_xcd = 0 that is all it differs in from slam_stream_create. */
+ * another's: DESIGN.md 4.6).  With reserve_per_xcd = 0 the mask names every CU.  Two differences from slam_stream_create remain,
+ * both measured (tools/exp/stream_flags.hip, round 5): the stream has a hardware queue of its own, and it is a BLOCKING stream
+ * (hipExtStreamCreateWithCUMask makes hipStreamDefault streams: hipStreamGetFlags = 0) -- a kernel on it waits for whatever the
+ * process has put on the legacy null stream (a synchronous hipMemcpy, a framework's default stream) and the null stream waits for
+ * it, where every other stream of this library is hipStreamNonBlocking.  The library itself enqueues nothing on the null stream in
+ * its asynchronous calls; a caller that does serialises with these streams.  reserve_per_xcd > 0 needs the CU numbering this was
+ * measured on -- an unpartitioned gfx950 of 256 CUs -- and returns SLAM_E_UNSUPPORTED elsewhere. */
 int slam_stream_create_reserving_cus(slam_stream_t *stream, int reserve_per_xcd);
 int slam_stream_destroy(slam_stream_t stream);
 int slam_stream_synchronize(slam_stream_t stream);

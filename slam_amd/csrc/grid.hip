@@ -1350,7 +1350,8 @@ int slam_grid_create(int size_x, int size_y, double resolution, const slam_grid_
     v.pose_x = v.pose_y = 0.0;
     v.rolling = g->prm.rolling ? 1 : 0;
     v.hits = g->d_planes;
-    v.misses = g->d_planes + g->cells;
+    v.misses = g->d_planes + g->cells; // (endpoints_kernel addresses both planes through `hits` with an int key: misses == hits + cells,
+                                       // and 2 * cells fits an int -- slam_grid_create refuses grids of 2^30 cells or more)
     v.updates = g->d_updates;
     v.dirty = g->d_dirty;
     v.acc_hits = v.acc_misses = nullptr;

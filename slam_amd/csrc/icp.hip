@@ -1312,6 +1312,11 @@ int icp_new(const slam_icp_params *params, slam_icp **out)
     if (const char *e = getenv("SLAM_ICP_FAR_DIV")) h->far_div = std::max(atoi(e), 1);
 #endif
     int rc = SLAM_OK;
+    if (h->prm.mode == SLAM_ICP_P2L && h->split_launch) {
+        // (the point-to-line solver has the one-launch schedule only: a request for the two-launch form is refused, not ignored)
+        set_error("split_launch is a point-to-point measurement form: SLAM_ICP_P2L runs both search forms in one launch");
+        rc = SLAM_E_UNSUPPORTED;
+    }
     if (h->G & (h->G - 1) || h->G > 64) {
         set_error("lanes_per_point must be one of 1,2,4,8,16,32,64 (got %d)", h->G);
         rc = SLAM_E_INVALID;

@@ -376,6 +376,15 @@ int slam_stream_create_reserving_cus(slam_stream_t *stream, int reserve_per_xcd)
     SLAM_HIP(hipGetDevice(&dev));
     SLAM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     constexpr int kXcd = 8; // MI355X: bit i of a CU mask is a CU of XCD i % 8 (measured: tools/exp/cumask.hip)
+    if (reserve_per_xcd > 0) {
+        // which bit is which XCD was measured on ONE layout: an unpartitioned gfx950 of 256 CUs (SPX).  A partition (CPX: 32 CUs of one
+        // XCD) or another part would pass a divisibility check and silently keep the wrong CUs free
+        hipDeviceProp_t prop;
+        SLAM_HIP(hipGetDeviceProperties(&prop, dev));
+        SLAM_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0 && n_cu == 256, SLAM_E_UNSUPPORTED,
+                     "slam_stream_create_reserving_cus: the CU-mask layout is known for an unpartitioned gfx950 (256 CUs, 8 XCDs) only; this is %s with %d CUs",
+                     prop.gcnArchName, n_cu);
+    }
     SLAM_REQUIRE(n_cu > 0 && n_cu % kXcd == 0 && reserve_per_xcd < n_cu / kXcd, SLAM_E_INVALID,
                  "slam_stream_create_reserving_cus: cannot keep %d CUs per XCD free on a device of %d CUs", reserve_per_xcd, n_cu);
     const int             words = (n_cu + 31) / 32, off = kXcd * reserve_per_xcd;
