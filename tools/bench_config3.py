@@ -16,7 +16,7 @@ from slam_amd import api, synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def measure_cpp(clouds, poses, advance=10, passes=2, forms=("seq",)):
+def measure_cpp(clouds, poses, advance=10, passes=3, forms=("seq",)):
     """The same sequence through the C++ drop-in (include/slam_amd/ccicp.hpp, what ros/scan_registration_node.cpp calls where
     the reference calls icpTools.cpp:222-298): tests/cpp/ccicp_sequence.cpp compiled with g++ against the shipped library,
     clouds handed over as files, the target advanced every `advance` clouds.  Returns the program's JSON line as a dict."""

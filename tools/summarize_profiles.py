@@ -198,4 +198,80 @@ regs = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_regs.
 if regs.returncode == 0 and regs.stdout:
     open(os.path.join(dst, tag + "_kernel_registers.txt"), "w").write(
         "# python tools/kernel_regs.py (llvm-readelf --notes of slam_amd/lib/obj/*.o), csrc sha256 %s\n%s" % (csrc_sha(), regs.stdout))
+
+
+def design_table():
+    """profiles/<tag>_design_table.md: the numbers of DESIGN.md section 4, one row per kernel of the default bench line, made from
+    the files written above and nothing else (time from the kernel trace of the pipelined run, registers from the code objects,
+    counters from the --pmc passes in which each kernel runs alone on the chip).  DESIGN.md includes it verbatim
+    (tests/test_design_table.py checks that it does): a figure in that table cannot be older than its profile."""
+    want = ["icp_fit_pair_kernel", "icp_fit_fused_kernel", "icp_fit_spread_kernel", "beams_from_scans_kernel", "tile_items_wg_kernel",
+            "raycast_tiled_kernel", "endpoints_kernel", "finalize_reset_rows_kernel", "finalize_kernel"]
+    alg = {  # SURVEY 8(d) algorithmic bytes per launch of the default bench line (config 2), where the kernel has a byte figure
+        "icp_fit_pair_kernel": ("16*P + S*(8*M + 96)", 16 * 276242 + 256 * (8 * 10000 + 96)),
+    }
+    stats = {}
+    for which, fn in (("", "_kernel_stats.csv"), ("p2l", "_p2l_kernel_stats.csv"), ("ep", "_endpoints_kernel_stats.csv")):
+        f = os.path.join(dst, tag + fn)
+        if os.path.exists(f):
+            for r in csv.DictReader(open(f)):
+                stats.setdefault(which, {}).setdefault(r["kernel"], r)
+    regs = {}
+    f = os.path.join(dst, tag + "_kernel_registers.txt")
+    if os.path.exists(f):
+        for line in open(f):
+            m = re.match(r"(\w+)\s+(\S.*?)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s+(\d+)\s*$", line)
+            if m:
+                base = re.match(r"(\w+)", m.group(2)).group(1)
+                v, vs, sg, ss, scr, lds = (int(m.group(i)) for i in range(3, 9))
+                e = regs.setdefault(base, {"vgpr": [], "sgpr": [], "sspill": [], "scratch": []})
+                e["vgpr"].append(v), e["sgpr"].append(sg), e["sspill"].append(ss), e["scratch"].append(scr)
+    rng = lambda v: ("%d" % v[0]) if min(v) == max(v) else "%d-%d" % (min(v), max(v))
+    rows = []
+
+    def row(label, k, st, tr):
+        r_ = st.get(k)
+        t_ = tr.get(k, {})
+        g_ = regs.get(k)
+        busy, lanes = t_.get("valu_busy_frac"), t_.get("valu_active_lane_share")
+        a_ = alg.get(k)
+        avg_ms = float(r_["avg_ns"]) * 1e-6 if r_ else None
+        rows.append("| `%s`%s | %s | %s | %s | %s | %s | %s | %s | %s | %s |" % (
+            k, label, r_["calls"] if r_ else "-", ("%.1f" % (float(r_["avg_ns"]) / 1e3)) if r_ else "-",
+            ("%s / %s (%s spilled) / %s B" % (rng(g_["vgpr"]), rng(g_["sgpr"]), rng(g_["sspill"]), rng(g_["scratch"]))) if g_ else "-",
+            ("%.1f %%" % (100 * busy)) if busy is not None else "-", ("%.1f %%" % (100 * lanes)) if lanes is not None else "-",
+            ("%.1f %%" % (100 * busy * lanes)) if busy is not None and lanes is not None else "-",
+            ("%.0f %%" % (100 * t_["lds_bank_conflict_share"])) if "lds_bank_conflict_share" in t_ else "-",
+            ("%.2f MB" % (t_["hbm_bytes_per_launch"] / 1e6)) if "hbm_bytes_per_launch" in t_ else "-",
+            ("%.1f MB = %s -> %.1f GB/s = %.4f of 8 TB/s" % (a_[1] / 1e6, a_[0], a_[1] / avg_ms / 1e6, a_[1] / avg_ms / 1e6 / 8000.0)) if a_ and avg_ms else "-"))
+
+    tr = json.load(open(os.path.join(dst, tag + "_traffic.json"))) if os.path.exists(os.path.join(dst, tag + "_traffic.json")) else {}
+    for k in want:
+        if k in stats.get("", {}) or k in tr:
+            row("", k, stats.get("", {}), tr)
+    f = os.path.join(dst, tag + "_p2l_traffic.json")
+    if os.path.exists(f) and "p2l" in stats:
+        row(" (`--mode p2l`)", "icp_fit_pair_kernel", stats["p2l"], json.load(open(f)))
+    f = os.path.join(dst, tag + "_endpoints_traffic.json")
+    if os.path.exists(f) and "ep" in stats:
+        row(" (endpoint leg alone)", "endpoints_kernel", stats["ep"], json.load(open(f)))
+    head = ("<!-- generated by tools/summarize_profiles.py %s from profiles/%s_*; do not edit: regenerate -->\n"
+            "| kernel | launches in the trace | avg us per launch (pipelined mix) | VGPR / SGPR / scratch (code objects) | VALU busy (alone) | active lanes | "
+            "= of the chip's lane-slots | LDS bank-conflict share | HBM traffic per launch (counters) | algorithmic bytes (SURVEY 8d) -> of the HBM peak |\n"
+            "|---|---|---|---|---|---|---|---|---|---|\n" % (tag, tag))
+    bench = os.path.join(dst, tag + "_bench.json")
+    foot = ""
+    if os.path.exists(bench):
+        try:
+            b = json.loads([l for l in open(bench) if l.startswith("{")][-1])
+            foot = ("\nThe un-profiled line of the same build (`profiles/%s_bench.json`): **%.4f ms per step = %.1f M registered scan-points/s**, %s; "
+                    "`roofline.frac` %.4f (%.1f GB/s of algorithmic bytes per launch of `%s`, %.4f ms per launch, HIP events in the run); "
+                    "kernel sources sha256 `%s`.\n" % (tag, b["ms_per_step"], b["value"] / 1e6, "%.1f G cell-updates/s" % (b.get("grid_cell_updates_per_s", 0) / 1e9),
+                                                        b["roofline"]["frac"], b["roofline"]["achieved"], b["roofline"]["kernel"], b["roofline"]["avg_launch_ms"], csrc_sha()[:16]))
+        except Exception as ex:
+            foot = "\n(bench line unreadable: %r)\n" % (ex,)
+    open(os.path.join(dst, tag + "_design_table.md"), "w").write(head + "\n".join(rows) + "\n" + foot)
+
+
+design_table()
 print("wrote", sorted(f for f in os.listdir(dst) if f.startswith(tag)))
