@@ -261,7 +261,10 @@ public:
     // in doICPMatch (:225-239) -- a window that changes what the target's index is built from ends a batch.  Same poses as
     // setSceneCloud + doICPMatch one by one (tests/test_gpu_cpp_adapters.py).  A scene with fewer than 5 points returns
     // orientation.w == 9999 in its place (:179-184).
-    static constexpr int kSeqLanes = 8, kSeqBatch = 16;
+#ifndef SLAM_CCICP_SEQ_LANES
+#define SLAM_CCICP_SEQ_LANES 4 // (8: 0.21 ms per match in three runs of four and 0.39 in the fourth, the host held inside the graph launches; 4: 0.23-0.25 every run; 2: 0.26 -- tools/exp/c3_lanes.sh)
+#endif
+    static constexpr int kSeqLanes = SLAM_CCICP_SEQ_LANES, kSeqBatch = 16;
     std::vector<Pose> matchSequence(const float *const *scenes, const int *n_points, int count, int stride, const Pose *init)
     {
         std::vector<Pose> out((size_t)std::max(count, 0));
@@ -280,6 +283,7 @@ public:
     void setSequenceGraphs(bool graphs) { use_graphs_ = graphs; } // (measurements: the scene chains call by call)
     // host clock of the batches so far, ms: scene chains enqueued | everything enqueued | results back (cumulative within a batch)
     const double *sequenceTimes() const { return seq_ms_; }
+    double sequenceUploadMs() const { return seq_up_ms_; } // of which: the host inside the scenes' upload calls
 
     double getResidual() const { return -1; } // :637-641 ("TODO: calculate this somehow")
     // :644-650: copies of seg_target, seg_scene, ground_target, ground_scene as x, y, z per point
@@ -646,7 +650,7 @@ private:
     SeqSlot       seq_slot_[kSeqBatch];
     bool          seq_made_ = false, use_graphs_ = true;
     int           seq_batches_ = 0;
-    double        seq_ms_[3] = {0, 0, 0};
+    double        seq_ms_[3] = {0, 0, 0}, seq_up_ms_ = 0;
     double       *d_seq_slots_ = nullptr, *d_seq_pack_ = nullptr; // [kSeqBatch][2 * ICP_MAX_PTS] points each
     SeqIo        *d_seq_io_ = nullptr, *h_seq_io_ = nullptr;
     double       *d_seq_pose_ = nullptr, *h_seq_pose_ = nullptr;  // [kSeqBatch][4] R, [kSeqBatch][2] t, [kSeqBatch][2] z + neighbours
@@ -727,7 +731,9 @@ private:
             const int np = n_points[k];
             reserve_on(l.raw, sizeof(float) * (size_t)(np + 1) * stride, l.stream);
             reserve_on(l.ground, 16 * (size_t)(np + 1), l.stream);
+            const auto t_up = std::chrono::steady_clock::now();
             if (np > 0) ok(slam_memcpy_h2d_async(l.raw.p, scenes[k], sizeof(float) * (size_t)np * stride, l.stream));
+            seq_up_ms_ += since(t_up);
             double *slot = d_seq_slots_ + 2 * kSlotPts * (size_t)k;
             // The chain is some thirty short launches: enqueued one by one they cost the host 0.08 ms per scene; replayed as a hipGraph
             // 0.01 (measured, tools/exp/c3_batch_time.sh: the batch itself is bound by the device either way).  A scene of the same size as the one this slot held before (a lidar's clouds

@@ -139,8 +139,8 @@ int main(int argc, char **argv)
     }
     if (form == "batch" && icp.sequenceBatches() > seq_b0) { // the last pass's batches
         const int nb = icp.sequenceBatches() - seq_b0;
-        std::fprintf(stderr, "matchSequence: %d batches; host ms per batch: scene chains enqueued %.3f, all enqueued %.3f, results back %.3f\n", nb,
-                     (icp.sequenceTimes()[0] - seq_t0[0]) / nb, (icp.sequenceTimes()[1] - seq_t0[1]) / nb, (icp.sequenceTimes()[2] - seq_t0[2]) / nb);
+        std::fprintf(stderr, "matchSequence: %d batches; host ms per batch: scene chains enqueued %.3f, all enqueued %.3f, results back %.3f (uploads, all passes: %.3f ms)\n", nb,
+                     (icp.sequenceTimes()[0] - seq_t0[0]) / nb, (icp.sequenceTimes()[1] - seq_t0[1]) / nb, (icp.sequenceTimes()[2] - seq_t0[2]) / nb, icp.sequenceUploadMs());
     }
     if (FILE *f = std::fopen((dir + "/poses_out.f64").c_str(), "wb")) {
         std::fwrite(poses.data(), 8, poses.size(), f);

@@ -204,7 +204,7 @@ def measure(n_clouds=50, cell=0.0, dump_case=None, advance=10):
             cpp["throughput_forms"]["what"] = (
                 "beside the sequential form (one cloud at a time: the reference's usage and this adapter's default): 'ahead' = "
                 "CCICP::prepareSceneCloud(cloud k+1) before doICPMatch(cloud k), the next cloud's upload and scene chain on a second "
-                "stream; 'batch' = CCICP::matchSequence, the clouds between two target replacements with their scene chains on eight "
+                "stream; 'batch' = CCICP::matchSequence, the clouds between two target replacements with their scene chains on four "
                 "streams and their fits as ONE slam_icp_fit_batch_dev (initial poses known beforehand); clouds in pinned host memory")
         cpp_detail = {k: cpp.pop(k) for k in ("poses", "truth", "init", "target_of")}
         cpp["target"] = "replaced by the cloud just matched every %d clouds (setTargetCloud): a match is against a cloud at most %d poses back" % (advance, advance)
