@@ -230,3 +230,27 @@ def test_ccicp_sequence_with_a_target_replacement_matches_the_oracle_chain(tmp_p
     assert set(target_of) == {0, 5}
     assert np.abs(np.array(err_gpu) - np.array(err_oracle)).max() < 2e-4          # the same error against the truth, match by match
     assert abs(line["mean_xy_error_m"] - float(np.mean(err_oracle))) < 2e-4 and max(err_oracle) < 0.5
+
+
+@pytest.mark.gpu
+def test_ccicp_throughput_forms_on_the_edges(tmp_path):
+    """tests/cpp/ccicp_forms_test.cpp: CCICP::prepareSceneCloud with the right and the wrong cloud prepared (poses bit-identical to the
+    sequential form, read-outs behind an adopted scene), CCICP::matchSequence over 23 scenes (three batches: 16 at most, and a pose
+    whose crop window leaves nothing of the target ends one), a 4-point scene inside a batch (orientation.w == 9999, icpTools.cpp:
+    179-184).  The program checks itself against its own sequential run; the sequential form against the oracle is the test above."""
+    exe = compile_cpp(str(tmp_path), "ccicp_forms_test")
+    d = str(tmp_path)
+    n = 24
+    clouds, poses = zip(*[synth.make_cloud3d(k, n_loop=50) for k in range(n)])
+    init = []
+    for k in range(1, n):
+        pa, pb = poses[0], poses[k]
+        ca, sa = np.cos(pa[2]), np.sin(pa[2])
+        rel = (ca * (pb[0] - pa[0]) + sa * (pb[1] - pa[1]), -sa * (pb[0] - pa[0]) + ca * (pb[1] - pa[1]), pb[2] - pa[2])
+        init.append([rel[0] + 0.1, rel[1] - 0.1, 0.0] + _quat_rpy(0.0, 0.0, rel[2] + 0.02))
+    for k, c in enumerate(clouds):
+        np.ascontiguousarray(c, np.float32).tofile(os.path.join(d, "cloud%d.f32" % k))
+    np.array(init, np.float64).tofile(os.path.join(d, "init.f64"))
+    p = subprocess.run([exe, d, str(n)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-1500:]
+    assert p.stdout.strip().endswith("OK") and "BAD" not in p.stdout

@@ -596,3 +596,31 @@ def test_exact_ties_through_every_batch_form(form):
     icp, R, t, res, tr = check_against_oracle(m_ga, m_nga, batch, 12, 1e-9, nn=O.NN_BRUTE, **kw)
     assert (res["n_corr"] > 300).all()
     icp.close()
+
+
+@pytest.mark.parametrize("map_points", [3000, 5000])
+def test_list_lattice_choice_changes_time_not_results(map_points):
+    """slam_icp_params::list_min_halo (round 5): WHICH halo-list lattice is built -- the finest that fits LDS (< 0, the rule of
+    rounds 1-4), the first whose halo reaches 0.125 m (the default), a coarse one -- is a schedule decision: every form of the search
+    is exact, so iterations and correspondence counts are equal and poses agree to the rounding of differently grouped sums, and all
+    of them equal the oracle.  Models sparser than config 2's are where the choice differs (a 10 k-point room gets the same lattice
+    from all three)."""
+    m_ga, m_nga = synth.make_map(map_points)
+    model = O.IcpModel(m_ga, m_nga)
+    batch = synth.make_batch(48)
+    Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R, batch.t, O.icp_params(30, 1e-6, 5.0))
+    seen, ref = set(), None
+    for halo in (-1.0, 0.0, 0.3):
+        for pair in (-1, 2):
+            icp = api.Icp(m_ga, m_nga, max_iter=30, min_delta=1e-6, spread_scans=-1, pair_scans=pair, list_min_halo=halo)
+            info = icp.index_info()
+            assert info["two_forms"] and info["list_halo"] >= (halo if halo > 0 else (0.125 if halo == 0 else 0.0)) - 1e-6
+            seen.add(round(info["list_pitch"], 4))
+            R, t, res, _ = icp.fit_batch(batch)
+            assert np.array_equal(res["iters"], iters) and np.array_equal(res["n_corr"], ncorr), (halo, pair)
+            assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL, (halo, pair)
+            if ref is None:
+                ref = (R, t)
+            assert np.abs(R - ref[0]).max() < 1e-9 and np.abs(t - ref[1]).max() < 1e-9, (halo, pair)
+            icp.close()
+    assert len(seen) >= 2, "the three settings built the same lattice: nothing was tested (%s)" % seen
