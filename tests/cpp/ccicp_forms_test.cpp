@@ -111,6 +111,39 @@ int main(int argc, char **argv)
         check(worst < 1e-9, "matchSequence: every other pose equals the sequential form's", worst);
         check(icp.sequenceBatches() >= 3, "matchSequence: more than one batch (16 scenes at most; the far pose's window ends one)", icp.sequenceBatches());
     }
+    // (4) scenes of DIFFERENT sizes, twice over: a lane's buffers grow (its captured chains are made for other pointers then), a slot
+    // sees a size it has not seen (call by call), then the same size again (captured), then replays
+    {
+        std::vector<int> cut;
+        for (int k = 0; k < n - 1; ++k) cut.push_back(k == i_tiny ? 4 : (int)((cnt[k] / 2) + ((long)cnt[k] / 2) * ((k * 7919) % 97) / 97));
+        std::vector<slam_amd::Pose> want;
+        {
+            slam_amd::CCICP icp(slam_amd::SCAN_TO_SCAN);
+            icp.setTargetCloud(clouds[0].data(), (int)clouds[0].size() / 3, 3, p0);
+            for (int rep = 0; rep < 2; ++rep)
+                for (int k = 0; k < n - 1; ++k) {
+                    icp.setSceneCloud(ptr[k], cut[k], 3);
+                    want.push_back(icp.doICPMatch(ip[k]));
+                }
+        }
+        slam_amd::CCICP icp(slam_amd::SCAN_TO_SCAN);
+        icp.setTargetCloud(clouds[0].data(), (int)clouds[0].size() / 3, 3, p0);
+        double worst = 0, worst_ahead = 0;
+        for (int rep = 0; rep < 2; ++rep) {
+            const std::vector<slam_amd::Pose> r = icp.matchSequence(ptr.data(), cut.data(), n - 1, 3, ip.data());
+            for (int k = 0; k < n - 1; ++k)
+                if (k != i_tiny) worst = std::fmax(worst, diff(r[(size_t)k], want[(size_t)(rep * (n - 1) + k)]));
+        }
+        // ... and the same object one cloud at a time afterwards, with the next one prepared: the forms share the object's state
+        for (int k = 0; k < n - 1; ++k) {
+            icp.setSceneCloud(ptr[k], cut[k], 3);
+            if (k + 1 < n - 1) icp.prepareSceneCloud(ptr[k + 1], cut[k + 1], 3);
+            const slam_amd::Pose r = icp.doICPMatch(ip[k]);
+            if (k != i_tiny) worst_ahead = std::fmax(worst_ahead, diff(r, want[(size_t)k]));
+        }
+        check(worst < 1e-9, "matchSequence over scenes of different sizes, twice (re-captured chains, grown buffers): poses equal the sequential form's", worst);
+        check(worst_ahead == 0.0, "the same object cloud by cloud afterwards, next cloud prepared: bit-identical to the sequential form", worst_ahead);
+    }
     std::printf("%s\n", g_bad ? "FAILED" : "OK");
     return g_bad ? 5 : 0;
 }
