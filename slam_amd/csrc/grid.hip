@@ -197,6 +197,14 @@ constexpr int kTile = 128;             // cells per tile side
 #define SLAM_WALK_UNROLL 4
 #endif
 constexpr int kWalkUnroll = SLAM_WALK_UNROLL; // steps per trip of the raycast walk loop
+// Lanes of a block start their walks kWalkStagger-fold staggered: lane j waits (j % kWalkStagger) trips.  The 64 beams of a block
+// are adjacent beams of ONE scan: near the sensor they run through the same cells, and in lock-step they are on the same cell in the
+// same instruction -- LDS atomics of one instruction to one address are served one after the other (bank-conflict share 55 %).
+// Staggered, neighbours are kWalkUnroll cells apart along the beam when they add.
+#ifndef SLAM_WALK_STAGGER
+#define SLAM_WALK_STAGGER 4 // round 5: the raycast call 0.1325 -> 0.1026 ms with one workgroup per CU, 0.110 -> 0.092 with two; step 0.304 -> 0.295 (2: 0.115, 6: 0.103, 8: 0.106, 16: 0.122; tools/exp/stagger_ab.sh)
+#endif
+constexpr int kWalkStagger = SLAM_WALK_STAGGER;
 constexpr int kTileStride = kTile + 1; // LDS row pitch in words: vertical neighbours fall on adjacent banks
 constexpr int kTileThreads = 1024;
 constexpr int kChunk = 1024;           // beams per pre-pass workgroup
@@ -790,8 +798,11 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
                     if (leader) atomicAdd(reinterpret_cast<unsigned *>(tb + a4), run);
                 }
             };
+            int delay = kWalkStagger > 1 ? lane % kWalkStagger : 0;
             while (__any(miss >= kWalkUnroll)) {
-                if (miss >= kWalkUnroll) {
+                if (kWalkStagger > 1 && delay > 0) {
+                    --delay;
+                } else if (miss >= kWalkUnroll) {
 #pragma unroll
                     for (int k = 0; k < kWalkUnroll; ++k) {
                         add_miss();
