@@ -197,12 +197,16 @@ constexpr int kTile = 128;             // cells per tile side
 #define SLAM_WALK_UNROLL 4
 #endif
 constexpr int kWalkUnroll = SLAM_WALK_UNROLL; // steps per trip of the raycast walk loop
-// Lanes of a block start their walks kWalkStagger-fold staggered: lane j waits (j % kWalkStagger) trips.  The 64 beams of a block
-// are adjacent beams of ONE scan: near the sensor they run through the same cells, and in lock-step they are on the same cell in the
-// same instruction -- LDS atomics of one instruction to one address are served one after the other (bank-conflict share 55 %).
-// Staggered, neighbours are kWalkUnroll cells apart along the beam when they add.
+// Lanes of a block walk STAGGERED: lane j takes (j % kWalkStagger) single steps before the lock-step trips begin (round 5).  The 64
+// beams of a block are adjacent beams of ONE scan: near the sensor they run through the same cells, and in lock-step from the same
+// start they are on the same cell in the same instruction -- LDS atomics of one instruction to one address are served one after the
+// other (bank-conflict share 55 %, VALU busy 35 %).  Staggered, neighbours are a cell or more apart along the beam when they add:
+// the raycast call of config 2 0.1325 -> 0.0983 ms with one workgroup per CU, 0.110 -> 0.090 with two (VALU busy 56 %); the pipelined
+// step 0.304 -> 0.295 ms.  Measured (tools/exp/stagger_ab.sh, ms per call with one workgroup per CU): steps ahead 2 / 3 / 4 / 6 / 8 /
+// 12 / 16 / 32 -> 0.120 / 0.112 / 0.105 / 0.100 / 0.098 / 0.100 / 0.104 / 0.130; whole trips of delay instead (4 steps each), 2 / 4 /
+// 6 / 8 / 16-fold -> 0.115 / 0.103 / 0.103 / 0.106 / 0.122.  Bit-exact either way: the adds commute.
 #ifndef SLAM_WALK_STAGGER
-#define SLAM_WALK_STAGGER 4 // round 5: the raycast call 0.1325 -> 0.1026 ms with one workgroup per CU, 0.110 -> 0.092 with two; step 0.304 -> 0.295 (2: 0.115, 6: 0.103, 8: 0.106, 16: 0.122; tools/exp/stagger_ab.sh)
+#define SLAM_WALK_STAGGER 8
 #endif
 constexpr int kWalkStagger = SLAM_WALK_STAGGER;
 constexpr int kTileStride = kTile + 1; // LDS row pitch in words: vertical neighbours fall on adjacent banks
@@ -798,11 +802,16 @@ __global__ __launch_bounds__(kTileThreads, 8) void raycast_tiled_kernel(GridView
                     if (leader) atomicAdd(reinterpret_cast<unsigned *>(tb + a4), run);
                 }
             };
-            int delay = kWalkStagger > 1 ? lane % kWalkStagger : 0;
+#pragma unroll
+            for (int k = 0; k < kWalkStagger - 1; ++k) { // the stagger: lane j is j % kWalkStagger cells ahead when the trips begin
+                if (lane % kWalkStagger > k && miss > 0) {
+                    add_miss();
+                    advance();
+                    --miss;
+                }
+            }
             while (__any(miss >= kWalkUnroll)) {
-                if (kWalkStagger > 1 && delay > 0) {
-                    --delay;
-                } else if (miss >= kWalkUnroll) {
+                if (miss >= kWalkUnroll) {
 #pragma unroll
                     for (int k = 0; k < kWalkUnroll; ++k) {
                         add_miss();
