@@ -26,6 +26,9 @@ def measure_cpp(clouds, poses, advance=10, passes=3, forms=("seq",)):
     # (children of a profiled run must not inherit the profiler: g++ and the C++ program would run with its library preloaded
     # and leave kernel-stats files of their own beside the parent's)
     env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTX"))}
+    # (... nor bench.py's GPU_MAX_HW_QUEUES=8, which is for ITS streams: the program stands for a user's, with the runtime's defaults --
+    # CCICP::matchSequence deals its scene chains over four streams for the runtime's four queues: 0.23-0.25 ms per match there, 0.30-0.32 with 8)
+    env.pop("GPU_MAX_HW_QUEUES", None)
     with tempfile.TemporaryDirectory() as d:
         exe = os.path.join(d, "ccicp_sequence")
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(ROOT, "include"),
