@@ -533,6 +533,7 @@ def main():
     ap.add_argument("--merge-every", type=int, default=8, help="config 5: chunks between merges over the GPUs + finalize")
     ap.add_argument("--reg-streams", type=int, default=0, help="config 5: slam_mapper_params::registration_streams (0 = library default)")
     ap.add_argument("--slots", type=int, default=0, help="config 5: slam_mapper_params::slots (0 = library default)")
+    ap.add_argument("--pair-scans", type=int, default=0, help="config 5: slam_icp_params::pair_scans of the mapper's registrations (0 = library default)")
     ap.add_argument("--mode", choices=["p2p", "p2l"], default="p2p",
                     help="the ICP step: p2p = what the reference compiles and calls (icpPointToPoint.cpp:33-172); p2l = the solver "
                          "north_star names, point-to-line error + 3x3 normal equations (icpPointToPlane.cpp:37-107, stale upstream)")
@@ -967,6 +968,9 @@ def main():
             sa = sb = api.Stream()
             run_steps(1, pipelined=False)
             sync()
+    import gc
+    gc.collect()
+    gc.disable()                      # (see run_config5: a full collection inside the timed region is an accident of the run)
     t_ref0 = time.perf_counter()
     ev_ref.record(SA[0] if launch == "pipeline" else sa)
     ev_ref.synchronize()
@@ -981,6 +985,7 @@ def main():
     barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     pace_timed = dict(pace)
     for g_ in grids:
         settle(g_)
@@ -1282,7 +1287,7 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, rk, sync, barr
     m_ga, m_nga = synth.make_map(5000)
     mp = api.Mapper(m_ga, m_nga, grid=dict(rolling=0, min_cluster_points=20, raycast_wg_per_cu=args.raycast_wg), grid_size_x=GRID, grid_size_y=GRID,
                     resolution=RES, max_scans=chunk, max_points=max(c.n_points for c in chunks),
-                    icp=dict(max_iter=N_ITERS, min_delta=-1.0, list_min_halo=args.list_min_halo,
+                    icp=dict(max_iter=N_ITERS, min_delta=-1.0, list_min_halo=args.list_min_halo, pair_scans=args.pair_scans,
                              **(dict(mode=api.ICP_P2L, normals_k=10) if args.mode == "p2l" else {})),
                     window_chunks=args.window, rebuild_every=args.rebuild_every, keep_prior=1, target_points=5000,
                     thin_res=args.thin, merge_every=args.merge_every, registration_streams=args.reg_streams, slots=args.slots)
@@ -1298,6 +1303,12 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, rk, sync, barr
     sync()
     upd_warm = mp.grid.total_updates()       # the warm-up chunks' updates are not the timed chunks'
     barrier()
+    # (no cyclic garbage collection inside the timed region: with torch imported a full collection is 30 ms, and where the interpreter's
+    # allocation count puts it is an accident of the run -- chunks of 512 scans had it between the last push and the first wait, every
+    # time: 2.3 ms per chunk instead of 0.57, tools/exp/c5_torch_gap.py)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     pending, worst = [], 0.0
     for k in range(n_chunks):
@@ -1313,6 +1324,7 @@ def run_config5(args, api, synth, m_ga, m_nga, rank, world, comm, rk, sync, barr
     sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     upd = mp.grid.total_updates() - upd_warm
     st = mp.stats()
     if rk is not None:

@@ -549,6 +549,13 @@ int slam_mapper_create(const slam_mapper_params *params, const double *m_ga, int
             params->pipelined && (params->registration_streams == 2 || (!params->window_chunks && params->registration_streams == 0)) &&
             m->prm.icp.pair_scans == 0 && 2 * params->max_scans > cus)
             m->prm.icp.pair_scans = 2;
+        // A sliding target's chunks register one scan per workgroup whatever their size: a pair workgroup fills its CU's register
+        // file, and the rebuild's thirty short kernels -- written to run BESIDE a registration workgroup -- would each wait for a
+        // whole launch to end.  Measured (round 5, tools/exp/c5_chunk.sh): chunks of 512 scans, which the library pairs by default
+        // (two scans per CU), 2.3-2.6 ms per chunk with rebuilds of 5-15 ms that the producer ends up waiting for; one scan per
+        // workgroup: see DESIGN.md 6.
+        else if (params->window_chunks && params->registration_streams != 2 && m->prm.icp.pair_scans == 0)
+            m->prm.icp.pair_scans = -1;
         (void)hipGetLastError();
     }
     int rc = slam_grid_create(params->grid_size_x, params->grid_size_y, params->resolution, &m->prm.grid, &m->grid);

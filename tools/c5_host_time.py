@@ -8,7 +8,7 @@ from slam_amd import api, synth
 import ctypes as C
 
 kw = dict(a.split("=") for a in sys.argv[1:])
-chunk, n_chunks = 256, int(kw.get("chunks", 40))
+chunk, n_chunks = int(kw.get("chunk", 256)), int(kw.get("chunks", 40))
 nofill = int(kw.get("nofill", 0))      # 1: every slot's pinned buffers are filled once (the device's rate without the producer's copies)
 api.set_device(0)
 chunks = [synth.make_batch(chunk, n_loop=n_chunks * chunk, first=k * chunk) for k in range(n_chunks)]
