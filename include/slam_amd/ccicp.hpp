@@ -615,8 +615,6 @@ private:
         Ahead &a = ahead_;
         a.pending = false;
         ok(slam_stream_wait_event(stream_, a.done));
-        ok(slam_event_record(a.done, stream_)); // ... and the second stream for whatever the match's stream still does with the buffers it gets
-        ok(slam_stream_wait_event(a.stream, a.done));
         std::swap(scene_raw_, a.raw);
         std::swap(scene_ground_, a.ground);
         std::swap(d_scene_pts_, a.d_pts);
@@ -624,6 +622,10 @@ private:
         std::swap(cc_, a.cc);
         // the scan block and the counts of the chain: into the match's io block, device to device (32 bytes)
         ok(slam_memcpy_d2d(d_io_ + kOffScan, a.d_io + kOffScan, kOffNgt - kOffScan, stream_));
+        // ... and the second stream waits for whatever the match's stream still does with the buffers it gets back -- this copy included:
+        // the next prepared chain writes a.d_io
+        ok(slam_event_record(a.done, stream_));
+        ok(slam_stream_wait_event(a.stream, a.done));
         scene_n_in_ = a.n;
         scene_stride_ = a.stride;
         scene_ready_ = true;
@@ -637,13 +639,14 @@ private:
         slam_ccicp_t *cc = nullptr;
         slam_stream_t stream = nullptr;
         Cloud         raw, ground;
+        int           max_n = 0, epoch = 0; // the largest scene its handles have seen; bumped when they may have re-allocated their scratch
     };
     struct SeqIo { // per scene, device and pinned mirror: [scan {0, n, n_ga, -} | counts {obs, gnd, flt, err}]
         int32_t scan[4], counts[4];
     };
     struct SeqSlot { // what the chain of scene k of a batch was last enqueued with, and its captured replay
         slam_graph_t graph = nullptr;
-        int          n = -1, stride = 0;
+        int          n = -1, stride = 0, epoch = -1;
         const void  *raw = nullptr, *ground = nullptr;
     };
     SeqLane       lane_[kSeqLanes];
@@ -739,7 +742,10 @@ private:
             // 0.01 (measured, tools/exp/c3_batch_time.sh: the batch itself is bound by the device either way).  A scene of the same size as the one this slot held before (a lidar's clouds
             // are) replays the chain as a hipGraph captured on its second use: same kernels, same arguments, one launch.
             SeqSlot &q = seq_slot_[k];
-            const bool same = q.n == np && q.stride == stride && q.raw == l.raw.p && q.ground == l.ground.p;
+            // (a captured chain holds the pointers of the lane's buffers AND of its handles' scratch, which grows with the largest scene the
+            // lane has seen: a larger scene on the lane -- through any of its slots -- ends every replay made before it)
+            if (np > l.max_n) l.max_n = np, ++l.epoch;
+            const bool same = q.n == np && q.stride == stride && q.raw == l.raw.p && q.ground == l.ground.p && q.epoch == l.epoch;
             auto chain = [&]() {
                 ok(slam_ccicp_scene_dev(l.cc, l.gseg, (const float *)l.raw.p, np, stride, 1, 0, 0.0, 0.0, 0.0, ICP_MAX_PTS, slot, d_seq_io_[k].scan,
                                         (float *)l.ground.p, d_seq_io_[k].counts, l.stream));
@@ -763,7 +769,7 @@ private:
                 if (q.graph) slam_graph_destroy(q.graph);
                 q.graph = nullptr;
                 chain();
-                q.n = np, q.stride = stride, q.raw = l.raw.p, q.ground = l.ground.p;
+                q.n = np, q.stride = stride, q.raw = l.raw.p, q.ground = l.ground.p, q.epoch = l.epoch;
             }
             ok(slam_event_record(seq_ev_[k], l.stream));
         };
