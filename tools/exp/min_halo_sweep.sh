@@ -21,6 +21,5 @@ for H in -1 0.08 0.1 0.125 0.15 0.2 0.3; do
   done
   timeout -k 10 200 python bench.py --config 5 --stream-scans 10240 --list-min-halo $H > $O/c5_$H.json 2> $O/c5_$H.err
   line "config5 1 lane halo>=$H" $O/c5_$H.json
-  timeout -k 10 200 python bench.py --config 5 --stream-scans 10240 --list-min-halo $H --reg-streams 2 --rebuild-lag 8 > $O/c5l2_$H.json 2> $O/c5l2_$H.err
-  line "config5 2 lanes lag 8 halo>=$H" $O/c5l2_$H.json
+  
 done
