@@ -123,7 +123,7 @@ typedef struct {
     int    build_on_host;   /* 1 = build the model index with the single-threaded host code instead of the
                                device kernels (the reference the device build is verified against: same bytes) */
     int    first_iterations;/* default schedule: ring-search iterations before a scan may change to list sweeps
-                               (0 = library default: 10 point-to-point, 4 point-to-line) */
+                               (0 = library default: 10 point-to-point, 2 point-to-line) */
     int    far_div;         /* default schedule: hand over once at most n / far_div queries are beyond the lists'
                                certified radius (0 = library default, 32) */
     int    split_launch;    /* 1 = the two search forms as two launches instead of one (same results) */

@@ -1297,11 +1297,12 @@ int icp_new(const slam_icp_params *params, slam_icp **out)
     h->G = h->prm.lanes_per_point > 0 ? h->prm.lanes_per_point : (h->prm.lanes_per_point == -1 ? 0 : 2);
     h->two_phase = h->prm.lanes_per_point == 0; // either solver (the point-to-line lists carry a normal per entry)
     if (h->prm.first_iterations > 0) h->switch_iter = h->prm.first_iterations;
-    // Point-to-line steps settle a scan within the lists' certified radius in three or four iterations (no classes, no gate; the
-    // hand-over itself still waits for the guard, far_div): round 5, tools/exp/switch_pairs.py, config 2's scans, 512 in pairs
-    // 0.459 / 0.467 / 0.480 / 0.492 / 0.506 ms for 4 / 6 / 8 / 10 / 12 first iterations, one per workgroup 0.306 / 0.309 / 0.313 /
-    // 0.320 / 0.321; point-to-point is flat from 4 to 9 (the guard decides) and keeps its 10.
-    else if (h->prm.mode == SLAM_ICP_P2L) h->switch_iter = 4;
+    // Point-to-line steps settle a scan within the lists' certified radius in two or three iterations (no classes, no gate; the
+    // hand-over itself still waits for the guard, far_div): round 5, tools/exp/switch_pairs.py and switch_far_p2l.py, config 2's
+    // scans, 512 in pairs 0.447 / 0.447 / 0.449 / 0.456 / 0.467 / 0.480 / 0.492 / 0.506 ms for 1 / 2 / 3 / 4 / 6 / 8 / 10 / 12 first
+    // iterations (far_div 8 ... 128: the same), one per workgroup 0.306 / 0.309 / 0.313 / 0.320 for 4 / 6 / 8 / 10; point-to-point is
+    // flat from 3 to 10 at far_div 16-32 and slower below (tools/exp/switch_far.py): it keeps its 10.
+    else if (h->prm.mode == SLAM_ICP_P2L) h->switch_iter = 2;
     if (h->prm.far_div > 0) h->far_div = h->prm.far_div;
     h->split_launch = h->prm.split_launch != 0;
     h->pair = h->prm.pair_scans > 0 ? std::min(h->prm.pair_scans, 2) : (h->prm.pair_scans < 0 ? -1 : 0);

@@ -332,6 +332,32 @@ def test_point_to_line_mode_matches_own_oracle(form):
     icp.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("pairs", [False, True])
+def test_point_to_line_hand_over_edge_iteration_counts(pairs):
+    """Point-to-line scans may hand over to the list form after TWO first iterations (round 5; the guard decides): max_iter below,
+    at and just above that, an explicit later hand-over, and min_delta reached in either form -- steps, poses and the delta of
+    every executed step against the oracle, one scan and two scans per workgroup."""
+    m_ga, m_nga = synth.make_map(5000)
+    model = O.IcpModel(m_ga, m_nga, normals_k=10)
+    batch = synth.make_batch(7, n_loop=256)
+    form = dict(spread_scans=-1, pair_scans=2 if pairs else -1)
+    for max_iter, min_delta, first in ((1, -1.0, 0), (2, -1.0, 0), (3, -1.0, 0), (4, -1.0, 0), (12, -1.0, 6), (40, 1e-3, 0), (40, 1e-7, 0)):
+        icp = api.Icp(m_ga, m_nga, mode=api.ICP_P2L, normals_k=10, max_iter=max_iter, min_delta=min_delta, first_iterations=first, **form)
+        info = icp.index_info()
+        assert info["two_forms"] and info["first_iterations"] == (first or 2)
+        R, t, res, trace = icp.fit_batch(batch, trace=True)
+        for s in range(batch.n_scans):
+            t_ga, t_nga = batch.scan(s)
+            Ro, to, tr, steps = model.fit(t_ga, t_nga, batch.R[s], batch.t[s], O.icp_params(max_iter, min_delta, 5.0, O.NN_KDTREE, O.MODE_P2L))
+            if res["iters"][s] != steps or np.abs(trace[s, :steps, 6] - tr[:steps, 6]).max() >= 1e-7:   # an exact distance tie: the arbiter
+                Ro, to, tr, steps = model.fit(t_ga, t_nga, batch.R[s], batch.t[s], O.icp_params(max_iter, min_delta, 5.0, O.NN_BRUTE, O.MODE_P2L))
+            assert res["iters"][s] == steps, (max_iter, min_delta, s)
+            assert np.abs(trace[s, :steps, 6] - tr[:steps, 6]).max() < 1e-7, (max_iter, min_delta, s)
+            assert np.abs(t[s] - to).max() < POS_TOL and ang_diff(yaw(R[s]), yaw(Ro)).max() < ANG_TOL
+        icp.close()
+
+
 def test_point_to_line_host_fit_and_early_exit():
     """Icp::fit's shape (icp.h:65) in point-to-line mode: one scan through slam_icp_fit (the spread form), stopping on
     min_delta after the same number of steps as the oracle; a template of fewer than 5 points leaves R, t untouched."""
