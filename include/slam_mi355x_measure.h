@@ -16,6 +16,8 @@ int slam_icp_debug_phase_ms(slam_icp_t *icp, double out[2], int *calls);
 /* in-kernel stamps of the last batch launched with SLAM_ICP_STAMPS=1: [scan][wavefront][9] ticks / their means */
 int slam_icp_debug_stamps_raw(slam_icp_t *icp, long long *out, int cap_rows, int *rows);
 int slam_icp_debug_stamps(slam_icp_t *icp, double out[9]);
+/* the spread form's stamps of the last launch made with SLAM_SPREAD_STAMPS=1: [parts][iters][16]: wall-clock ticks of 10 ns and counts (icp_single.hip), scan 0 */
+int slam_icp_debug_spread_stamps(slam_icp_t *icp, long long *out, size_t cap, int *parts, int *iters);
 #ifdef __cplusplus
 }
 #endif

@@ -33,7 +33,7 @@ class IcpParams(C.Structure):
                 ("normals_k", C.c_int), ("lanes_per_point", C.c_int), ("cell_size", C.c_double),
                 ("force_global", C.c_int), ("build_on_host", C.c_int), ("first_iterations", C.c_int),
                 ("far_div", C.c_int), ("split_launch", C.c_int), ("spread_scans", C.c_int), ("pair_scans", C.c_int),
-                ("spread_wait_us", C.c_int), ("wave_tiles", C.c_int), ("list_min_halo", C.c_double)]
+                ("spread_wait_us", C.c_int), ("wave_tiles", C.c_int), ("list_min_halo", C.c_double), ("spread_tile", C.c_int)]
 
 
 class IcpResult(C.Structure):

@@ -1273,6 +1273,7 @@ void slam_icp_default_params(slam_icp_params *p)
     p->pair_scans = 0;
     p->spread_wait_us = 0;
     p->wave_tiles = 0;
+    p->spread_tile = 0;
     p->list_min_halo = 0.0;
 }
 
@@ -1683,6 +1684,19 @@ int slam_icp_debug_stamps(slam_icp_t *icp, double out[9])
     for (int i = 0; i < icp->n_stamps; ++i)
         for (int k = 0; k < kStampSlots; ++k) out[k] += (double)v[(size_t)i * kStampSlots + k];
     for (int k = 0; k < kStampSlots; ++k) out[k] /= icp->n_stamps;
+    return SLAM_OK;
+}
+
+// diagnostic: the spread form's stamps of the last launch made with SLAM_SPREAD_STAMPS=1: [parts][iters][16] ticks of 10 ns
+int slam_icp_debug_spread_stamps(slam_icp_t *icp, long long *out, size_t cap, int *parts, int *iters)
+{
+    SLAM_REQUIRE(icp && out && parts && iters && icp->n_stamps < 0, SLAM_E_INVALID, "no spread stamps collected");
+    SLAM_HIP(hipDeviceSynchronize());
+    const size_t n = (size_t)(-icp->n_stamps) * (size_t)icp->spread_stamp_iters * 16;
+    SLAM_REQUIRE(cap >= n, SLAM_E_INVALID, "buffer too small: %zu stamps", n);
+    SLAM_HIP(hipMemcpy(out, icp->w_stamps.p, n * sizeof(long long), hipMemcpyDeviceToHost));
+    *parts = -icp->n_stamps;
+    *iters = icp->spread_stamp_iters;
     return SLAM_OK;
 }
 

@@ -175,6 +175,7 @@ struct slam_icp {
     int             far_div = 32;        // see FitArgs
     int             switch_iter = 10;    // ring-search iterations before a scan may change to list sweeps (tools/switch_sweep.sh); point-to-line: 2 (icp_new)
     int             n_stamps = 0;
+    int             spread_stamp_iters = 0; // measurement build: iterations per workgroup in the spread form's stamps (n_stamps < 0)
     bool            want_step_pose = false; // set around slam_icp_fit()
     int             last_n = 0, last_nga = 0; // template of the last slam_icp_fit()
     double          last_indist = 0;

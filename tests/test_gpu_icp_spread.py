@@ -236,3 +236,94 @@ def test_fit_beside_a_running_grid_update():
     assert dt < 1.0, "24 fits beside 32 raycasts took %.3f s" % dt
     icp.close()
     g.close()
+
+
+# ---- the tile form (round 6): a model that does not fit LDS, scene points dealt over the workgroups along a Morton curve,
+# their state in LDS slots, the tile of the index they can reach staged into LDS (icp_single.hip)
+
+def one_scan_batch(s_ga, s_nga, R0, t0):
+    pts = np.ascontiguousarray(np.concatenate([np.asarray(s_ga, np.float64).reshape(-1, 2), np.asarray(s_nga, np.float64).reshape(-1, 2)]))
+    return synth.ScanBatch(pts, np.array([0, len(pts)], np.int32), np.array([len(s_ga)], np.int32),
+                           np.asarray(R0, np.float64).reshape(1, 4), np.asarray(t0, np.float64).reshape(1, 2), np.zeros((1, 3)))
+
+
+def test_tile_form_on_config3_matches():
+    """Three matches of config 3 (tests/golden/spread_case3.npz: 19 999 + 871 model points, cells of hundreds of stacked wall
+    points; scenes of ~600 voxel centroids in the filter's order): oracle, tile form, and the form without tiles step by step."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "spread_case3.npz"))
+    m_ga, m_nga = d["m_ga"].astype(np.float64), d["m_nga"].astype(np.float64)
+    model = O.IcpModel(m_ga, m_nga)
+    icp = api.Icp(m_ga, m_nga)
+    plain = api.Icp(m_ga, m_nga, spread_tile=-1)
+    assert not icp.index_info()["in_lds"]
+    for k in (1, 5, 9):
+        batch = one_scan_batch(d["s_ga%d" % k], d["s_nga%d" % k], d["R%d" % k], d["t%d" % k])
+        Ro, to, otr, steps = model.fit(d["s_ga%d" % k], d["s_nga%d" % k], d["R%d" % k].reshape(2, 2), d["t%d" % k], O.icp_params(20, 1e-6, 5.0))
+        R, t, res, tr = icp.fit_batch(batch, trace=True)
+        Rp, tp, resp, trp = plain.fit_batch(batch, trace=True)
+        assert res["iters"][0] == steps == resp["iters"][0]
+        for it in range(steps):                                   # the same correspondences in every step
+            assert tr[0, it, 7] == otr[it, 7] == trp[0, it, 7], (k, it)
+            assert np.abs(tr[0, it, :6] - otr[it, :6]).max() < 1e-9 and np.abs(tr[0, it, :6] - trp[0, it, :6]).max() < 1e-9, (k, it)
+        R2, t2, res2, _ = icp.fit_batch(batch)
+        assert np.array_equal(R, R2) and np.array_equal(t, t2)   # bitwise reproducible
+    icp.close()
+    plain.close()
+
+
+@pytest.mark.parametrize("mode", ["p2p", "p2l"])
+def test_tile_form_far_starts_and_many_scans(mode):
+    """Starts 0.6 m / 0.1 rad off (queries leave their first tiles: searches through L2 and stagings until the budget is spent),
+    1, 3 and 16 scans per launch (256, 85, 16 workgroups each: one to five passes of slots per workgroup), both solvers, against
+    the oracle and the form without tiles."""
+    m_ga, m_nga = synth.make_map(39998)
+    kw = dict(mode=api.ICP_P2L, normals_k=10) if mode == "p2l" else {}
+    omode = (O.NN_KDTREE, O.MODE_P2L) if mode == "p2l" else (O.NN_KDTREE,)
+    model = O.IcpModel(m_ga, m_nga, **({"normals_k": 10} if mode == "p2l" else {}))
+    icp = api.Icp(m_ga, m_nga, max_iter=25, min_delta=1e-6, spread_tile=1, **kw)
+    plain = api.Icp(m_ga, m_nga, max_iter=25, min_delta=1e-6, spread_tile=-1, **kw)
+    for n_scans in (1, 3, 16):
+        batch = synth.make_batch(n_scans, n_loop=256)
+        rs = np.random.RandomState(n_scans)
+        for s in range(n_scans):
+            x, y, th = batch.true_poses[s]
+            R0, t0 = synth.pose_to_Rt(x + rs.uniform(-0.6, 0.6), y + rs.uniform(-0.6, 0.6), th + rs.uniform(-0.1, 0.1))
+            batch.R[s], batch.t[s] = R0.reshape(4), t0
+        Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R, batch.t, O.icp_params(25, 1e-6, 5.0, *omode))
+        R, t, res, _ = icp.fit_batch(batch)
+        Rp, tp, resp, _ = plain.fit_batch(batch)
+        assert np.array_equal(res["iters"], resp["iters"]) and np.array_equal(res["n_corr"], resp["n_corr"])
+        assert np.abs(t - tp).max() < 1e-9 and np.abs(R - Rp).max() < 1e-9
+        assert np.array_equal(res["iters"], iters) and np.array_equal(res["n_corr"], ncorr)
+        assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL
+    icp.close()
+    plain.close()
+
+
+def test_tile_form_ties_and_ragged_scans():
+    """The edge cases of test_spread_edge_cases with the index kept in HBM/L2 (the tile form): exact distance ties on a gridded
+    model with duplicates leave the tile for the exact search (lowest original index, the brute-force arbiter's rule), scans
+    below 5 points, without correspondences, with a skipped class; plus a scan of 2049 points (beyond the tile form: the same
+    launch serves it without tiles)."""
+    rs = np.random.RandomState(11)
+    gx, gy = np.meshgrid(np.arange(60) * 0.5, np.arange(40) * 0.5)
+    grid = np.stack([gx.ravel(), gy.ravel()], 1)
+    m_nga = np.concatenate([grid, grid[:200]])
+    m_ga = grid[:3] + 0.1
+    R0, t0 = synth.pose_to_Rt(0.1, -0.05, 0.01)
+    scans = [grid[rs.choice(len(grid), 500)] + 0.25, np.zeros((3, 2)), np.full((10, 2), 900.0),
+             grid[rs.choice(len(grid), 64)] + rs.randn(64, 2) * 0.02,
+             grid[rs.choice(len(grid), 2049)] + rs.randn(2049, 2) * 0.02,
+             grid[rs.choice(len(grid), 700)] + 0.25 + rs.randn(700, 2) * 1e-3]   # near-ties: decided on the tile
+    nga = [0, 1, 0, 10, 0, 0]
+    off = np.cumsum([0] + [len(x) for x in scans]).astype(np.int32)
+    Rs, ts = np.tile(R0.reshape(4), (6, 1)), np.tile(t0, (6, 1))
+    Rs[0], ts[0] = [1, 0, 0, 1], [0, 0]
+    batch = synth.ScanBatch(np.ascontiguousarray(np.concatenate(scans)), off, np.array(nga, np.int32), Rs, ts, np.zeros((6, 3)))
+    icp, R, t, res, _ = check_against_oracle(m_ga, m_nga, batch, 15, 1e-6, nn=O.NN_BRUTE, force_global=1, spread_tile=1)
+    assert not icp.index_info()["in_lds"]
+    assert res["iters"][1] == 0 and np.array_equal(R[1], R0.reshape(4)) and np.array_equal(t[1], t0)
+    assert (res["iters"][2], res["n_corr"][2], res["delta"][2]) == (1, 0, -1.0)
+    assert res["n_corr"][3] == 54
+    icp.close()
