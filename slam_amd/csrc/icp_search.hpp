@@ -760,8 +760,10 @@ __device__ inline Best nn_search_rows_impl(const IndexPtrs<StartT> &ix, const Mo
         int y_lo = max(cy - r, 0), y_hi = min(cy + r, L.ny - 1);
         int x_lo = max(cx - r, 0), x_hi = min(cx + r, L.nx - 1);
         const bool covers = (x_lo == 0) & (y_lo == 0) & (x_hi == L.nx - 1) & (y_hi == L.ny - 1);
+        float      Rd = 1.0e30f; // the disk of the best so far, in cells
         if (b.d < FLT_MAX) {
             const float R = (disk_radius(b.d) + L.margin) * L.inv_h;
+            Rd = R;
             x_lo = max(x_lo, ifloor(fx - R));
             x_hi = min(x_hi, ifloor(fx + R));
             y_lo = max(y_lo, ifloor(fy - R));
@@ -776,12 +778,22 @@ __device__ inline Best nn_search_rows_impl(const IndexPtrs<StartT> &ix, const Mo
             const int y = y0 + slot, row = y * L.nx;
             int       a1 = 0, e1 = 0, a2 = 0, e2 = 0; // the row's one or two spans of the sorted array
             if (y <= y_hi) {
+                // the row's cells under the disk of the level's best (round 6): a point of lattice row y is at least dy rows from the
+                // query, so within Rd of it only if no farther than sqrt(Rd^2 - dy^2) columns -- a far query beside a wall of stacked
+                // lidar points reads the one or two cells per row that the disk touches where its bounding square holds metres of wall
+                int xl = x_lo, xh = x_hi;
+                if (Rd < 1.0e29f) {
+                    const float dy = fmaxf(fmaxf((float)y - fy, fy - (float)(y + 1)), 0.0f);
+                    const float half = __builtin_amdgcn_sqrtf(fmaxf(Rd * Rd - dy * dy, 0.0f)) + 1.0e-3f;
+                    xl = max(xl, ifloor(fx - half));
+                    xh = min(xh, ifloor(fx + half));
+                }
                 if (rp >= 0 && y >= cy - rp && y <= cy + rp) {
-                    const int l1 = min(x_hi, cx - rp - 1), f2 = max(x_lo, cx + rp + 1);
-                    if (x_lo <= l1) a1 = (int)start[row + x_lo], e1 = (int)start[row + l1 + 1];
-                    if (f2 <= x_hi) a2 = (int)start[row + f2], e2 = (int)start[row + x_hi + 1];
-                } else if (x_lo <= x_hi) {
-                    a1 = (int)start[row + x_lo], e1 = (int)start[row + x_hi + 1];
+                    const int l1 = min(xh, cx - rp - 1), f2 = max(xl, cx + rp + 1);
+                    if (xl <= l1) a1 = (int)start[row + xl], e1 = (int)start[row + l1 + 1];
+                    if (f2 <= xh) a2 = (int)start[row + f2], e2 = (int)start[row + xh + 1];
+                } else if (xl <= xh) {
+                    a1 = (int)start[row + xl], e1 = (int)start[row + xh + 1];
                 }
             }
             const bool heavy = (e1 - a1) + (e2 - a2) > 8 * lpr;

@@ -278,7 +278,8 @@ __device__ inline bool nn_search_gate(const IndexPtrs<StartT> &ix, const ModelVi
     b.d = FLT_MAX, b.pos = -1, b.oidx = 0xffffffffu;
     empty_out = 0.0f;
     if (mv.n_cls[cls] <= 0) return true;
-    const int R = (int)ceilf((gate_r + L.margin) * L.inv_h);
+    // (two cells beyond the gate: the radius an empty square proves is what the point's certificate lives on while the fit moves it)
+    const int R = (int)ceilf((gate_r + L.margin) * L.inv_h) + 2;
     if (2 * R + 1 > kRows * G) return false;
     const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
     const int   cx = clampi(ifloor(fx), 0, L.nx - 1), cy = clampi(ifloor(fy), 0, L.ny - 1);
