@@ -593,6 +593,14 @@ def main():
                          "(whichever of the two was not given), take the maximum over the ranks and keep the fastest; reported as "
                          "merge.calibration.  On by default with more than one rank (no multi-GPU lease has measured which setting RCCL's "
                          "kernels need beside 0.6 ms registration workgroups); with --force-dist only when asked for")
+    ap.add_argument("--test-kill-rank", type=int, default=-1,
+                    help="tests only: this rank ends with SIGKILL behind its warm-up (the others must notice and exit: slam_amd.ranks)")
+    ap.add_argument("--no-calibrate", action="store_true",
+                    help="N>1 over RCCL: skip the calibration (about 1 700 steps before the warm-up) and run with the one-GPU defaults; recorded "
+                         "in the line as config.calibration_skipped, so that a run that was cut short can be told from one that hung")
+    ap.add_argument("--regions", type=int, default=5,
+                    help="timed regions of `steps` steps each, run back to back behind the one warm-up; the MEDIAN region is reported "
+                         "(ms_per_step_runs lists them all)")
     ap.add_argument("--start-stagger-us", type=float, default=125.0,
                     help="pipelined launch: the host waits this long between enqueueing the first registration of a run and the second "
                          "(on the other registration stream), so that the two streams are out of step from the start as they are in "
@@ -746,7 +754,7 @@ def main():
         icp = api.Icp(m_ga, m_nga, max_iter=N_ITERS, min_delta=-1.0, cell_size=args.cell, pair_scans=2, **mode_kw)
     # three priority levels: never the same hardware queue (see mapper.hip)
     pq = args.private_queues
-    calibrating = merging and args.backend == "nccl" and launch == "pipeline" and (world > 1 or args.calibrate) and \
+    calibrating = merging and args.backend == "nccl" and launch == "pipeline" and (world > 1 or args.calibrate) and not args.no_calibrate and \
         (args.reg_cu_cap is None or args.merge_order is None or args.grid_lag is None)
     cal_caps = [args.reg_cu_cap] if args.reg_cu_cap is not None else [0, 1, 2, 4]
     cal_orders = [args.merge_order] if args.merge_order is not None else ["late", "early"]
@@ -901,7 +909,23 @@ def main():
         # which launch setting leaves RCCL's kernels room on THIS node: a few steps of each, the slowest rank's clock, the
         # fastest setting kept for the warm-up and the timed steps (every rank sees the same all-reduced times: same choice)
         calibration = {"tried": []}
-        streams_of = {c: reg_streams(c) for c in cal_caps}
+        # (a registration stream that leaves CUs alone is refused -- SLAM_E_UNSUPPORTED -- on a device whose CU layout the mask was not
+        # measured on, e.g. a partitioned one: such caps are dropped, on every rank alike, instead of ending the run in calibration)
+        streams_of = {}
+        for c in cal_caps:
+            try:
+                streams_of[c] = reg_streams(c)
+            except api.SlamError as ex:
+                if ex.code != api.E_UNSUPPORTED:
+                    raise
+        ok_caps = [1 if c in streams_of else 0 for c in cal_caps]
+        if multi:
+            ok_caps = [int(v) for v in rk.all_reduce(torch.tensor(ok_caps, dtype=torch.int64), torch.distributed.ReduceOp.MIN,
+                                                     "registration-stream caps every rank supports").tolist()]
+        calibration["caps_dropped_unsupported"] = [c for c, ok in zip(cal_caps, ok_caps) if not ok]
+        cal_caps = [c for c, ok in zip(cal_caps, ok_caps) if ok]
+        if not cal_caps:
+            _RK.fail("no registration-stream setting is supported on this device")
         # late: the grid update (and the merge) of a step is enqueued `lag` registrations after its own; early: with it (no lag)
         settings = [(c, l, "late") for c in cal_caps for l in cal_lags if "late" in cal_orders] + \
                    [(c, 0, "early") for c in cal_caps if "early" in cal_orders]
@@ -968,30 +992,43 @@ def main():
             sa = sb = api.Stream()
             run_steps(1, pipelined=False)
             sync()
+    if multi and args.test_kill_rank == rank:
+        import signal
+        os.kill(os.getpid(), signal.SIGKILL)
     import gc
     gc.collect()
     gc.disable()                      # (see run_config5: a full collection inside the timed region is an accident of the run)
-    t_ref0 = time.perf_counter()
-    ev_ref.record(SA[0] if launch == "pipeline" else sa)
-    ev_ref.synchronize()
-    t_ref1 = time.perf_counter()         # the event's device time lies between the two host readings
-    t0 = time.perf_counter()
-    if graph is not None:
-        for k in range(args.steps):
-            graph.launch()
-    else:
-        run_steps(args.steps, pipelined=launch == "pipeline", timed=True)
-    sync()
-    barrier()
-    sync()
-    elapsed = time.perf_counter() - t0
+    # The timed region -- exactly `steps` steps between a barrier + device synchronisation on either side -- is run `regions`
+    # times back to back and the MEDIAN region is the one reported (ms_per_step, value); every region's figure goes into
+    # ms_per_step_runs.  One region of 20 steps is 6 ms: a single sample of it carried the start-of-run transient of the first
+    # launches (4-7 % between the driver's 20 steps and this file's 50); five regions cost 25 ms more and say how far they agree.
+    region_s = []
+    for region in range(max(args.regions, 1)):
+        t_ref0 = time.perf_counter()
+        ev_ref.record(SA[0] if launch == "pipeline" else sa)
+        ev_ref.synchronize()
+        t_ref1 = time.perf_counter()         # the event's device time lies between the two host readings
+        t0 = time.perf_counter()
+        if graph is not None:
+            for k in range(args.steps):
+                graph.launch()
+        else:
+            run_steps(args.steps, pipelined=launch == "pipeline", timed=True)
+        sync()
+        barrier()
+        sync()
+        region_s.append(time.perf_counter() - t0)
+    if multi:
+        region_s = [rk.max_over_ranks(e_) for e_ in region_s]     # every region by its slowest rank, then the median region
+    elapsed = float(np.median(region_s))
+    n_regions = len(region_s)
     gc.enable()
     pace_timed = dict(pace)
     for g_ in grids:
         settle(g_)
     merge_stats = comm.stats() if comm is not None else None
     if upd_per_step is None:      # no warm-up to count them in: the timed steps' own updates, before anything else runs
-        upd_per_step = sum(g_.total_updates() for g_ in grids) // max(args.steps, 1)
+        upd_per_step = sum(g_.total_updates() for g_ in grids) // max(args.steps * n_regions, 1)
     live_ms = [a_.elapsed_ms(b_) for a_, b_ in live] if (graph is None and args.steps > 0) else []
     # How far ahead of the device the enqueue thread ran: registrations k and k + len(SA) share a stream, and that stream never runs
     # dry as long as the enqueue of the later one has returned before the earlier one ends on the device.  Device end times come
@@ -1026,7 +1063,6 @@ def main():
     grid = grids[(len(ev) - 1) % len(grids)]            # the grid of the last step: what the checks below read
 
     if multi:
-        elapsed = rk.max_over_ranks(elapsed)
         cnt = rk.all_reduce(torch.tensor([P, upd_per_step], dtype=torch.int64), what="sum of the ranks' points and updates")
         total_pts, total_upd = int(cnt[0].item()), int(cnt[1].item())
     if merging:
@@ -1148,6 +1184,10 @@ def main():
             "metric": "registered_scan_points_per_s", "value": total_pts * args.steps / elapsed,
             "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": step_ms, "higher_is_better": True,
+            "ms_per_step_runs": [e_ / max(args.steps, 1) * 1e3 for e_ in region_s],
+            "timed_regions": {"n": n_regions, "reported": "median",
+                              "what": "the timed region (`steps` steps between barrier + device synchronisation) run n times back to back behind "
+                                      "the one warm-up; ms_per_step and value are the MEDIAN region's, ms_per_step_runs lists all of them in order"},
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 pose / f32 distance / int32 counts",
             "data": "synthetic",
             "icp_step": "point-to-line, 3x3 normal equations per iteration (icpPointToPlane.cpp:37-107; SLAM_ICP_P2L)" if p2l else
@@ -1169,7 +1209,8 @@ def main():
                        "raycast_worklist": grid.raycast_stats(),
                        "merge_rows": list(merge_rows_seen[-1]) if merging and merge_rows_seen else None,
                        "reg_cu_cap_per_xcd": args.reg_cu_cap, "grid_lag": args.grid_lag, "merge_order": args.merge_order if merging else None,
-                       "merge_thread": bool(use_thread) if merging else None},
+                       "merge_thread": bool(use_thread) if merging else None,
+                       "calibration_skipped": bool(args.no_calibrate) if merging else None},
             "grid_cell_updates_per_s": total_upd * args.steps / elapsed,
             "cell_updates_per_step": total_upd,
             "point_iterations_per_s": total_pts * N_ITERS * args.steps / elapsed,
@@ -1199,7 +1240,7 @@ def main():
             out["merge"] = None if not merging else {
                 "transport": "rccl" if ms_.get("transport") == 0 else "host-staged (gloo rehearsal)",
                 "rccl_version": ms_.get("rccl_version"), "ranks": ms_.get("n_ranks"),
-                "merges_in_timed_region": ms_.get("merges"),
+                "merges_in_timed_region": ms_.get("merges"), "timed_regions": n_regions,
                 "rows_per_merge": ms_.get("rows", 0) / n_m, "bytes_per_merge_per_rank": ms_.get("bytes", 0) / n_m,
                 "merge_wait_ms": ms_.get("wait_ms", 0.0) / n_m,
                 "backpressure_wait_ms": (pace_timed["ms"] / max(pace_timed["n"], 1)) if use_thread else None,

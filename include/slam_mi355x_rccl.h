@@ -28,7 +28,9 @@ typedef struct slam_comm slam_comm_t;
 
 int  slam_comm_unique_id(char id[SLAM_COMM_ID_BYTES]);                       /* rank 0: ncclGetUniqueId */
 int  slam_comm_create(const char id[SLAM_COMM_ID_BYTES], int rank, int n_ranks, slam_comm_t **out);
-int  slam_comm_adopt(void *nccl_comm, slam_comm_t **out);                     /* wrap an ncclComm_t (not owned) */
+int  slam_comm_adopt(void *nccl_comm, slam_comm_t **out);                     /* wrap an ncclComm_t (not owned).  After SLAM_E_TIMEOUT /
+                                                                                 * SLAM_E_COMM every entry point on it returns that code and
+                                                                                 * enqueues nothing more; ncclCommAbort is its OWNER's call */
 /* A communicator whose collectives go through the HOST: for ranks RCCL cannot connect (several processes on ONE GPU:
  * rehearsals of the N > 1 path on a one-GPU box) or for a transport of the caller's own (MPI, gloo).  Every entry point
  * below works the same way on it; the library stages the rows through pinned memory and calls `allreduce` on host

@@ -60,13 +60,14 @@ struct slam_comm {
     std::condition_variable cv_job, cv_done;
     std::deque<Job>         jobs;
     unsigned long long      posted = 0, completed = 0;
+    long long               async_merges = 0;     // merges the helper thread has issued since slam_comm_stats_reset
     Outcome                 outcome[kDone];
     bool                    stop = false;
     int                     device = 0;
     std::atomic<int>        failed{SLAM_OK};      // sticky: the first failure of a merge (a peer gone, a time-out)
-    bool                    aborted = false;      // ncclCommAbort has run: `comm` is gone
+    std::atomic<bool>       aborted{false};       // ncclCommAbort has run: `comm` is gone (read without the lock by usable / comm_health)
     char                    failed_msg[256] = "";
-    double                  timeout_s = 60.0;     // a united range that has not arrived by then is a lost rank
+    std::atomic<double>     timeout_s{60.0};      // a united range that has not arrived by then is a lost rank (read by the helper thread's polls)
     double                  helper_wait_ms = 0.0; // the helper thread's waits for united ranges
     int32_t   *h_stage = nullptr;   // pinned staging of the host-staged transport
     size_t     cap_stage = 0;       // ints
@@ -151,6 +152,8 @@ void mark_failed(slam_comm *c, int rc)
         c->aborted = true;
         (void)ncclCommAbort(c->comm);
     }
+    // (an ADOPTED communicator is its owner's to abort: this library enqueues nothing more on it -- every entry point, the plain
+    // all-reduces included, returns the failure from here on -- and slam_comm_check tells the owner, who calls ncclCommAbort)
 }
 
 // The host's one wait of a merge: the united range's event, polled -- so that a lost rank ends in an error code and not in a
@@ -173,7 +176,7 @@ int wait_range(slam_comm *c, hipEvent_t ev, double *waited_ms)
             if ((rc = comm_health(c)) != SLAM_OK) break;
             next_health = now + std::chrono::milliseconds(1);
             const double s = std::chrono::duration<double>(now - t0).count();
-            if (s > c->timeout_s) {
+            if (s > c->timeout_s.load()) {
                 set_error("rank %d of %d: the united row range of a merge has not arrived after %.1f s: another rank has stopped "
                           "(or never began this merge)", c->rank, c->n_ranks, s);
                 rc = SLAM_E_TIMEOUT;
@@ -240,6 +243,7 @@ int slam_comm_create(const char id[SLAM_COMM_ID_BYTES], int rank, int n_ranks, s
     c->owned = true;
     c->rank = rank;
     c->n_ranks = n_ranks;
+    (void)hipGetDevice(&c->device); // the helper thread binds to the device the communicator was made on
     *out = c;
     return SLAM_OK;
 }
@@ -256,6 +260,7 @@ int slam_comm_create_host(int rank, int n_ranks, slam_host_allreduce_fn allreduc
     c->host_ctx = ctx;
     c->rank = rank;
     c->n_ranks = n_ranks;
+    (void)hipGetDevice(&c->device);
     *out = c;
     return SLAM_OK;
 }
@@ -269,6 +274,7 @@ int slam_comm_adopt(void *nccl_comm, slam_comm_t **out)
     c->owned = false;
     (void)ncclCommUserRank(c->comm, &c->rank);
     (void)ncclCommCount(c->comm, &c->n_ranks);
+    if (ncclCommCuDevice(c->comm, &c->device) != ncclSuccess) (void)hipGetDevice(&c->device);
     *out = c;
     return SLAM_OK;
 }
@@ -325,7 +331,10 @@ int slam_comm_get_stats(slam_comm_t *comm, slam_comm_stats *out)
     out->bytes = comm->bytes;
     out->wait_ms = comm->wait_ms;
     out->helper_wait_ms = comm->helper_wait_ms;
-    out->async_merges = (long long)comm->completed;
+    {
+        std::lock_guard<std::mutex> lk(comm->mu);
+        out->async_merges = comm->async_merges;
+    }
     const long long n = comm->ar_recorded < slam_comm::kTimed ? comm->ar_recorded : slam_comm::kTimed;
     for (long long i = 0; i < n; ++i) {
         hipEvent_t *ev = comm->ev_ar[i];
@@ -345,11 +354,24 @@ int slam_comm_stats_reset(slam_comm_t *comm)
     comm->merges = comm->rows = comm->bytes = 0;
     comm->wait_ms = comm->helper_wait_ms = 0.0;
     comm->ar_recorded = 0;
+    {
+        std::lock_guard<std::mutex> lk(comm->mu);
+        comm->async_merges = 0;
+    }
     return SLAM_OK;
 }
 
+#define SLAM_COMM_ALIVE(comm)                                  \
+    do {                                                       \
+        if ((comm) && (comm)->failed.load() != SLAM_OK) {      \
+            set_error("%s", (comm)->failed_msg);               \
+            return (comm)->failed.load();                      \
+        }                                                      \
+    } while (0)
+
 int slam_grid_allreduce(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream)
 {
+    SLAM_COMM_ALIVE(comm); // (a communicator that has failed takes no more work: on an adopted one the collectives already enqueued never end)
     SLAM_REQUIRE(grid && usable(comm), SLAM_E_INVALID, "slam_grid_allreduce: bad arguments (or a communicator that has failed)");
     int32_t *planes = nullptr;
     size_t   n = 0;
@@ -365,6 +387,7 @@ int slam_grid_allreduce(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stre
 
 int slam_grid_allreduce_rows(slam_grid_t *grid, slam_comm_t *comm, int row_lo, int row_hi, slam_stream_t stream)
 {
+    SLAM_COMM_ALIVE(comm);
     SLAM_REQUIRE(grid && usable(comm), SLAM_E_INVALID, "slam_grid_allreduce_rows: bad arguments");
     if (row_hi < row_lo) return SLAM_OK;
     int32_t *planes = nullptr;
@@ -492,18 +515,11 @@ static void worker_main(slam_comm *c)
             o.hi = hi;
             snprintf(o.err, sizeof o.err, "%s", rc == SLAM_OK ? "" : slam_last_error());
             ++c->completed;
+            ++c->async_merges;
         }
         c->cv_done.notify_all();
     }
 }
-
-#define SLAM_COMM_ALIVE(comm)                                  \
-    do {                                                       \
-        if ((comm) && (comm)->failed.load() != SLAM_OK) {      \
-            set_error("%s", (comm)->failed_msg);               \
-            return (comm)->failed.load();                      \
-        }                                                      \
-    } while (0)
 
 int slam_grid_merge_begin(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t stream)
 {
@@ -568,8 +584,12 @@ int slam_grid_merge_async(slam_grid_t *grid, slam_comm_t *comm, slam_stream_t st
     SLAM_TRY(slam_grid_window_cell(grid, &job.cell_x, &job.cell_y));
     std::unique_lock<std::mutex> lk(comm->mu);
     if (!comm->worker.joinable()) {
-        SLAM_HIP(hipGetDevice(&comm->device));
-        comm->worker = std::thread(worker_main, comm);
+        try {
+            comm->worker = std::thread(worker_main, comm);
+        } catch (const std::exception &ex) { // (std::system_error: no thread to be had -- nothing may throw through the C boundary)
+            set_error("slam_grid_merge_async: the helper thread could not be started (%s)", ex.what());
+            return SLAM_E_NOMEM;
+        }
     }
     if (comm->posted - comm->completed >= (unsigned long long)slam_comm::kMaxPosted) { // back-pressure on the caller's thread
         const auto t0 = std::chrono::steady_clock::now();
@@ -618,8 +638,7 @@ int slam_comm_drain(slam_comm_t *comm)
 int slam_comm_set_timeout(slam_comm_t *comm, double seconds)
 {
     SLAM_REQUIRE(comm && seconds > 0, SLAM_E_INVALID, "slam_comm_set_timeout: bad arguments");
-    std::lock_guard<std::mutex> lk(comm->mu);
-    comm->timeout_s = seconds;
+    comm->timeout_s.store(seconds);
     return SLAM_OK;
 }
 

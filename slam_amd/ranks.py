@@ -34,6 +34,7 @@ class Ranks:
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.heartbeat_s, self.dead_after_s = heartbeat_s, dead_after_s
         self._stop = threading.Event()
+        self._closing = threading.Event()     # close() was called: keep beating, stop judging the others
         self._thread = None
         self.store = None
         if watchdog and self.world > 1:
@@ -98,6 +99,12 @@ class Ranks:
             beat += 1
             try:
                 self.store.set("hb/%d" % self.rank, str(beat))
+                if self._closing.is_set():
+                    # between close() and the return of its barrier this rank is alive and must look it: a peer that still works
+                    # would otherwise see a frozen counter and give up after dead_after_s although the barrier's time-out allows
+                    # the longer skew.  It no longer judges the others (rank 0's orderly exit takes the store with it: not a lost
+                    # peer); the barrier's own time-out still guards it.
+                    continue
                 if self.store.check(["failed"]):
                     who, _, why = self.store.get("failed").decode(errors="replace").partition(":")
                     if who != str(self.rank):
@@ -111,17 +118,18 @@ class Ranks:
                     elif now - t_last > self.dead_after_s:
                         self._peer_lost("rank %d has stopped responding (no heartbeat for %.0f s)" % (r, now - t_last))
             except Exception as ex:
-                if self._stop.is_set():
+                if self._stop.is_set() or self._closing.is_set():
                     return
                 self._peer_lost("the job's store is gone (%s): rank 0, which hosts it, has ended" % (str(ex).splitlines()[0] if str(ex) else repr(ex)))
 
     def close(self):
-        """Orderly end: the watchdog off (rank 0's exit takes the store with it: not a lost peer), the last barrier -- its
-        time-out still guards it --, the process group down."""
+        """Orderly end: stop judging the others (rank 0's exit takes the store with it: not a lost peer) but KEEP BEATING until the
+        last barrier has returned -- its time-out still guards it --, then the heartbeat off and the process group down."""
+        self._closing.set()
+        self.barrier("closing barrier")
         self._stop.set()
         if self._thread is not None:
             self._thread.join(timeout=2 * self.heartbeat_s + 1.0)
-        self.barrier("closing barrier")
         try:
             self.dist.destroy_process_group()
         except Exception:

@@ -483,3 +483,15 @@ def ccicp_height(ground, pose7):
     f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     nc = f(g.ctypes.data if len(g) else None, len(g), g.shape[1] if g.ndim == 2 else 3, pose, C.addressof(z), idx)
     return z.value, nc, list(idx)
+
+
+def roll(plane, dx, dy, fill=0):
+    """Window after Grid::shiftOrigin(dx,dy) + the clears of mls.cpp:433-477: cell (i,j) shows old (i+dx, j+dy)."""
+    sy, sx = plane.shape
+    out = np.full_like(plane, fill)
+    xs = np.arange(sx) + dx
+    ys = np.arange(sy) + dy
+    vx = (xs >= 0) & (xs < sx)
+    vy = (ys >= 0) & (ys < sy)
+    out[np.ix_(vy, vx)] = plane[np.ix_(ys[vy], xs[vx])]
+    return out

@@ -27,6 +27,9 @@ def test_bench_line_contract_and_arithmetic():
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     pts = 276242                                               # config 2's 256 scans
     assert abs(d["value"] - pts / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    # the figure is the MEDIAN of five timed regions of `steps` steps each, all of them in the line
+    runs = d["ms_per_step_runs"]
+    assert len(runs) == 5 == d["timed_regions"]["n"] and abs(sorted(runs)[2] - d["ms_per_step"]) < 1e-9
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
@@ -56,7 +59,7 @@ def test_bench_force_dist_runs_the_n_gt_1_pipeline_over_a_real_rccl_communicator
     assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["no_merge"] is False
     m = d["merge"]
     assert m["transport"] == "rccl" and m["rccl_version"] > 20000 and m["ranks"] == 1
-    assert m["merges_in_timed_region"] == 4
+    assert m["timed_regions"] == 5 and m["merges_in_timed_region"] == 4 * 5        # five timed regions of `steps` steps each
     lo, hi = d["config"]["merge_rows"]
     assert 0 <= lo <= hi < 2000 and abs(m["rows_per_merge"] - (hi - lo + 1)) < 8       # the room's rows, step after step
     assert m["bytes_per_merge_per_rank"] == m["rows_per_merge"] * 2000 * 8            # [hits | misses] int32 of those rows
@@ -73,7 +76,7 @@ def test_bench_force_dist_runs_the_n_gt_1_pipeline_over_a_real_rccl_communicator
     # ... and the same steps with the merge on the enqueue thread (rounds 2-4), still there behind a switch
     d0 = _bench("--force-dist", "--merge-thread", "0", "--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline")
     assert d0["config"]["merge_thread"] is False and d0["merge"]["merges_by_helper_thread"] == 0
-    assert d0["merge"]["merges_in_timed_region"] == 4 and d0["config"]["merge_rows"] == d["config"]["merge_rows"]
+    assert d0["merge"]["merges_in_timed_region"] == 4 * 5 and d0["config"]["merge_rows"] == d["config"]["merge_rows"]
 
 
 @pytest.mark.gpu

@@ -11,7 +11,8 @@ import pytest
 
 import oracle_lib as O
 from slam_amd import api
-from test_gpu_stream import roll
+
+from oracle_lib import roll
 
 pytestmark = pytest.mark.gpu
 

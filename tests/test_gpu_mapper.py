@@ -9,7 +9,7 @@ import pytest
 
 import oracle_lib as O
 from slam_amd import api, synth
-from test_gpu_stream import roll
+from oracle_lib import roll
 
 pytestmark = pytest.mark.gpu
 

@@ -13,7 +13,7 @@ import pytest
 
 import oracle_lib as O
 from slam_amd import synth
-from test_gpu_stream import roll
+from oracle_lib import roll
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -207,6 +207,59 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert d["config"]["scans_per_gpu"] == 64
 
 
+@pytest.mark.gpu
+def test_bench_six_processes_rehearsal_on_one_gpu():
+    """the N > 1 path of bench.py with as many PROCESSES as a one-GPU box lets a test put on its card (six: the
+    pool's guard; the driver's own N = 8 run is the first with eight) -- through the launcher the driver uses, gloo standing in
+    for RCCL, 32 scans per rank.  bench.py itself asserts that the merged planes hold every rank's updates exactly once."""
+    import json
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "6",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "6", "--steps", "2", "--warmup", "1", "--scans", "32",
+           "--backend", "gloo", "--one-device", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 6 and d["value"] > 0 and d["config"]["merge_rows"] is not None
+    assert d["config"]["scans_per_gpu"] == 32 and len(d["ms_per_step_runs"]) == 5
+    assert d["merge"]["ranks"] == 6 and d["merge"]["merges_in_timed_region"] == 2 * 5
+
+
+@pytest.mark.gpu
+def test_bench_a_killed_rank_ends_the_other_five():
+    """... and one of the six killed behind its warm-up (SIGKILL: no goodbye): the other five end with a non-zero code within
+    --dead-after (+ a heartbeat and the interpreter's exit) and say which rank they lost.  The ranks are children of this test,
+    started with the launcher's environment and without the launcher -- torch.distributed.run would end the survivors itself."""
+    import signal
+    import subprocess
+    import time
+    port = _free_port()
+    procs = []
+    for r in range(6):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="6", LOCAL_RANK=str(r), LOCAL_WORLD_SIZE="6", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "6", "--steps", "2", "--warmup", "1",
+                                       "--scans", "32", "--backend", "gloo", "--one-device", "--no-cpu-baseline", "--dead-after", "6",
+                                       "--rank-timeout", "60", "--test-kill-rank", "4"],
+                                      cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    try:
+        procs[4].wait(timeout=300)
+        t_dead = time.monotonic()
+        assert procs[4].returncode == -signal.SIGKILL
+        for r, p in enumerate(procs):
+            if r == 4:
+                continue
+            _, err = p.communicate(timeout=40)
+            assert p.returncode not in (0, None), (r, err[-500:])
+            assert "rank 4" in err or "store" in err or "FAILED" in err, (r, err[-500:])
+        assert time.monotonic() - t_dead < 40.0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.send_signal(signal.SIGKILL)
+                p.wait()
+
+
 def _n_gpus():
     """devices visible to a torch process -- counted in a child: importing torch HERE would map a second HIP runtime
     (torch's bundled one) beside the library's into the test process, and RCCL then finds no device"""
@@ -275,6 +328,13 @@ def _run_two_ranks(how, dead_after=4.0, timeout=20.0):
 
 def test_ranks_all_finish_when_nobody_fails():
     res = _run_two_ranks("none")
+    assert [rc for rc, _, _ in res] == [0, 0], res
+
+
+def test_a_rank_waiting_in_close_is_not_taken_for_dead():
+    """rank 1 reaches close() 7 s before rank 0 (dead_after_s = 4): it keeps beating until its closing barrier has
+    returned, so rank 0 -- still working, still watching -- does not give up on it; both end with 0."""
+    res = _run_two_ranks("late")
     assert [rc for rc, _, _ in res] == [0, 0], res
 
 
