@@ -93,7 +93,7 @@ def test_bench_calibrates_the_n_gt_1_launch_setting():
     assert c["kept"] == {"reg_cu_cap_per_xcd": best["reg_cu_cap_per_xcd"], "grid_lag": best["grid_lag"] or 3, "merge_order": best["merge_order"]}
     assert d["config"]["reg_cu_cap_per_xcd"] == c["kept"]["reg_cu_cap_per_xcd"] and d["config"]["merge_order"] == c["kept"]["merge_order"]
     assert all(0.2 < t["ms_per_step"] < 5.0 for t in c["tried"])
-    assert d["merge"]["merges_in_timed_region"] == 4 and d["max_pose_error_m"] < 0.05
+    assert d["merge"]["merges_in_timed_region"] == 4 * 5 and d["max_pose_error_m"] < 0.05 and d["merge"]["calibration"]["caps_dropped_unsupported"] == []
     # a setting given on the command line is not calibrated over
     d = _bench("--force-dist", "--calibrate", "--merge-order", "late", "--grid-lag", "3", "--steps", "4", "--warmup", "2", "--no-extras", "--no-cpu-baseline")
     assert [(t["reg_cu_cap_per_xcd"], t["grid_lag"], t["merge_order"]) for t in d["merge"]["calibration"]["tried"]] == \
