@@ -421,6 +421,12 @@ int  slam_gseg_classify_ga_dev(slam_gseg_t *h, const float *d_obstacle_xyz, int 
 /* the same where the number of points is known on the device only (*d_n, at most n_capacity): no host round trip */
 int  slam_gseg_classify_ga_counted_dev(slam_gseg_t *h, const float *d_obstacle_xyz, const int32_t *d_n, int n_capacity,
                                        int stride, uint8_t *d_flags, slam_stream_t stream);
+/* ... and with the extent of the points the classification keeps (pcl::getMinMax3D over the finite points whose flag is not
+ * 255: what setSceneCloud's voxel filter starts from, icpTools.cpp:620-633) accumulated in the same pass: d_mm[0..2] minima,
+ * d_mm[3..5] maxima as ORDERED floats (the bits with the sign bit flipped for positive, all bits for negative values), which
+ * the caller has set to 0xffffffff / 0 beforehand */
+int  slam_gseg_classify_ga_extent_dev(slam_gseg_t *h, const float *d_obstacle_xyz, const int32_t *d_n, int n_capacity,
+                                      int stride, uint8_t *d_flags, uint32_t *d_mm, slam_stream_t stream);
 /* per polar bin (72 x 200): 1 = in the ground model (value = prototype height), 2 = candidate
  * that stayed out (value = GP mean), 0 = no signal point; INSAC iterations per sector */
 int  slam_gseg_read_model(slam_gseg_t *h, uint8_t *bin_state, double *bin_value, int32_t *sector_iterations);

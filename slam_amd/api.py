@@ -96,7 +96,7 @@ EXPORTS = [
     "slam_grid_enable_accumulator", "slam_grid_fold",
     "slam_gseg_default_params", "slam_gseg_create", "slam_gseg_destroy", "slam_gseg_reserve",
     "slam_gseg_segment", "slam_gseg_segment_dev", "slam_gseg_split_dev", "slam_gseg_read_model",
-    "slam_gseg_classify_ga_dev", "slam_gseg_classify_ga_counted_dev",
+    "slam_gseg_classify_ga_dev", "slam_gseg_classify_ga_counted_dev", "slam_gseg_classify_ga_extent_dev",
     "slam_ccicp_create", "slam_ccicp_destroy", "slam_ccicp_voxel_downsample_dev", "slam_ccicp_split_dev",
     "slam_ccicp_height_dev", "slam_ccicp_bin_order_dev", "slam_ccicp_select_dev", "slam_ccicp_scene_dev",
     "slam_ccicp_height_pose_dev", "slam_ccicp_split_box_dev", "slam_ccicp_height_rpy_pose_dev", "slam_ccicp_scene_cloud_dev", "slam_ccicp_pack_scans_dev",

@@ -6,6 +6,7 @@
 // (oracle/ccicp_oracle.c); parity is unpinned there and tolerance-based where PCL's float sums are
 // order-dependent.  Everything stays on the device between ground segmentation (gseg.hip) and
 // slam_icp_create / slam_icp_fit_batch_dev; results are deterministic (integer sums, index-ordered output).
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstddef>
@@ -108,12 +109,29 @@ __device__ inline long long voxel_of(const VoxelGridView &g, const float *p)
 // lanes fall into the same voxel.  Runs of equal voxels in adjacent lanes are added up inside the wavefront (a
 // segmented scan over the run heads) and the run's last lane issues the atomics: integer sums, so the result does not
 // depend on who adds -- and the hot voxels see a fraction of the same-address atomics (80 -> 35 us per 70 k-point cloud).
+__device__ inline VoxelGridView voxel_geometry(const unsigned *mm, float leaf_x, float leaf_y, float leaf_z, long long capacity, bool *overflow);
 __global__ __launch_bounds__(256) void voxel_accumulate_kernel(VoxelGridView g, const float *xyz, const unsigned char *flag,
-                                                               int n, int stride, Voxel *vox, const VoxelGridView *d_g = nullptr,
-                                                               const int *d_n = nullptr)
+                                                               int n, int stride, Voxel *vox, VoxelGridView *d_g = nullptr,
+                                                               const int *d_n = nullptr, const unsigned *d_mm = nullptr,
+                                                               float3 leaf = make_float3(0.f, 0.f, 0.f), long long capacity = 0, int *d_err = nullptr)
 {
     const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-    if (d_g) g = *d_g; // the lattice worked out on the device (voxel_geometry_kernel)
+    if (d_g && !d_mm) g = *d_g; // the lattice worked out on the device (voxel_geometry_kernel)
+    if (d_mm) {
+        // ... or here, by every block for itself from the extent the classification left (the chain of slam_ccicp_scene_dev: one
+        // launch less); block 0 leaves it for the compaction behind this kernel
+        __shared__ VoxelGridView gs;
+        if (threadIdx.x == 0) {
+            bool overflow = false;
+            gs = voxel_geometry(d_mm, leaf.x, leaf.y, leaf.z, capacity, &overflow);
+            if (blockIdx.x == 0) {
+                *d_g = gs;
+                if (overflow) atomicOr(d_err, 1);
+            }
+        }
+        __syncthreads();
+        g = gs;
+    }
     long long          key = -1; // no contribution
     unsigned long long sx = 0, sy = 0, sz = 0, cf = 0; // cf: count in the high word, ground_adj count in the low (Voxel::sflag, ::count)
     if (i < bound(n, d_n)) {
@@ -263,6 +281,19 @@ struct VoxelEmit {
     }
 };
 
+struct VoxelEmitClean { // ... and leaves the voxel as the next cloud must find it
+    Voxel *vox;
+    float *out;
+    __device__ void operator()(long long v, int pos) const
+    {
+        VoxelEmit{vox, out}(v, pos);
+        Voxel z;
+        z.sx = z.sy = z.sz = 0;
+        z.sflag = z.count = 0;
+        vox[v] = z;
+    }
+};
+
 // points whose label is in a mask, in cloud order, as (x, y, z, 0) records
 struct LabelPred {
     const unsigned char *labels;
@@ -383,10 +414,8 @@ __global__ __launch_bounds__(256) void bin_gather_kernel(const float *xyz, const
 // ---- the chain of slam_ccicp_scene_dev: what the stepwise entry points work out on the host, on the device
 // the voxel lattice from the extent (slam_ccicp_voxel_downsample_dev's host code, PCL voxel_grid.hpp); err |= 1 when it
 // does not fit the accumulator (n_vox = 0 then: nothing is accumulated)
-__global__ void voxel_geometry_kernel(const unsigned *mm, float leaf_x, float leaf_y, float leaf_z, long long capacity,
-                                      VoxelGridView *g, int *err)
+__device__ inline VoxelGridView voxel_geometry(const unsigned *mm, float leaf_x, float leaf_y, float leaf_z, long long capacity, bool *overflow)
 {
-    if (threadIdx.x || blockIdx.x) return;
     VoxelGridView v;
     const float   leaf[3] = {leaf_x, leaf_y, leaf_z};
     long long     nv = 1;
@@ -407,8 +436,17 @@ __global__ void voxel_geometry_kernel(const unsigned *mm, float leaf_x, float le
         if (nv <= 0 || nv > capacity) bad = true;
     }
     v.n_vox = bad ? 0 : nv;
-    if (bad && mm[0] != 0xffffffffu) atomicOr(err, 1);
-    *g = v;
+    *overflow = bad && mm[0] != 0xffffffffu;
+    return v;
+}
+
+__global__ void voxel_geometry_kernel(const unsigned *mm, float leaf_x, float leaf_y, float leaf_z, long long capacity,
+                                      VoxelGridView *g, int *err)
+{
+    if (threadIdx.x || blockIdx.x) return;
+    bool overflow = false;
+    *g = voxel_geometry(mm, leaf_x, leaf_y, leaf_z, capacity, &overflow);
+    if (overflow) atomicOr(err, 1);
 }
 
 __global__ __launch_bounds__(256) void voxel_zero_kernel(const VoxelGridView *g, Voxel *vox)
@@ -553,6 +591,128 @@ __global__ void height_fit_kernel(const float *ground, int stride, const unsigne
     out[1] = (double)nc;
 }
 
+// ---- stable compaction in ONE launch (round 6): per-block counts, a decoupled look-back for the block's offset, the ordered
+// write -- for up to two outputs fed from one pass over the input (pred(i) = the output item i goes to, -1: none).  A match of
+// config 3 is bound by its launches (45 of 3-47 us per cloud in round 5): the five compactions of the scene chain were fifteen of them.
+// status[c][b]: {epoch : 24 | flag : 8 | value : 32} of output c and block b -- flag 1: the block's own count, 2: the count of all
+// blocks up to and including it; a word of another epoch is a word not yet written (no fill between launches: the handle counts
+// the launches).  Blocks are dispatched in index order and publish their count before they wait for anything, so a block only ever
+// waits for blocks that are running or done (the grids are at most a few hundred blocks: all resident).  CONCAT: output 1 is
+// written BEHIND output 0 (min(total 0, limit) on): its blocks wait for the last block's prefix of output 0.
+constexpr unsigned long long kStatAgg = 1ull << 32, kStatPre = 2ull << 32;
+constexpr unsigned kSpinLimit = 1u << 22; // (a safeguard, not a path: a few seconds, then the error bit and whatever is there)
+typedef unsigned long long __attribute__((address_space(1))) g_u64;
+__device__ inline unsigned long long stat_load(const unsigned long long *p)
+{
+    return __hip_atomic_load((g_u64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline void stat_store(unsigned long long *p, unsigned epoch, unsigned long long flag, unsigned v)
+{
+    __hip_atomic_store((g_u64 *)p, ((unsigned long long)epoch << 40) | flag | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline unsigned long long stat_wait(const unsigned long long *p, unsigned epoch, unsigned long long need, int *err)
+{
+    unsigned long long w = stat_load(p);
+    for (unsigned spin = 0; (unsigned)(w >> 40) != epoch || !(w & need); ++spin) {
+        if (spin > kSpinLimit) {
+            if (err) atomicOr(err, 4);
+            return ((unsigned long long)epoch << 40) | kStatPre;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        w = stat_load(p);
+    }
+    return w;
+}
+
+template <int NC, bool CONCAT, class Pred, class Emit, class Tail>
+__global__ __launch_bounds__(kScanThreads) void compact1_kernel(Pred pred, Emit emit, Tail tail, Domain dom, unsigned long long *status,
+                                                               unsigned epoch, int limit, int *err)
+{
+    static_assert(NC == 1 || NC == 2, "one or two outputs");
+    const long long n = dom.size();
+    constexpr int   kPer = kItems / kScanThreads;
+    const long long base = (long long)blockIdx.x * kItems + (long long)threadIdx.x * kPer;
+    const int       lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x, nb = gridDim.x;
+    unsigned        mask[NC];
+    int             cnt[NC], x[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) mask[c] = 0;
+    for (int k = 0; k < kPer; ++k)
+        if (base + k < n) {
+            const int c = pred(base + k);
+            if (c == 0) mask[0] |= 1u << k;
+            if (NC > 1 && c == 1) mask[NC - 1] |= 1u << k;
+        }
+    __shared__ int wsum[NC][kScanThreads / 64], excl_s[NC], base1_s;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        cnt[c] = __popc(mask[c]);
+        x[c] = cnt[c];
+        for (int off = 1; off < 64; off <<= 1) {
+            const int y = __shfl_up(x[c], off);
+            if (lane >= off) x[c] += y;
+        }
+        if (lane == 63) wsum[c][wave] = x[c];
+    }
+    __syncthreads();
+    int w[NC], agg[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        w[c] = agg[c] = 0;
+        for (int k = 0; k < kScanThreads / 64; ++k) {
+            w[c] += k < wave ? wsum[c][k] : 0;
+            agg[c] += wsum[c][k];
+        }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            unsigned long long *st = status + (size_t)c * nb;
+            if (lane == 0) stat_store(st + b, epoch, b == 0 ? kStatPre : kStatAgg, (unsigned)agg[c]);
+            int excl = 0;
+            for (int look = b - 1; look >= 0; look -= 64) {
+                const int                idx = look - lane;
+                const unsigned long long wd = idx >= 0 ? stat_wait(st + idx, epoch, kStatAgg | kStatPre, err) : (((unsigned long long)epoch << 40) | kStatPre);
+                // the nearest block (lowest lane) that knows its inclusive prefix ends the walk: the counts of the blocks nearer than
+                // it plus that prefix (lanes beyond block 0 stand for a prefix of nothing)
+                const unsigned long long pre = __ballot((wd & kStatPre) != 0);
+                const int                first = pre ? __builtin_ctzll(pre) : 64;
+                int                      v = lane <= first ? (int)(unsigned)wd : 0;
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                excl += v;
+                if (pre) break;
+            }
+            if (lane == 0) {
+                if (b > 0) stat_store(st + b, epoch, kStatPre, (unsigned)(excl + agg[c]));
+                excl_s[c] = excl;
+            }
+        }
+    }
+    __syncthreads();
+    int pos[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) pos[c] = excl_s[c] + w[c] + x[c] - cnt[c];
+    if (NC > 1 && CONCAT) {
+        if (threadIdx.x == 0) base1_s = min((int)(unsigned)stat_wait(status + (nb - 1), epoch, kStatPre, err), limit);
+        __syncthreads();
+        pos[NC - 1] += base1_s;
+    }
+    for (int k = 0; k < kPer; ++k) {
+        if (mask[0] & (1u << k)) {
+            if (pos[0] < limit) emit(base + k, 0, pos[0]);
+            ++pos[0];
+        }
+        if (NC > 1 && (mask[NC - 1] & (1u << k))) {
+            if (pos[NC - 1] - (CONCAT ? base1_s : 0) < limit) emit(base + k, 1, pos[NC - 1]);
+            ++pos[NC - 1];
+        }
+    }
+    if (b == nb - 1 && threadIdx.x == 0) {
+        int tot[2] = {excl_s[0] + agg[0], NC > 1 ? excl_s[NC - 1] + agg[NC - 1] : 0};
+        tail(tot);
+    }
+}
+
 struct DevBuf {
     void  *p = nullptr;
     size_t cap = 0;
@@ -594,16 +754,71 @@ int compact(Pred pred, Emit emit, long long n, int limit, DevBuf &blocks, int *d
     return SLAM_OK;
 }
 
+struct NoTail {
+    int *total0, *total1;
+    __device__ void operator()(const int tot[2]) const
+    {
+        if (total0) *total0 = tot[0];
+        if (total1) *total1 = tot[1];
+    }
+};
+template <class Pred>
+struct OneOutput { // a yes/no predicate as the class function of a one-output compaction
+    Pred pred;
+    __device__ int operator()(long long i) const { return pred(i) ? 0 : -1; }
+};
+template <class Emit>
+struct OneEmit {
+    Emit emit;
+    __device__ void operator()(long long i, int, int pos) const { emit(i, pos); }
+};
+
 } // namespace
 
 struct slam_ccicp {
     DevBuf vox, blocks, blocks2, small; // small: 6 min/max words, totals, 4 packed NN results
+    DevBuf status;                      // the one-launch compactions' look-back words (compact1)
+    unsigned epoch = 0;                 // ... and the launch they belong to (24 bits)
+    size_t vox_clean = 0;               // voxels of `vox` known to be zero (the chain's compaction leaves them so)
     DevBuf keys, sort_tmp;
     long long max_voxels = 1ll << 26;
     // the chain (slam_ccicp_scene_dev): per-point scratch for the cloud's capacity, the lattice and the counts on the device
     DevBuf labels, obs, flags, filtered, chain; // chain: VoxelGridView, counts, wheel points, packed neighbours
     long long chain_voxels = 1ll << 21;         // accumulator capacity of the chain (64 MB): 0.5 x 0.5 x 2 m over 360 x 360 x 30 m
 };
+
+namespace {
+// One launch of compact1_kernel over n items (n = the capacity where d_n / d_n64 hold the count): at least one block, so that
+// the tail runs whatever n is.
+template <int NC, bool CONCAT, class Pred, class Emit, class Tail>
+int compact1(slam_ccicp *h, Pred pred, Emit emit, Tail tail, long long n, int limit, hipStream_t st, const int *d_n = nullptr,
+             const long long *d_n64 = nullptr, int *d_err = nullptr)
+{
+    const int    n_blocks = (int)std::max<long long>((n + kItems - 1) / kItems, 1);
+    const size_t need = sizeof(unsigned long long) * 2 * (size_t)n_blocks;
+    if (need > h->status.cap) {
+        SLAM_TRY(h->status.reserve(need));
+        SLAM_HIP(hipMemsetAsync(h->status.p, 0, h->status.cap, st)); // epoch 0: no launch's
+        h->epoch = 0;
+    }
+    if (++h->epoch >= (1u << 24)) { // (sixteen million launches on)
+        SLAM_HIP(hipMemsetAsync(h->status.p, 0, h->status.cap, st));
+        h->epoch = 1;
+    }
+    const Domain dom = {n, d_n, d_n64};
+    hipLaunchKernelGGL((compact1_kernel<NC, CONCAT, Pred, Emit, Tail>), dim3(n_blocks), dim3(kScanThreads), 0, st, pred, emit, tail, dom,
+                       static_cast<unsigned long long *>(h->status.p), h->epoch, limit, d_err);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+// the three-step compaction's interface on the one-launch kernel
+template <class Pred, class Emit>
+int compact_one(slam_ccicp *h, Pred pred, Emit emit, long long n, int limit, int *d_total, hipStream_t st, const int *d_n = nullptr,
+                const long long *d_n64 = nullptr)
+{
+    return compact1<1, false>(h, OneOutput<Pred>{pred}, OneEmit<Emit>{emit}, NoTail{d_total, nullptr}, n, limit, st, d_n, d_n64);
+}
+} // namespace
 
 // Several scenes of slam_ccicp_scene_dev as ONE batch for slam_icp_fit_batch_dev (the throughput form of config 3): scene k's
 // points behind those of the scenes before it, scan_off / scan_nga as that call reads them.  blockIdx.y = scene.
@@ -686,6 +901,7 @@ int slam_ccicp_voxel_downsample_dev(slam_ccicp_t *h, const float *d_xyz, const u
     SLAM_TRY(h->vox.reserve(sizeof(Voxel) * (size_t)nv));
     Voxel *vox = static_cast<Voxel *>(h->vox.p);
     SLAM_HIP(hipMemsetAsync(vox, 0, sizeof(Voxel) * (size_t)nv, st));
+    h->vox_clean = 0; // (the chain of slam_ccicp_scene_dev shares the accumulator and expects it zero)
     hipLaunchKernelGGL(voxel_accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, d_xyz, d_flag, n, stride, vox);
     int *d_total = reinterpret_cast<int *>(mm + 8);
     SLAM_TRY(compact(VoxelUsed{vox}, VoxelEmit{vox, d_out}, nv, max_out, h->blocks, d_total, st));
@@ -829,15 +1045,88 @@ struct ChainSmall { // layout of slam_ccicp::chain
     unsigned long long best[4];
 };
 
-__global__ void chain_init_kernel(ChainSmall *c)
-{
-    if (threadIdx.x || blockIdx.x) return;
-    for (int d = 0; d < 3; ++d) c->mm[d] = 0xffffffffu, c->mm[3 + d] = 0u;
-    c->n_obs = c->n_gnd = c->n_flt = c->tot[0] = c->tot[1] = c->err = 0;
-    c->g.n_vox = 0;
-}
+// obstacle cloud (output 0) and ground cloud (output 1) from one pass over the labels
+struct ObsGndPred {
+    const unsigned char *labels;
+    unsigned             obs_mask;
+    int                  want_ground;
+    __device__ int operator()(long long i) const
+    {
+        const unsigned l = labels[i];
+        return ((obs_mask >> l) & 1u) ? 0 : ((want_ground && l == 1u) ? 1 : -1);
+    }
+};
+struct ObsGndEmit {
+    const float *xyz;
+    int          stride;
+    float4      *obs, *gnd;
+    __device__ void operator()(long long i, int c, int pos) const
+    {
+        const float *q = xyz + (size_t)i * stride;
+        (c ? gnd : obs)[pos] = make_float4(q[0], q[1], q[2], 0.f);
+    }
+};
+// ... its tail starts the chain's bookkeeping afresh (what a launch of its own did): the counts it has, the extent and the
+// error bits for the kernels behind it
+struct ObsGndTail {
+    ChainSmall *c;
+    __device__ void operator()(const int tot[2]) const
+    {
+        c->n_obs = tot[0];
+        c->n_gnd = tot[1];
+        c->n_flt = 0;
+        c->err = 0;
+        for (int d = 0; d < 3; ++d) c->mm[d] = 0xffffffffu, c->mm[3 + d] = 0u;
+    }
+};
+struct FltTail {
+    int *n_flt;
+    __device__ void operator()(const int tot[2]) const { *n_flt = tot[0]; }
+};
+// doICPMatch's marshalling as ONE pass: class of a point that survives the crop (0 = GA, 1 = NGA), GA in front of NGA
+struct SplitClass {
+    SplitPred p; // (want_ga unused)
+    __device__ int operator()(long long i) const
+    {
+        const float *q = p.xyzg + (size_t)i * p.stride;
+        if (p.crop && !(finite3(q) && q[0] >= p.x_lo && q[0] <= p.x_hi && q[1] >= p.y_lo && q[1] <= p.y_hi)) return -1;
+        return q[3] > 0.5f ? 0 : 1; // isGA, PointcloudXYZGD.h:28-30
+    }
+};
+struct SplitEmit2 {
+    const float *xyzg;
+    int          stride;
+    double      *out;
+    __device__ void operator()(long long i, int, int pos) const
+    {
+        const float *q = xyzg + (size_t)i * stride;
+        out[2 * (size_t)pos] = (double)q[0]; // icpTools.cpp:252, 267: float coordinates widened
+        out[2 * (size_t)pos + 1] = (double)q[1];
+    }
+};
+// ... and the scan descriptor {0, n_ga + n_nga, n_ga} of the one scan slam_icp_fit_batch_dev then registers, the class totals
+// capped as CCICP::doICPMatch caps them (ICP_MAX_PTS - 1, icpTools.cpp:256,259), and the chain's counts
+struct SceneTail {
+    ChainSmall *c;
+    int         cap;
+    int        *scan, *counts;
+    __device__ void operator()(const int tot[2]) const
+    {
+        c->tot[0] = tot[0], c->tot[1] = tot[1];
+        const int ga = min(tot[0], cap - 1), nga = min(tot[1], cap - 1);
+        scan[0] = 0;
+        scan[1] = ga + nga;
+        scan[2] = ga;
+        counts[0] = c->n_obs;
+        counts[1] = c->n_gnd;
+        counts[2] = c->n_flt;
+        counts[3] = c->err;
+    }
+};
 } // namespace
 
+// Launches of one scene (voxel filter on): bin, INSAC, label | obstacle + ground | mark, flag + extent | accumulate (+ lattice) |
+// voxels | split + descriptor = 9 -- round 5: 30, eight of them fills and copies.
 int slam_ccicp_scene_dev(slam_ccicp_t *h, slam_gseg_t *seg, const float *d_xyz, int n, int stride, int voxel, int crop,
                          double cur_x, double cur_y, double crop_dist, int cap, double *d_pts, int32_t *d_scan, float *d_ground,
                          int32_t *d_counts, slam_stream_t stream)
@@ -854,27 +1143,28 @@ int slam_ccicp_scene_dev(slam_ccicp_t *h, slam_gseg_t *seg, const float *d_xyz, 
     ChainSmall    *c = static_cast<ChainSmall *>(h->chain.p);
     unsigned char *lab = static_cast<unsigned char *>(h->labels.p), *flg = static_cast<unsigned char *>(h->flags.p);
     float         *obs = static_cast<float *>(h->obs.p), *flt = static_cast<float *>(h->filtered.p);
-    hipLaunchKernelGGL(chain_init_kernel, dim3(1), dim3(64), 0, st, c);
-    // segmentGround (icpTools.cpp:106-119): the outcloud CCICP classifies and the ground cloud
+    // segmentGround (icpTools.cpp:106-119): the outcloud CCICP classifies and the ground cloud, one pass over the labels
     SLAM_TRY(slam_gseg_segment_dev(seg, d_xyz, n, stride, lab, stream));
-    SLAM_TRY(compact(LabelPred{lab, (1u << 2) | (1u << 3)}, Xyz4Emit{d_xyz, stride, reinterpret_cast<float4 *>(obs)}, n, n, h->blocks,
-                     &c->n_obs, st));
-    if (d_ground)
-        SLAM_TRY(compact(LabelPred{lab, 1u << 1}, Xyz4Emit{d_xyz, stride, reinterpret_cast<float4 *>(d_ground)}, n, n, h->blocks2,
-                         &c->n_gnd, st));
-    // classifyPoints (:36-103) on however many obstacle points there are
-    SLAM_TRY(slam_gseg_classify_ga_counted_dev(seg, obs, &c->n_obs, n, 4, flg, stream));
+    SLAM_TRY((compact1<2, false>(h, ObsGndPred{lab, (1u << 2) | (1u << 3), d_ground ? 1 : 0},
+                                 ObsGndEmit{d_xyz, stride, reinterpret_cast<float4 *>(obs), reinterpret_cast<float4 *>(d_ground)}, ObsGndTail{c}, n, n,
+                                 st)));
     if (n > 0) {
+        // classifyPoints (:36-103) on however many obstacle points there are, and the extent of what it keeps
+        SLAM_TRY(slam_gseg_classify_ga_extent_dev(seg, obs, &c->n_obs, n, 4, flg, c->mm, stream));
         if (voxel) { // setSceneCloud's voxel filter (:620-633), leaf 0.5, 0.5, 2
-            hipLaunchKernelGGL(minmax_kernel, dim3((n + 255) / 256), dim3(256), 0, st, obs, flg, n, 4, c->mm, &c->n_obs);
-            hipLaunchKernelGGL(voxel_geometry_kernel, dim3(1), dim3(64), 0, st, c->mm, 0.5f, 0.5f, 2.0f, h->chain_voxels, &c->g, &c->err);
+            // the accumulator is zero where no scene has left a sum: the compaction below clears what it reads
+            if (sizeof(Voxel) * (size_t)h->chain_voxels > h->vox.cap) h->vox_clean = 0;
             SLAM_TRY(h->vox.reserve(sizeof(Voxel) * (size_t)h->chain_voxels));
             Voxel *vox = static_cast<Voxel *>(h->vox.p);
-            hipLaunchKernelGGL(voxel_zero_kernel, dim3(1024), dim3(256), 0, st, &c->g, vox);
-            hipLaunchKernelGGL(voxel_accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, st, VoxelGridView(), obs, flg, n, 4, vox,
-                               &c->g, &c->n_obs);
+            if (h->vox_clean < (size_t)h->chain_voxels) {
+                SLAM_HIP(hipMemsetAsync(vox, 0, sizeof(Voxel) * (size_t)h->chain_voxels, st));
+                h->vox_clean = (size_t)h->chain_voxels;
+            }
+            hipLaunchKernelGGL(voxel_accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, st, VoxelGridView(), obs, flg, n, 4, vox, &c->g,
+                               &c->n_obs, c->mm, make_float3(0.5f, 0.5f, 2.0f), h->chain_voxels, &c->err);
             // (there are never more occupied voxels than points: n bounds the output)
-            SLAM_TRY(compact(VoxelUsed{vox}, VoxelEmit{vox, flt}, h->chain_voxels, n, h->blocks, &c->n_flt, st, nullptr, &c->g.n_vox));
+            SLAM_TRY((compact1<1, false>(h, OneOutput<VoxelUsed>{VoxelUsed{vox}}, OneEmit<VoxelEmitClean>{VoxelEmitClean{vox, flt}}, FltTail{&c->n_flt},
+                                         h->chain_voxels, n, st, nullptr, &c->g.n_vox, &c->err)));
         } else { // setTargetCloud: classified, bin by bin, no voxel filter (:591-595)
             SLAM_TRY(h->keys.reserve(2 * sizeof(unsigned long long) * (size_t)n));
             unsigned long long *k_in = static_cast<unsigned long long *>(h->keys.p), *k_out = k_in + n;
@@ -886,22 +1176,18 @@ int slam_ccicp_scene_dev(slam_ccicp_t *h, slam_gseg_t *seg, const float *d_xyz, 
             hipLaunchKernelGGL(bin_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, st, obs, flg, 4, k_out, n,
                                reinterpret_cast<float4 *>(flt), &c->n_flt);
         }
-        // doICPMatch marshalling (:225-276): crop, split by class with the cap, GA in front of NGA
-        SplitPred p;
-        p.xyzg = flt;
-        p.stride = 4;
-        p.crop = crop;
-        p.x_lo = (float)(-crop_dist + cur_x);
-        p.x_hi = (float)(crop_dist + cur_x);
-        p.y_lo = (float)(-crop_dist + cur_y);
-        p.y_hi = (float)(crop_dist + cur_y);
-        p.want_ga = 1;
-        SLAM_TRY(compact(p, SplitEmit{flt, 4, d_pts, nullptr, 0}, n, cap - 1, h->blocks, &c->tot[0], st, &c->n_flt));
-        p.want_ga = 0;
-        SLAM_TRY(compact(p, SplitEmit{flt, 4, d_pts, &c->tot[0], cap - 1}, n, cap - 1, h->blocks2, &c->tot[1], st, &c->n_flt));
     }
-    hipLaunchKernelGGL(scene_scan_kernel, dim3(1), dim3(64), 0, st, c->tot, cap, &c->n_obs, &c->n_gnd, &c->n_flt, d_scan, d_counts);
-    SLAM_HIP(hipMemcpyAsync(d_counts + 3, &c->err, sizeof(int), hipMemcpyDeviceToDevice, st));
+    // doICPMatch marshalling (:225-276): crop, split by class with the cap, GA in front of NGA -- and the scan's descriptor
+    SplitClass p;
+    p.p.xyzg = flt;
+    p.p.stride = 4;
+    p.p.want_ga = 0;
+    p.p.crop = crop;
+    p.p.x_lo = (float)(-crop_dist + cur_x);
+    p.p.x_hi = (float)(crop_dist + cur_x);
+    p.p.y_lo = (float)(-crop_dist + cur_y);
+    p.p.y_hi = (float)(crop_dist + cur_y);
+    SLAM_TRY((compact1<2, true>(h, p, SplitEmit2{flt, 4, d_pts}, SceneTail{c, cap, d_scan, d_counts}, n, cap - 1, st, &c->n_flt, nullptr, &c->err)));
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }

@@ -15,6 +15,7 @@
 // Cholesky-factored once per outer iteration and every candidate needs one
 // forward substitution: f = c^T A^-1 z, Vf = sf - |L^-1 c|^2 (values agree with
 // the inverse to rounding).  (3) labels: one thread per point.
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -281,9 +282,16 @@ __global__ __launch_bounds__(kSecThreads) void gseg_insac_kernel(GsegParams p, c
 
 __global__ __launch_bounds__(256) void gseg_label_kernel(GsegParams p, const float *xyz, int n, int stride,
                                                          const int *bin_of, const unsigned char *state,
-                                                         const double *value, unsigned char *labels)
+                                                         const double *value, unsigned char *labels, int *count,
+                                                         unsigned long long *proto)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    // the bins' counts and prototypes have done their work (the INSAC kernel has read them): cleared here for the next cloud,
+    // instead of two fills in front of every segmentation (round 6: a match is bound by its launches)
+    if (i < NA * NL) {
+        count[i] = 0;
+        proto[i] = ~0ull;
+    }
     if (i >= n) return;
     unsigned char lab = 0; // dropped
     const int     b = bin_of[i];
@@ -339,34 +347,71 @@ __device__ inline int ga_bin(const float *q)
 }
 
 // (d_n: the number of points where only the device knows it; n is then the capacity the launch was sized for)
-__global__ __launch_bounds__(256) void ga_mark_kernel(const float *xyz, int n, int stride, unsigned char *occ, const int *d_n)
+// A cell is occupied when it holds the call's EPOCH (1..255): the lattice is filled once in 255 calls instead of once per call
+// (1.44 MB and a launch of its own in front of every classification).
+__global__ __launch_bounds__(256) void ga_mark_kernel(const float *xyz, int n, int stride, unsigned char *occ, const int *d_n,
+                                                      unsigned char epoch)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (d_n) n = min(n, *d_n);
     if (i >= n) return;
     const int b = ga_bin(xyz + (size_t)i * stride);
-    if (b >= 0) occ[b] = 1;
+    if (b >= 0) occ[b] = epoch;
 }
 
+__device__ inline unsigned ga_order_f32(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// ... and, where the caller goes on to the voxel filter (slam_ccicp_scene_dev), the extent of the points the classification
+// keeps -- getMinMax3D over the finite points whose flag is not 255, as ccicp.hip's minmax_kernel forms it -- in the same
+// pass: mm[6] ordered-float minima and maxima (nullable).
 __global__ __launch_bounds__(256) void ga_flag_kernel(const float *xyz, int n, int stride, const unsigned char *occ,
-                                                      unsigned char *flags, const int *d_n)
+                                                      unsigned char *flags, const int *d_n, unsigned char epoch, unsigned *mm)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (d_n) n = min(n, *d_n);
-    if (i >= n) return;
-    const int     b = ga_bin(xyz + (size_t)i * stride);
     unsigned char f = 255;
-    if (b >= 0) {
-        const int bi = b / kGaBins, bj = b % kGaBins;
-        if (!(bi == 0 || bi == kGaBins - 1 || bj == 0 || bj == kGaBins - 1)) { // :72-77
-            int ground = 0;
-            for (int q = bi - 1; q <= bi + 1; ++q)
-                for (int r = bj - 1; r <= bj + 1; ++r)
-                    if (!(q == bi && r == bj) && !occ[q * kGaBins + r]) ++ground;
-            f = ground >= 2; // :96 GRD_ADJ_THRESH
+    unsigned      lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
+    if (i < n) {
+        const float *p = xyz + (size_t)i * stride;
+        const int    b = ga_bin(p);
+        if (b >= 0) {
+            const int bi = b / kGaBins, bj = b % kGaBins;
+            if (!(bi == 0 || bi == kGaBins - 1 || bj == 0 || bj == kGaBins - 1)) { // :72-77
+                int ground = 0;
+                for (int q = bi - 1; q <= bi + 1; ++q)
+                    for (int r = bj - 1; r <= bj + 1; ++r)
+                        if (!(q == bi && r == bj) && occ[q * kGaBins + r] != epoch) ++ground;
+                f = ground >= 2; // :96 GRD_ADJ_THRESH
+            }
+        }
+        flags[i] = f;
+        if (mm && f != 255 && isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))
+            for (int d = 0; d < 3; ++d) lo[d] = hi[d] = ga_order_f32(p[d]);
+    }
+    if (!mm) return; // (uniform)
+    __shared__ unsigned red[4][6];
+    for (int d = 0; d < 3; ++d) {
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[d] = min(lo[d], (unsigned)__shfl_xor((int)lo[d], off));
+            hi[d] = max(hi[d], (unsigned)__shfl_xor((int)hi[d], off));
+        }
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][d] = lo[d], red[threadIdx.x >> 6][3 + d] = hi[d];
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) { // one atomic per block and bound, where it would change the value (ccicp.hip, minmax_kernel)
+        const int d = threadIdx.x;
+        unsigned  v = red[0][d];
+        for (int w = 1; w < 4; ++w) v = d < 3 ? min(v, red[w][d]) : max(v, red[w][d]);
+        if (d < 3) {
+            if (v != 0xffffffffu && v < __hip_atomic_load(&mm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&mm[d], v);
+        } else {
+            if (v != 0u && v > __hip_atomic_load(&mm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mm[d], v);
         }
     }
-    flags[i] = f;
 }
 
 } // namespace
@@ -381,7 +426,8 @@ struct slam_gseg {
     int       *d_iters = nullptr;
     int       *d_bin_of = nullptr;
     size_t     cap_points = 0;
-    unsigned char *d_ga_occ = nullptr; // 1200 x 1200 occupancy of classifyPoints
+    unsigned char *d_ga_occ = nullptr; // 1200 x 1200 occupancy of classifyPoints: the epoch of the last call that marked the cell
+    int        ga_epoch = 0;      // 1..255; 0: the lattice has to be cleared first
     void      *d_stage = nullptr; // host-API staging: points + labels
     size_t     cap_stage = 0;
 };
@@ -439,6 +485,8 @@ int slam_gseg_create(const slam_gseg_params *params, slam_gseg_t **out)
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_value, sizeof(double) * NA * NL);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_scratch, sizeof(double) * 2 * (size_t)NA * NL * NL);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_iters, sizeof(int) * NA);
+    if (e == hipSuccess) e = hipMemset(h->d_count, 0, sizeof(int) * NA * NL);
+    if (e == hipSuccess) e = hipMemset(h->d_proto, 0xff, sizeof(unsigned long long) * NA * NL);
     if (e != hipSuccess) {
         slam_gseg_destroy(h);
         SLAM_HIP(e);
@@ -471,16 +519,15 @@ int slam_gseg_segment_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride,
     SLAM_TRY(require_device());
     SLAM_TRY(gseg_reserve(h, (size_t)(n > 0 ? n : 1)));
     hipStream_t st = as_stream(stream);
-    SLAM_HIP(hipMemsetAsync(h->d_count, 0, sizeof(int) * NA * NL, st));
-    SLAM_HIP(hipMemsetAsync(h->d_proto, 0xff, sizeof(unsigned long long) * NA * NL, st));
+    // (the bins' counts and prototypes are clean: slam_gseg_create cleared them, every labelling since has cleared them again)
     if (n > 0)
         hipLaunchKernelGGL(gseg_bin_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->prm, d_xyz, n, stride,
                            h->d_bin_of, h->d_count, h->d_proto);
     hipLaunchKernelGGL(gseg_insac_kernel, dim3(NA), dim3(kSecThreads), 0, st, h->prm, d_xyz, stride, h->d_count,
                        h->d_proto, h->d_state, h->d_value, h->d_scratch, h->d_iters);
     if (n > 0)
-        hipLaunchKernelGGL(gseg_label_kernel, dim3((n + 255) / 256), dim3(256), 0, st, h->prm, d_xyz, n, stride,
-                           h->d_bin_of, h->d_state, h->d_value, d_labels);
+        hipLaunchKernelGGL(gseg_label_kernel, dim3((std::max(n, NA * NL) + 255) / 256), dim3(256), 0, st, h->prm, d_xyz, n, stride,
+                           h->d_bin_of, h->d_state, h->d_value, d_labels, h->d_count, h->d_proto);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }
@@ -525,18 +572,31 @@ int slam_gseg_split_dev(slam_gseg_t *h, const float *d_xyz, int n, int stride, c
 }
 
 static int classify_ga(slam_gseg_t *h, const float *d_obstacle_xyz, int n, const int32_t *d_n, int stride, uint8_t *d_flags,
-                       slam_stream_t stream)
+                       slam_stream_t stream, unsigned *d_mm = nullptr)
 {
     SLAM_TRY(require_device());
     if (n == 0) return SLAM_OK;
     if (!h->d_ga_occ) SLAM_HIP(hipMalloc((void **)&h->d_ga_occ, (size_t)kGaBins * kGaBins));
     hipStream_t st = as_stream(stream);
-    SLAM_HIP(hipMemsetAsync(h->d_ga_occ, 0, (size_t)kGaBins * kGaBins, st));
-    hipLaunchKernelGGL(ga_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_obstacle_xyz, n, stride, h->d_ga_occ, d_n);
+    if (h->ga_epoch <= 0 || h->ga_epoch >= 255) { // every 255th call (and the first): no cell holds a live epoch afterwards
+        SLAM_HIP(hipMemsetAsync(h->d_ga_occ, 0, (size_t)kGaBins * kGaBins, st));
+        h->ga_epoch = 0;
+    }
+    const unsigned char epoch = (unsigned char)++h->ga_epoch;
+    hipLaunchKernelGGL(ga_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_obstacle_xyz, n, stride, h->d_ga_occ, d_n, epoch);
     hipLaunchKernelGGL(ga_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_obstacle_xyz, n, stride, h->d_ga_occ,
-                       d_flags, d_n);
+                       d_flags, d_n, epoch, d_mm);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
+}
+
+// ccicp.hip's chain: classification + the extent of what it keeps, in the classification's two launches
+int slam_gseg_classify_ga_extent_dev(slam_gseg_t *h, const float *d_obstacle_xyz, const int32_t *d_n, int n_capacity, int stride,
+                                     uint8_t *d_flags, uint32_t *d_mm, slam_stream_t stream)
+{
+    SLAM_REQUIRE(h && d_n && n_capacity >= 0 && stride >= 3 && d_mm && (n_capacity == 0 || (d_obstacle_xyz && d_flags)), SLAM_E_INVALID,
+                 "slam_gseg_classify_ga_extent_dev: bad arguments");
+    return classify_ga(h, d_obstacle_xyz, n_capacity, d_n, stride, d_flags, stream, d_mm);
 }
 
 int slam_gseg_classify_ga_dev(slam_gseg_t *h, const float *d_obstacle_xyz, int n, int stride, uint8_t *d_flags,
