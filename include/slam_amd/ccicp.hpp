@@ -203,21 +203,31 @@ public:
         hp[4] = initPose.x, hp[5] = initPose.y;
         std::memset(h_io_ + kOffRes, 0, 32); // result and height: a scan below 5 points leaves them untouched
         hp[kOffZ / 8] = initPose.z;
+        // The match's launches: the fit (two: the spread form and the form that redoes what it could not finish), the height (two).
+        // Nothing is copied around them (round 6: a match is bound by its launches, 45 in round 5): the initial pose is read from
+        // this block where it lies (pinned memory is the device's to read), and the last kernel leaves the device block's 128 bytes
+        // here again.
+        const bool in_place = !scene_ready_ || !icp_;
         if (!scene_ready_) { // no scene cloud: an empty one
             std::memset(h_io_ + kOffScan, 0, 32);
             ok(slam_memcpy_h2d_async(d_io_, h_io_, kOffNgt, stream_));
-        } else {
-            ok(slam_memcpy_h2d_async(d_io_, h_io_, kOffScan, stream_));
+        } else if (in_place) {
+            ok(slam_memcpy_h2d_async(d_io_, h_io_, kOffScan, stream_)); // (no target: the height is that of the initial pose)
         }
         // IcpPointToPoint icp(refPts...) + icp.fit(...) (:187-188): the scene's size stays on the device
-        if (icp_)
-            ok(slam_icp_fit_batch_dev(icp_, d_scene_pts_, io_scan(), io_scan() + 2, 1, io_R(), io_t(), 5.0,
-                                      reinterpret_cast<slam_icp_result *>(d_io_ + kOffRes), nullptr, stream_));
+        if (icp_) {
+            if (in_place)
+                ok(slam_icp_fit_batch_dev(icp_, d_scene_pts_, io_scan(), io_scan() + 2, 1, io_R(), io_t(), 5.0,
+                                          reinterpret_cast<slam_icp_result *>(d_io_ + kOffRes), nullptr, stream_));
+            else
+                ok(slam_icp_fit_batch_from_dev(icp_, d_scene_pts_, io_scan(), io_scan() + 2, 1, hp, hp + 4, io_R(), io_t(), 5.0,
+                                               reinterpret_cast<slam_icp_result *>(d_io_ + kOffRes), nullptr, stream_));
+        }
         // doHeightInterpolate(ground_target, result_2d) (:295, :301-381) for the pose the fit left on the device
-        ok(slam_ccicp_height_rpy_pose_dev(cc_, (const float *)ground_target_.p, reinterpret_cast<const int32_t *>(d_io_ + kOffNgt),
-                                          ground_target_n_, 4, io_R(), io_t(), initPose.z, roll0, pitch0,
-                                          reinterpret_cast<double *>(d_io_ + kOffZ), stream_));
-        fetch_io(); // the one read-back of the match
+        ok(slam_ccicp_height_rpy_pose_mirror_dev(cc_, (const float *)ground_target_.p, reinterpret_cast<const int32_t *>(d_io_ + kOffNgt),
+                                                 ground_target_n_, 4, io_R(), io_t(), initPose.z, roll0, pitch0,
+                                                 reinterpret_cast<double *>(d_io_ + kOffZ), h_io_, d_io_, kIoBytes, stream_));
+        ok(slam_stream_synchronize(stream_)); // the match's one wait: its result block is here
         scene_known_ = scene_ready_;
         const int32_t *scan = h_scan();
         n_scene_[0] = scan[2], n_scene_[1] = scan[1] - scan[2];

@@ -513,6 +513,13 @@ int slam_ccicp_height_pose_dev(slam_ccicp_t *h, const float *d_ground, const int
 int slam_ccicp_height_rpy_pose_dev(slam_ccicp_t *h, const float *d_ground, const int32_t *d_n_ground, int n_capacity,
                                    int stride, const double *d_R, const double *d_t, double z0, double roll, double pitch,
                                    double *d_out, slam_stream_t stream);
+/* ... and, behind the height, `mirror_bytes` (a multiple of 8, at most 4096) copied from mirror_src (device) to mirror_dst by the
+ * last kernel of the call: with mirror_dst in pinned host memory (slam_host_alloc) the caller's result block -- pose, result,
+ * height, scan descriptor -- is on the host when the stream has drained, without a copy of its own behind the match */
+int slam_ccicp_height_rpy_pose_mirror_dev(slam_ccicp_t *h, const float *d_ground, const int32_t *d_n_ground, int n_capacity,
+                                          int stride, const double *d_R, const double *d_t, double z0, double roll, double pitch,
+                                          double *d_out, void *mirror_dst, const void *mirror_src, size_t mirror_bytes,
+                                          slam_stream_t stream);
 /* The throughput form of a sequence of matches (BASELINE config 3; scan_registration.cpp:109-173 is one cloud at a time): n <= 32
  * scenes made by slam_ccicp_scene_dev -- on as many streams as the caller likes, each with its own slam_ccicp_t / slam_gseg_t --
  * gathered into ONE batch for slam_icp_fit_batch_dev: d_out_pts = their points one scene after the other (room for the sum),

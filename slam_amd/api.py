@@ -99,7 +99,7 @@ EXPORTS = [
     "slam_gseg_classify_ga_dev", "slam_gseg_classify_ga_counted_dev", "slam_gseg_classify_ga_extent_dev",
     "slam_ccicp_create", "slam_ccicp_destroy", "slam_ccicp_voxel_downsample_dev", "slam_ccicp_split_dev",
     "slam_ccicp_height_dev", "slam_ccicp_bin_order_dev", "slam_ccicp_select_dev", "slam_ccicp_scene_dev",
-    "slam_ccicp_height_pose_dev", "slam_ccicp_split_box_dev", "slam_ccicp_height_rpy_pose_dev", "slam_ccicp_scene_cloud_dev", "slam_ccicp_pack_scans_dev",
+    "slam_ccicp_height_pose_dev", "slam_ccicp_split_box_dev", "slam_ccicp_height_rpy_pose_dev", "slam_ccicp_height_rpy_pose_mirror_dev", "slam_ccicp_scene_cloud_dev", "slam_ccicp_pack_scans_dev",
     "slam_mapper_default_params", "slam_mapper_create", "slam_mapper_destroy", "slam_mapper_next_slot", "slam_mapper_slots",
     "slam_mapper_chunk_buffers", "slam_mapper_push", "slam_mapper_wait", "slam_mapper_finish", "slam_mapper_grid",
     "slam_mapper_target", "slam_mapper_stats", "slam_mapper_set_merge",

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void voxel_accumulate_kernel(VoxelGridView g, 
     }
 }
 
-// ---- stable compaction in three steps: per-block counts, scan of the block counts, ordered write
+// ---- stable compaction (compact1_kernel below)
 // the domain of a compaction: n items, or fewer where a count on the device says so
 struct Domain {
     long long        n;
@@ -186,81 +186,6 @@ struct Domain {
         return m;
     }
 };
-
-template <class Pred>
-__global__ __launch_bounds__(kScanThreads) void count_kernel(Pred pred, Domain dom, int *block_cnt)
-{
-    const long long n = dom.size();
-    const long long base = (long long)blockIdx.x * kItems;
-    int             c = 0;
-    for (int k = threadIdx.x; k < kItems; k += kScanThreads)
-        if (base + k < n && pred(base + k)) ++c;
-    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
-    __shared__ int w[kScanThreads / 64];
-    if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int t = 0;
-        for (int k = 0; k < kScanThreads / 64; ++k) t += w[k];
-        block_cnt[blockIdx.x] = t;
-    }
-}
-
-__global__ __launch_bounds__(1024) void scan_blocks_kernel(int *block_cnt, int n_blocks, int *total)
-{
-    __shared__ int carry, wsum[16];
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n_blocks; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < n_blocks ? block_cnt[i] : 0;
-        int       x = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            const int y = __shfl_up(x, off);
-            if ((threadIdx.x & 63) >= off) x += y;
-        }
-        if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
-        __syncthreads();
-        int w = 0;
-        for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) w += wsum[k];
-        const int incl = carry + w + x;
-        if (i < n_blocks) block_cnt[i] = incl - v; // exclusive
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = carry;
-}
-
-// positions of the block's selected items in index order: thread t owns items [t*16, t*16+16)
-template <class Pred, class Emit>
-__global__ __launch_bounds__(kScanThreads) void write_kernel(Pred pred, Emit emit, Domain dom, const int *block_off,
-                                                            int limit)
-{
-    const long long n = dom.size();
-    constexpr int   kPer = kItems / kScanThreads;
-    const long long base = (long long)blockIdx.x * kItems + (long long)threadIdx.x * kPer;
-    unsigned        mask = 0;
-    for (int k = 0; k < kPer; ++k)
-        if (base + k < n && pred(base + k)) mask |= 1u << k;
-    const int c = __popc(mask);
-    int       x = c;
-    for (int off = 1; off < 64; off <<= 1) {
-        const int y = __shfl_up(x, off);
-        if ((threadIdx.x & 63) >= off) x += y;
-    }
-    __shared__ int wsum[kScanThreads / 64];
-    if ((threadIdx.x & 63) == 63) wsum[threadIdx.x >> 6] = x;
-    __syncthreads();
-    int w = 0;
-    for (int k = 0; k < (int)(threadIdx.x >> 6); ++k) w += wsum[k];
-    int pos = block_off[blockIdx.x] + w + x - c;
-    for (int k = 0; k < kPer; ++k)
-        if (mask & (1u << k)) {
-            if (pos < limit) emit(base + k, pos);
-            ++pos;
-        }
-}
 
 struct VoxelUsed {
     const Voxel *vox;
@@ -341,15 +266,26 @@ struct SplitEmit {
 
 // four wheel points against all ground points: exact squared L2 in float (KdTreeFLANN, k = 1), packed
 // (distance bits, index) minimum -> lowest index on a tie
+struct HeightPose { // the pose the wheel points come from, where it lies on the device (null R: the points are given)
+    const double *R, *t;
+    double        z0, roll, pitch;
+};
+__device__ inline void height_pose(const double *R, const double *t, double z0, double roll, double pitch, float4 *q);
 __global__ __launch_bounds__(256) void height_nn_kernel(const float *ground, int n, int stride, float4 q0, float4 q1,
                                                         float4 q2, float4 q3, unsigned long long *best /*[4]*/,
-                                                        const float4 *d_q = nullptr, const int *d_n = nullptr)
+                                                        const float4 *d_q = nullptr, const int *d_n = nullptr, HeightPose hp = HeightPose{nullptr, nullptr, 0, 0, 0})
 {
     const int          i = blockIdx.x * 256 + threadIdx.x;
     unsigned long long b[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+    __shared__ float4  qs[4];
+    if (hp.R) { // every block works the four wheel points out for itself (a launch of one thread did: round 6, a match is bound by its launches)
+        if (threadIdx.x == 0) height_pose(hp.R, hp.t, hp.z0, hp.roll, hp.pitch, qs);
+        __syncthreads();
+    }
     if (i < bound(n, d_n)) {
         const float *c = ground + (size_t)i * stride;
-        const float4 q[4] = {d_q ? d_q[0] : q0, d_q ? d_q[1] : q1, d_q ? d_q[2] : q2, d_q ? d_q[3] : q3};
+        const float4 q[4] = {hp.R ? qs[0] : (d_q ? d_q[0] : q0), hp.R ? qs[1] : (d_q ? d_q[1] : q1), hp.R ? qs[2] : (d_q ? d_q[2] : q2),
+                             hp.R ? qs[3] : (d_q ? d_q[3] : q3)};
         for (int k = 0; k < 4; ++k) {
             const float dx = c[0] - q[k].x, dy = c[1] - q[k].y, dz = c[2] - q[k].z;
             const float dd = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
@@ -497,6 +433,16 @@ __host__ __device__ inline void wheel_points(const double pose[7], float4 q[4])
         }
 }
 
+__device__ inline void height_pose(const double *R, const double *t, double z0, double roll, double pitch, float4 *q /*[4]*/)
+{
+    const double yaw = atan2(R[2], R[0]); // icpTools.cpp:195-197
+    const double hy = yaw * 0.5, hp = pitch * 0.5, hr = roll * 0.5;
+    const double cy = cos(hy), sy = sin(hy), cp = cos(hp), sp = sin(hp), cr = cos(hr), sr = sin(hr);
+    const double pose[7] = {t[0], t[1], z0, sr * cp * cy - cr * sp * sy, cr * sp * cy + sr * cp * sy, cr * cp * sy - sr * sp * cy,
+                            cr * cp * cy + sr * sp * sy};
+    wheel_points(pose, q);
+}
+
 __global__ void height_pose_kernel(const double *R, const double *t, double z0, double roll, double pitch, float4 *q /*[4]*/,
                                    unsigned long long *best)
 {
@@ -571,10 +517,13 @@ __host__ __device__ inline double height_from_neighbours(const float corr[4][3],
     return (double)(float)((float)nrm[2] * ROBO_HEIGHT + (float)mean[2]);      // :376
 }
 
-__global__ void height_fit_kernel(const float *ground, int stride, const unsigned long long *best, double z0, double *out /*[2]*/)
+__global__ void height_fit_kernel(const float *ground, int stride, unsigned long long *best, double z0, double *out /*[2]*/, bool clear = false,
+                                  unsigned long long *mirror_dst = nullptr, const unsigned long long *mirror_src = nullptr, int mirror_words = 0)
 {
     if (threadIdx.x || blockIdx.x) return;
     const unsigned long long b[4] = {best[0], best[1], best[2], best[3]};
+    if (clear)
+        for (int k = 0; k < 4; ++k) best[k] = ~0ull; // as the next call's neighbour search must find them
     float                    all[4][3];
     for (int k = 0; k < 4; ++k) { // four independent gathers (index 0 where there is no neighbour: read, not used)
         const size_t idx = b[k] == ~0ull ? 0 : (size_t)(unsigned)(b[k] & 0xffffffffu);
@@ -589,6 +538,8 @@ __global__ void height_fit_kernel(const float *ground, int stride, const unsigne
         }
     out[0] = height_from_neighbours(corr, nc, z0);
     out[1] = (double)nc;
+    // the caller's result block, as it stands now, to where the host reads it (pinned memory: no copy behind the match)
+    for (int k = 0; k < mirror_words; ++k) mirror_dst[k] = mirror_src[k];
 }
 
 // ---- stable compaction in ONE launch (round 6): per-block counts, a decoupled look-back for the block's offset, the ordered
@@ -735,25 +686,6 @@ struct DevBuf {
     }
 };
 
-template <class Pred, class Emit>
-int compact(Pred pred, Emit emit, long long n, int limit, DevBuf &blocks, int *d_total, hipStream_t st, const int *d_n = nullptr,
-            const long long *d_n64 = nullptr)
-{
-    if (n <= 0) { // nothing to select from: the total is zero all the same
-        SLAM_HIP(hipMemsetAsync(d_total, 0, sizeof(int), st));
-        return SLAM_OK;
-    }
-    const int n_blocks = (int)((n + kItems - 1) / kItems);
-    SLAM_TRY(blocks.reserve(sizeof(int) * (size_t)(n_blocks + 1)));
-    int         *bc = static_cast<int *>(blocks.p);
-    const Domain dom = {n, d_n, d_n64};
-    hipLaunchKernelGGL((count_kernel<Pred>), dim3(n_blocks), dim3(kScanThreads), 0, st, pred, dom, bc);
-    hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, st, bc, n_blocks, d_total);
-    hipLaunchKernelGGL((write_kernel<Pred, Emit>), dim3(n_blocks), dim3(kScanThreads), 0, st, pred, emit, dom, bc, limit);
-    SLAM_HIP(hipGetLastError());
-    return SLAM_OK;
-}
-
 struct NoTail {
     int *total0, *total1;
     __device__ void operator()(const int tot[2]) const
@@ -776,10 +708,11 @@ struct OneEmit {
 } // namespace
 
 struct slam_ccicp {
-    DevBuf vox, blocks, blocks2, small; // small: 6 min/max words, totals, 4 packed NN results
+    DevBuf vox, small;                  // small: 6 min/max words, totals, 4 packed NN results
     DevBuf status;                      // the one-launch compactions' look-back words (compact1)
     unsigned epoch = 0;                 // ... and the launch they belong to (24 bits)
     size_t vox_clean = 0;               // voxels of `vox` known to be zero (the chain's compaction leaves them so)
+    const void *best_of = nullptr;      // the chain block whose packed neighbours (ChainSmall::best) have been set to "none"
     DevBuf keys, sort_tmp;
     long long max_voxels = 1ll << 26;
     // the chain (slam_ccicp_scene_dev): per-point scratch for the cloud's capacity, the lattice and the counts on the device
@@ -904,7 +837,7 @@ int slam_ccicp_voxel_downsample_dev(slam_ccicp_t *h, const float *d_xyz, const u
     h->vox_clean = 0; // (the chain of slam_ccicp_scene_dev shares the accumulator and expects it zero)
     hipLaunchKernelGGL(voxel_accumulate_kernel, dim3((n + 255) / 256), dim3(256), 0, st, g, d_xyz, d_flag, n, stride, vox);
     int *d_total = reinterpret_cast<int *>(mm + 8);
-    SLAM_TRY(compact(VoxelUsed{vox}, VoxelEmit{vox, d_out}, nv, max_out, h->blocks, d_total, st));
+    SLAM_TRY(compact_one(h, VoxelUsed{vox}, VoxelEmit{vox, d_out}, nv, max_out, d_total, st));
     int total = 0;
     SLAM_HIP(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, st));
     SLAM_HIP(hipStreamSynchronize(st));
@@ -923,8 +856,7 @@ int slam_ccicp_select_dev(slam_ccicp_t *h, const float *d_xyz, int n, int stride
     if (n == 0) return SLAM_OK;
     hipStream_t st = as_stream(stream);
     int        *d_tot = reinterpret_cast<int *>(static_cast<unsigned *>(h->small.p) + 26);
-    SLAM_TRY(compact(LabelPred{d_labels, label_mask}, Xyz4Emit{d_xyz, stride, reinterpret_cast<float4 *>(d_out_xyz4)}, n, n,
-                     h->blocks, d_tot, st));
+    SLAM_TRY(compact_one(h, LabelPred{d_labels, label_mask}, Xyz4Emit{d_xyz, stride, reinterpret_cast<float4 *>(d_out_xyz4)}, n, n, d_tot, st));
     SLAM_HIP(hipMemcpyAsync(n_out, d_tot, sizeof(int), hipMemcpyDeviceToHost, st));
     SLAM_HIP(hipStreamSynchronize(st));
     return SLAM_OK;
@@ -974,9 +906,9 @@ int slam_ccicp_split_box_dev(slam_ccicp_t *h, const float *d_xyzg, int n, int st
     p.y_lo = box ? box[2] : 0.f;
     p.y_hi = box ? box[3] : 0.f;
     p.want_ga = 1;
-    SLAM_TRY(compact(p, SplitEmit{d_xyzg, stride, d_ga_xy, nullptr, 0}, n, cap - 1, h->blocks, d_tot, st)); // ICP_MAX_PTS-1 (:256,:259)
+    SLAM_TRY(compact_one(h, p, SplitEmit{d_xyzg, stride, d_ga_xy, nullptr, 0}, n, cap - 1, d_tot, st)); // ICP_MAX_PTS-1 (:256,:259)
     p.want_ga = 0;
-    SLAM_TRY(compact(p, SplitEmit{d_xyzg, stride, d_nga_xy, nullptr, 0}, n, cap - 1, h->blocks2, d_tot + 1, st));
+    SLAM_TRY(compact_one(h, p, SplitEmit{d_xyzg, stride, d_nga_xy, nullptr, 0}, n, cap - 1, d_tot + 1, st));
     int tot[2];
     SLAM_HIP(hipMemcpyAsync(tot, d_tot, sizeof tot, hipMemcpyDeviceToHost, st));
     SLAM_HIP(hipStreamSynchronize(st));
@@ -1210,17 +1142,32 @@ int slam_ccicp_height_rpy_pose_dev(slam_ccicp_t *h, const float *d_ground, const
                                    const double *d_R, const double *d_t, double z0, double roll, double pitch, double *d_out,
                                    slam_stream_t stream)
 {
+    return slam_ccicp_height_rpy_pose_mirror_dev(h, d_ground, d_n_ground, n_capacity, stride, d_R, d_t, z0, roll, pitch, d_out, nullptr, nullptr, 0,
+                                                 stream);
+}
+
+int slam_ccicp_height_rpy_pose_mirror_dev(slam_ccicp_t *h, const float *d_ground, const int32_t *d_n_ground, int n_capacity, int stride,
+                                          const double *d_R, const double *d_t, double z0, double roll, double pitch, double *d_out,
+                                          void *mirror_dst, const void *mirror_src, size_t mirror_bytes, slam_stream_t stream)
+{
     SLAM_REQUIRE(h && d_n_ground && d_R && d_t && d_out && n_capacity >= 0 && stride >= 3 && (d_ground || n_capacity == 0),
                  SLAM_E_INVALID, "slam_ccicp_height_rpy_pose_dev: bad arguments");
+    SLAM_REQUIRE(mirror_bytes == 0 || (mirror_dst && mirror_src && mirror_bytes % 8 == 0 && mirror_bytes <= 4096), SLAM_E_INVALID,
+                 "slam_ccicp_height_rpy_pose_mirror_dev: the mirrored block is a multiple of 8 bytes, at most 4096");
     hipStream_t st = as_stream(stream);
     SLAM_TRY(h->chain.reserve(sizeof(ChainSmall)));
     ChainSmall *c = static_cast<ChainSmall *>(h->chain.p);
-    hipLaunchKernelGGL(height_pose_kernel, dim3(1), dim3(64), 0, st, d_R, d_t, z0, roll, pitch, c->q, c->best);
+    // (the four packed neighbours start as "none": set once for the block as it is, put back by every fit)
+    if (h->best_of != h->chain.p) {
+        SLAM_HIP(hipMemsetAsync(c->best, 0xff, sizeof c->best, st));
+        h->best_of = h->chain.p;
+    }
     if (n_capacity > 0)
         hipLaunchKernelGGL(height_nn_kernel, dim3((n_capacity + 255) / 256), dim3(256), 0, st, d_ground, n_capacity, stride,
                            make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), c->best,
-                           c->q, d_n_ground);
-    hipLaunchKernelGGL(height_fit_kernel, dim3(1), dim3(64), 0, st, d_ground, stride, c->best, z0, d_out);
+                           nullptr, d_n_ground, HeightPose{d_R, d_t, z0, roll, pitch});
+    hipLaunchKernelGGL(height_fit_kernel, dim3(1), dim3(64), 0, st, d_ground, stride, c->best, z0, d_out, true,
+                       static_cast<unsigned long long *>(mirror_dst), static_cast<const unsigned long long *>(mirror_src), (int)(mirror_bytes / 8));
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }

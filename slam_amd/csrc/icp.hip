@@ -1499,6 +1499,7 @@ int slam_icp_fit_batch_from_dev(slam_icp_t *icp, const double *d_pts, const int3
 #endif
     // few scans (one, in the reference's own usage): each scan spread over many workgroups of one persistent launch
     fa.only = nullptr;
+    fa.spread_tag = 0;
     if (takes_spread_form(icp, n_scans) && !fa.stamps) {
         // ... and behind it the workgroup-per-scan form for the scans whose workgroups did not all become resident together
         // (another spread launch or a persistent kernel holding CUs: icp_single.hip): its workgroups find their scan's flag

@@ -186,6 +186,7 @@ struct slam_icp {
     // slam_icp_fit: a spread launch whose workgroups did not become resident together (a persistent kernel of this or another
     // process holds CUs) costs its 5 ms first-exchange limit before the one-workgroup form redoes the scan.  After such a fit the
     // handle's next fits go straight to the one-workgroup form and try the spread form again later (icp_single.hip).
+    unsigned        spread_tag = 1;             // tag base of the next spread launch (FitArgs::spread_tag)
     int             spread_backoff = 0;         // single fits still to be done without the spread form
     bool            skip_spread = false;        // set around one slam_icp_fit_batch_dev call
     const int      *d_last_redo = nullptr;      // redo flags of the last spread launch (device, in w_single), or null

@@ -85,7 +85,7 @@ __device__ inline bool spread_exchange(const ModelView &mv, const FitArgs &fa, c
     const int lane = (int)threadIdx.x & 63;
     bool      ok = true;
     // this workgroup's nine sums go out as granules ...
-    const unsigned      tag = (unsigned)iter + 1u;
+    const unsigned      tag = fa.spread_tag + (unsigned)iter + 1u;
     unsigned long long *gbuf = gran + (size_t)(iter & 1) * parts * kGranPerWg;
     if (lane < kNumAcc) {
         double mine = 0.0;
@@ -110,7 +110,7 @@ __device__ inline bool spread_exchange(const ModelView &mv, const FitArgs &fa, c
                 all &= (unsigned)(v[k] >> 32) == tag;
             }
             if (all && !(iter == 0 && first_ticks == 0)) break; // (spread_wait_us < 0: every scan is handed over, for the tests)
-            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)fa.spread_tag ||
                 __builtin_amdgcn_s_memrealtime() - t_begin >= (iter == 0 ? first_ticks : kSpinTicks)) {
                 ok = false;
                 break;
@@ -121,7 +121,7 @@ __device__ inline bool spread_exchange(const ModelView &mv, const FitArgs &fa, c
         for (int k = 0; k < kNumAcc; ++k) tot[k] += __hiloint2double((int)(unsigned)v[2 * k], (int)(unsigned)v[2 * k + 1]);
     }
     ok = __all(ok);
-    if (!ok && lane == 0) __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the others stop spinning
+    if (!ok && lane == 0) __hip_atomic_store(abort_word, (int)fa.spread_tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // the others stop spinning
     SPREAD_STAMP(3);
     const double v8 = wave_sum8(tot), v9 = wave_sum(tot[8]);
     double       S[kNumAcc];
@@ -1063,7 +1063,8 @@ __device__ inline void spread_finish(const FitArgs &fa, const FitState &fs, int 
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         // workgroup 0 decides: if IT saw every exchange through, the pose is complete whatever the others did afterwards
-        if (!ok) flags[gridDim.y + s] = 1; // redo: the one-workgroup form takes this scan, from the pose left untouched here
+        flags[gridDim.y + s] = ok ? 0 : 1; // redo: the one-workgroup form takes this scan, from the pose left untouched here (written
+                                           // either way: nothing clears the flags between launches)
         if (ok) {
             fa.R[4 * s + 0] = fs.r00;
             fa.R[4 * s + 1] = fs.r01;
@@ -1098,10 +1099,13 @@ __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitAr
             else
                 fa.t[2 * s + threadIdx.x - 4] = fa.t0[2 * s + threadIdx.x - 4];
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0 && fa.result) {
-            fa.result[s].iters = 0;
-            fa.result[s].n_corr = 0;
-            fa.result[s].delta = 0.0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            flags[gridDim.y + s] = 0; // nothing to redo
+            if (fa.result) {
+                fa.result[s].iters = 0;
+                fa.result[s].n_corr = 0;
+                fa.result[s].delta = 0.0;
+            }
         }
         return;
     }
@@ -1175,12 +1179,24 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
     SLAM_HIP(hipGetDevice(&dev));
     SLAM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     const int    parts = spread_parts(n_scans, std::max(n_cu, 1));
+    // Scratch of the launch: [abort | redo] words per scan at fixed places in front, the granules behind.  Nothing is filled between
+    // launches (a fill was a launch of its own in front of every fit): a granule counts when it carries THIS launch's tag, an abort
+    // word when it holds this launch's tag base, and the redo words are written by every scan's first workgroup either way.  Tag
+    // bases only grow (by max_iter + 2 per launch); the buffer is cleared when it is made, grows, or the 32 bits run out.
+    const size_t flag_bytes = sizeof(int) * 2 * (size_t)std::max(n_cu, n_scans);
     const size_t gran_bytes = sizeof(unsigned long long) * 2 * (size_t)parts * kGranPerWg * (size_t)n_scans;
-    const size_t flag_bytes = sizeof(int) * 2 * (size_t)n_scans;
-    SLAM_TRY(h->w_single.reserve(gran_bytes + flag_bytes));
-    SLAM_HIP(hipMemsetAsync(h->w_single.p, 0, gran_bytes + flag_bytes, st)); // tag 0 = nothing published; no abort, no redo
-    unsigned long long *gran = static_cast<unsigned long long *>(h->w_single.p);
-    int                *flags = reinterpret_cast<int *>(static_cast<unsigned char *>(h->w_single.p) + gran_bytes);
+    const size_t had = h->w_single.cap;
+    SLAM_TRY(h->w_single.reserve(flag_bytes + gran_bytes));
+    const unsigned span = (unsigned)std::max(fa.max_iter, 0) + 2u;
+    if (h->w_single.cap != had || h->spread_tag + span < h->spread_tag || h->spread_tag == 0) {
+        SLAM_HIP(hipMemsetAsync(h->w_single.p, 0, h->w_single.cap, st));
+        h->spread_tag = 1;
+    }
+    FitArgs fa_tagged = fa;
+    fa_tagged.spread_tag = h->spread_tag;
+    h->spread_tag += span;
+    int                *flags = static_cast<int *>(h->w_single.p);
+    unsigned long long *gran = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(h->w_single.p) + flag_bytes);
     *redo_flags = flags + n_scans;
     h->d_last_redo = flags + n_scans;
     std::lock_guard<std::mutex> lk(g_spread_mu);
@@ -1241,16 +1257,16 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
     if (h->in_lds) {
         auto kern = p2l ? icp_fit_spread_kernel<uint16_t, true, SLAM_ICP_P2L> : icp_fit_spread_kernel<uint16_t, true, SLAM_ICP_P2P>;
         SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-        hipLaunchKernelGGL(kern, grid, dim3(kSB), h->lds_bytes, st, h->mv, fa, gran, flags, first_ticks, qstate, qcap, wide_max, 0, kSB, 0.0f, 0.0f, sstamps);
+        hipLaunchKernelGGL(kern, grid, dim3(kSB), h->lds_bytes, st, h->mv, fa_tagged, gran, flags, first_ticks, qstate, qcap, wide_max, 0, kSB, 0.0f, 0.0f, sstamps);
     } else if (h->start32) {
         auto kern = p2l ? icp_fit_spread_kernel<uint32_t, false, SLAM_ICP_P2L> : icp_fit_spread_kernel<uint32_t, false, SLAM_ICP_P2P>;
         SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)global_lds));
-        hipLaunchKernelGGL(kern, grid, dim3(kSB), global_lds, st, h->mv, fa, gran, flags, first_ticks, qstate, qcap, wide_max, tile_on, tile_lanes, slack_moves,
+        hipLaunchKernelGGL(kern, grid, dim3(kSB), global_lds, st, h->mv, fa_tagged, gran, flags, first_ticks, qstate, qcap, wide_max, tile_on, tile_lanes, slack_moves,
                            slack_cells, sstamps);
     } else {
         auto kern = p2l ? icp_fit_spread_kernel<uint16_t, false, SLAM_ICP_P2L> : icp_fit_spread_kernel<uint16_t, false, SLAM_ICP_P2P>;
         SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)global_lds));
-        hipLaunchKernelGGL(kern, grid, dim3(kSB), global_lds, st, h->mv, fa, gran, flags, first_ticks, qstate, qcap, wide_max, tile_on, tile_lanes, slack_moves,
+        hipLaunchKernelGGL(kern, grid, dim3(kSB), global_lds, st, h->mv, fa_tagged, gran, flags, first_ticks, qstate, qcap, wide_max, tile_on, tile_lanes, slack_moves,
                            slack_cells, sstamps);
     }
     SLAM_HIP(hipGetLastError());

@@ -29,7 +29,11 @@ def measure_cpp(clouds, poses, advance=10, passes=3, forms=("seq",)):
     # (... nor bench.py's GPU_MAX_HW_QUEUES=8, which is for ITS streams: the program stands for a user's, with the runtime's defaults --
     # CCICP::matchSequence deals its scene chains over four streams for the runtime's four queues: 0.23-0.25 ms per match there, 0.30-0.32 with 8)
     env.pop("GPU_MAX_HW_QUEUES", None)
-    with tempfile.TemporaryDirectory() as d:
+    keep = os.environ.get("SLAM_C3_KEEP_DIR")      # tools/profile_round.sh: the binary and its inputs stay there, for rocprofv3 on the binary itself
+    import contextlib
+    if keep:
+        os.makedirs(keep, exist_ok=True)
+    with (contextlib.nullcontext(keep) if keep else tempfile.TemporaryDirectory()) as d:
         exe = os.path.join(d, "ccicp_sequence")
         subprocess.check_call(["g++", "-std=c++17", "-O2", "-pthread", "-I", os.path.join(ROOT, "include"),
                                os.path.join(ROOT, "tests", "cpp", "ccicp_sequence.cpp"), "-o", exe,
@@ -162,6 +166,7 @@ def measure(n_clouds=50, cell=0.0, dump_case=None, advance=10):
         d_z = api.DeviceArray((2,), np.float64)
         h_pose = np.zeros(6)
         st = api.Stream()
+        ev = [(api.Event(), api.Event()) for _ in range(n_clouds)]
         errs, iters, t_all = [], [], 0.0
         for k in range(1, n_clouds):
             rel = relative(poses[0], poses[k])
@@ -171,8 +176,10 @@ def measure(n_clouds=50, cell=0.0, dump_case=None, advance=10):
             h_pose[:4], h_pose[4:] = R0.reshape(4), t0_
             api.check(L.slam_memcpy_h2d(d_xyz.ptr, xyz.ctypes.data, xyz.nbytes, None))
             api.check(L.slam_memcpy_h2d_async(d_pose.ptr, h_pose.ctypes.data, 48, st.ptr))
+            ev[k][0].record(st)
             api.check(L.slam_ccicp_scene_dev(cc.h, seg.h, d_xyz.ptr, len(xyz), 3, 1, 0, 0.0, 0.0, 75.0, 20000, d_pts.ptr, d_scan.ptr,
                                              None, d_counts.ptr, st.ptr))
+            ev[k][1].record(st)
             icp.fit_batch_dev(d_pts, d_scan, d_scan.view(2, (1,)), 1, d_R, d_t, 5.0, d_res, None, st)
             api.check(L.slam_ccicp_height_pose_dev(cc.h, d_gt.ptr, d_ngt.ptr, n_gnd_t, 4, d_R.ptr, d_t.ptr, 0.0, d_z.ptr, st.ptr))
             st.synchronize()
@@ -181,8 +188,10 @@ def measure(n_clouds=50, cell=0.0, dump_case=None, advance=10):
             errs.append(np.hypot(pose[4] - rel[0], pose[5] - rel[1])); iters.append(int(res["iters"]))
             chain_poses.append((pose[4], pose[5], np.arctan2(pose[2], pose[0]), z[0], int(res["iters"]), int(res["n_corr"])))
         icp.close()
+        chain_front_ms[:] = [ev[k][0].elapsed_ms(ev[k][1]) for k in range(1, n_clouds)]
         return t_all, errs, iters
 
+    chain_front_ms = []                                                      # device time of slam_ccicp_scene_dev per cloud (HIP events)
     chain_poses = []                                                         # (x, y, yaw, z, iterations, correspondences) per match
     run()                                                                    # warm-up: buffers, code objects
     t_model, t_create, t_front, t_icp, t_h, errs, iters, n_model, n_scene = run()
@@ -234,7 +243,8 @@ def measure(n_clouds=50, cell=0.0, dump_case=None, advance=10):
                                "through the stepwise host API"
                                % (n, len(clouds[0]))},
         "workload": "config 3: %d clouds x %d rays registered against the first through the CCICP chain" % (n, len(clouds[0])),
-        "ms_per_cloud": {"front end (segment, classify, voxel, split)": round(t_front / n * 1e3, 3),
+        "ms_per_cloud": {"front end, device chain (slam_ccicp_scene_dev: 9 launches, HIP events)": round(float(np.mean(chain_front_ms)), 3),
+                         "front end (segment, classify, voxel, split)": round(t_front / n * 1e3, 3),
                          "icp fit (one scan, host API)": round(t_icp / n * 1e3, 3), "height": round(t_h / n * 1e3, 3),
                          "total": round(total / n * 1e3, 3)},
         "clouds_per_s": n / t_chain, "rays_per_s": n * len(clouds[0]) / t_chain,
