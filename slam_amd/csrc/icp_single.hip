@@ -412,11 +412,48 @@ __device__ inline TileLds tile_lds(unsigned char *smem)
     return t;
 }
 
+// ... for a model whose index lies in LDS (behind kScratchBytes, icp_fit_spread_kernel): reduction block and header in the scratch in
+// front of it, the slots behind it; the "tile" is the index itself (tstart = its cell tables, tpts = its points)
+static_assert(kTileHeadBytes + 128u <= kScratchBytes, "the spread form's scratch holds the tile form's reduction block and header");
+constexpr unsigned kSlotBytes = 16u + 16u + 8u + 8u + 4u + 4u + 4u + 4u;
+__device__ inline TileLds tile_lds_whole(unsigned char *smem, const ModelView &mv, int slots)
+{
+    TileLds        t;
+    unsigned char *p = smem;
+    t.partial = reinterpret_cast<double *>(p);
+    t.bc = t.partial + kSW * 4 * kNumAcc;
+    p += kTileHeadBytes;
+    t.hdr = reinterpret_cast<int *>(p);
+    unsigned char *blob = smem + kScratchBytes;
+    t.tstart = reinterpret_cast<unsigned short *>(blob);
+    t.tpts = reinterpret_cast<float2 *>(blob + mv.off_pts);
+    t.rloff = t.rdelta = t.rga = nullptr;
+    p = blob + ((mv.blob_bytes + 15u) & ~15u);
+    t.P = reinterpret_cast<double2 *>(p);
+    p += 16 * slots;
+    t.snrm = reinterpret_cast<double2 *>(p);
+    p += 16 * slots;
+    t.sxy = reinterpret_cast<float2 *>(p);
+    p += 8 * slots;
+    t.scq = reinterpret_cast<float2 *>(p);
+    p += 8 * slots;
+    t.spos = reinterpret_cast<int *>(p);
+    p += 4 * slots;
+    t.sempty = reinterpret_cast<float *>(p);
+    p += 4 * slots;
+    t.sidx = reinterpret_cast<int *>(p);
+    p += 4 * slots;
+    t.snpos = reinterpret_cast<int *>(p);
+    return t;
+}
+
 // hdr words
 enum { kHdrRect = 0 /* [2][4] x_lo y_lo x_hi y_hi */, kHdrMiss = 8, kHdrValid = 9 /* [2] */, kHdrRow0 = 11 /* [2] */, kHdrSoff = 13 /* [2] */, kHdrShift = 15 /* column-group shift of class 0 | of class 1 << 8 */, kHdrScan = 16 /* [8] wave totals */, kHdrDebug = 24 /* measurement build: searches through L2 this iteration */ };
 
 struct TileCls {
     int X0, Y0, X1, Y1, row0, soff, pitch, valid, shift; // cell-table entry g of a row = the start of column X0 + (g << shift)
+    int tp_off, tp_max, whole; // the class's points begin at tpts[tp_off], tp_max of them less one; whole: the tile is the class's whole
+                               // index as it lies in LDS (a model that fits: local positions are global ones, no row offsets)
 };
 
 __device__ inline int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -433,6 +470,7 @@ __device__ inline TileCls tile_cls(const int *hdr, int c)
     t.shift = (uniform_i(hdr[kHdrShift]) >> (8 * c)) & 0xff;
     t.pitch = ((t.X1 - t.X0) >> t.shift) + 2;
     t.valid = uniform_i(hdr[kHdrValid + c]);
+    t.tp_off = 0, t.tp_max = kTilePtsMax - 1, t.whole = 0;
     return t;
 }
 
@@ -530,26 +568,27 @@ __device__ inline int tile_search(const TileCls &tc, const TileLds &tl, const La
             // (a row without cells under the disk reads its first entry twice: an empty span)
             a[r] = (int)tl.tstart[base + (on ? (xa - tc.X0) >> tc.shift : 0)];
             e[r] = (int)tl.tstart[base + (on ? ((xb - tc.X0) >> tc.shift) + 1 : 0)];
-            dl[r] = tl.rdelta[tc.row0 + tr];
+            dl[r] = tc.whole ? 0 : tl.rdelta[tc.row0 + tr];
         }
         float  d2nd = FLT_MAX;
         float2 c[4];
+        const float2 *tp = tl.tpts + tc.tp_off;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c[r] = tl.tpts[min(a[r] + lig, kTilePtsMax - 1)];
+        for (int r = 0; r < 4; ++r) c[r] = tp[min(a[r] + lig, tc.tp_max)];
 #pragma unroll
         for (int r = 0; r < 4; ++r) scan_step(b, d2nd, a[r] + lig < e[r] ? dist2(c[r], qx, qy) : FLT_MAX, a[r] + lig);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             int i = a[r] + lig + G;
             for (; i + 3 * G < e[r]; i += 4 * G) {
-                const float2 m0 = tl.tpts[i], m1 = tl.tpts[i + G], m2 = tl.tpts[i + 2 * G], m3 = tl.tpts[i + 3 * G];
+                const float2 m0 = tp[i], m1 = tp[i + G], m2 = tp[i + 2 * G], m3 = tp[i + 3 * G];
                 const float  d_0 = dist2(m0, qx, qy), d_1 = dist2(m1, qx, qy), d_2 = dist2(m2, qx, qy), d_3 = dist2(m3, qx, qy);
                 scan_step(b, d2nd, d_0, i);
                 scan_step(b, d2nd, d_1, i + G);
                 scan_step(b, d2nd, d_2, i + 2 * G);
                 scan_step(b, d2nd, d_3, i + 3 * G);
             }
-            for (; i < e[r]; i += G) scan_step(b, d2nd, dist2(tl.tpts[i], qx, qy), i);
+            for (; i < e[r]; i += G) scan_step(b, d2nd, dist2(tp[i], qx, qy), i);
         }
         tie = scan_tie(b, d2nd);
         if (G == 64) {
@@ -579,7 +618,7 @@ __device__ inline int tile_search(const TileCls &tc, const TileLds &tl, const La
             b.pos = seed_pos;
             m = seed_xy;
         } else {
-            m = tl.tpts[b.pos];
+            m = tp[b.pos];
             // the winner's row: the spans are disjoint runs of the tile
             int d = dl[0];
 #pragma unroll
@@ -608,11 +647,11 @@ __device__ inline int tile_search(const TileCls &tc, const TileLds &tl, const La
                 const int base = tc.soff + r * tc.pitch;
                 a = (int)tl.tstart[base + ((xa - tc.X0) >> tc.shift)];     // (column groups: a superset of the cells wanted)
                 e = (int)tl.tstart[base + ((xb - tc.X0) >> tc.shift) + 1];
-                dl = tl.rdelta[tc.row0 + r];
+                dl = tc.whole ? 0 : tl.rdelta[tc.row0 + r];
             }
         }
         const bool heavy = e - a > 8 * lpr;
-        if (!heavy) tile_scan(b, tie, bdelta, tl.tpts, a, e, dl, sub, lpr, qx, qy);
+        if (!heavy) tile_scan(b, tie, bdelta, tl.tpts + tc.tp_off, a, e, dl, sub, lpr, qx, qy);
         unsigned long long hm = group_bits<G>(__ballot(heavy && sub == 0), group_base);
         while (hm) {
             const int src = __builtin_ctzll(hm);
@@ -623,7 +662,7 @@ __device__ inline int tile_search(const TileCls &tc, const TileLds &tl, const La
             } else {
                 A = __shfl(a, src, G), E = __shfl(e, src, G), D = __shfl(dl, src, G);
             }
-            tile_scan(b, tie, bdelta, tl.tpts, A, E, D, lig, G, qx, qy);
+            tile_scan(b, tie, bdelta, tl.tpts + tc.tp_off, A, E, D, lig, G, qx, qy);
         }
     }
     const int mine = b.pos;
@@ -660,7 +699,7 @@ __device__ inline int tile_search(const TileCls &tc, const TileLds &tl, const La
         const unsigned long long who = group_bits<G>(__ballot(mine == b.pos), group_base);
         const int src = __builtin_ctzll(who);
         const int dl = G == 64 ? __builtin_amdgcn_readlane(bdelta, src) : __shfl(bdelta, src, G);
-        m = tl.tpts[b.pos];
+        m = tl.tpts[tc.tp_off + b.pos];
         b.pos += dl;
     }
     empty_out = __fsqrt_rn(b.d) * 0.999999f; // the class has no point nearer than its nearest
@@ -818,12 +857,16 @@ __device__ inline void tile_stage(const TileLds &tl, const ModelView &mv, const 
     __syncthreads();
 }
 
-template <int G, typename StartT, int MODE>
+// WHOLE (a model whose index fits LDS; ix points into the copy there): the tile is the index itself -- nothing is ranked (any deal of
+// the points will do) and nothing staged; what the form brings is the rest: the points and their search state in LDS slots behind the
+// index instead of global memory, the seeded search as straight code, certificates that last (config 1's own usage, one
+// 1081-beam scan against the 10 k map: 7.5 -> ... us per iteration).  slot_room: bytes of LDS behind the index.
+template <int G, typename StartT, int MODE, bool WHOLE = false>
 __device__ inline bool tile_iterations(const ModelView &mv, const FitArgs &fa, const IndexPtrs<StartT> &ix, unsigned char *smem,
                                        unsigned long long *gran, int *abort_word, unsigned long long first_ticks, int parts, int n_act, int s,
                                        int off, int n, int nga, FitState &fs, float slack_moves, float slack_cells, int tile_dbg, long long *sstamps)
 {
-    const TileLds  tl = tile_lds(smem);
+    const TileLds  tl = WHOLE ? tile_lds_whole(smem, mv, (n + n_act - 1) / n_act) : tile_lds(smem);
     double        *partial = tl.partial, *bc = tl.bc;
     const Lattice &L = mv.lat;
     const int      tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -834,6 +877,18 @@ __device__ inline bool tile_iterations(const ModelView &mv, const FitArgs &fa, c
     double r00 = fs.r00, r01 = fs.r01, r10 = fs.r10, r11 = fs.r11, t0 = fs.t0, t1 = fs.t1, delta = fs.delta;
     const double gate = MODE == SLAM_ICP_P2L ? (double)INFINITY : fa.indist; // icpPointToPlane.cpp:55-77: no gate
     const float  gate_r = MODE == SLAM_ICP_P2L ? 1.0e30f : ulp_above(ulp_above((float)sqrt(fmax(fa.indist, 0.0)))); // every inlier is nearer
+    if (WHOLE) { // the points as they come
+        if (tid < cnt) {
+            tl.sidx[tid] = lo + tid;
+            tl.P[tid] = fa.pts[off + lo + tid];
+            tl.spos[tid] = -1;
+            tl.sempty[tid] = 0.0f;
+            tl.scq[tid] = make_float2(0.0f, 0.0f);
+            tl.snpos[tid] = -1;
+        }
+        if (tid == 0) tl.hdr[kHdrMiss] = 0, tl.hdr[kHdrDebug] = 0;
+        __syncthreads();
+    } else
     // ---- the scan's points along the Morton curve of the lattice under the initial pose, class first
     {
         unsigned *keys = reinterpret_cast<unsigned *>(tl.tpts);
@@ -879,7 +934,18 @@ __device__ inline bool tile_iterations(const ModelView &mv, const FitArgs &fa, c
     int      iters = 0, n_corr = 0, restages = 0, missed = 0;
     bool     staged = false;
     float    move_r = 0.0f, move_t = 0.0f;
-    TileCls  tc0 = tile_cls(tl.hdr, 0), tc1 = tile_cls(tl.hdr, 1);
+    TileCls  tc0, tc1;
+    if (WHOLE) {
+        tc0.X0 = tc0.Y0 = 0, tc0.X1 = L.nx - 1, tc0.Y1 = L.ny - 1, tc0.row0 = 0, tc0.shift = 0, tc0.pitch = L.nx, tc0.whole = 1;
+        tc1 = tc0;
+        tc0.soff = (int)(mv.off_start[0] / sizeof(StartT)), tc1.soff = (int)(mv.off_start[1] / sizeof(StartT));
+        tc0.tp_off = mv.base[0], tc1.tp_off = mv.base[1];
+        tc0.tp_max = max(mv.n_cls[0] - 1, 0), tc1.tp_max = max(mv.n_cls[1] - 1, 0);
+        tc0.valid = mv.n_cls[0] > 0, tc1.valid = mv.n_cls[1] > 0;
+        staged = true; // (nothing to stage, ever)
+    } else {
+        tc0 = tile_cls(tl.hdr, 0), tc1 = tile_cls(tl.hdr, 1);
+    }
     for (int iter = 0; iter < fa.max_iter; ++iter) {
         double acc[kNumAcc];
 #pragma unroll
@@ -891,7 +957,7 @@ __device__ inline bool tile_iterations(const ModelView &mv, const FitArgs &fa, c
             sp[0] = r00, sp[1] = r01, sp[2] = r10, sp[3] = r11, sp[4] = t0, sp[5] = t1;
         }
         // (re)stage: after the first step, and when a query has left its rectangle
-        if (iter >= 1 && (!staged || (missed != 0 && restages < kTileRestage))) {
+        if (!WHOLE && iter >= 1 && (!staged || (missed != 0 && restages < kTileRestage))) {
             if (staged) ++restages;
             staged = true;
 #ifdef SLAM_MEASURE
@@ -1084,8 +1150,8 @@ __device__ inline void spread_finish(const FitArgs &fa, const FitState &fs, int 
 // grid (parts, n_scans); a workgroup whose scan does not need it exits at once
 template <typename StartT, bool LDS, int MODE>
 __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitArgs fa, unsigned long long *gran, int *flags /* [2][n_scans] abort | redo */,
-                                                                unsigned long long first_ticks, float2 *qstate, int qcap, int wide_max, int tile_on, int tile_lanes, float slack_moves,
-                                                                float slack_cells, long long *sstamps)
+                                                                unsigned long long first_ticks, float2 *qstate, int qcap, int wide_max, int tile_on, int tile_lanes, int slot_room,
+                                                                float slack_moves, float slack_cells, long long *sstamps)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int s = blockIdx.y, parts = (int)gridDim.x, part = blockIdx.x;
@@ -1122,6 +1188,10 @@ __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitAr
         const int na = want < 1 ? 1 : (want > parts ? parts : want);
         if (n <= kTileMaxN && (n + na - 1) / na <= kTileSlots) tiled = true, n_act = na;
     }
+    if (LDS && tile_on) { // the index in LDS is its own tile: the form's slots go behind it, if they fit
+        const int q = (n + n_act - 1) / n_act;
+        if (q <= kSB && (int)kSlotBytes * q <= slot_room) tiled = true;
+    }
     if (part >= n_act) return;
     const unsigned char *base = mv.blob;
     if (LDS) {
@@ -1144,9 +1214,9 @@ __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitAr
     fs.n_corr = 0;
     fs.hand_over = false;
     unsigned long long *g = gran + (size_t)s * 2 * parts * kGranPerWg;
-    if (!LDS && tiled) {
-        const bool okt = wide ? tile_iterations<64, StartT, MODE>(mv, fa, ix, smem, g, flags + s, first_ticks, parts, n_act, s, off, n, nga, fs, slack_moves, slack_cells, tile_on, sstamps)
-                              : tile_iterations<16, StartT, MODE>(mv, fa, ix, smem, g, flags + s, first_ticks, parts, n_act, s, off, n, nga, fs, slack_moves, slack_cells, tile_on, sstamps);
+    if (tiled) {
+        const bool okt = wide ? tile_iterations<64, StartT, MODE, LDS>(mv, fa, ix, smem, g, flags + s, first_ticks, parts, n_act, s, off, n, nga, fs, slack_moves, slack_cells, tile_on, sstamps)
+                              : tile_iterations<16, StartT, MODE, LDS>(mv, fa, ix, smem, g, flags + s, first_ticks, parts, n_act, s, off, n, nga, fs, slack_moves, slack_cells, tile_on, sstamps);
         spread_finish(fa, fs, flags, s, okt);
         return;
     }
@@ -1244,7 +1314,7 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
     // gives a query 64 lanes).  On a model of a few points per cell a search through L2 is three or four dependent loads, the pass is
     // bound by its instructions either way, and staging costs what the tiles save (2 x 19 999 room points, one 1081-beam scan:
     // 200 us per fit without tiles, 212 with) -- there the form is taken only when asked for (spread_tile = 1).
-    int   tile_on = h->prm.spread_tile > 0 || (h->prm.spread_tile == 0 && h->max_cell_points > kDenseCell) ? 1 : 0;
+    int   tile_on = h->prm.spread_tile > 0 || (h->prm.spread_tile == 0 && (h->in_lds || h->max_cell_points > kDenseCell)) ? 1 : 0;
     float slack_moves = 3.0f, slack_cells = 1.0f;
     int   tile_lanes = kSB; // lanes of a workgroup with a scene point in a pass (icp_fit_spread_kernel)
 #ifdef SLAM_MEASURE
@@ -1254,19 +1324,24 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
     if (const char *e = getenv("SLAM_TILE_LANES")) tile_lanes = std::min(std::max(atoi(e), 64), (int)kSB);
 #endif
     const size_t global_lds = tile_on ? (size_t)kTileLdsBytes : (size_t)kScratchBytes;
+    // an index in LDS: the tile form's slots behind it, as many as the CU's 160 KB leave (64 bytes per scene point of a workgroup)
+    const size_t lds_top = ((h->lds_bytes + 15) & ~(size_t)15);
+    const int    slot_room = h->in_lds && tile_on && lds_top < kLdsTotal ? (int)std::min<size_t>(kLdsTotal - lds_top, (size_t)kSlotBytes * kSB) : 0;
     if (h->in_lds) {
         auto kern = p2l ? icp_fit_spread_kernel<uint16_t, true, SLAM_ICP_P2L> : icp_fit_spread_kernel<uint16_t, true, SLAM_ICP_P2P>;
         SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-        hipLaunchKernelGGL(kern, grid, dim3(kSB), h->lds_bytes, st, h->mv, fa_tagged, gran, flags, first_ticks, qstate, qcap, wide_max, 0, kSB, 0.0f, 0.0f, sstamps);
+        SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(lds_top + slot_room)));
+        hipLaunchKernelGGL(kern, grid, dim3(kSB), lds_top + slot_room, st, h->mv, fa_tagged, gran, flags, first_ticks, qstate, qcap, wide_max, tile_on, kSB, slot_room,
+                           0.0f, 0.0f, sstamps);
     } else if (h->start32) {
         auto kern = p2l ? icp_fit_spread_kernel<uint32_t, false, SLAM_ICP_P2L> : icp_fit_spread_kernel<uint32_t, false, SLAM_ICP_P2P>;
         SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)global_lds));
-        hipLaunchKernelGGL(kern, grid, dim3(kSB), global_lds, st, h->mv, fa_tagged, gran, flags, first_ticks, qstate, qcap, wide_max, tile_on, tile_lanes, slack_moves,
+        hipLaunchKernelGGL(kern, grid, dim3(kSB), global_lds, st, h->mv, fa_tagged, gran, flags, first_ticks, qstate, qcap, wide_max, tile_on, tile_lanes, 0, slack_moves,
                            slack_cells, sstamps);
     } else {
         auto kern = p2l ? icp_fit_spread_kernel<uint16_t, false, SLAM_ICP_P2L> : icp_fit_spread_kernel<uint16_t, false, SLAM_ICP_P2P>;
         SLAM_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)global_lds));
-        hipLaunchKernelGGL(kern, grid, dim3(kSB), global_lds, st, h->mv, fa_tagged, gran, flags, first_ticks, qstate, qcap, wide_max, tile_on, tile_lanes, slack_moves,
+        hipLaunchKernelGGL(kern, grid, dim3(kSB), global_lds, st, h->mv, fa_tagged, gran, flags, first_ticks, qstate, qcap, wide_max, tile_on, tile_lanes, 0, slack_moves,
                            slack_cells, sstamps);
     }
     SLAM_HIP(hipGetLastError());
