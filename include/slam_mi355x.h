@@ -149,13 +149,14 @@ typedef struct {
                                with this set, the first whose HALO is at least this many metres, if one fits (any, otherwise).  A
                                list answers a query whose neighbour is nearer than its halo; the others go to the cooperative
                                round.  0 = library default, < 0 = no preference (the finest that fits) */
-    int    spread_tile;     /* spread form against a model whose index does not fit LDS (one cloud at a time against up to 2 x 19 999
-                               points: scan_registration.cpp:139-159, icpTools.h:21): every workgroup takes scene points that are
-                               neighbours in space, keeps them and their search state in LDS and stages the TILE of the index they can
-                               reach -- searches run on the tile, a query that leaves it goes through L2 (icp_single.hip, DESIGN.md
-                               4.1b).  Same correspondences; the sums in another order.  0 = library default: for models with cells of
-                               more than 64 points (a lidar cloud's walls; config 3: 0.45 -> 0.23 ms per fit), 1 = whenever the index is
-                               not in LDS, -1 = never */
+    int    spread_tile;     /* spread form (one cloud at a time against up to 2 x 19 999 points: scan_registration.cpp:139-159,
+                               icpTools.h:21): every workgroup keeps its scene points and their search state -- last neighbour, radius
+                               proved empty -- in LDS for the whole fit and searches from last iteration's neighbour in straight-line
+                               code (icp_single.hip).  For a model that does not fit LDS the workgroups take scene points
+                               that are neighbours in space and either (1) stage the TILE of the index they can reach into LDS -- for
+                               cells of more than 64 points, a lidar cloud's walls: config 3 0.45 -> 0.22 ms per fit -- or (2) search the
+                               index where it lies.  Same correspondences; the sums in another order.  0 = library default (by the
+                               model), 1 / 2 = that form wherever the index is not in LDS, -1 = the round-5 form */
 } slam_icp_params;
 
 typedef struct {

@@ -535,10 +535,11 @@ __device__ inline void tile_scan(Best &b, bool &tie, int &bdelta, const float2 *
 // The seeded search on the tile, for a seed at squared distance d0 from the query.  0: done -- b.d, b.pos (class-relative GLOBAL
 // position), m (the neighbour), empty_out as the search on the index would leave them; 1: the seed's disk is not inside the tile's
 // rectangle; 2: an exact tie (the exact search decides).
-template <int G>
+template <int G, typename TS = unsigned short /* an entry of the cell tables: 16 bits in a tile and in an LDS index, StartT in HBM/L2 */>
 __device__ inline int tile_search(const TileCls &tc, const TileLds &tl, const Lattice &L, float qx, float qy, int lig, float d0, int seed_pos,
                                   float2 seed_xy, Best &b, float2 &m, float &empty_out)
 {
+    const TS *tstart = reinterpret_cast<const TS *>(tl.tstart);
     const float rad = disk_radius(d0);
     const float fx = (qx - L.x0) * L.inv_h, fy = (qy - L.y0) * L.inv_h;
     const float R = (rad + L.margin) * L.inv_h;
@@ -566,8 +567,8 @@ __device__ inline int tile_search(const TileCls &tc, const TileLds &tl, const La
             const bool  on = (y <= y_hi) & (xa <= xb);
             const int   tr = min(y, y_hi) - tc.Y0, base = tc.soff + tr * tc.pitch;
             // (a row without cells under the disk reads its first entry twice: an empty span)
-            a[r] = (int)tl.tstart[base + (on ? (xa - tc.X0) >> tc.shift : 0)];
-            e[r] = (int)tl.tstart[base + (on ? ((xb - tc.X0) >> tc.shift) + 1 : 0)];
+            a[r] = (int)tstart[base + (on ? (xa - tc.X0) >> tc.shift : 0)];
+            e[r] = (int)tstart[base + (on ? ((xb - tc.X0) >> tc.shift) + 1 : 0)];
             dl[r] = tc.whole ? 0 : tl.rdelta[tc.row0 + tr];
         }
         float  d2nd = FLT_MAX;
@@ -645,8 +646,8 @@ __device__ inline int tile_search(const TileCls &tc, const TileLds &tl, const La
             if (xa <= xb) {
                 const int r = y - tc.Y0;
                 const int base = tc.soff + r * tc.pitch;
-                a = (int)tl.tstart[base + ((xa - tc.X0) >> tc.shift)];     // (column groups: a superset of the cells wanted)
-                e = (int)tl.tstart[base + ((xb - tc.X0) >> tc.shift) + 1];
+                a = (int)tstart[base + ((xa - tc.X0) >> tc.shift)];     // (column groups: a superset of the cells wanted)
+                e = (int)tstart[base + ((xb - tc.X0) >> tc.shift) + 1];
                 dl = tc.whole ? 0 : tl.rdelta[tc.row0 + r];
             }
         }
@@ -861,12 +862,18 @@ __device__ inline void tile_stage(const TileLds &tl, const ModelView &mv, const 
 // the points will do) and nothing staged; what the form brings is the rest: the points and their search state in LDS slots behind the
 // index instead of global memory, the seeded search as straight code, certificates that last (config 1's own usage, one
 // 1081-beam scan against the 10 k map: 7.5 -> ... us per iteration).  slot_room: bytes of LDS behind the index.
-template <int G, typename StartT, int MODE, bool WHOLE = false>
+// WHOLE = 2: the index where it lies in HBM/L2, for models of a few points per cell (staging tiles costs what they save there): the
+// same slots, certificates and straight-line seeded search, its three dependent round trips through L2 instead of LDS.
+template <int G, typename StartT, int MODE, int WHOLE = 0>
 __device__ inline bool tile_iterations(const ModelView &mv, const FitArgs &fa, const IndexPtrs<StartT> &ix, unsigned char *smem,
                                        unsigned long long *gran, int *abort_word, unsigned long long first_ticks, int parts, int n_act, int s,
                                        int off, int n, int nga, FitState &fs, float slack_moves, float slack_cells, int tile_dbg, long long *sstamps)
 {
-    const TileLds  tl = WHOLE ? tile_lds_whole(smem, mv, (n + n_act - 1) / n_act) : tile_lds(smem);
+    TileLds        tl = WHOLE == 1 ? tile_lds_whole(smem, mv, (n + n_act - 1) / n_act) : tile_lds(smem);
+    if (WHOLE == 2) {
+        tl.tstart = reinterpret_cast<unsigned short *>(const_cast<unsigned char *>(mv.blob));
+        tl.tpts = reinterpret_cast<float2 *>(const_cast<unsigned char *>(mv.blob + mv.off_pts));
+    }
     double        *partial = tl.partial, *bc = tl.bc;
     const Lattice &L = mv.lat;
     const int      tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -961,10 +968,10 @@ __device__ inline bool tile_iterations(const ModelView &mv, const FitArgs &fa, c
             if (staged) ++restages;
             staged = true;
 #ifdef SLAM_MEASURE
-            if (tile_dbg & 6) { // what a staging costs warm: first the same tile (2) or one three metres off (4), then the real one
+            if (tile_dbg & 12) { // what a staging costs warm: first the same tile (2) or one three metres off (4), then the real one
                 Pose Tx = T;
-                if (tile_dbg & 4) Tx.t0 += 3.0, Tx.t1 += 3.0;
-                tile_stage<StartT, MODE>(tl, mv, ix, Tx, cnt, nga, tile_dbg & 4 ? (double)INFINITY : gate, move_r, move_t, slack_moves, slack_cells);
+                if (tile_dbg & 8) Tx.t0 += 3.0, Tx.t1 += 3.0;
+                tile_stage<StartT, MODE>(tl, mv, ix, Tx, cnt, nga, tile_dbg & 8 ? (double)INFINITY : gate, move_r, move_t, slack_moves, slack_cells);
                 SPREAD_STAMP(1);
             }
 #endif
@@ -1014,7 +1021,9 @@ __device__ inline bool tile_iterations(const ModelView &mv, const FitArgs &fa, c
                     if (!done && spos >= 0) {
                         const float d0 = dist2(sxy, qx, qy);
                         if ((double)d0 < gate) { // the seed is an inlier: the nearest point lies in the seed's disk
-                            const int st = tc.valid ? tile_search<G>(tc, tl, L, qx, qy, lig, d0, spos, sxy, b, m, empty) : 1;
+                            const int st = !tc.valid ? 1
+                                           : (WHOLE == 2 ? tile_search<G, StartT>(tc, tl, L, qx, qy, lig, d0, spos, sxy, b, m, empty)
+                                                         : tile_search<G>(tc, tl, L, qx, qy, lig, d0, spos, sxy, b, m, empty));
 
                             done = st == 0;
                             if (st == 1 && lig == 0) tl.hdr[kHdrMiss] = 1; // the workgroup stages again before the next iteration
@@ -1183,11 +1192,12 @@ __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitAr
     // 237 -> 266 us per fit; 128 lanes: 326)
     int  n_act = active_parts(n, wide ? 64 : 16, parts);
     bool tiled = false;
-    if (!LDS && tile_on) {
+    if (!LDS && (tile_on & 3) == 1) { // tiles staged into LDS
         const int want = (int)(((long long)n * (wide ? 64 : 16) + tile_lanes - 1) / tile_lanes);
         const int na = want < 1 ? 1 : (want > parts ? parts : want);
         if (n <= kTileMaxN && (n + na - 1) / na <= kTileSlots) tiled = true, n_act = na;
     }
+    if (!LDS && (tile_on & 3) == 2 && (n + n_act - 1) / n_act <= kTileSlots) tiled = true; // the index where it lies, slots in LDS
     if (LDS && tile_on) { // the index in LDS is its own tile: the form's slots go behind it, if they fit
         const int q = (n + n_act - 1) / n_act;
         if (q <= kSB && (int)kSlotBytes * q <= slot_room) tiled = true;
@@ -1215,8 +1225,16 @@ __global__ __launch_bounds__(kSB) void icp_fit_spread_kernel(ModelView mv, FitAr
     fs.hand_over = false;
     unsigned long long *g = gran + (size_t)s * 2 * parts * kGranPerWg;
     if (tiled) {
-        const bool okt = wide ? tile_iterations<64, StartT, MODE, LDS>(mv, fa, ix, smem, g, flags + s, first_ticks, parts, n_act, s, off, n, nga, fs, slack_moves, slack_cells, tile_on, sstamps)
-                              : tile_iterations<16, StartT, MODE, LDS>(mv, fa, ix, smem, g, flags + s, first_ticks, parts, n_act, s, off, n, nga, fs, slack_moves, slack_cells, tile_on, sstamps);
+        bool okt;
+        if (LDS)
+            okt = wide ? tile_iterations<64, StartT, MODE, LDS ? 1 : 0>(mv, fa, ix, smem, g, flags + s, first_ticks, parts, n_act, s, off, n, nga, fs, slack_moves, slack_cells, tile_on, sstamps)
+                       : tile_iterations<16, StartT, MODE, LDS ? 1 : 0>(mv, fa, ix, smem, g, flags + s, first_ticks, parts, n_act, s, off, n, nga, fs, slack_moves, slack_cells, tile_on, sstamps);
+        else if ((tile_on & 3) == 2)
+            okt = wide ? tile_iterations<64, StartT, MODE, LDS ? 1 : 2>(mv, fa, ix, smem, g, flags + s, first_ticks, parts, n_act, s, off, n, nga, fs, slack_moves, slack_cells, tile_on, sstamps)
+                       : tile_iterations<16, StartT, MODE, LDS ? 1 : 2>(mv, fa, ix, smem, g, flags + s, first_ticks, parts, n_act, s, off, n, nga, fs, slack_moves, slack_cells, tile_on, sstamps);
+        else
+            okt = wide ? tile_iterations<64, StartT, MODE, LDS ? 1 : 0>(mv, fa, ix, smem, g, flags + s, first_ticks, parts, n_act, s, off, n, nga, fs, slack_moves, slack_cells, tile_on, sstamps)
+                       : tile_iterations<16, StartT, MODE, LDS ? 1 : 0>(mv, fa, ix, smem, g, flags + s, first_ticks, parts, n_act, s, off, n, nga, fs, slack_moves, slack_cells, tile_on, sstamps);
         spread_finish(fa, fs, flags, s, okt);
         return;
     }
@@ -1310,20 +1328,23 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
     const bool p2l = h->prm.mode == SLAM_ICP_P2L; // the nine sums and the solve differ, nothing else
     // the tile form (an index in HBM/L2 only): how far a tile reaches beyond its queries' disks -- slack_moves times a query's last
     // move plus slack_cells lattice cells
-    // Tiles pay where a search through L2 is long: cells of hundreds of points (a lidar cloud's stacked wall points; the same test that
-    // gives a query 64 lanes).  On a model of a few points per cell a search through L2 is three or four dependent loads, the pass is
-    // bound by its instructions either way, and staging costs what the tiles save (2 x 19 999 room points, one 1081-beam scan:
-    // 200 us per fit without tiles, 212 with) -- there the form is taken only when asked for (spread_tile = 1).
-    int   tile_on = h->prm.spread_tile > 0 || (h->prm.spread_tile == 0 && (h->in_lds || h->max_cell_points > kDenseCell)) ? 1 : 0;
+    // Which form (slam_icp_params::spread_tile; 0 = by the model).  Tiles staged into LDS pay where a search through L2 is long: cells
+    // of hundreds of points (a lidar cloud's stacked wall points; the same test that gives a query 64 lanes).  On a model of a few
+    // points per cell a search through L2 is a few dependent loads and staging costs what the tiles save (2 x 19 999 room points, one
+    // 1081-beam scan: 187 us per fit in the plain form, 209 with tiles): there the index stays where it is and the form brings its
+    // slots, certificates and straight-line seeded search (form 2).  An index in LDS is its own tile.
+    const int form = h->prm.spread_tile > 0 ? std::min(h->prm.spread_tile, 2) : (h->max_cell_points > kDenseCell ? 1 : 2);
+    int       tile_on = h->prm.spread_tile < 0 ? 0 : (h->in_lds ? 1 : form);
     float slack_moves = 3.0f, slack_cells = 1.0f;
     int   tile_lanes = kSB; // lanes of a workgroup with a scene point in a pass (icp_fit_spread_kernel)
 #ifdef SLAM_MEASURE
-    if (const char *e = getenv("SLAM_SPREAD_TILE")) tile_on = atoi(e); // 0 off, 1 on, +2 / +4: the first staging done twice (tile_iterations)
+    if (const char *e = getenv("SLAM_SPREAD_TILE")) tile_on = atoi(e); // 0 off, 1 tiles, 2 the index where it lies; +4 / +8: the first staging done twice
     if (const char *e = getenv("SLAM_TILE_SLACK_MOVES")) slack_moves = (float)atof(e);
     if (const char *e = getenv("SLAM_TILE_SLACK_CELLS")) slack_cells = (float)atof(e);
     if (const char *e = getenv("SLAM_TILE_LANES")) tile_lanes = std::min(std::max(atoi(e), 64), (int)kSB);
 #endif
-    const size_t global_lds = tile_on ? (size_t)kTileLdsBytes : (size_t)kScratchBytes;
+    const size_t global_lds = (tile_on & 3) == 1 ? (size_t)kTileLdsBytes
+                              : ((tile_on & 3) == 2 ? (size_t)(kTileHeadBytes + 128u + kTileSlots * kSlotBytes) : (size_t)kScratchBytes);
     // an index in LDS: the tile form's slots behind it, as many as the CU's 160 KB leave (64 bytes per scene point of a workgroup)
     const size_t lds_top = ((h->lds_bytes + 15) & ~(size_t)15);
     const int    slot_room = h->in_lds && tile_on && lds_top < kLdsTotal ? (int)std::min<size_t>(kLdsTotal - lds_top, (size_t)kSlotBytes * kSB) : 0;

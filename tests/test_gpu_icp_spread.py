@@ -272,8 +272,9 @@ def test_tile_form_on_config3_matches():
     plain.close()
 
 
+@pytest.mark.parametrize("form", [1, 2])
 @pytest.mark.parametrize("mode", ["p2p", "p2l"])
-def test_tile_form_far_starts_and_many_scans(mode):
+def test_tile_form_far_starts_and_many_scans(mode, form):
     """Starts 0.6 m / 0.1 rad off (queries leave their first tiles: searches through L2 and stagings until the budget is spent),
     1, 3 and 16 scans per launch (256, 85, 16 workgroups each: one to five passes of slots per workgroup), both solvers, against
     the oracle and the form without tiles."""
@@ -281,7 +282,7 @@ def test_tile_form_far_starts_and_many_scans(mode):
     kw = dict(mode=api.ICP_P2L, normals_k=10) if mode == "p2l" else {}
     omode = (O.NN_KDTREE, O.MODE_P2L) if mode == "p2l" else (O.NN_KDTREE,)
     model = O.IcpModel(m_ga, m_nga, **({"normals_k": 10} if mode == "p2l" else {}))
-    icp = api.Icp(m_ga, m_nga, max_iter=25, min_delta=1e-6, spread_tile=1, **kw)
+    icp = api.Icp(m_ga, m_nga, max_iter=25, min_delta=1e-6, spread_tile=form, **kw)   # 1: tiles staged into LDS, 2: the index where it lies
     plain = api.Icp(m_ga, m_nga, max_iter=25, min_delta=1e-6, spread_tile=-1, **kw)
     for n_scans in (1, 3, 16):
         batch = synth.make_batch(n_scans, n_loop=256)
@@ -301,7 +302,8 @@ def test_tile_form_far_starts_and_many_scans(mode):
     plain.close()
 
 
-def test_tile_form_ties_and_ragged_scans():
+@pytest.mark.parametrize("form", [1, 2])
+def test_tile_form_ties_and_ragged_scans(form):
     """The edge cases of test_spread_edge_cases with the index kept in HBM/L2 (the tile form): exact distance ties on a gridded
     model with duplicates leave the tile for the exact search (lowest original index, the brute-force arbiter's rule), scans
     below 5 points, without correspondences, with a skipped class; plus a scan of 2049 points (beyond the tile form: the same
@@ -321,7 +323,7 @@ def test_tile_form_ties_and_ragged_scans():
     Rs, ts = np.tile(R0.reshape(4), (6, 1)), np.tile(t0, (6, 1))
     Rs[0], ts[0] = [1, 0, 0, 1], [0, 0]
     batch = synth.ScanBatch(np.ascontiguousarray(np.concatenate(scans)), off, np.array(nga, np.int32), Rs, ts, np.zeros((6, 3)))
-    icp, R, t, res, _ = check_against_oracle(m_ga, m_nga, batch, 15, 1e-6, nn=O.NN_BRUTE, force_global=1, spread_tile=1)
+    icp, R, t, res, _ = check_against_oracle(m_ga, m_nga, batch, 15, 1e-6, nn=O.NN_BRUTE, force_global=1, spread_tile=form)
     assert not icp.index_info()["in_lds"]
     assert res["iters"][1] == 0 and np.array_equal(R[1], R0.reshape(4)) and np.array_equal(t[1], t0)
     assert (res["iters"][2], res["n_corr"][2], res["delta"][2]) == (1, 0, -1.0)
