@@ -172,7 +172,8 @@ for name in ("bench.json", "config3.json", "config4.json", "config5.json", "buil
             except ValueError:
                 pass
 # the side runs: kernel stats of the merged raycast, config 3 and the index build; counters of the merged raycast
-for sub, out in (("stats_merge", "raycast_merge_kernel_stats.csv"), ("stats_c3", "config3_kernel_stats.csv"), ("stats_build", "build_kernel_stats.csv")):
+for sub, out in (("stats_merge", "raycast_merge_kernel_stats.csv"), ("stats_c3", "config3_kernel_stats.csv"), ("stats_build", "build_kernel_stats.csv"),
+                 ("stats_c3cpp", "config3_cpp_kernel_stats.csv")):
     st = sorted(glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv")), key=os.path.getmtime)
     if st:
         rows = list(csv.DictReader(open(st[-1])))
@@ -181,6 +182,33 @@ for sub, out in (("stats_merge", "raycast_merge_kernel_stats.csv"), ("stats_c3",
             w.writerow(["kernel", "calls", "total_ns", "avg_ns", "pct", "min_ns", "max_ns"])
             for r in rows:
                 w.writerow([kname(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
+# round 6: launches per match of the C++ adapter's default path, from the kernel trace of the binary (2 passes x 19 matches; the
+# target is replaced every 10 clouds: its launches -- index build, bin order -- are told apart by their count)
+tr = sorted(glob.glob(os.path.join(src, "stats_c3cpp", "*", "*kernel_stats.csv")), key=os.path.getmtime)
+if tr:
+    rows = list(csv.DictReader(open(tr[-1])))
+    fits = sum(int(r["Calls"]) for r in rows if "icp_fit_spread_kernel" in r["Name"])
+    per_match, elsewhere = {}, {}
+    for r in rows:
+        (per_match if int(r["Calls"]) >= fits else elsewhere)[kname(r["Name"])] = (per_match if int(r["Calls"]) >= fits else elsewhere).get(kname(r["Name"]), 0) + int(r["Calls"])
+    try:
+        line = json.loads([l for l in open(os.path.join(src, "config3_cpp_profiled.json")) if l.startswith("{")][-1])
+    except Exception:
+        line = None
+    json.dump({"matches_traced": fits,
+               "launches_per_match": round(sum(per_match.values()) / max(fits, 1), 2),
+               "kernels_launched_at_least_once_per_match": per_match,
+               "kernels_of_the_target_updates_and_start_up": elsewhere,
+               "runtime_copy_or_fill_kernels_per_match": round(sum(v for k, v in per_match.items() if "rocclr" in k) / max(fits, 1), 2),
+               "line_of_the_traced_run": line,
+               "what": "rocprofv3 --kernel-trace --stats of tests/cpp/ccicp_sequence (form seq: setSceneCloud + doICPMatch per cloud, "
+                       "20 clouds, target replaced every 10, two passes); a kernel counts towards a match when it was launched at least "
+                       "once per match"},
+              open(os.path.join(dst, tag + "_config3_launches.json"), "w"), indent=1)
+for name, out in (("spread_time.json", "spread_time.json"), ("spread_stamps.json", "spread_stamps.json"), ("latency_chase.txt", "latency_chase.txt")):
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p):
+        shutil.copy(p, os.path.join(dst, tag + "_" + out))
 macc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(src, "pmc_merge", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
