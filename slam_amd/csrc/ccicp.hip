@@ -22,7 +22,7 @@ using namespace slam;
 
 namespace {
 
-constexpr int kItems = 4096; // cells / points per compaction block
+constexpr int kItems = 1024; // cells / points per compaction block (round 6: 4096 -- a 131 072-point cloud was 32 blocks on 256 CUs)
 constexpr int kScanThreads = 256;
 constexpr double kFix = 16777216.0; // 2^24: coordinates summed as 64-bit fixed point (exact, order-free)
 
@@ -583,7 +583,11 @@ __global__ __launch_bounds__(kScanThreads) void compact1_kernel(Pred pred, Emit 
     const long long n = dom.size();
     constexpr int   kPer = kItems / kScanThreads;
     const long long base = (long long)blockIdx.x * kItems + (long long)threadIdx.x * kPer;
-    const int       lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x, nb = gridDim.x;
+    // the blocks that have items (the launch is sized for the capacity, the count may be the device's: a voxel lattice of a few
+    // thousand cells in an accumulator of two million): the others leave at once, the last of THESE runs the tail
+    const int nb = (int)min((long long)gridDim.x, max((n + kItems - 1) / kItems, 1ll));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
+    if (b >= nb) return;
     unsigned        mask[NC];
     int             cnt[NC], x[NC];
 #pragma unroll
