@@ -102,6 +102,19 @@ __device__ inline double gp_cov(double r1, double r2, float sig_f, float p_l)
     return (double)sig_f * exp((double)coeff * (diff * diff));
 }
 
+#ifdef SLAM_MEASURE
+__device__ long long g_insac_dbg[NA][8]; // ticks of 10 ns per sector: setup, matrix, factorisation, solves, candidates, verdict; [6] rounds
+#define INSAC_T(k)                                                          \
+    do {                                                                    \
+        if (tid == 0) {                                                     \
+            const long long now_ = (long long)__builtin_amdgcn_s_memrealtime(); \
+            g_insac_dbg[sec][k] += now_ - t_last_;                          \
+            t_last_ = now_;                                                 \
+        }                                                                   \
+    } while (0)
+#else
+#define INSAC_T(k) do { } while (0)
+#endif
 // One workgroup per sector: :196-468 up to the per-bin verdict
 //   state[b] = 1: bin is in the ground model, value = its prototype height
 //   state[b] = 2: bin stayed a candidate, value = GP mean f_s at its range
@@ -121,7 +134,11 @@ __global__ __launch_bounds__(kSecThreads) void gseg_insac_kernel(GsegParams p, c
 
     const int    sec = blockIdx.x, tid = threadIdx.x;
     const float  sf = (float)p.p_sf, pl = (float)p.p_l;
-    double      *Lm = scratch + (size_t)sec * NL * NL; // lower-triangular factor, row-major [i*NL + j]
+    double      *Lm = scratch + (size_t)sec * NL * NL; // lower-triangular factor, row-major [i*NL + j] 
+#ifdef SLAM_MEASURE
+    long long t_last_ = (long long)__builtin_amdgcn_s_memrealtime();
+    if (tid < 8) g_insac_dbg[sec][tid] = 0;
+#endif
 
     // ---- signal points :205-219
     for (int b = tid; b < NL; b += kSecThreads) {
@@ -138,131 +155,211 @@ __global__ __launch_bounds__(kSecThreads) void gseg_insac_kernel(GsegParams p, c
         t_idx[b] = b;
     }
     __syncthreads();
-    // ---- sort by (height, bin) :229 : rank of every valid entry by counting
-    for (int b = tid; b < NL; b += kSecThreads) {
-        if (!t_valid[b]) continue;
-        int rank = 0;
-        for (int o = 0; o < NL; ++o)
-            if (t_valid[o] && (t_height[o] < t_height[b] || (t_height[o] == t_height[b] && o < b))) ++rank;
+    // ---- sort by (height, bin) :229 : the signal bins gathered (a few dozen of the 200), then the rank of each among them by counting
+    // (round 6: the counts, the sort over the signal bins only and the seed selection by the whole workgroup -- one thread walking
+    // 200 LDS words, every thread ranking against all 200 bins, one thread walking the sorted list: 16 of the kernel's 38 us per sector)
+    __shared__ int s_wcnt[kSecThreads / 64];
+    __shared__ int v_bin[NL];
+    {
+        const bool               valid = tid < NL && t_valid[tid];
+        const unsigned long long vm = __ballot(valid);
+        if ((tid & 63) == 0) s_wcnt[tid >> 6] = __popcll(vm);
+        __syncthreads();
+        int at = __popcll(vm & ((1ull << (tid & 63)) - 1ull));
+        for (int w = 0; w < (tid >> 6); ++w) at += s_wcnt[w];
+        if (valid) v_bin[at] = tid;
+    }
+    const int ns0 = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    __syncthreads();
+    if (tid < ns0) {
+        const int    b = v_bin[tid];
+        const double hb = t_height[b];
+        int          rank = 0;
+        for (int o = 0; o < ns0; ++o) {
+            const int    ob = v_bin[o];
+            const double ho = t_height[ob];
+            rank += (ho < hb || (ho == hb && ob < b)) ? 1 : 0;
+        }
         s_range[rank] = t_range[b];
         s_height[rank] = t_height[b];
         s_idx[rank] = b;
     }
-    if (tid == 0) {
-        int ns = 0;
-        for (int b = 0; b < NL; ++b) ns += t_valid[b];
-        s_ns = ns;
-    }
     __syncthreads();
-    // ---- seeds :235-277: the first npt sorted entries that pass the gates
-    if (tid == 0) {
-        int       ns = s_ns, nm = 0;
-        const int npt = ns < p.num_seedpoints ? ns : p.num_seedpoints;
-        int       w = 0; // write cursor of the compacted candidate list
-        for (int r = 0; r < ns; ++r) {
-            const bool take = nm < npt && s_range[r] < p.max_seed_range && fabs(s_height[r]) < p.max_seed_height;
+    // ---- seeds :235-277: the first npt sorted entries that pass the gates; the others, in order, are the candidates
+    {
+        const int  npt = ns0 < p.num_seedpoints ? ns0 : p.num_seedpoints;
+        const bool pass = tid < ns0 && s_range[tid] < p.max_seed_range && fabs(s_height[tid]) < p.max_seed_height;
+        const unsigned long long pm = __ballot(pass);
+        if ((tid & 63) == 0) s_wcnt[tid >> 6] = __popcll(pm);
+        __syncthreads();
+        int before = __popcll(pm & ((1ull << (tid & 63)) - 1ull)); // passes in front of this entry
+        for (int w = 0; w < (tid >> 6); ++w) before += s_wcnt[w];
+        const int  all_pass = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        const int  nm = all_pass < npt ? all_pass : npt, taken_before = before < npt ? before : npt;
+        const bool take = pass && before < npt;
+        if (tid < ns0) {
             if (take) {
-                m_range[nm] = s_range[r];
-                m_height[nm] = s_height[r];
-                m_idx[nm] = s_idx[r];
-                ++nm;
-            } else {
-                s_range[w] = s_range[r];
-                s_height[w] = s_height[r];
-                s_idx[w] = s_idx[r];
-                ++w;
+                m_range[before] = s_range[tid];
+                m_height[before] = s_height[tid];
+                m_idx[before] = s_idx[tid];
+            } else { // (t_* are free since the sort: the candidates are compacted there, then moved back)
+                t_range[tid - taken_before] = s_range[tid];
+                t_height[tid - taken_before] = s_height[tid];
+                t_idx[tid - taken_before] = s_idx[tid];
             }
         }
-        s_ns = w;
-        s_nm = nm;
-        s_sufficient = nm >= 2; // :272-277
-        s_keep = (nm >= 2) && (w > 0); // :289-290
-        s_iters = 0;
+        __syncthreads();
+        const int w = ns0 - nm;
+        if (tid < w) {
+            s_range[tid] = t_range[tid];
+            s_height[tid] = t_height[tid];
+            s_idx[tid] = t_idx[tid];
+        }
+        if (tid == 0) {
+            s_ns = w;
+            s_nm = nm;
+            s_sufficient = nm >= 2; // :272-277
+            s_keep = (nm >= 2) && (w > 0); // :289-290
+            s_iters = 0;
+        }
     }
     __syncthreads();
 
+    INSAC_T(0);
     while (s_keep) { // :295-377
         const int nm = s_nm, ns = s_ns;
+        double *Yg = scratch + (size_t)NA * NL * NL + (size_t)sec * NL * NL; // [candidate][nm]: the candidates' substitution rows
+        // (round 6: the factor and these rows in LDS -- 90 KB -- changed nothing: the rounds are chains of f64 roots and divisions)
+        auto L = [&](int i, int j) -> double & { return Lm[i * NL + j]; };
+        auto Yk = [&](int k, int i) -> double & { return Yg[(size_t)k * NL + i]; };
         // A = C_XX + sn*I (lower triangle), then Cholesky in place, one column per step
         for (int e = tid; e < nm * nm; e += kSecThreads) {
             const int i = e / nm, j = e % nm;
-            if (j <= i) Lm[i * NL + j] = gp_cov(m_range[i], m_range[j], sf, pl) + (i == j ? p.p_sn : 0.0);
+            if (j <= i) L(i, j) = gp_cov(m_range[i], m_range[j], sf, pl) + (i == j ? p.p_sn : 0.0);
         }
         __threadfence_block();
         __syncthreads();
+        INSAC_T(1);
         for (int c = 0; c < nm; ++c) {
-            if (tid == 0) Lm[c * NL + c] = sqrt(Lm[c * NL + c]);
+            // (every thread takes the root of the pivot for itself -- the same value -- and thread 0 stores it: a barrier less per column)
+            const double d = sqrt(L(c, c));
+            for (int i = c + 1 + tid; i < nm; i += kSecThreads) L(i, c) /= d;
             __threadfence_block();
             __syncthreads();
-            const double d = Lm[c * NL + c];
-            for (int i = c + 1 + tid; i < nm; i += kSecThreads) Lm[i * NL + c] /= d;
-            __threadfence_block();
-            __syncthreads();
+            if (tid == 0) L(c, c) = d;
             // trailing update of the lower triangle
             const int rem = nm - c - 1;
             for (int e = tid; e < rem * rem; e += kSecThreads) {
                 const int i = c + 1 + e / rem, j = c + 1 + e % rem;
-                if (j <= i) Lm[i * NL + j] -= Lm[i * NL + c] * Lm[j * NL + c];
+                if (j <= i) L(i, j) -= L(i, c) * L(j, c);
             }
             __threadfence_block();
             __syncthreads();
         }
-        // alpha = A^-1 z (thread 0: two triangular solves of length nm)
-        if (tid == 0) {
+        INSAC_T(2);
+        // alpha = A^-1 z: two triangular solves of length nm.  Up to 64 model bins (a sector has a few dozen) by the first wavefront,
+        // a row per lane, column by column: lane j's value is final at step j, goes to the others through a scalar register, and
+        // every later row takes its term off -- forward the terms arrive in the order one thread would subtract them (the same bits),
+        // backward in the opposite order (a last-bit difference in alpha; the labels of every test cloud are the oracle's, whose
+        // solve is an LU anyway).  One thread walking both triangles was 7 of the kernel's 38 us per sector.
+        if (nm <= 64) {
+            if (tid < 64) {
+                const int    lane = tid;
+                const double dii = lane < nm ? L(lane, lane) : 1.0;
+                double       sv = lane < nm ? m_height[lane] : 0.0, yv = 0.0;
+                for (int j = 0; j < nm; ++j) {
+                    const double mine = sv / dii; // (every lane divides; lane j's quotient is the one that counts)
+                    const double aj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), j), __builtin_amdgcn_readlane(__double2loint(mine), j));
+                    if (lane == j) yv = aj;
+                    if (lane > j && lane < nm) sv -= L(lane, j) * aj;
+                }
+                sv = yv;
+                double xv = 0.0;
+                for (int j = nm - 1; j >= 0; --j) {
+                    const double mine = sv / dii;
+                    const double xj = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(mine), j), __builtin_amdgcn_readlane(__double2loint(mine), j));
+                    if (lane == j) xv = xj;
+                    if (lane < j) sv -= L(j, lane) * xj;
+                }
+                if (lane < nm) alpha[lane] = xv;
+            }
+        } else if (tid == 0) {
             for (int i = 0; i < nm; ++i) {
                 double s = m_height[i];
-                for (int j = 0; j < i; ++j) s -= Lm[i * NL + j] * alpha[j];
-                alpha[i] = s / Lm[i * NL + i];
+                for (int j = 0; j < i; ++j) s -= L(i, j) * alpha[j];
+                alpha[i] = s / L(i, i);
             }
             for (int i = nm - 1; i >= 0; --i) {
                 double s = alpha[i];
-                for (int j = i + 1; j < nm; ++j) s -= Lm[j * NL + i] * alpha[j];
-                alpha[i] = s / Lm[i * NL + i];
+                for (int j = i + 1; j < nm; ++j) s -= L(j, i) * alpha[j];
+                alpha[i] = s / L(i, i);
             }
         }
         __syncthreads();
+        INSAC_T(3);
         // every candidate: f = c . alpha ; Vf = sf - |L^-1 c|^2   (one thread per candidate, own scratch row)
-        double *Y = scratch + (size_t)NA * NL * NL + (size_t)sec * NL * NL; // [candidate][nm]
         for (int k = tid; k < ns; k += kSecThreads) {
-            double *y = Y + (size_t)k * NL;
             double  f = 0.0, q = 0.0;
             for (int i = 0; i < nm; ++i) {
                 const double c = gp_cov(s_range[k], m_range[i], sf, pl);
                 f += c * alpha[i];
                 double s = c;
-                for (int j = 0; j < i; ++j) s -= Lm[i * NL + j] * y[j];
-                s /= Lm[i * NL + i];
-                y[i] = s;
+                for (int j = 0; j < i; ++j) s -= L(i, j) * Yk(k, j);
+                s /= L(i, i);
+                Yk(k, i) = s;
                 q += s * s;
             }
             f_s[k] = f;
             v_f[k] = gp_cov(s_range[k], s_range[k], sf, pl) - q;
         }
         __syncthreads();
-        // :331-369: all candidates are judged against THIS iteration's model; inliers join in order
-        if (tid == 0) {
-            int nm2 = nm, w = 0;
-            for (int k = 0; k < ns; ++k) {
-                const double met = (s_height[k] - f_s[k]) / sqrt(p.p_sn + v_f[k] * v_f[k]);
-                if (v_f[k] < p.p_tmodel && fabs(met) < p.p_tdata) {
-                    m_range[nm2] = s_range[k];
-                    m_height[nm2] = s_height[k];
-                    m_idx[nm2] = s_idx[k];
-                    ++nm2;
-                } else {
-                    s_range[w] = s_range[k];
-                    s_height[w] = s_height[k];
-                    s_idx[w] = s_idx[k];
-                    f_s[w] = f_s[k];
-                    ++w;
+        INSAC_T(4);
+        // :331-369: all candidates are judged against THIS iteration's model; inliers join in order -- every candidate by its own
+        // thread, their places by counting (one thread walking the list was 3 of the kernel's 38 us per sector)
+        {
+            bool inl = false;
+            if (tid < ns) {
+                const double met = (s_height[tid] - f_s[tid]) / sqrt(p.p_sn + v_f[tid] * v_f[tid]);
+                inl = v_f[tid] < p.p_tmodel && fabs(met) < p.p_tdata;
+            }
+            const unsigned long long im = __ballot(inl);
+            if ((tid & 63) == 0) s_wcnt[tid >> 6] = __popcll(im);
+            __syncthreads();
+            int before = __popcll(im & ((1ull << (tid & 63)) - 1ull));
+            for (int w = 0; w < (tid >> 6); ++w) before += s_wcnt[w];
+            const int n_inl = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+            if (tid < ns) {
+                if (inl) {
+                    m_range[nm + before] = s_range[tid];
+                    m_height[nm + before] = s_height[tid];
+                    m_idx[nm + before] = s_idx[tid];
+                } else { // (compacted through the free t_* arrays)
+                    t_range[tid - before] = s_range[tid];
+                    t_height[tid - before] = s_height[tid];
+                    t_idx[tid - before] = s_idx[tid];
+                    alpha[tid] = f_s[tid]; // (alpha is free until the next round's solve: f_s's values on their way to their new places)
                 }
             }
-            s_keep = !(nm2 == nm || w == 0); // :374-375
-            s_nm = nm2;
-            s_ns = w;
-            ++s_iters;
+            __syncthreads();
+            const int w = ns - n_inl;
+            if (tid < ns && !inl) f_s[tid - before] = alpha[tid];
+            if (tid < w) {
+                s_range[tid] = t_range[tid];
+                s_height[tid] = t_height[tid];
+                s_idx[tid] = t_idx[tid];
+            }
+            if (tid == 0) {
+                s_keep = !(n_inl == 0 || w == 0); // :374-375
+                s_nm = nm + n_inl;
+                s_ns = w;
+                ++s_iters;
+            }
         }
         __syncthreads();
+        INSAC_T(5);
+#ifdef SLAM_MEASURE
+        if (tid == 0) g_insac_dbg[sec][6] += 1;
+#endif
     }
 
     // ---- verdict per bin :385-454
@@ -614,6 +711,27 @@ int slam_gseg_classify_ga_counted_dev(slam_gseg_t *h, const float *d_obstacle_xy
                  "slam_gseg_classify_ga_counted_dev: bad arguments");
     return classify_ga(h, d_obstacle_xyz, n_capacity, d_n, stride, d_flags, stream);
 }
+
+#ifdef SLAM_MEASURE
+// measurement build: mean microseconds per sector of the last segmentation's INSAC kernel in {setup, matrix, factorisation, solves,
+// candidates, verdict}, [6] = mean rounds, [7] = the slowest sector's total
+int slam_gseg_debug_insac(double out[8])
+{
+    long long h[NA][8];
+    SLAM_HIP(hipDeviceSynchronize());
+    SLAM_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_insac_dbg), sizeof h));
+    double worst = 0;
+    for (int k = 0; k < 8; ++k) out[k] = 0;
+    for (int s = 0; s < NA; ++s) {
+        double tot = 0;
+        for (int k = 0; k < 6; ++k) out[k] += h[s][k] * 0.01 / NA, tot += h[s][k] * 0.01;
+        out[6] += (double)h[s][6] / NA;
+        worst = tot > worst ? tot : worst;
+    }
+    out[7] = worst;
+    return SLAM_OK;
+}
+#endif
 
 int slam_gseg_read_model(slam_gseg_t *h, uint8_t *bin_state, double *bin_value, int32_t *sector_iterations)
 {
