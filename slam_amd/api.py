@@ -141,6 +141,10 @@ def lib():
     L.slam_ccicp_scene_cloud_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.slam_ccicp_pack_scans_dev.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.slam_gseg_classify_ga_counted_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.slam_gseg_classify_ga_extent_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.slam_ccicp_height_rpy_pose_mirror_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                        C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                                        C.c_void_p]
     L.slam_grid_destroy.restype = None
     L.slam_icp_default_params.restype = None
     L.slam_grid_default_params.restype = None
