@@ -1500,6 +1500,7 @@ int slam_icp_fit_batch_from_dev(slam_icp_t *icp, const double *d_pts, const int3
     // few scans (one, in the reference's own usage): each scan spread over many workgroups of one persistent launch
     fa.only = nullptr;
     fa.spread_tag = 0;
+    fa.redo_mirror = icp->redo_mirror;
     if (takes_spread_form(icp, n_scans) && !fa.stamps) {
         // ... and behind it the workgroup-per-scan form for the scans whose workgroups did not all become resident together
         // (another spread launch or a persistent kernel holding CUs: icp_single.hip): its workgroups find their scan's flag
@@ -1529,10 +1530,12 @@ int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t
     const int n = n_tga + n_tnga;
     // One block in HBM and one pinned block on the host, the same layout: the template's points, then a header
     //   [scan_off 0, n | nGA | pad] [R t] [result] [pose of the last executed step]
-    // so that a fit is one copy in, one launch, one copy out (the reference's fit() is synchronous too).
+    // so that a fit is one copy in and two launches (the reference's fit() is synchronous too).  What comes back -- pose, result,
+    // whether the spread form had to hand the scan to the one-workgroup form -- the kernels write into the pinned block themselves
+    // (device-visible host memory, a handful of posted stores at the end of a fit): no copy command behind the fit.
     const size_t pts_bytes = 16 * (size_t)n, hdr = pts_bytes, o_pose_in = hdr + 16, o_res = o_pose_in + 48, o_step = o_res + 16,
-                 o_redo = o_step + 48, total = o_redo + 16;
-    SLAM_TRY(icp->w_pts.reserve(total));
+                 o_redo = o_step + 48, o_pose_out = o_redo + 16, o_res_out = o_pose_out + 48, total = o_res_out + 16;
+    SLAM_TRY(icp->w_pts.reserve(o_redo));
     unsigned char *hp = static_cast<unsigned char *>(pinned_scratch(total));
     SLAM_REQUIRE(hp, SLAM_E_NOMEM, "slam_icp_fit: no pinned staging memory");
     unsigned char *dp = static_cast<unsigned char *>(icp->w_pts.p);
@@ -1542,38 +1545,42 @@ int slam_icp_fit(slam_icp_t *icp, const double *t_ga, int n_tga, const double *t
     hh[0] = 0, hh[1] = n, hh[2] = n_tga, hh[3] = 0;
     memcpy(hp + o_pose_in, R, 32);
     memcpy(hp + o_pose_in + 32, t, 16);
-    memset(hp + o_res, 0, 16);
+    memcpy(hp + o_pose_out, hp + o_pose_in, 48); // (a fit without a correspondence leaves R, t as they were: icp.cpp:120)
+    slam_icp_result *h_res = reinterpret_cast<slam_icp_result *>(hp + o_res_out);
+    memset(h_res, 0, sizeof *h_res);
+    h_res->iters = -2; // no kernel leaves this
+    int *h_redo = reinterpret_cast<int *>(hp + o_redo);
+    *h_redo = 0;
     hipStream_t st = nullptr;
-    SLAM_HIP(hipMemcpyAsync(dp, hp, o_step, hipMemcpyHostToDevice, st));
+    SLAM_HIP(hipMemcpyAsync(dp, hp, o_res, hipMemcpyHostToDevice, st));
     icp->want_step_pose = true;
     icp->step_pose_off = o_step;
     icp->spread_points_hint = n;
     icp->skip_spread = icp->spread_backoff > 0; // the spread form lost its CUs a moment ago: not again right away
     if (icp->skip_spread) --icp->spread_backoff;
-    icp->d_last_redo = nullptr;
-    *reinterpret_cast<int *>(hp + o_redo) = 0;
-    const int rc_fit = slam_icp_fit_batch_dev(icp, reinterpret_cast<double *>(dp), reinterpret_cast<int32_t *>(dp + hdr),
-                                              reinterpret_cast<int32_t *>(dp + hdr + 8), 1,
-                                              reinterpret_cast<double *>(dp + o_pose_in), reinterpret_cast<double *>(dp + o_pose_in + 32),
-                                              indist, reinterpret_cast<slam_icp_result *>(dp + o_res), nullptr, st);
+    icp->redo_mirror = h_redo;
+    const int rc_fit = slam_icp_fit_batch_from_dev(icp, reinterpret_cast<double *>(dp), reinterpret_cast<int32_t *>(dp + hdr),
+                                                   reinterpret_cast<int32_t *>(dp + hdr + 8), 1,
+                                                   reinterpret_cast<double *>(dp + o_pose_in), reinterpret_cast<double *>(dp + o_pose_in + 32),
+                                                   reinterpret_cast<double *>(hp + o_pose_out), reinterpret_cast<double *>(hp + o_pose_out + 32),
+                                                   indist, h_res, nullptr, st);
     icp->want_step_pose = false;
     icp->skip_spread = false;
+    icp->redo_mirror = nullptr;
     SLAM_TRY(rc_fit);
-    if (icp->d_last_redo) SLAM_HIP(hipMemcpyAsync(hp + o_redo, icp->d_last_redo, sizeof(int), hipMemcpyDeviceToHost, st));
     icp->last_n = n;
     icp->last_nga = n_tga;
     icp->last_indist = indist;
     icp->have_last = true;
-    SLAM_HIP(hipMemcpyAsync(hp + o_pose_in, dp + o_pose_in, 64, hipMemcpyDeviceToHost, st)); // R, t, result
     SLAM_HIP(hipStreamSynchronize(st));
     slam_icp_result res;
-    memcpy(&res, hp + o_res, sizeof res);
-    if (*reinterpret_cast<const int *>(hp + o_redo) != 0) icp->spread_backoff = 16; // redone by the one-workgroup form: 5 ms late
+    memcpy(&res, h_res, sizeof res);
+    if (*h_redo != 0) icp->spread_backoff = 16; // redone by the one-workgroup form: 5 ms late
     // (a scan whose spread-form workgroups did not become resident together was redone by the one-workgroup form inside the
     // call above: there is no outcome without a pose)
     SLAM_REQUIRE(res.iters >= 0, SLAM_E_HIP, "slam_icp_fit: the registration kernels left no result (iters = %d)", res.iters);
-    memcpy(R, hp + o_pose_in, 32);
-    memcpy(t, hp + o_pose_in + 32, 16);
+    memcpy(R, hp + o_pose_out, 32);
+    memcpy(t, hp + o_pose_out + 32, 16);
     if (result) *result = res;
     return SLAM_OK;
 }

@@ -189,7 +189,7 @@ struct slam_icp {
     unsigned        spread_tag = 1;             // tag base of the next spread launch (FitArgs::spread_tag)
     int             spread_backoff = 0;         // single fits still to be done without the spread form
     bool            skip_spread = false;        // set around one slam_icp_fit_batch_dev call
-    const int      *d_last_redo = nullptr;      // redo flags of the last spread launch (device, in w_single), or null
+    int            *redo_mirror = nullptr;      // set around slam_icp_fit(): where the spread launch leaves its redo flag for the host (pinned)
     bool            build_beside = false;       // the index build's kernels must fit beside a resident registration workgroup (mapper)
     double          build_ms[4] = {0, 0, 0, 0}; // enqueueing the build, its one wait (the other two: unused since the plan moved to the device)
     slam_icp_pending *pending = nullptr;        // between build_index_begin and build_index_finish

@@ -1242,6 +1242,8 @@ struct FitArgs {
     int            far_div;       // hand over once at most n / far_div queries are beyond the lists' certified radius
     const int     *only;          // nullable; per scan: the workgroup-per-scan kernels run scan s only if only[s] != 0 (the
                                   // scans a spread launch could not finish, icp_single.hip)
+    int           *redo_mirror;   // nullable; spread form: the redo flag of every scan once more, where the HOST reads it (pinned memory:
+                                  // slam_icp_fit learns without a copy of its own whether the one-workgroup form had to take the scan)
     unsigned       spread_tag;    // spread form: the launch's tag base -- granule tags are spread_tag + iteration + 1, a scan's abort word
                                   // holds spread_tag itself when raised; no launch repeats another's (icp_single.hip: no fill between launches)
 };

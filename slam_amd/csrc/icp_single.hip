@@ -1140,6 +1140,7 @@ __device__ inline void spread_finish(const FitArgs &fa, const FitState &fs, int 
         // workgroup 0 decides: if IT saw every exchange through, the pose is complete whatever the others did afterwards
         flags[gridDim.y + s] = ok ? 0 : 1; // redo: the one-workgroup form takes this scan, from the pose left untouched here (written
                                            // either way: nothing clears the flags between launches)
+        if (fa.redo_mirror) fa.redo_mirror[s] = ok ? 0 : 1;
         if (ok) {
             fa.R[4 * s + 0] = fs.r00;
             fa.R[4 * s + 1] = fs.r01;
@@ -1286,7 +1287,6 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
     int                *flags = static_cast<int *>(h->w_single.p);
     unsigned long long *gran = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(h->w_single.p) + flag_bytes);
     *redo_flags = flags + n_scans;
-    h->d_last_redo = flags + n_scans;
     std::lock_guard<std::mutex> lk(g_spread_mu);
     hipEvent_t &done = g_spread_done[dev & 15];
     // (a stream that is being captured into a hipGraph may neither wait for an event of uncaptured work nor lend its own to
