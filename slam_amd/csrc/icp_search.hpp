@@ -365,6 +365,7 @@ __device__ inline void scan_range_rt(Best &b, bool &tie, const float2 *pts, cons
 // A long span by all G lanes of the group, eight loads in flight per lane (a span of thousands of points is a
 // few round trips), then the rest four at a time.  Seed-aware like scan_range_rt.
 constexpr int kDeep = 8;
+constexpr int kProbeFromLevel = 4; // nn_search_rows_impl: levels of this radius (cells) and beyond are probed before they are read, when no candidate exists yet
 template <int G, typename StartT, bool EXACT>
 __device__ inline void scan_range_deep(Best &b, bool &tie, const float2 *pts, const StartT *oidx, int a, int e, int lig, float qx,
                                        float qy)
@@ -708,6 +709,15 @@ struct Seed {
 // lanes take in two steps (a lidar cloud holds hundreds of points per cell near the sensor) is left to the
 // whole group, one such row after the other.  The query's own cell is part of the first level.  Visits the same
 // cells as nn_search_impl, so the result is the same (ties: flagged by the fast form, resolved by the exact one).
+// the minimum of a float over the G lanes of a query's group, in every lane
+template <int G>
+__device__ inline float group_fmin(float v)
+{
+#pragma unroll
+    for (int o = 1; o < G; o <<= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
 template <int G, typename StartT, bool EXACT>
 __device__ inline Best nn_search_rows_impl(const IndexPtrs<StartT> &ix, const ModelView &mv, int cls, float qx, float qy,
                                            int lig, double gate, bool &tie, const Seed seed, float move, float &empty_out)
@@ -761,8 +771,42 @@ __device__ inline Best nn_search_rows_impl(const IndexPtrs<StartT> &ix, const Mo
         int x_lo = max(cx - r, 0), x_hi = min(cx + r, L.nx - 1);
         const bool covers = (x_lo == 0) & (y_lo == 0) & (x_hi == L.nx - 1) & (y_hi == L.ny - 1);
         float      Rd = 1.0e30f; // the disk of the best so far, in cells
-        if (b.d < FLT_MAX) {
-            const float R = (disk_radius(b.d) + L.margin) * L.inv_h;
+        // A level entered WITHOUT a candidate (no seed, nothing in the levels inside) used to read every point of its square
+        // ring -- at r = 16 cells a thousand cells, of which the nearest point's disk touches a few dozen: 20 us for one query of
+        // config 3's first iteration (a scene point beside the vehicle, the rings of lidar returns 1-2 m around it), the whole
+        // workgroup waiting at the barrier.  Probe first: per lattice row the point(s) of the cells nearest the query's column
+        // -- two or three dependent loads, all rows at once -- give an upper bound within about a cell of the nearest
+        // distance; the level then reads the cells under THAT disk only.  (The bound only prunes: the nearest point lies
+        // inside its disk and is found by the scan itself, ties and all.)
+        float cand = b.d;
+        if (cand == FLT_MAX && r >= kProbeFromLevel) {
+            float pd = FLT_MAX;
+            for (int y0 = y_lo; y0 <= y_hi; y0 += G) {
+                const int y = y0 + lig, row = y * L.nx;
+                if (y <= y_hi) {
+                    if (rp >= 0 && y >= cy - rp && y <= cy + rp) {
+                        const int l1 = min(x_hi, cx - rp - 1), f2 = max(x_lo, cx + rp + 1);
+                        if (x_lo <= l1) {
+                            const int a = (int)start[row + x_lo], e = (int)start[row + l1 + 1];
+                            if (e > a) pd = fminf(pd, dist2(pts[e - 1], qx, qy)); // the last point left of the inner square
+                        }
+                        if (f2 <= x_hi) {
+                            const int a = (int)start[row + f2], e = (int)start[row + x_hi + 1];
+                            if (e > a) pd = fminf(pd, dist2(pts[a], qx, qy)); // the first point right of it
+                        }
+                    } else if (x_lo <= x_hi) {
+                        const int a = (int)start[row + x_lo], e = (int)start[row + x_hi + 1];
+                        if (e > a) {
+                            const int c = (int)start[row + clampi(cx, x_lo, x_hi)]; // the first point at or right of the query's column
+                            pd = fminf(pd, fminf(dist2(pts[min(c, e - 1)], qx, qy), dist2(pts[max(c - 1, a)], qx, qy)));
+                        }
+                    }
+                }
+            }
+            cand = group_fmin<G>(pd);
+        }
+        if (cand < FLT_MAX) {
+            const float R = (disk_radius(cand) + L.margin) * L.inv_h;
             Rd = R;
             x_lo = max(x_lo, ifloor(fx - R));
             x_hi = min(x_hi, ifloor(fx + R));

@@ -893,7 +893,7 @@ __device__ inline bool tile_iterations(const ModelView &mv, const FitArgs &fa, c
             tl.scq[tid] = make_float2(0.0f, 0.0f);
             tl.snpos[tid] = -1;
         }
-        if (tid == 0) tl.hdr[kHdrMiss] = 0, tl.hdr[kHdrDebug] = 0;
+        if (tid == 0) tl.hdr[kHdrMiss] = 0, tl.hdr[kHdrDebug] = 0, tl.hdr[26] = 0, tl.hdr[27] = 0;
         __syncthreads();
     } else
     // ---- the scan's points along the Morton curve of the lattice under the initial pose, class first
@@ -935,7 +935,7 @@ __device__ inline bool tile_iterations(const ModelView &mv, const FitArgs &fa, c
             tl.snpos[tid] = -1;
         }
         if (tid < 2) tl.hdr[kHdrValid + tid] = 0;
-        if (tid == 0) tl.hdr[kHdrMiss] = 0, tl.hdr[kHdrDebug] = 0;
+        if (tid == 0) tl.hdr[kHdrMiss] = 0, tl.hdr[kHdrDebug] = 0, tl.hdr[26] = 0, tl.hdr[27] = 0;
         __syncthreads();
     }
     int      iters = 0, n_corr = 0, restages = 0, missed = 0;
@@ -1009,6 +1009,10 @@ __device__ inline bool tile_iterations(const ModelView &mv, const FitArgs &fa, c
                     float  empty = 0.0f;
                     bool   done = false, far = false;
                     const TileCls &tc = cls ? tc1 : tc0;
+#ifdef SLAM_MEASURE
+                    const unsigned long long q_t0 = sstamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+                    unsigned                 q_how = 0u; // 1: gate square, 2: rows on the index, 4: tile
+#endif
                     // every model point lies inside the lattice's rectangle: a query farther from it than the inlier gate has no
                     // correspondence whatever its nearest point is (icpPointToPoint.cpp:76) -- no search, no state (a scene cloud
                     // seen from the next pose has parts the target never saw: a third of config 3's queries)
@@ -1052,9 +1056,17 @@ __device__ inline bool tile_iterations(const ModelView &mv, const FitArgs &fa, c
                             if (b.pos >= 0) m = ix.pts[mv.base[cls] + b.pos];
 #ifdef SLAM_MEASURE
                             if (lig == 0) atomicAdd(&tl.hdr[kHdrDebug], have ? 0x10000 : 1);
+                            q_how |= have ? 1u : 2u;
 #endif
                         }
                     }
+#ifdef SLAM_MEASURE
+                    if (sstamps && s == 0 && lig == 0) { // the slowest query of the workgroup this iteration: ticks, slot, how it was searched
+                        if (done && !far) q_how |= 4u;
+                        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - q_t0;
+                        atomicMax(reinterpret_cast<unsigned long long *>(&tl.hdr[26]), (dt << 32) | ((unsigned long long)k << 8) | (unsigned)(cls << 3) | q_how);
+                    }
+#endif
                     if (lig == 0) {
                         if (MODE == SLAM_ICP_P2L) {
                             if (b.pos >= 0) {
@@ -1094,6 +1106,12 @@ __device__ inline bool tile_iterations(const ModelView &mv, const FitArgs &fa, c
             long long *st = sstamps + ((size_t)blockIdx.x * fa.max_iter + iter) * kSpreadStampSlots;
             st[7] = tl.hdr[kHdrDebug];
             tl.hdr[kHdrDebug] = 0;
+            const unsigned long long key = *reinterpret_cast<unsigned long long *>(&tl.hdr[26]);
+            *reinterpret_cast<unsigned long long *>(&tl.hdr[26]) = 0ull;
+            const int kq = (int)((key >> 8) & 0xffffu);
+            st[12] = (long long)key;
+            st[13] = (long long)(((unsigned long long)__float_as_uint(tl.scq[kq].y) << 32) | __float_as_uint(tl.scq[kq].x));
+            st[14] = tl.spos[kq];
 
         }
 #endif

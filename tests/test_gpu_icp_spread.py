@@ -329,3 +329,81 @@ def test_tile_form_ties_and_ragged_scans(form):
     assert (res["iters"][2], res["n_corr"][2], res["delta"][2]) == (1, 0, -1.0)
     assert res["n_corr"][3] == 54
     icp.close()
+
+
+def _random_model(rs, n_total, with_duplicates):
+    """Model shapes the index meets: blobs of hundreds of points inside one lattice cell (stacked lidar returns), walls (lines with
+    centimetre noise), thin scatter, exact duplicates; points tagged GA / NGA at random with one class possibly small."""
+    parts = []
+    n_blob = n_total // 3
+    for _ in range(rs.randint(6, 30)):
+        c = rs.uniform(-18, 18, 2)
+        parts.append(c + rs.normal(0, rs.choice([0.005, 0.02, 0.08]), (n_blob // 12, 2)))
+    n_wall = n_total // 3
+    for _ in range(8):
+        a, b = rs.uniform(-20, 20, 2), rs.uniform(-20, 20, 2)
+        u = rs.uniform(0, 1, (n_wall // 8, 1))
+        parts.append(a + u * (b - a) + rs.normal(0, 0.01, (n_wall // 8, 2)))
+    pts = np.concatenate(parts)
+    rest = max(n_total - len(pts), 16)
+    pts = np.concatenate([pts, rs.uniform(-22, 22, (rest, 2))])
+    if with_duplicates:
+        pts[rs.randint(0, len(pts), 200)] = pts[rs.randint(0, len(pts), 200)]
+    pts = pts[rs.permutation(len(pts))][:n_total]
+    n_ga = int(len(pts) * rs.choice([0.03, 0.3, 0.5]))
+    return np.ascontiguousarray(pts[:n_ga]), np.ascontiguousarray(pts[n_ga:])
+
+
+def _random_scans(rs, m_ga, m_nga, n_scans):
+    """Scans = model points seen from a pose 0.05-0.8 m / up to 0.12 rad off, with noise, a share of points the model never saw
+    (inside and far outside its lattice), ragged sizes."""
+    pts, off, nga, Rs, ts = [], [0], [], [], []
+    for s in range(n_scans):
+        n = int(rs.choice([7, 60, 400, 1100, 1900]))
+        k_ga = min(int(n * rs.uniform(0.05, 0.6)), len(m_ga))
+        ga = m_ga[rs.randint(0, len(m_ga), k_ga)] + rs.normal(0, 0.01, (k_ga, 2))
+        ng = m_nga[rs.randint(0, len(m_nga), n - k_ga)] + rs.normal(0, 0.01, (n - k_ga, 2))
+        for a in (ga, ng):                                        # outliers: unseen parts, and points far outside the lattice
+            k = len(a) // 5
+            if k:
+                a[:k] = rs.uniform(-30, 30, (k, 2))
+            if len(a) > 3:
+                a[-1] = rs.uniform(200, 400, 2)
+        th, tx, ty = rs.uniform(-0.12, 0.12), rs.uniform(-0.8, 0.8), rs.uniform(-0.8, 0.8)
+        c, sn = np.cos(th), np.sin(th)
+        Rt = np.array([[c, -sn], [sn, c]])
+        # the scan in its own frame: model = R p + t  ->  p = R^T (model - t); the fit starts from the identity
+        ga, ng = (ga - [tx, ty]) @ Rt, (ng - [tx, ty]) @ Rt
+        pts += [ga, ng]
+        off.append(off[-1] + n)
+        nga.append(k_ga)
+        Rs.append([1.0, 0.0, 0.0, 1.0])
+        ts.append([0.0, 0.0])
+    return synth.ScanBatch(np.ascontiguousarray(np.concatenate(pts)), np.array(off, np.int32), np.array(nga, np.int32),
+                           np.array(Rs, np.float64), np.array(ts, np.float64), np.zeros((n_scans, 3)))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_spread_forms_on_random_models(seed):
+    """Seeded random models (dense blobs, walls, scatter, duplicates; 6 k - 36 k points: index in LDS, just above it, at the cap) and
+    ragged scans with outliers: every spread form -- tiles staged into LDS, the index where it lies, round 5's form -- against
+    the oracle: iteration counts and correspondences equal, poses to the tolerance, the forms among themselves to 1e-9."""
+    rs = np.random.RandomState(1000 + seed)
+    n_total = [6000, 21000, 36000, 14000, 25000, 30000][seed]
+    m_ga, m_nga = _random_model(rs, n_total, with_duplicates=seed % 2 == 0)
+    model = O.IcpModel(m_ga, m_nga)
+    n_scans = [2, 2, 5, 4, 3, 16][seed]
+    batch = _random_scans(rs, m_ga, m_nga, n_scans)
+    Ro, to, iters, ncorr, delta = model.fit_batch(batch.pts, batch.scan_off, batch.scan_nga, batch.R, batch.t, O.icp_params(20, 1e-6, 5.0, O.NN_KDTREE))
+    first = None
+    for form in (1, 2, -1):
+        icp = api.Icp(m_ga, m_nga, max_iter=20, min_delta=1e-6, spread_tile=form)
+        R, t, res, _ = icp.fit_batch(batch)
+        icp.close()
+        assert np.array_equal(res["iters"], iters), (form, res["iters"], iters)
+        assert np.array_equal(res["n_corr"], ncorr), (form, res["n_corr"], ncorr)
+        assert np.abs(t - to).max() < POS_TOL and ang_diff(yaw(R), yaw(Ro)).max() < ANG_TOL, form
+        if first is None:
+            first = (R, t)
+        else:
+            assert np.abs(t - first[1]).max() < 1e-9 and np.abs(R - first[0]).max() < 1e-9, form

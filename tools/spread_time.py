@@ -102,6 +102,19 @@ def stamp_report(s, n_iter):
         out["stagings_slowest"] = sorted(ev, key=lambda e: -e[4])[:6]
         out["stagings_largest"] = sorted(ev, key=lambda e: -e[1])[:6]
         out["stagings_median"] = sorted(ev, key=lambda e: e[4])[len(ev) // 2]
+    if (raw[:, :, 12] != 0).any():
+        # the slowest query of the slowest workgroups, iteration by iteration: [us, how (1 gate square, 2 rows on the index, 4 tile), class, x, y, neighbour]
+        q = []
+        for k in range(min(n_iter, 4)):
+            key = raw[:, k, 12].astype(np.uint64)
+            order = np.argsort(-(key >> np.uint64(32)).astype(np.int64))[:4]
+            row = []
+            for w in order:
+                kk = int(key[w])
+                xy = np.array([int(raw[w, k, 13]) & 0xffffffff, (int(raw[w, k, 13]) >> 32) & 0xffffffff], np.uint32).view(np.float32)
+                row.append([round((kk >> 32) * 0.01, 2), kk & 7, (kk >> 3) & 1, round(float(xy[0]), 3), round(float(xy[1]), 3), int(raw[w, k, 14])])
+            q.append(row)
+        out["slowest_queries"] = q
     if (stage > 0).any():
         out["stage_us"] = [round(float((stage[:, k][stage[:, k] > 0] - s[:, k, 0][stage[:, k] > 0]).max()), 2) if (stage[:, k] > 0).any() else 0 for k in range(n_iter)]
     return out
@@ -118,7 +131,10 @@ def main():
         kw["spread_tile"] = -1
     elif os.environ.get("SLAM_SPREAD_TILE") is not None:
         kw["spread_tile"] = 1
-    icp = api.Icp(m_ga, m_nga, **kw)
+    kw3 = dict(kw)
+    if os.environ.get("SLAM_SPREAD_CELL"):          # the pitch of config 3's index forced (sweeps)
+        kw3["cell_size"] = float(os.environ["SLAM_SPREAD_CELL"])
+    icp = api.Icp(m_ga, m_nga, **kw3)
     model = O.IcpModel(m_ga, m_nga)
     out["config3_index"] = icp.index_info()
     for k in (1, 5, 9):
