@@ -545,29 +545,34 @@ __global__ void height_fit_kernel(const float *ground, int stride, unsigned long
 // ---- stable compaction in ONE launch (round 6): per-block counts, a decoupled look-back for the block's offset, the ordered
 // write -- for up to two outputs fed from one pass over the input (pred(i) = the output item i goes to, -1: none).  A match of
 // config 3 is bound by its launches (45 of 3-47 us per cloud in round 5): the five compactions of the scene chain were fifteen of them.
-// status[c][b]: {epoch : 24 | flag : 8 | value : 32} of output c and block b -- flag 1: the block's own count, 2: the count of all
-// blocks up to and including it; a word of another epoch is a word not yet written (no fill between launches: the handle counts
-// the launches).  Blocks are dispatched in index order and publish their count before they wait for anything, so a block only ever
-// waits for blocks that are running or done (the grids are at most a few hundred blocks: all resident).  CONCAT: output 1 is
-// written BEHIND output 0 (min(total 0, limit) on): its blocks wait for the last block's prefix of output 0.
-constexpr unsigned long long kStatAgg = 1ull << 32, kStatPre = 2ull << 32;
+// status[1 + c * nb + b]: {epoch : 34 | flag : 2 | value : 28} of output c and block b -- flag 1: the block's own count, 2: the count of
+// all blocks up to and including it; a word of another epoch is a word not yet written (no fill between launches).  The epoch lives
+// on the DEVICE, in status[0]: every block reads it when it starts, the last block -- which has seen a word of every other block,
+// written after that block's read -- moves it on when the launch is done.  (It was a counter of the handle passed by value until a
+// hipGraph replay of the scene chain froze it: the replay took last replay's words for this one's.)  Blocks are dispatched in index
+// order and publish their count before they wait for anything, so a block only ever waits for blocks that are running or done (the
+// grids are at most a few hundred blocks: all resident).  CONCAT: output 1 is written BEHIND output 0 (min(total 0, limit) on): its
+// blocks wait for the last block's prefix of output 0.
+constexpr int                kStatValueBits = 28, kStatEpochShift = 30;
+constexpr unsigned long long kStatAgg = 1ull << kStatValueBits, kStatPre = 2ull << kStatValueBits, kStatValueMask = (1ull << kStatValueBits) - 1ull,
+                             kStatEpochMask = (1ull << (64 - kStatEpochShift)) - 1ull;
 constexpr unsigned kSpinLimit = 1u << 22; // (a safeguard, not a path: a few seconds, then the error bit and whatever is there)
 typedef unsigned long long __attribute__((address_space(1))) g_u64;
 __device__ inline unsigned long long stat_load(const unsigned long long *p)
 {
     return __hip_atomic_load((g_u64 *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ inline void stat_store(unsigned long long *p, unsigned epoch, unsigned long long flag, unsigned v)
+__device__ inline void stat_store(unsigned long long *p, unsigned long long epoch, unsigned long long flag, unsigned v)
 {
-    __hip_atomic_store((g_u64 *)p, ((unsigned long long)epoch << 40) | flag | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store((g_u64 *)p, (epoch << kStatEpochShift) | flag | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ inline unsigned long long stat_wait(const unsigned long long *p, unsigned epoch, unsigned long long need, int *err)
+__device__ inline unsigned long long stat_wait(const unsigned long long *p, unsigned long long epoch, unsigned long long need, int *err)
 {
     unsigned long long w = stat_load(p);
-    for (unsigned spin = 0; (unsigned)(w >> 40) != epoch || !(w & need); ++spin) {
+    for (unsigned spin = 0; (w >> kStatEpochShift) != epoch || !(w & need); ++spin) {
         if (spin > kSpinLimit) {
             if (err) atomicOr(err, 4);
-            return ((unsigned long long)epoch << 40) | kStatPre;
+            return (epoch << kStatEpochShift) | kStatPre;
         }
         __builtin_amdgcn_s_sleep(1);
         w = stat_load(p);
@@ -576,8 +581,8 @@ __device__ inline unsigned long long stat_wait(const unsigned long long *p, unsi
 }
 
 template <int NC, bool CONCAT, class Pred, class Emit, class Tail>
-__global__ __launch_bounds__(kScanThreads) void compact1_kernel(Pred pred, Emit emit, Tail tail, Domain dom, unsigned long long *status,
-                                                               unsigned epoch, int limit, int *err)
+__global__ __launch_bounds__(kScanThreads) void compact1_kernel(Pred pred, Emit emit, Tail tail, Domain dom, unsigned long long *status_epoch,
+                                                               int limit, int *err)
 {
     static_assert(NC == 1 || NC == 2, "one or two outputs");
     const long long n = dom.size();
@@ -588,6 +593,8 @@ __global__ __launch_bounds__(kScanThreads) void compact1_kernel(Pred pred, Emit 
     const int nb = (int)min((long long)gridDim.x, max((n + kItems - 1) / kItems, 1ll));
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, b = blockIdx.x;
     if (b >= nb) return;
+    const unsigned long long epoch = stat_load(status_epoch) & kStatEpochMask; // (the same in every block of the launch: see above)
+    unsigned long long      *status = status_epoch + 1;
     unsigned        mask[NC];
     int             cnt[NC], x[NC];
 #pragma unroll
@@ -627,12 +634,12 @@ __global__ __launch_bounds__(kScanThreads) void compact1_kernel(Pred pred, Emit 
             int excl = 0;
             for (int look = b - 1; look >= 0; look -= 64) {
                 const int                idx = look - lane;
-                const unsigned long long wd = idx >= 0 ? stat_wait(st + idx, epoch, kStatAgg | kStatPre, err) : (((unsigned long long)epoch << 40) | kStatPre);
+                const unsigned long long wd = idx >= 0 ? stat_wait(st + idx, epoch, kStatAgg | kStatPre, err) : ((epoch << kStatEpochShift) | kStatPre);
                 // the nearest block (lowest lane) that knows its inclusive prefix ends the walk: the counts of the blocks nearer than
                 // it plus that prefix (lanes beyond block 0 stand for a prefix of nothing)
                 const unsigned long long pre = __ballot((wd & kStatPre) != 0);
                 const int                first = pre ? __builtin_ctzll(pre) : 64;
-                int                      v = lane <= first ? (int)(unsigned)wd : 0;
+                int                      v = lane <= first ? (int)(wd & kStatValueMask) : 0;
                 for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
                 excl += v;
                 if (pre) break;
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(kScanThreads) void compact1_kernel(Pred pred, Emit 
 #pragma unroll
     for (int c = 0; c < NC; ++c) pos[c] = excl_s[c] + w[c] + x[c] - cnt[c];
     if (NC > 1 && CONCAT) {
-        if (threadIdx.x == 0) base1_s = min((int)(unsigned)stat_wait(status + (nb - 1), epoch, kStatPre, err), limit);
+        if (threadIdx.x == 0) base1_s = min((int)(stat_wait(status + (nb - 1), epoch, kStatPre, err) & kStatValueMask), limit);
         __syncthreads();
         pos[NC - 1] += base1_s;
     }
@@ -665,6 +672,8 @@ __global__ __launch_bounds__(kScanThreads) void compact1_kernel(Pred pred, Emit 
     if (b == nb - 1 && threadIdx.x == 0) {
         int tot[2] = {excl_s[0] + agg[0], NC > 1 ? excl_s[NC - 1] + agg[NC - 1] : 0};
         tail(tot);
+        // the launch after this one is another epoch (every block of THIS launch has read its own: the look-back above saw them all)
+        __hip_atomic_store((g_u64 *)status_epoch, (epoch + 1ull) & kStatEpochMask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -713,8 +722,7 @@ struct OneEmit {
 
 struct slam_ccicp {
     DevBuf vox, small;                  // small: 6 min/max words, totals, 4 packed NN results
-    DevBuf status;                      // the one-launch compactions' look-back words (compact1)
-    unsigned epoch = 0;                 // ... and the launch they belong to (24 bits)
+    DevBuf status;                      // the one-launch compactions' epoch (word 0, kept by the kernels) and look-back words (compact1)
     size_t vox_clean = 0;               // voxels of `vox` known to be zero (the chain's compaction leaves them so)
     const void *best_of = nullptr;      // the chain block whose packed neighbours (ChainSmall::best) have been set to "none"
     DevBuf keys, sort_tmp;
@@ -731,20 +739,16 @@ template <int NC, bool CONCAT, class Pred, class Emit, class Tail>
 int compact1(slam_ccicp *h, Pred pred, Emit emit, Tail tail, long long n, int limit, hipStream_t st, const int *d_n = nullptr,
              const long long *d_n64 = nullptr, int *d_err = nullptr)
 {
+    SLAM_REQUIRE(n < (1ll << kStatValueBits), SLAM_E_INVALID, "compaction over %lld items: the look-back words count to 2^28", n);
     const int    n_blocks = (int)std::max<long long>((n + kItems - 1) / kItems, 1);
-    const size_t need = sizeof(unsigned long long) * 2 * (size_t)n_blocks;
+    const size_t need = sizeof(unsigned long long) * (1 + 2 * (size_t)n_blocks);
     if (need > h->status.cap) {
-        SLAM_TRY(h->status.reserve(need));
-        SLAM_HIP(hipMemsetAsync(h->status.p, 0, h->status.cap, st)); // epoch 0: no launch's
-        h->epoch = 0;
-    }
-    if (++h->epoch >= (1u << 24)) { // (sixteen million launches on)
-        SLAM_HIP(hipMemsetAsync(h->status.p, 0, h->status.cap, st));
-        h->epoch = 1;
+        SLAM_TRY(h->status.reserve(std::max<size_t>(need, 1 << 16)));
+        SLAM_HIP(hipMemsetAsync(h->status.p, 0, h->status.cap, st)); // epoch 0, and no word carries a flag
     }
     const Domain dom = {n, d_n, d_n64};
     hipLaunchKernelGGL((compact1_kernel<NC, CONCAT, Pred, Emit, Tail>), dim3(n_blocks), dim3(kScanThreads), 0, st, pred, emit, tail, dom,
-                       static_cast<unsigned long long *>(h->status.p), h->epoch, limit, d_err);
+                       static_cast<unsigned long long *>(h->status.p), limit, d_err);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }

@@ -444,16 +444,19 @@ __device__ inline int ga_bin(const float *q)
 }
 
 // (d_n: the number of points where only the device knows it; n is then the capacity the launch was sized for)
-// A cell is occupied when it holds the call's EPOCH (1..255): the lattice is filled once in 255 calls instead of once per call
-// (1.44 MB and a launch of its own in front of every classification).
-__global__ __launch_bounds__(256) void ga_mark_kernel(const float *xyz, int n, int stride, unsigned char *occ, const int *d_n,
-                                                      unsigned char epoch)
+// A cell is occupied when it holds the call's EPOCH: the lattice is cleared when it is made, never again (a fill of its own in
+// front of every classification was a launch and 1.44 MB).  The epoch lives on the DEVICE -- state[0], read by both kernels of a
+// call, moved on by the workgroup of the second kernel that finishes last (state[1] counts them) -- so that a hipGraph replay of
+// the two launches is another call like any other (as a counter of the handle passed by value it froze in the replay, and last
+// replay's cells counted as this one's: round 6).  32 bits: four billion classifications.
+__global__ __launch_bounds__(256) void ga_mark_kernel(const float *xyz, int n, int stride, unsigned *occ, const int *d_n,
+                                                      const unsigned *state)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (d_n) n = min(n, *d_n);
     if (i >= n) return;
     const int b = ga_bin(xyz + (size_t)i * stride);
-    if (b >= 0) occ[b] = epoch;
+    if (b >= 0) occ[b] = state[0];
 }
 
 __device__ inline unsigned ga_order_f32(float f)
@@ -465,10 +468,19 @@ __device__ inline unsigned ga_order_f32(float f)
 // ... and, where the caller goes on to the voxel filter (slam_ccicp_scene_dev), the extent of the points the classification
 // keeps -- getMinMax3D over the finite points whose flag is not 255, as ccicp.hip's minmax_kernel forms it -- in the same
 // pass: mm[6] ordered-float minima and maxima (nullable).
-__global__ __launch_bounds__(256) void ga_flag_kernel(const float *xyz, int n, int stride, const unsigned char *occ,
-                                                      unsigned char *flags, const int *d_n, unsigned char epoch, unsigned *mm)
+__device__ inline void ga_call_done(unsigned *state, unsigned epoch)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    __syncthreads(); // (every lane of the workgroup has read the lattice)
+    if (threadIdx.x == 0 && atomicAdd(&state[1], 1u) == gridDim.x - 1u) {
+        state[1] = 0u;
+        state[0] = epoch + 1u == 0u ? 1u : epoch + 1u;
+    }
+}
+__global__ __launch_bounds__(256) void ga_flag_kernel(const float *xyz, int n, int stride, const unsigned *occ,
+                                                      unsigned char *flags, const int *d_n, unsigned *state, unsigned *mm)
+{
+    const int      i = blockIdx.x * 256 + threadIdx.x;
+    const unsigned epoch = state[0]; // (moved on only when every workgroup of this launch is through)
     if (d_n) n = min(n, *d_n);
     unsigned char f = 255;
     unsigned      lo[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, hi[3] = {0u, 0u, 0u};
@@ -489,7 +501,10 @@ __global__ __launch_bounds__(256) void ga_flag_kernel(const float *xyz, int n, i
         if (mm && f != 255 && isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))
             for (int d = 0; d < 3; ++d) lo[d] = hi[d] = ga_order_f32(p[d]);
     }
-    if (!mm) return; // (uniform)
+    if (!mm) { // (uniform)
+        ga_call_done(state, epoch);
+        return;
+    }
     __shared__ unsigned red[4][6];
     for (int d = 0; d < 3; ++d) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -509,6 +524,7 @@ __global__ __launch_bounds__(256) void ga_flag_kernel(const float *xyz, int n, i
             if (v != 0u && v > __hip_atomic_load(&mm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mm[d], v);
         }
     }
+    ga_call_done(state, epoch);
 }
 
 } // namespace
@@ -523,8 +539,8 @@ struct slam_gseg {
     int       *d_iters = nullptr;
     int       *d_bin_of = nullptr;
     size_t     cap_points = 0;
-    unsigned char *d_ga_occ = nullptr; // 1200 x 1200 occupancy of classifyPoints: the epoch of the last call that marked the cell
-    int        ga_epoch = 0;      // 1..255; 0: the lattice has to be cleared first
+    unsigned  *d_ga_occ = nullptr; // 1200 x 1200 occupancy of classifyPoints: the epoch of the last call that marked the cell; behind it
+                                   // the calls' state {epoch, workgroups through}, kept by the kernels
     void      *d_stage = nullptr; // host-API staging: points + labels
     size_t     cap_stage = 0;
 };
@@ -673,16 +689,17 @@ static int classify_ga(slam_gseg_t *h, const float *d_obstacle_xyz, int n, const
 {
     SLAM_TRY(require_device());
     if (n == 0) return SLAM_OK;
-    if (!h->d_ga_occ) SLAM_HIP(hipMalloc((void **)&h->d_ga_occ, (size_t)kGaBins * kGaBins));
     hipStream_t st = as_stream(stream);
-    if (h->ga_epoch <= 0 || h->ga_epoch >= 255) { // every 255th call (and the first): no cell holds a live epoch afterwards
-        SLAM_HIP(hipMemsetAsync(h->d_ga_occ, 0, (size_t)kGaBins * kGaBins, st));
-        h->ga_epoch = 0;
+    constexpr size_t kCells = (size_t)kGaBins * kGaBins;
+    if (!h->d_ga_occ) {
+        SLAM_HIP(hipMalloc((void **)&h->d_ga_occ, sizeof(unsigned) * (kCells + 2)));
+        SLAM_HIP(hipMemsetAsync(h->d_ga_occ, 0, sizeof(unsigned) * (kCells + 2), st)); // no cell holds an epoch, no workgroup is through
+        SLAM_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(h->d_ga_occ + kCells), 1, 1, st)); // the first call's epoch
     }
-    const unsigned char epoch = (unsigned char)++h->ga_epoch;
-    hipLaunchKernelGGL(ga_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_obstacle_xyz, n, stride, h->d_ga_occ, d_n, epoch);
+    unsigned *state = h->d_ga_occ + kCells;
+    hipLaunchKernelGGL(ga_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_obstacle_xyz, n, stride, h->d_ga_occ, d_n, state);
     hipLaunchKernelGGL(ga_flag_kernel, dim3((n + 255) / 256), dim3(256), 0, st, d_obstacle_xyz, n, stride, h->d_ga_occ,
-                       d_flags, d_n, epoch, d_mm);
+                       d_flags, d_n, state, d_mm);
     SLAM_HIP(hipGetLastError());
     return SLAM_OK;
 }

@@ -1295,13 +1295,23 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
     const size_t had = h->w_single.cap;
     SLAM_TRY(h->w_single.reserve(flag_bytes + gran_bytes));
     const unsigned span = (unsigned)std::max(fa.max_iter, 0) + 2u;
-    if (h->w_single.cap != had || h->spread_tag + span < h->spread_tag || h->spread_tag == 0) {
+    // (a stream that is being captured into a hipGraph: see below for the order; for the tags it means that the launch will run
+    // again and again with the SAME base -- last replay's granules would count as this one's.  A captured launch takes the fill in
+    // front of it into the graph and tags from a range of its own, the upper half, that no uncaptured launch uses.)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (st && hipStreamIsCapturing(st, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusNone;
+    }
+    const bool     ordered = cap == hipStreamCaptureStatusNone;
+    constexpr unsigned kCapturedTag = 0x80000000u;
+    if (!ordered || h->w_single.cap != had || h->spread_tag + span >= kCapturedTag || h->spread_tag == 0) {
         SLAM_HIP(hipMemsetAsync(h->w_single.p, 0, h->w_single.cap, st));
-        h->spread_tag = 1;
+        if (ordered) h->spread_tag = 1;
     }
     FitArgs fa_tagged = fa;
-    fa_tagged.spread_tag = h->spread_tag;
-    h->spread_tag += span;
+    fa_tagged.spread_tag = ordered ? h->spread_tag : kCapturedTag;
+    if (ordered) h->spread_tag += span;
     int                *flags = static_cast<int *>(h->w_single.p);
     unsigned long long *gran = reinterpret_cast<unsigned long long *>(static_cast<unsigned char *>(h->w_single.p) + flag_bytes);
     *redo_flags = flags + n_scans;
@@ -1309,12 +1319,6 @@ int launch_fit_spread(slam_icp *h, const FitArgs &fa, int n_scans, hipStream_t s
     hipEvent_t &done = g_spread_done[dev & 15];
     // (a stream that is being captured into a hipGraph may neither wait for an event of uncaptured work nor lend its own to
     // other streams: a captured spread launch is ordered by its graph alone -- if it ever meets another one, the redo path covers it)
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (st && hipStreamIsCapturing(st, &cap) != hipSuccess) {
-        (void)hipGetLastError();
-        cap = hipStreamCaptureStatusNone;
-    }
-    const bool ordered = cap == hipStreamCaptureStatusNone;
     if (!done)
         SLAM_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
     else if (ordered)

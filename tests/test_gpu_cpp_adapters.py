@@ -233,6 +233,37 @@ def test_ccicp_sequence_with_a_target_replacement_matches_the_oracle_chain(tmp_p
 
 
 @pytest.mark.gpu
+def test_ccicp_forms_agree_once_the_scene_chains_replay_as_graphs(tmp_path):
+    """matchSequence replays a scene slot's chain as a hipGraph from the slot's third use on: whatever a launch of the chain takes
+    from the HOST at enqueue time (a counter, an epoch) is frozen in the replay.  Four passes over twelve clouds -- the last one
+    all replays -- against the sequential form and the form with two chains in flight: the same poses (round 6: the epochs of
+    the one-launch compactions and of the GA lattice were host counters; 2.6 cm in one of config 3's 49 matches)."""
+    exe = compile_cpp(str(tmp_path), "ccicp_sequence")
+    d = str(tmp_path)
+    n, advance = 12, 6
+    clouds, poses = zip(*[synth.make_cloud3d(k, n_loop=50) for k in range(n)])
+    init, truth = [], []
+    for k in range(1, n):
+        j = ((k - 1) // advance) * advance
+        pa, pb = poses[j], poses[k]
+        ca, sa = np.cos(pa[2]), np.sin(pa[2])
+        rel = (ca * (pb[0] - pa[0]) + sa * (pb[1] - pa[1]), -sa * (pb[0] - pa[0]) + ca * (pb[1] - pa[1]), pb[2] - pa[2])
+        init.append([rel[0] + 0.1, rel[1] - 0.1, 0.0] + _quat_rpy(0.0, 0.0, rel[2] + 0.02))
+        truth.append(list(rel))
+    for k, c in enumerate(clouds):
+        np.ascontiguousarray(c, np.float32).tofile(os.path.join(d, "cloud%d.f32" % k))
+    np.array(init, np.float64).tofile(os.path.join(d, "init.f64"))
+    np.array(truth, np.float64).tofile(os.path.join(d, "truth.f64"))
+    got = {}
+    for form in ("seq", "ahead", "batch"):
+        p = subprocess.run([exe, d, str(n), str(advance), "4", form], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        got[form] = np.fromfile(os.path.join(d, "poses_out.f64"), np.float64).reshape(n - 1, 7)
+    assert np.array_equal(got["seq"], got["ahead"])
+    assert np.abs(got["seq"] - got["batch"]).max() < 1e-9, np.abs(got["seq"] - got["batch"]).max(axis=1)
+
+
+@pytest.mark.gpu
 def test_ccicp_throughput_forms_on_the_edges(tmp_path):
     """tests/cpp/ccicp_forms_test.cpp: CCICP::prepareSceneCloud with the right and the wrong cloud prepared (poses bit-identical to the
     sequential form, read-outs behind an adopted scene), CCICP::matchSequence over 23 scenes (three batches: 16 at most, and a pose

@@ -407,3 +407,44 @@ def test_spread_forms_on_random_models(seed):
             first = (R, t)
         else:
             assert np.abs(t - first[1]).max() < 1e-9 and np.abs(R - first[0]).max() < 1e-9, form
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_spread_fit_replayed_as_a_graph(big):
+    """One scan's fit captured into a hipGraph (slam_graph_begin_capture) and replayed with other initial poses in the device
+    arrays it reads: every replay is a fit of its own (the launch's granule tags are the host's at capture time: a replay takes a
+    fill and a tag range of its own into the graph instead of meeting its predecessor's granules)."""
+    m_ga, m_nga = synth.make_map(39998 if big else 10000)
+    model = O.IcpModel(m_ga, m_nga)
+    icp = api.Icp(m_ga, m_nga, max_iter=20, min_delta=1e-6)
+    batch = synth.make_batch(4, n_loop=256)
+    ga, nga = batch.scan(0)
+    pts = np.ascontiguousarray(np.concatenate([ga, nga]))
+    d_pts = api.DeviceArray.from_host(pts, np.float64)
+    d_off = api.DeviceArray.from_host(np.array([0, len(pts)], np.int32))
+    d_nga = api.DeviceArray.from_host(np.array([len(ga)], np.int32))
+    d_R0, d_t0 = api.DeviceArray((1, 4), np.float64), api.DeviceArray((1, 2), np.float64)
+    d_R, d_t = api.DeviceArray((1, 4), np.float64), api.DeviceArray((1, 2), np.float64)
+    d_res = api.DeviceArray((1,), api.RESULT_DTYPE)
+    st = api.Stream()
+    x, y, th = batch.true_poses[0]
+    starts = [synth.pose_to_Rt(x + dx, y + dy, th + dth) for dx, dy, dth in ((0.1, -0.1, 0.02), (-0.3, 0.2, -0.05), (0.05, 0.4, 0.08), (0.1, -0.1, 0.02))]
+    d_R0.upload(np.asarray(starts[0][0], np.float64).reshape(1, 4)), d_t0.upload(np.asarray(starts[0][1], np.float64).reshape(1, 2))
+    icp.fit_batch_from_dev(d_pts, d_off, d_nga, 1, d_R0, d_t0, d_R, d_t, 5.0, d_res, None, st)    # (buffers made outside the capture)
+    st.synchronize()
+    graph = api.Graph(st)
+    with graph:
+        icp.fit_batch_from_dev(d_pts, d_off, d_nga, 1, d_R0, d_t0, d_R, d_t, 5.0, d_res, None, st)
+    for R0, t0 in starts:
+        d_R0.upload(np.asarray(R0, np.float64).reshape(1, 4)), d_t0.upload(np.asarray(t0, np.float64).reshape(1, 2))
+        graph.launch(st)
+        st.synchronize()
+        Ro, to, tro, steps = model.fit(ga, nga, np.asarray(R0).reshape(2, 2), np.asarray(t0), O.icp_params(20, 1e-6, 5.0))
+        res = d_res.download()[0]
+        assert res["iters"] == steps and res["n_corr"] == int(tro[steps - 1, 7])
+        assert np.abs(d_t.download()[0] - to).max() < POS_TOL and ang_diff(yaw(d_R.download()[0]), yaw(Ro)).max() < ANG_TOL
+    # ... and an ordinary launch behind the replays does not take their granules for its own
+    icp.fit_batch_from_dev(d_pts, d_off, d_nga, 1, d_R0, d_t0, d_R, d_t, 5.0, d_res, None, st)
+    st.synchronize()
+    assert np.abs(d_t.download()[0] - to).max() < POS_TOL
+    icp.close()
