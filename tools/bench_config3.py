@@ -70,6 +70,10 @@ def measure_cpp(clouds, poses, advance=10, passes=3, forms=("seq",)):
                     "max_pose_difference_vs_seq": {"xy_m": float(np.abs(got[:, :2] - out["poses"][:, :2]).max()),
                                                    "z_m": float(np.abs(got[:, 2] - out["poses"][:, 2]).max()),
                                                    "quat": float(np.abs(got[:, 3:] - out["poses"][:, 3:]).max())}}
+                f = out["throughput_forms"][form]
+                f["same_poses_as_seq"] = bool(max(f["max_pose_difference_vs_seq"].values()) < 1e-9)
+                if not f["same_poses_as_seq"]:
+                    print("bench_config3: form %s DIFFERS from the sequential form: %r" % (form, f["max_pose_difference_vs_seq"]), file=sys.stderr)
         out["truth"] = np.array(truth)
         out["init"] = np.array(init)
         out["target_of"] = [((k - 1) // advance) * advance if advance > 0 else 0 for k in range(1, len(clouds))]
