@@ -468,10 +468,14 @@ __device__ inline unsigned ga_order_f32(float f)
 // ... and, where the caller goes on to the voxel filter (slam_ccicp_scene_dev), the extent of the points the classification
 // keeps -- getMinMax3D over the finite points whose flag is not 255, as ccicp.hip's minmax_kernel forms it -- in the same
 // pass: mm[6] ordered-float minima and maxima (nullable).
-__device__ inline void ga_call_done(unsigned *state, unsigned epoch)
+__device__ inline void ga_call_done(unsigned *state, unsigned epoch, int n)
 {
+    // (the launch is sized for the cloud's capacity, n is what the device says there is: only the workgroups with points take a
+    // ticket -- same-address atomics are served one after the other, 11 ns each -- and a call without points marked nothing)
+    const unsigned active = (unsigned)((n + 255) / 256);
+    if (blockIdx.x >= active) return;
     __syncthreads(); // (every lane of the workgroup has read the lattice)
-    if (threadIdx.x == 0 && atomicAdd(&state[1], 1u) == gridDim.x - 1u) {
+    if (threadIdx.x == 0 && atomicAdd(&state[1], 1u) == active - 1u) {
         state[1] = 0u;
         state[0] = epoch + 1u == 0u ? 1u : epoch + 1u;
     }
@@ -502,7 +506,7 @@ __global__ __launch_bounds__(256) void ga_flag_kernel(const float *xyz, int n, i
             for (int d = 0; d < 3; ++d) lo[d] = hi[d] = ga_order_f32(p[d]);
     }
     if (!mm) { // (uniform)
-        ga_call_done(state, epoch);
+        ga_call_done(state, epoch, n);
         return;
     }
     __shared__ unsigned red[4][6];
@@ -524,7 +528,7 @@ __global__ __launch_bounds__(256) void ga_flag_kernel(const float *xyz, int n, i
             if (v != 0u && v > __hip_atomic_load(&mm[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&mm[d], v);
         }
     }
-    ga_call_done(state, epoch);
+    ga_call_done(state, epoch, n);
 }
 
 } // namespace

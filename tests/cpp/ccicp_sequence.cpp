@@ -63,13 +63,13 @@ int main(int argc, char **argv)
 
     slam_amd::CCICP icp(slam_amd::SCAN_TO_SCAN);
     if (std::getenv("SEQ_NO_GRAPHS")) icp.setSequenceGraphs(false); // (measurements)
-    double t_match = 0, t_target = 0, worst = 0, sum_err = 0, iters = 0, corr = 0;
+    double t_match = 0, t_target = 0, worst = 0, sum_err = 0, iters = 0, corr = 0, t_set = 0; // t_set: of t_match, the host inside setSceneCloud
     int    n_match = 0, n_target = 0, builds0 = 0;
     std::vector<double> poses;
     int    seq_b0 = 0;
     double seq_t0[3] = {0, 0, 0};
     for (int pass = 0; pass < passes; ++pass) {
-        t_match = t_target = worst = sum_err = iters = corr = 0;
+        t_match = t_target = worst = sum_err = iters = corr = t_set = 0;
         seq_b0 = icp.sequenceBatches();
         for (int j = 0; j < 3; ++j) seq_t0[j] = icp.sequenceTimes()[j];
         n_match = n_target = 0;
@@ -123,6 +123,7 @@ int main(int argc, char **argv)
             const slam_amd::Pose pose = pose_of(k);
             a = clk::now();
             icp.setSceneCloud(cloud_ptr[k], cloud_n[k], 3); // scan_registration.cpp:139
+            t_set += ms(a, clk::now());
             if (form == "ahead" && k + 1 < n_clouds) icp.prepareSceneCloud(cloud_ptr[k + 1], cloud_n[k + 1], 3);
             const slam_amd::Pose r = icp.doICPMatch(pose);                       // :159
             t_match += ms(a, clk::now());
@@ -148,8 +149,10 @@ int main(int argc, char **argv)
     }
     std::printf("{\"form\": \"%s\", \"matches\": %d, \"ms_per_match\": %.4f, \"clouds_per_s\": %.1f, \"target_updates\": %d, \"ms_per_target_update\": %.4f, "
                 "\"target_index_builds\": %d, \"ms_per_cloud_with_target_updates\": %.4f, \"mean_icp_iterations\": %.2f, "
-                "\"mean_correspondences\": %.1f, \"mean_xy_error_m\": %.4f, \"max_xy_error_m\": %.4f, \"rays_per_cloud\": %zu}\n",
+                "\"mean_correspondences\": %.1f, \"mean_xy_error_m\": %.4f, \"max_xy_error_m\": %.4f, \"rays_per_cloud\": %zu, "
+                "\"ms_in_set_scene_cloud\": %.4f}\n",
                 form.c_str(), n_match, t_match / n_match, 1e3 * n_match / t_match, n_target, t_target / n_target, icp.targetBuilds() - builds0,
-                (t_match + t_target) / n_match, iters / n_match, corr / n_match, sum_err / n_match, worst, clouds[0].size() / 3);
+                (t_match + t_target) / n_match, iters / n_match, corr / n_match, sum_err / n_match, worst, clouds[0].size() / 3,
+                n_match ? t_set / n_match : 0.0);
     return 0;
 }
