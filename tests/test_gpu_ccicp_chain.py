@@ -124,3 +124,23 @@ def test_match_and_height_from_the_chain_without_the_host_knowing_sizes():
     icp.close()
     seg.close()
     cc.close()
+
+
+def test_chain_on_one_pair_of_handles_over_clouds_of_many_sizes():
+    """The one-launch compactions keep their look-back words and their epoch on the device, the GA lattice its call epoch: nothing is
+    cleared between calls.  One pair of handles over clouds whose sizes sit on and around the compaction's block size (1024 items),
+    shrink and grow again -- a word a larger cloud left behind is never taken for a smaller one's -- each against the stepwise path."""
+    seg, cc = api.GroundSegmentation(), api.Ccicp()
+    base = synth.make_cloud3d(2, n_loop=50)[0]
+    rs = np.random.RandomState(11)
+    for n in (70000, 1024, 1025, 5, len(base), 1023, 2049, 4096, 1, 33000):
+        xyz = np.ascontiguousarray(base[rs.permutation(len(base))[:n]])
+        voxel = n % 2 == 0
+        a = stepwise(seg, cc, xyz, voxel, None if n % 3 else (5.0, -5.0))
+        b = chain(seg, cc, xyz, voxel, None if n % 3 else (5.0, -5.0))
+        assert b["err"] == 0, n
+        assert (a["n_obs"], a["n_gnd"], a["n_flt"]) == (b["n_obs"], b["n_gnd"], b["n_flt"]), n
+        for k in ("ga", "nga", "ground"):
+            assert a[k].shape == b[k].shape and np.array_equal(a[k], b[k], equal_nan=True), (n, k)
+    seg.close()
+    cc.close()
