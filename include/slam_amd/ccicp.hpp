@@ -405,13 +405,18 @@ private:
     // cover to select everything
     void extent_of(const float *xyz, int n, int stride)
     {
-        ext_[0] = ext_[2] = INFINITY, ext_[1] = ext_[3] = -INFINITY;
+        // (without branches and library calls: 131 072 points in 0.3 ms where isfinite / fmin / fmax behind a `continue` took 1.5 --
+        // a third of a target update)
+        float x0 = INFINITY, x1 = -INFINITY, y0 = INFINITY, y1 = -INFINITY;
         for (int i = 0; i < n; ++i) {
             const float *p = xyz + (size_t)i * stride;
-            if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;
-            ext_[0] = std::fmin(ext_[0], p[0]), ext_[1] = std::fmax(ext_[1], p[0]);
-            ext_[2] = std::fmin(ext_[2], p[1]), ext_[3] = std::fmax(ext_[3], p[1]);
+            const float  x = p[0], y = p[1], z = p[2];
+            const bool   fin = (x - x == 0.0f) & (y - y == 0.0f) & (z - z == 0.0f);
+            const float  xa = fin ? x : INFINITY, xb = fin ? x : -INFINITY, ya = fin ? y : INFINITY, yb = fin ? y : -INFINITY;
+            x0 = xa < x0 ? xa : x0, x1 = xb > x1 ? xb : x1;
+            y0 = ya < y0 ? ya : y0, y1 = yb > y1 ? yb : y1;
         }
+        ext_[0] = x0, ext_[1] = x1, ext_[2] = y0, ext_[3] = y1;
     }
     void reset_box() { box_[0] = box_[2] = -INFINITY, box_[1] = box_[3] = INFINITY; }
     bool covers(const float b[4]) const { return ext_[0] >= b[0] && ext_[1] <= b[1] && ext_[2] >= b[2] && ext_[3] <= b[3]; }
