@@ -1283,6 +1283,12 @@ def main():
                                                      "clouds_per_s", "stepwise_clouds_per_s", "model_points", "mean_icp_iterations", "target_model_ms")}
             except Exception as ex:   # the headline line must not depend on the extra leg
                 out["config3"] = {"error": str(ex)}
+            try:   # the grid half one cloud at a time through the C++ drop-in, as local_mapper runs it
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                import mls_time
+                out["local_mapper_cloud"] = mls_time.measure(4)
+            except Exception as ex:
+                out["local_mapper_cloud"] = {"error": str(ex)}
             # short runs of the other GPU configs of BASELINE.json, each in a process of its own (this one stays idle):
             # one GPU's share of config 4 (1024 scans into 4000 x 4000, pipelined steps) and config 5 (the streaming mapper
             # with its sliding-window target, PCIe inclusive)

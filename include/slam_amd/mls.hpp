@@ -67,6 +67,7 @@ public:
     {
         slam_device_synchronize();
         for (void *p : {d_cloud_, d_labels_, d_gnd_, d_obs_, d_counts_}) slam_free(p);
+        slam_host_free(h_pin_);
         slam_gseg_destroy(gseg_);
         slam_grid_destroy(h_);
     }
@@ -105,7 +106,9 @@ public:
     void setPose(const Pose &p) { setPose(p.x, p.y); }
     // mls.cpp:59-150, the one-cloud form: segmentGround (groundSegmentation.cpp:91-468) on the device, the drv
     // (obstacle below robot height) and ground clouds, then the two point loops in the reference's order
-    void addToOccupancy(const float *cloud_xyz, int n, int stride = 3)
+    void addToOccupancy(const float *cloud_xyz, int n, int stride = 3) { add_cloud(cloud_xyz, n, stride, nullptr, nullptr); }
+    // ... of the cloud as it is (R null) or turned by R (row-major) and offset by t first
+    void add_cloud(const float *cloud_xyz, int n, int stride, const double *R, const double *t)
     {
         if (!h_ || n <= 0) return;
         if (!gseg_ && slam_gseg_create(nullptr, &gseg_) != SLAM_OK) return warn();
@@ -122,22 +125,59 @@ public:
         }
         if (!d_counts_ && slam_malloc(&d_counts_, 16) != SLAM_OK) return warn();
         if (stride > 8) return (void)std::fprintf(stderr, "MLS::addToOccupancy: stride %d > 8 floats\n", stride);
-        if (slam_memcpy_h2d(d_cloud_, cloud_xyz, sizeof(float) * (size_t)n * stride, nullptr) != SLAM_OK) return warn();
+        // the cloud as it came, behind the place the segmentation reads (d_cloud_ holds 8 floats per point: a turned copy of at
+        // most 3 in front, the upload of at most 5 ... 8 behind it when a transform is asked for)
+        const bool turn = R != nullptr;
+        float     *d_up = turn ? static_cast<float *>(d_cloud_) + 3 * (size_t)cap_ : static_cast<float *>(d_cloud_);
+        if (turn && stride > 5) return (void)std::fprintf(stderr, "MLS::addToMap: stride %d > 5 floats\n", stride);
+        if (slam_memcpy_h2d(d_up, cloud_xyz, sizeof(float) * (size_t)n * stride, nullptr) != SLAM_OK) return warn();
+        if (turn) { // mls.cpp:34-53 on the device (round 6: the host loop was 0.15 of a cloud's 0.35 ms)
+            if (slam_grid_transform_cloud_dev(d_up, n, stride, R, t, static_cast<float *>(d_cloud_), nullptr) != SLAM_OK) return warn();
+            stride = 3;
+        }
         if (slam_gseg_segment_dev(gseg_, (const float *)d_cloud_, n, stride, (uint8_t *)d_labels_, nullptr) != SLAM_OK) return warn();
         if (slam_gseg_split_dev(gseg_, (const float *)d_cloud_, n, stride, (const uint8_t *)d_labels_, (float *)d_gnd_, (float *)d_obs_,
                                 (int32_t *)d_counts_, nullptr) != SLAM_OK)
             return warn();
-        int32_t counts[2] = {0, 0}; // ground, obstacle
-        if (slam_memcpy_d2h(counts, d_counts_, sizeof counts, nullptr) != SLAM_OK) return warn();
-        if (slam_grid_add_scan_inorder_dev(h_, (const float *)d_obs_, counts[1], (const float *)d_gnd_, counts[0], 4, nullptr) != SLAM_OK)
-            return warn();
-        if (!disable_pointcloud_ && counts[1] > 0) { // *global_cloud += drv_cloud (:144-149)
-            std::vector<float> drv(4 * (size_t)counts[1]);
-            if (slam_memcpy_d2h(drv.data(), d_obs_, 16 * (size_t)counts[1], nullptr) != SLAM_OK) return warn();
-            for (int i = 0; i < counts[1]; ++i) global_cloud_.insert(global_cloud_.end(), &drv[4 * (size_t)i], &drv[4 * (size_t)i] + 3);
+        // the two counts, and the drv cloud where global_cloud is kept, come back into PINNED memory (a read-back into pageable
+        // memory is staged by the runtime: 0.1 ms for the cloud's 300 KB)
+        if (!pin_reserve(64)) return warn();
+        int32_t *counts = static_cast<int32_t *>(h_pin_); // ground, obstacle
+        if (slam_memcpy_d2h(counts, d_counts_, 2 * sizeof(int32_t), nullptr) != SLAM_OK) return warn();
+        const int32_t n_gnd = counts[0], n_drv = counts[1];
+        const float  *drv_ = nullptr;
+        if (!disable_pointcloud_ && n_drv > 0) { // *global_cloud += drv_cloud (:144-149): read back BEFORE the grid update is
+            if (!pin_reserve(64 + 16 * (size_t)n_drv)) return warn(); // enqueued (it runs while the host appends)
+            drv_ = reinterpret_cast<const float *>(static_cast<unsigned char *>(h_pin_) + 64);
+            if (slam_memcpy_d2h(static_cast<unsigned char *>(h_pin_) + 64, d_obs_, 16 * (size_t)n_drv, nullptr) != SLAM_OK) return warn();
         }
-        last_counts_[0] = counts[1];
-        last_counts_[1] = counts[0];
+        counts = nullptr; // (pin_reserve may have moved the block)
+        if (slam_grid_add_scan_inorder_dev(h_, (const float *)d_obs_, n_drv, (const float *)d_gnd_, n_gnd, 4, nullptr) != SLAM_OK)
+            return warn();
+        if (drv_) {
+            const size_t at = global_cloud_.size();
+            global_cloud_.resize(at + 3 * (size_t)n_drv);
+            float *dst = global_cloud_.data() + at;
+            for (int i = 0; i < n_drv; ++i) {
+                dst[3 * (size_t)i] = drv_[4 * (size_t)i];
+                dst[3 * (size_t)i + 1] = drv_[4 * (size_t)i + 1];
+                dst[3 * (size_t)i + 2] = drv_[4 * (size_t)i + 2];
+            }
+        }
+        last_counts_[0] = n_drv;
+        last_counts_[1] = n_gnd;
+    }
+    bool pin_reserve(size_t bytes)
+    {
+        if (bytes <= pin_cap_) return true;
+        slam_device_synchronize();
+        slam_host_free(h_pin_);
+        h_pin_ = nullptr;
+        pin_cap_ = 0;
+        const size_t want = bytes + bytes / 2;
+        if (slam_host_alloc(&h_pin_, want) != SLAM_OK) return false;
+        pin_cap_ = want;
+        return true;
     }
     // mls.cpp:34-53: setPose, then (rolling) the cloud turned into the global orientation and offset by the
     // sub-cell residual curPose - pose (tf::poseMsgToEigen + pcl::transformPointCloud: computed in double, stored
@@ -154,6 +194,10 @@ public:
         const double xs = pose.qx * s2, ys = pose.qy * s2, zs = pose.qz * s2, wx = pose.qw * xs, wy = pose.qw * ys, wz = pose.qw * zs,
                      xx = pose.qx * xs, xy = pose.qx * ys, xz = pose.qx * zs, yy = pose.qy * ys, yz = pose.qy * zs, zz = pose.qz * zs;
         const double r[9] = {1.0 - (yy + zz), xy - wz, xz + wy, xy + wz, 1.0 - (xx + zz), yz - wx, xz - wy, yz + wx, 1.0 - (xx + yy)};
+        // (float)(r0 x + r1 y + r2 z + t) per coordinate, in double: slam_grid_transform_cloud_dev, the same floats as the host loop
+        // this was until round 6 (tests/test_gpu_cpp_adapters.py holds the map against the oracle's, which transforms on the host)
+        const double t3[3] = {tx, ty, tz};
+        if (stride <= 5) return add_cloud(cloud_xyz, n, stride, r, t3);
         trans_.resize(3 * (size_t)n);
         for (int i = 0; i < n; ++i) {
             const double px = cloud_xyz[(size_t)i * stride], py = cloud_xyz[(size_t)i * stride + 1], pz = cloud_xyz[(size_t)i * stride + 2];
@@ -238,6 +282,8 @@ private:
     void         *d_cloud_ = nullptr, *d_labels_ = nullptr, *d_gnd_ = nullptr, *d_obs_ = nullptr, *d_counts_ = nullptr;
     int           cap_ = 0, last_counts_[2] = {0, 0};
     std::vector<float> global_cloud_, trans_;
+    void              *h_pin_ = nullptr; // pinned: [counts | drv cloud]
+    size_t             pin_cap_ = 0;
 };
 
 } // namespace slam_amd

@@ -331,6 +331,12 @@ int slam_grid_finalize(slam_grid_t *g, slam_stream_t stream);
  * step keeps slam_grid_finalize + slam_grid_reset_counts. */
 int slam_grid_finalize_reset(slam_grid_t *g, slam_stream_t stream);
 
+/* MLS::addToMap's cloud transform (mls.cpp:34-53, pcl::transformPointCloud with the pose's rotation and an offset): out = (float)(R p + t)
+ * per point, R row-major, computed in double term by term as a host loop `r0*x + r1*y + r2*z + t` does (no contraction): the
+ * same floats.  d_out_xyz: n x 3 floats; it may not overlap d_in_xyz unless stride == 3 and the two are the same array. */
+int slam_grid_transform_cloud_dev(const float *d_in_xyz, int n, int stride, const double R[9], const double t[3], float *d_out_xyz,
+                                  slam_stream_t stream);
+
 /* One scan with the reference's own ordering and rounding (mls.cpp:73-142):
  * sequential += / -= on the per-cell double, thresholds after every point. */
 int slam_grid_add_scan_inorder(slam_grid_t *g, const float *obs, int n_obs, const float *gnd,

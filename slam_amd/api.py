@@ -90,7 +90,7 @@ EXPORTS = [
     "slam_grid_set_min_cluster_points", "slam_grid_set_max_range", "slam_grid_set_pose",
     "slam_grid_get_pose", "slam_grid_add_endpoints", "slam_grid_add_endpoints_dev",
     "slam_grid_raycast", "slam_grid_raycast_dev", "slam_grid_raycast_scans_dev", "slam_grid_reserve",
-    "slam_grid_finalize", "slam_grid_finalize_reset", "slam_grid_add_scan_inorder", "slam_grid_add_scan_inorder_dev", "slam_grid_read_counts",
+    "slam_grid_finalize", "slam_grid_finalize_reset", "slam_grid_add_scan_inorder", "slam_grid_add_scan_inorder_dev", "slam_grid_transform_cloud_dev", "slam_grid_read_counts",
     "slam_grid_read_occupancy", "slam_grid_read_num_pts", "slam_grid_total_updates",
     "slam_grid_info", "slam_grid_window_cell", "slam_grid_counts_dev", "slam_grid_mark_rows", "slam_grid_raycast_stats", "slam_grid_dirty_rows", "slam_grid_dirty_rows_dev",
     "slam_grid_enable_accumulator", "slam_grid_fold",
@@ -215,6 +215,7 @@ def lib():
     L.slam_grid_finalize_reset.argtypes = [_vp, _vp]
     L.slam_grid_add_scan_inorder.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int]
     L.slam_grid_add_scan_inorder_dev.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp]
+    L.slam_grid_transform_cloud_dev.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _vp, _vp]
     L.slam_grid_read_counts.argtypes = [_vp, _vp, _vp]
     L.slam_grid_read_occupancy.argtypes = [_vp, _vp]
     L.slam_grid_read_num_pts.argtypes = [_vp, _vp]

@@ -1671,6 +1671,40 @@ int slam_grid_finalize_reset(slam_grid_t *g, slam_stream_t stream)
     return SLAM_OK;
 }
 
+// MLS::addToMap's cloud transform (mls.cpp:34-53: tf::poseMsgToEigen + pcl::transformPointCloud): every point turned by the pose's
+// rotation and offset by t, computed in double and stored as float -- the arithmetic of the adapter's host loop term by term
+// (products and sums rounded one by one, no contraction), so the floats are the host's.
+namespace {
+struct CloudTransform {
+    double r[9], t[3];
+};
+__global__ __launch_bounds__(256) void transform_cloud_kernel(const float *in, int n, int stride, CloudTransform T, float *out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double px = in[(size_t)i * stride], py = in[(size_t)i * stride + 1], pz = in[(size_t)i * stride + 2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        out[3 * (size_t)i + k] = (float)__dadd_rn(
+            __dadd_rn(__dadd_rn(__dmul_rn(T.r[3 * k], px), __dmul_rn(T.r[3 * k + 1], py)), __dmul_rn(T.r[3 * k + 2], pz)), T.t[k]);
+}
+} // namespace
+
+int slam_grid_transform_cloud_dev(const float *d_in_xyz, int n, int stride, const double R[9], const double t[3], float *d_out_xyz,
+                                  slam_stream_t stream)
+{
+    SLAM_REQUIRE(n >= 0 && stride >= 3 && R && t && ((d_in_xyz && d_out_xyz) || n == 0), SLAM_E_INVALID,
+                 "slam_grid_transform_cloud_dev: bad arguments");
+    SLAM_TRY(require_device());
+    if (n == 0) return SLAM_OK;
+    CloudTransform T;
+    for (int k = 0; k < 9; ++k) T.r[k] = R[k];
+    for (int k = 0; k < 3; ++k) T.t[k] = t[k];
+    hipLaunchKernelGGL(transform_cloud_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), d_in_xyz, n, stride, T, d_out_xyz);
+    SLAM_HIP(hipGetLastError());
+    return SLAM_OK;
+}
+
 int slam_grid_add_scan_inorder_dev(slam_grid_t *g, const float *d_obs, int n_obs, const float *d_gnd, int n_gnd, int stride,
                                    slam_stream_t stream)
 {

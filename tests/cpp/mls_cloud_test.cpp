@@ -1,6 +1,8 @@
 // A C++ program written like local_mapper.cpp:65-130 uses MLS, over the adapter include/slam_amd/mls.hpp:
 // raw clouds and poses in (addToMap segments inside, mls.cpp:34-150), occupancy grid and global cloud out.
 //   mls_cloud_test <dir> <out> <n_clouds>
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <string>
@@ -30,6 +32,40 @@ int main(int argc, char **argv)
     const int         n_clouds = std::atoi(argv[3]);
     auto poses = read_all<double>(dir + "/poses.f64"); // x y z qx qy qz qw per cloud
 
+    // timing (tools/mls_time.py): <passes> > 0 runs the clouds that often through a second map first -- addToMap per cloud as
+    // local_mapper's callback does (local_mapper.cpp:107), getDrivability every <every> clouds (:120) -- and prints the wall clock
+    const int passes = argc > 4 ? std::atoi(argv[4]) : 0, every = argc > 5 ? std::atoi(argv[5]) : 5;
+    if (passes > 0) {
+        std::vector<std::vector<float>> clouds;
+        for (int k = 0; k < n_clouds; ++k) clouds.push_back(read_all<float>(dir + "/cloud" + std::to_string(k) + ".f32"));
+        slam_amd::MLS m(200, 200, 0.2, true);
+        m.setMinClusterPoints(20);
+        m.clearMap();
+        if (argc > 6 && std::atoi(argv[6])) m.setDisablePointCloud(true); // mls.h:223
+        double t_add = 0, t_drv = 0;
+        long   n_add = 0, n_drv = 0;
+        for (int pass = 0; pass < passes; ++pass) {
+            if (pass == 1) t_add = t_drv = 0, n_add = n_drv = 0; // (the first pass makes the buffers)
+            for (int k = 0; k < n_clouds; ++k) {
+                slam_amd::Pose p;
+                const double *q = &poses[7 * (size_t)k];
+                p.x = q[0], p.y = q[1], p.z = q[2], p.qx = q[3], p.qy = q[4], p.qz = q[5], p.qw = q[6];
+                auto a = std::chrono::steady_clock::now();
+                m.addToMap(clouds[(size_t)k].data(), (int)clouds[(size_t)k].size() / 3, 3, p);
+                auto b = std::chrono::steady_clock::now();
+                t_add += std::chrono::duration<double, std::milli>(b - a).count();
+                ++n_add;
+                if ((k + 1) % every == 0) {
+                    (void)m.getDrivability();
+                    t_drv += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b).count();
+                    ++n_drv;
+                }
+            }
+            if (!(argc > 6 && std::atoi(argv[6]))) m.filterPointCloud(0.1, 0.1), m.clearMap();
+        }
+        std::printf("{\"clouds\": %ld, \"ms_per_add_to_map\": %.4f, \"ms_per_get_drivability\": %.4f, \"points_per_cloud\": %zu}\n", n_add,
+                    t_add / (double)std::max(n_add, 1l), t_drv / (double)std::max(n_drv, 1l), clouds[0].size() / 3);
+    }
     slam_amd::MLS local_map(200, 200, 0.2, true); // local_mapper.cpp:29
     local_map.setMinClusterPoints(20);             // :86
     local_map.clearMap();                          // :93

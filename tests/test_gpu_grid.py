@@ -400,3 +400,29 @@ def test_event_query_does_not_block_and_tells_the_truth():
     st.synchronize()
     assert ev.query() is True and seen_false
     g.close()
+
+
+@pytest.mark.gpu
+def test_transform_cloud_is_the_host_loop_bit_for_bit():
+    """slam_grid_transform_cloud_dev (MLS::addToMap's pcl::transformPointCloud, mls.cpp:34-53): (float)(r0 x + r1 y + r2 z + t) per
+    coordinate in double, the products and sums rounded one by one as the adapter's host loop (and numpy) round them."""
+    import ctypes as C
+    rs = np.random.RandomState(4)
+    for n, stride in ((1, 3), (1000, 3), (131072, 4), (777, 5)):
+        cloud = (rs.randn(n, stride) * 30).astype(np.float32)
+        cloud[::97, 0] = np.nan
+        th = rs.uniform(-3, 3)
+        q = np.array([0.01, -0.02, np.sin(th / 2), np.cos(th / 2)])
+        q /= np.linalg.norm(q)
+        x, y, z, w = q
+        R = np.array([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                      2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], np.float64)
+        t = rs.uniform(-0.2, 0.2, 3)
+        d_in = api.DeviceArray.from_host(cloud)
+        d_out = api.DeviceArray((n, 3), np.float32)
+        api.check(api.lib().slam_grid_transform_cloud_dev(d_in.ptr, n, stride, R.ctypes.data_as(C.POINTER(C.c_double)),
+                                                          t.ctypes.data_as(C.POINTER(C.c_double)), d_out.ptr, None))
+        api.synchronize()
+        p = cloud[:, :3].astype(np.float64)
+        want = np.stack([((R[3 * k] * p[:, 0] + R[3 * k + 1] * p[:, 1]) + R[3 * k + 2] * p[:, 2]) + t[k] for k in range(3)], axis=1).astype(np.float32)
+        assert np.array_equal(d_out.download(), want, equal_nan=True), (n, stride)
