@@ -105,7 +105,7 @@ public:
     {
         slam_device_synchronize();
         if (icp_) slam_icp_destroy(icp_);
-        for (Cloud *c : {&raw_, &scene_raw_, &labels_, &obs_, &flags_, &seg_target_, &seg_scene_, &ground_target_, &ground_scene_, &scene_ground_})
+        for (Cloud *c : {&raw_, &scene_raw_, &scene_in_, &labels_, &obs_, &flags_, &seg_target_, &seg_scene_, &ground_target_, &ground_scene_, &scene_ground_})
             slam_free(c->p);
         free_ahead();
         free_seq();
@@ -172,6 +172,19 @@ public:
         upload(scene_raw_, xyz, n, stride);
         scene_n_in_ = n;
         scene_stride_ = stride;
+        enqueue_scene_chain();
+    }
+    // ... of the cloud turned by R (row-major) and offset by t first -- what scan_registration does to every cloud before it hands
+    // it over (roll / pitch compensation, scan_registration.cpp:128-139: pcl::transformPointCloud) -- with the transform on the
+    // device: (float)(r0 x + r1 y + r2 z + t) per coordinate in double, the floats a host loop gives (slam_grid_transform_cloud_dev)
+    void setSceneCloud(const float *xyz, int n, int stride, const double R[9], const double t[3])
+    {
+        ahead_.pending = ahead_.deferred = false;
+        upload(scene_in_, xyz, n, stride);
+        reserve(scene_raw_, sizeof(float) * 3 * (size_t)(n + 1));
+        ok(slam_grid_transform_cloud_dev((const float *)scene_in_.p, n, stride, R, t, (float *)scene_raw_.p, stream_));
+        scene_n_in_ = n;
+        scene_stride_ = 3;
         enqueue_scene_chain();
     }
     // the scene's chain from the cloud in scene_raw_ (setSceneCloud; again after a SCAN_TO_SCAN setTargetCloud borrowed its outputs)
@@ -871,7 +884,7 @@ private:
     slam_ccicp_t *cc_ = nullptr;
     slam_icp_t   *icp_ = nullptr;   // the target's index, kept across matches
     slam_stream_t stream_ = nullptr;
-    Cloud         raw_, scene_raw_, labels_, obs_, flags_, seg_target_, seg_scene_, ground_target_, ground_scene_, scene_ground_;
+    Cloud         raw_, scene_raw_, scene_in_ /* a cloud as it came, before setSceneCloud's transform */, labels_, obs_, flags_, seg_target_, seg_scene_, ground_target_, ground_scene_, scene_ground_;
     int           raw_n_ = 0, raw_stride_ = 3, obs_n_ = 0, seg_target_n_ = 0, seg_scene_n_ = 0, ground_target_n_ = 0,
         ground_scene_n_ = 0, num_corr_ = 0, last_iters_ = 0, scene_n_in_ = 0, scene_stride_ = 3, target_in_box_ = 0, target_builds_ = 0, stepwise_matches_ = 0;
     int     n_model_[2] = {0, 0}, n_scene_[2] = {0, 0};

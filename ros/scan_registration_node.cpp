@@ -81,14 +81,10 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input) // :109-181
                  xy = c.qx * ys, xz = c.qx * zs, yy = c.qy * ys, yz = c.qy * zs, zz = c.qz * zs;
     const double r[9] = {1.0 - (yy + zz), xy - wz, xz + wy, xy + wz, 1.0 - (xx + zz), yz - wx, xz - wy, yz + wx, 1.0 - (xx + yy)};
     const double tz = poseOut.pose.position.z;
-    std::vector<float> temp(3 * n);
-    for (size_t i = 0; i < n; ++i) {
-        const double px = input_cloud[3 * i], py = input_cloud[3 * i + 1], pz = input_cloud[3 * i + 2];
-        temp[3 * i] = (float)(r[0] * px + r[1] * py + r[2] * pz);
-        temp[3 * i + 1] = (float)(r[3] * px + r[4] * py + r[5] * pz);
-        temp[3 * i + 2] = (float)(r[6] * px + r[7] * py + r[8] * pz + tz);
-    }
-    icp->setSceneCloud(temp.data(), (int)n, 3); // :139
+    // (pcl::transformPointCloud: per coordinate (float)(r0 x + r1 y + r2 z + t) in double -- on the device, behind the upload: the
+    // adapter's setSceneCloud(cloud, R, t); a host loop over 131 072 points and a 1.5 MB vector per scan were here)
+    const double t3[3] = {0.0, 0.0, tz};
+    icp->setSceneCloud(input_cloud.data(), (int)n, 3, r, t3); // :139
 
 #if SLAM_SCAN_REG_DEBUG // :141-148 (`#define DEBUG 1`, :37): the segmented scene on mapping/scan_reg/scene.  With the device-resident
     {                     // adapter this is the one step of a scan that brings clouds back to the host: build with =0 where nobody listens

@@ -78,6 +78,31 @@ int main(int argc, char **argv)
         }
         check(seq[i_tiny].qw == 9999, "sequential: a 4-point scene returns orientation.w == 9999");
     }
+    // (1b) setSceneCloud(cloud, R, t): the roll / pitch compensation of scan_registration.cpp:128-139 on the device -- the poses of the
+    // same clouds turned by a host loop first (what ros/scan_registration_node.cpp did until round 6), bit for bit
+    {
+        const double roll = 0.03, pitch = -0.02, tz = 0.4;
+        const double cr = std::cos(roll), sr = std::sin(roll), cp = std::cos(pitch), sp = std::sin(pitch);
+        const double R[9] = {cp, sp * sr, sp * cr, 0.0, cr, -sr, -sp, cp * sr, cp * cr}, t3[3] = {0.0, 0.0, tz};
+        slam_amd::CCICP a(slam_amd::SCAN_TO_SCAN), b(slam_amd::SCAN_TO_SCAN);
+        a.setTargetCloud(clouds[0].data(), (int)clouds[0].size() / 3, 3, p0);
+        b.setTargetCloud(clouds[0].data(), (int)clouds[0].size() / 3, 3, p0);
+        double worst = 0;
+        for (int k = 0; k < 4; ++k) {
+            const size_t       m = (size_t)cnt[k];
+            std::vector<float> turned(3 * m);
+            for (size_t i = 0; i < m; ++i) {
+                const double px = ptr[k][3 * i], py = ptr[k][3 * i + 1], pz = ptr[k][3 * i + 2];
+                turned[3 * i] = (float)(R[0] * px + R[1] * py + R[2] * pz + t3[0]);
+                turned[3 * i + 1] = (float)(R[3] * px + R[4] * py + R[5] * pz + t3[1]);
+                turned[3 * i + 2] = (float)(R[6] * px + R[7] * py + R[8] * pz + t3[2]);
+            }
+            a.setSceneCloud(turned.data(), cnt[k], 3);
+            b.setSceneCloud(ptr[k], cnt[k], 3, R, t3);
+            worst = std::fmax(worst, diff(a.doICPMatch(ip[(size_t)k]), b.doICPMatch(ip[(size_t)k])));
+        }
+        check(worst == 0.0, "setSceneCloud(cloud, R, t): the poses of the clouds turned on the host, bit for bit", worst);
+    }
     // (2) two chains in flight: a prepared scene that is adopted, one that is not, read-outs behind an adopted scene
     {
         slam_amd::CCICP icp(slam_amd::SCAN_TO_SCAN);
