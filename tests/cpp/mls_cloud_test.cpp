@@ -38,14 +38,16 @@ int main(int argc, char **argv)
     if (passes > 0) {
         std::vector<std::vector<float>> clouds;
         for (int k = 0; k < n_clouds; ++k) clouds.push_back(read_all<float>(dir + "/cloud" + std::to_string(k) + ".f32"));
+        const bool nocloud = argc > 6 && std::atoi(argv[6]);
         slam_amd::MLS m(200, 200, 0.2, true);
         m.setMinClusterPoints(20);
         m.clearMap();
-        if (argc > 6 && std::atoi(argv[6])) m.setDisablePointCloud(true); // mls.h:223
-        double t_add = 0, t_drv = 0;
+        if (nocloud) m.setDisablePointCloud(true); // mls.h:223
+        double t_add = 0, t_drv = 0, t_flt = 0;
         long   n_add = 0, n_drv = 0;
+        size_t n_global = 0;
         for (int pass = 0; pass < passes; ++pass) {
-            if (pass == 1) t_add = t_drv = 0, n_add = n_drv = 0; // (the first pass makes the buffers)
+            if (pass == 1) t_add = t_drv = t_flt = 0, n_add = n_drv = 0; // (the first pass makes the buffers)
             for (int k = 0; k < n_clouds; ++k) {
                 slam_amd::Pose p;
                 const double *q = &poses[7 * (size_t)k];
@@ -55,16 +57,25 @@ int main(int argc, char **argv)
                 auto b = std::chrono::steady_clock::now();
                 t_add += std::chrono::duration<double, std::milli>(b - a).count();
                 ++n_add;
+                if (!nocloud) { // local_mapper.cpp:111: the global cloud filtered behind every cloud ("so it won't kill rviz")
+                    auto c = std::chrono::steady_clock::now();
+                    m.filterPointCloud(0.1, 0.1);
+                    t_flt += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c).count();
+                    n_global = m.getGlobalCloud().size() / 3;
+                    b = std::chrono::steady_clock::now();
+                }
                 if ((k + 1) % every == 0) {
                     (void)m.getDrivability();
                     t_drv += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - b).count();
                     ++n_drv;
                 }
             }
-            if (!(argc > 6 && std::atoi(argv[6]))) m.filterPointCloud(0.1, 0.1), m.clearMap();
+            if (!nocloud) m.clearMap();
         }
-        std::printf("{\"clouds\": %ld, \"ms_per_add_to_map\": %.4f, \"ms_per_get_drivability\": %.4f, \"points_per_cloud\": %zu}\n", n_add,
-                    t_add / (double)std::max(n_add, 1l), t_drv / (double)std::max(n_drv, 1l), clouds[0].size() / 3);
+        std::printf("{\"clouds\": %ld, \"ms_per_add_to_map\": %.4f, \"ms_per_get_drivability\": %.4f, \"ms_per_filter_point_cloud\": %.4f, "
+                    "\"global_cloud_points\": %zu, \"points_per_cloud\": %zu}\n", n_add,
+                    t_add / (double)std::max(n_add, 1l), t_drv / (double)std::max(n_drv, 1l), t_flt / (double)std::max(n_add, 1l), n_global,
+                    clouds[0].size() / 3);
     }
     slam_amd::MLS local_map(200, 200, 0.2, true); // local_mapper.cpp:29
     local_map.setMinClusterPoints(20);             // :86
