@@ -1220,19 +1220,26 @@ __device__ inline void normal_of_model_point(const ModelView &mv, int n, int pos
     };
     // (a point with a non-finite coordinate sits in cell 0 and is nobody's neighbour at a finite distance: it scans everything
     // and gets whatever that arithmetic gives)
-    for (int r = 0;; ++r) {
+    // Squares of growing radius around the own cell; of each only what the one before left out: whole rows above and below it, the
+    // two side spans of the rows beside it -- two look-ups a row whatever the radius.  (One cell per look-up, ring by ring, was fine
+    // for walls -- ten neighbours within a cell or two -- and 1 ms for a model of scattered points: 0.6 m to the tenth neighbour at a
+    // pitch of 0.25 m is a hundred look-ups, each a chain of dependent loads, and a straggler in the cloud's fringe thousands.)  The
+    // radius grows by one up to 2, then by half of itself: a square is never more than 2.25 x the one that would have sufficed.
+    int rp = -1;
+    for (int r = 0;; r += (r < 2 ? 1 : r / 2)) {
         const int y_lo = max(cy - r, 0), y_hi = min(cy + r, L.ny - 1), x_lo = max(cx - r, 0), x_hi = min(cx + r, L.nx - 1);
         for (int y = y_lo; y <= y_hi; ++y) {
-            if (r > 0 && y > cy - r && y < cy + r) { // the ring's two side cells of this row
-                if (cx - r >= 0) row_span(y, cx - r, cx - r);
-                if (cx + r <= L.nx - 1) row_span(y, cx + r, cx + r);
-            } else if (y == cy - r || y == cy + r || r == 0) {
-                row_span(y, x_lo, x_hi); // the ring's top / bottom row (or the own cell)
+            if (rp >= 0 && y >= cy - rp && y <= cy + rp) { // beside the square already seen: what lies left and right of it
+                row_span(y, x_lo, min(cx - rp - 1, x_hi));
+                row_span(y, max(cx + rp + 1, x_lo), x_hi);
+            } else {
+                row_span(y, x_lo, x_hi);
             }
         }
         const bool  covers = x_lo == 0 && y_lo == 0 && x_hi == L.nx - 1 && y_hi == L.ny - 1;
         const float bound = (float)r * L.h - L.margin; // every point outside the square of radius r is farther than this
         if (covers || (finite && bp[K - 1] >= 0 && bound > 0.0f && bd[K - 1] < bound * bound)) break;
+        rp = r;
     }
     double mx = 0, my = 0;
     int    k = 0;

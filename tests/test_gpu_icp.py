@@ -650,3 +650,23 @@ def test_list_lattice_choice_changes_time_not_results(map_points):
             assert np.abs(R - ref[0]).max() < 1e-9 and np.abs(t - ref[1]).max() < 1e-9, (halo, pair)
             icp.close()
     assert len(seen) >= 2, "the three settings built the same lattice: nothing was tested (%s)" % seen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [600, 12000, 39998])
+def test_point_to_line_normals_of_scattered_models(n):
+    """Normals by k-NN where the tenth neighbour is many cells away: scattered points (no walls), a dense blob, stragglers far out in
+    the fringe -- the search's squares grow past their first few radii and read side spans beside what they have seen (round 6;
+    a room's walls keep it within two cells) -- against the oracle's normals up to sign, and the handle made from device arrays."""
+    rs = np.random.RandomState(n)
+    pts = np.concatenate([rs.randn(n // 2, 2) * [30.0, 20.0], rs.rand(n - n // 2 - 40, 2) * [80.0, 60.0] - [40.0, 30.0],
+                          rs.randn(30, 2) * 0.02 + [5.0, 5.0], rs.rand(10, 2) * 600.0 - 300.0])
+    pts = np.ascontiguousarray(pts[rs.permutation(len(pts))])
+    m_ga, m_nga = pts[: len(pts) // 3], pts[len(pts) // 3:]
+    model = O.IcpModel(m_ga, m_nga, normals_k=10)
+    icp = api.Icp(m_ga, m_nga, mode=api.ICP_P2L, normals_k=10)
+    n_gpu, n_cpu = icp.normals(), model.normals()
+    dots = np.abs((n_gpu * n_cpu).sum(1))
+    # (ten points that are all but collinear or all but isotropic leave the direction to the last bits: allow a handful)
+    assert np.sort(dots)[5] > 1 - 1e-9 and dots.min() > 0.99, (np.sort(dots)[:8])
+    icp.close()
