@@ -64,6 +64,9 @@ int slam_memcpy_d2d(void *dst_dev, const void *src_dev, size_t bytes, slam_strea
 /* pinned host memory and copies that only enqueue (for overlapping transfers with kernels on
  * other streams; the host buffer must stay valid until the stream reaches the copy) */
 int slam_host_alloc(void **hptr, size_t bytes);
+/* 1 when hptr points into pinned host memory (slam_host_alloc, hipHostMalloc, hipHostRegister) -- memory an _async copy really
+ * is asynchronous from --, 0 otherwise (pageable memory: the runtime stages such a copy and the call waits) */
+int slam_host_is_pinned(const void *hptr);
 int slam_host_free(void *hptr);
 int slam_memcpy_h2d_async(void *dst_dev, const void *src_pinned, size_t bytes, slam_stream_t stream);
 int slam_memcpy_d2h_async(void *dst_pinned, const void *src_dev, size_t bytes, slam_stream_t stream);

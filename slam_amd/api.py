@@ -74,7 +74,7 @@ _lib = None
 EXPORTS = [
     "slam_last_error", "slam_version", "slam_device_count", "slam_set_device", "slam_device_info",
     "slam_malloc", "slam_free", "slam_memset", "slam_memcpy_h2d", "slam_memcpy_d2h",
-    "slam_memcpy_d2d", "slam_host_alloc", "slam_host_free", "slam_memcpy_h2d_async",
+    "slam_memcpy_d2d", "slam_host_is_pinned", "slam_host_alloc", "slam_host_free", "slam_memcpy_h2d_async",
     "slam_memcpy_d2h_async", "slam_stream_wait_event", "slam_graph_begin_capture", "slam_graph_end_capture",
     "slam_graph_launch", "slam_graph_destroy",
     "slam_stream_create", "slam_stream_create_with_priority", "slam_stream_create_reserving_cus", "slam_stream_destroy", "slam_stream_synchronize",
@@ -215,6 +215,7 @@ def lib():
     L.slam_grid_finalize_reset.argtypes = [_vp, _vp]
     L.slam_grid_add_scan_inorder.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int]
     L.slam_grid_add_scan_inorder_dev.argtypes = [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, _vp]
+    L.slam_host_is_pinned.argtypes = [_vp]
     L.slam_grid_transform_cloud_dev.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), _vp, _vp]
     L.slam_grid_read_counts.argtypes = [_vp, _vp, _vp]
     L.slam_grid_read_occupancy.argtypes = [_vp, _vp]

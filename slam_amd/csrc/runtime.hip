@@ -313,6 +313,17 @@ int slam_host_alloc(void **hptr, size_t bytes)
     return SLAM_OK;
 }
 
+int slam_host_is_pinned(const void *hptr)
+{
+    if (!hptr || require_device() != SLAM_OK) return 0;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, hptr) != hipSuccess) {
+        (void)hipGetLastError(); // (an ordinary host pointer is "invalid value" to the runtime)
+        return 0;
+    }
+    return a.type == hipMemoryTypeHost ? 1 : 0;
+}
+
 int slam_host_free(void *hptr)
 {
     if (!hptr) return SLAM_OK;

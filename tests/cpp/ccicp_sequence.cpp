@@ -3,7 +3,7 @@
 // setSceneCloud + doICPMatch; every `advance` clouds the cloud just matched becomes the new target (setTargetCloud,
 // SCAN_TO_SCAN: what the target callbacks :73-104 do when graph_slam publishes a new map).
 //   ccicp_sequence <dir> <n_clouds> <advance> [passes] [form]
-// form (round 5): "seq" (default) = one cloud at a time as above; "ahead" = the same calls with prepareSceneCloud(cloud k+1) before
+// form (round 5): "seq" (default) = one cloud at a time as above; "seqp" = the same on clouds in pinned memory (round 6: the upload only enqueues); "ahead" = the same calls with prepareSceneCloud(cloud k+1) before
 // doICPMatch(cloud k) -- two chains in flight; "batch" = CCICP::matchSequence over the clouds between two target replacements
 // (the initial poses are the file's either way: in the node they would be the previous results).  "ahead" and "batch" keep the
 // clouds in pinned memory (slam_host_alloc), so that their uploads do not hold the host.

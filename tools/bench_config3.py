@@ -63,6 +63,7 @@ def measure_cpp(clouds, poses, advance=10, passes=3, forms=("seq",)):
                 out["poses"] = got
             else:
                 # a throughput form beside the sequential one: its rate, and that it gives the same poses
+                form = {"seqp": "seq_pinned_clouds"}.get(form, form)
                 out.setdefault("throughput_forms", {})[form] = {
                     "ms_per_match": line["ms_per_match"], "clouds_per_s": line["clouds_per_s"],
                     "ms_per_cloud_with_target_updates": line["ms_per_cloud_with_target_updates"],
@@ -215,10 +216,10 @@ def measure(n_clouds=50, cell=0.0, dump_case=None, advance=10):
         dyaw = np.abs((yaw - want[:, 2] + np.pi) % (2 * np.pi) - np.pi)
         assert np.abs(got[:, :2] - want[:, :2]).max() < 1e-9 and dyaw.max() < 1e-9 and np.abs(got[:, 2] - want[:, 3]).max() < 1e-9, \
             "the C++ adapter and the Python-driven chain disagree"
-        cpp = measure_cpp(clouds, poses, advance, forms=("seq", "ahead", "batch"))
+        cpp = measure_cpp(clouds, poses, advance, forms=("seq", "seqp", "ahead", "batch"))
         if "throughput_forms" in cpp:
             cpp["throughput_forms"]["what"] = (
-                "beside the sequential form (one cloud at a time: the reference's usage and this adapter's default): 'ahead' = "
+                "beside the sequential form (one cloud at a time from pageable memory: the reference's usage and this adapter's default): 'seq_pinned_clouds' = the same calls on clouds in pinned memory (slam_host_alloc: the upload only enqueues); 'ahead' = "
                 "CCICP::prepareSceneCloud(cloud k+1) before doICPMatch(cloud k), the next cloud's upload and scene chain on a second "
                 "stream; 'batch' = CCICP::matchSequence, the clouds between two target replacements with their scene chains on four "
                 "streams and their fits as ONE slam_icp_fit_batch_dev (initial poses known beforehand); clouds in pinned host memory")
