@@ -320,7 +320,10 @@ public:
         return out;
     }
     int sequenceBatches() const { return seq_batches_; }
-    void setSequenceGraphs(bool graphs) { use_graphs_ = graphs; } // (measurements: the scene chains call by call)
+    // the scene chains of matchSequence replayed as hipGraphs from a scene slot's third use on.  Off since round 6: with nine launches a
+    // chain (thirty in round 5) the replay saves the host 0.2 ms per batch that the device-bound batch does not wait for, and the
+    // uploads beside graph launches take three times as long -- 0.144 against 0.133 ms per match (tools/exp/c3_graphs_ab.sh)
+    void setSequenceGraphs(bool graphs) { use_graphs_ = graphs; }
     // host clock of the batches so far, ms: scene chains enqueued | everything enqueued | results back (cumulative within a batch)
     const double *sequenceTimes() const { return seq_ms_; }
     double sequenceUploadMs() const { return seq_up_ms_; } // of which: the host inside the scenes' upload calls
@@ -703,7 +706,7 @@ private:
     };
     SeqLane       lane_[kSeqLanes];
     SeqSlot       seq_slot_[kSeqBatch];
-    bool          seq_made_ = false, use_graphs_ = true;
+    bool          seq_made_ = false, use_graphs_ = false;
     int           seq_batches_ = 0;
     double        seq_ms_[3] = {0, 0, 0}, seq_up_ms_ = 0;
     double       *d_seq_slots_ = nullptr, *d_seq_pack_ = nullptr; // [kSeqBatch][2 * ICP_MAX_PTS] points each

@@ -157,6 +157,7 @@ int main(int argc, char **argv)
                 }
         }
         slam_amd::CCICP icp(slam_amd::SCAN_TO_SCAN);
+        icp.setSequenceGraphs(true); // (opt-in since round 6: this section is about the captured chains)
         icp.setTargetCloud(clouds[0].data(), (int)clouds[0].size() / 3, 3, p0);
         double worst = 0, worst_ahead = 0;
         for (int rep = 0; rep < kReps; ++rep) {

@@ -62,7 +62,7 @@ int main(int argc, char **argv)
     auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 
     slam_amd::CCICP icp(slam_amd::SCAN_TO_SCAN);
-    if (std::getenv("SEQ_NO_GRAPHS")) icp.setSequenceGraphs(false); // (measurements)
+    if (std::getenv("SEQ_GRAPHS")) icp.setSequenceGraphs(true); // (the batch form's scene chains replayed as hipGraphs: off by default since round 6)
     double t_match = 0, t_target = 0, worst = 0, sum_err = 0, iters = 0, corr = 0, t_set = 0; // t_set: of t_match, the host inside setSceneCloud
     int    n_match = 0, n_target = 0, builds0 = 0;
     std::vector<double> poses;

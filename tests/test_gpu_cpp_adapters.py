@@ -255,12 +255,14 @@ def test_ccicp_forms_agree_once_the_scene_chains_replay_as_graphs(tmp_path):
     np.array(init, np.float64).tofile(os.path.join(d, "init.f64"))
     np.array(truth, np.float64).tofile(os.path.join(d, "truth.f64"))
     got = {}
-    for form in ("seq", "ahead", "batch"):
-        p = subprocess.run([exe, d, str(n), str(advance), "4", form], capture_output=True, text=True, timeout=600)
+    for form in ("seq", "ahead", "batch", "batch+graphs"):
+        env = dict(os.environ, SEQ_GRAPHS="1") if form.endswith("graphs") else dict(os.environ)   # (replays are opt-in since round 6)
+        p = subprocess.run([exe, d, str(n), str(advance), "4", form.split("+")[0]], capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode == 0, p.stderr[-2000:]
         got[form] = np.fromfile(os.path.join(d, "poses_out.f64"), np.float64).reshape(n - 1, 7)
     assert np.array_equal(got["seq"], got["ahead"])
-    assert np.abs(got["seq"] - got["batch"]).max() < 1e-9, np.abs(got["seq"] - got["batch"]).max(axis=1)
+    for form in ("batch", "batch+graphs"):
+        assert np.abs(got["seq"] - got[form]).max() < 1e-9, (form, np.abs(got["seq"] - got[form]).max(axis=1))
 
 
 @pytest.mark.gpu
