@@ -426,3 +426,17 @@ def test_transform_cloud_is_the_host_loop_bit_for_bit():
         p = cloud[:, :3].astype(np.float64)
         want = np.stack([((R[3 * k] * p[:, 0] + R[3 * k + 1] * p[:, 1]) + R[3 * k + 2] * p[:, 2]) + t[k] for k in range(3)], axis=1).astype(np.float32)
         assert np.array_equal(d_out.download(), want, equal_nan=True), (n, stride)
+
+
+@pytest.mark.gpu
+def test_host_is_pinned_tells_pinned_from_pageable():
+    """slam_host_is_pinned: what the C++ adapters ask before an upload (a copy from pinned memory only enqueues)."""
+    L = api.lib()
+    pin = api.PinnedArray((1024,), np.float32)
+    assert L.slam_host_is_pinned(pin.array.ctypes.data) == 1
+    assert L.slam_host_is_pinned(pin.array.ctypes.data + 400) == 1          # anywhere inside the block
+    page = np.zeros(1024, np.float32)
+    assert L.slam_host_is_pinned(page.ctypes.data) == 0
+    dev = api.DeviceArray((16,), np.float32)
+    assert L.slam_host_is_pinned(dev.ptr) == 0                             # device memory is not host memory
+    assert L.slam_host_is_pinned(None) == 0
