@@ -64,9 +64,15 @@ void target_gnd_cb(const sensor_msgs::PointCloud2ConstPtr &target_input) // :91-
 void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input) // :109-181
 {
     if (!(first_gnd && first_obs)) return; // wait for the first ground and obstacle targets (:114-115)
-    if (!slam_amd_ros::cloud_to_xyz(*input, input_cloud)) return; // local frame
+    // the message's own bytes where its layout allows (x, y, z side by side: every driver's), a copy of the three fields otherwise
+    const float *cloud = nullptr;
+    int          cloud_stride = 3;
+    size_t       n = 0;
+    if (!slam_amd_ros::cloud_xyz_view(*input, cloud, cloud_stride, n)) {
+        if (!slam_amd_ros::cloud_to_xyz(*input, input_cloud)) return; // local frame
+        cloud = input_cloud.data(), cloud_stride = 3, n = input_cloud.size() / 3;
+    }
     if (target_obs_cloud.empty()) return;
-    const size_t n = input_cloud.size() / 3;
     if (n < 20000) { // :122-125
         ROS_WARN_STREAM("Input Cloud is to small!! Size: " << n);
         return;
@@ -84,7 +90,7 @@ void cloud_cb(const sensor_msgs::PointCloud2ConstPtr &input) // :109-181
     // (pcl::transformPointCloud: per coordinate (float)(r0 x + r1 y + r2 z + t) in double -- on the device, behind the upload: the
     // adapter's setSceneCloud(cloud, R, t); a host loop over 131 072 points and a 1.5 MB vector per scan were here)
     const double t3[3] = {0.0, 0.0, tz};
-    icp->setSceneCloud(input_cloud.data(), (int)n, 3, r, t3); // :139
+    icp->setSceneCloud(cloud, (int)n, cloud_stride, r, t3); // :139
 
 #if SLAM_SCAN_REG_DEBUG // :141-148 (`#define DEBUG 1`, :37): the segmented scene on mapping/scan_reg/scene.  With the device-resident
     {                     // adapter this is the one step of a scan that brings clouds back to the host: build with =0 where nobody listens
