@@ -57,6 +57,32 @@ constexpr int kSpreadStampSlots = 16; // ... [7] searches through L2, [8..10] po
 #define SPREAD_STAMP(k) do { } while (0)
 #endif
 
+// the 18 granules of one workgroup (144 bytes, 16-byte aligned) as NINE 16-byte loads of the same scope as granule_load, issued
+// together and waited for once: the gather is bound by the loads a lane has to issue per poll (twice the loads, tried for lanes that
+// hold two workgroups, cost config 3 four per cent), and a granule validates itself -- a pair torn between its halves is two granules
+__device__ inline void granule_load18(const unsigned long long *g, unsigned long long v[18])
+{
+    uint4 r0, r1, r2, r3, r4, r5, r6, r7, r8;
+    asm volatile("global_load_dwordx4 %0, %9, off sc1\n\t"
+                 "global_load_dwordx4 %1, %9, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %9, off offset:32 sc1\n\t"
+                 "global_load_dwordx4 %3, %9, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %9, off offset:64 sc1\n\t"
+                 "global_load_dwordx4 %5, %9, off offset:80 sc1\n\t"
+                 "global_load_dwordx4 %6, %9, off offset:96 sc1\n\t"
+                 "global_load_dwordx4 %7, %9, off offset:112 sc1\n\t"
+                 "global_load_dwordx4 %8, %9, off offset:128 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&v"(r8)
+                 : "v"(g)
+                 : "memory");
+    const uint4 r[9] = {r0, r1, r2, r3, r4, r5, r6, r7, r8};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        v[2 * k] = ((unsigned long long)r[k].y << 32) | r[k].x;
+        v[2 * k + 1] = ((unsigned long long)r[k].w << 32) | r[k].z;
+    }
+}
 __device__ inline void granule_store(unsigned long long *g, unsigned tag, unsigned value)
 {
     __hip_atomic_store((gu64 *)g, ((unsigned long long)tag << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -104,11 +130,10 @@ __device__ inline bool spread_exchange(const ModelView &mv, const FitArgs &fa, c
         unsigned long long        v[kGranPerWg];
         for (;;) {
             bool all = true;
+            static_assert(kGranPerWg == 18, "granule_load18");
+            granule_load18(g, v);
 #pragma unroll
-            for (int k = 0; k < kGranPerWg; ++k) {
-                v[k] = granule_load(g + k);
-                all &= (unsigned)(v[k] >> 32) == tag;
-            }
+            for (int k = 0; k < kGranPerWg; ++k) all &= (unsigned)(v[k] >> 32) == tag;
             if (all && !(iter == 0 && first_ticks == 0)) break; // (spread_wait_us < 0: every scan is handed over, for the tests)
             if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)fa.spread_tag ||
                 __builtin_amdgcn_s_memrealtime() - t_begin >= (iter == 0 ? first_ticks : kSpinTicks)) {
